@@ -1,0 +1,180 @@
+/*
+ * ptamd.h - C ABI of libptamd.so: the MI355X (gfx950) implementation of the
+ * protein-transformer training hot path.
+ *
+ * The upstream reference has no FFI/plugin layer: its hot path sits behind plain
+ * Python call signatures.  Each entry point below names the
+ * reference function(s) whose arithmetic it replaces (paths relative to
+ * /root/reference/protein_transformer/), and `protein_transformer_amd/` keeps
+ * those Python signatures on top of this ABI via ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - row-major, innermost dimension contiguous, fp32 unless stated otherwise;
+ *   - no allocation inside the library: the caller owns outputs and workspaces
+ *     (query sizes with the *_workspace_bytes functions);
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); nothing
+ *     synchronises;
+ *   - return value: PTAMD_OK or a negative PTAMD_ERR_* code for host-detectable
+ *     problems; device-detected anomalies are OR-ed into a caller-provided
+ *     int32 status word (PTAMD_ST_* bits) and never trap.
+ *
+ * Shapes: B proteins, L padded residues, 12 angles / 14 atom slots per residue,
+ * T = B*L tokens, D model width, F feed-forward width, H heads, dk = D/H.
+ */
+#ifndef PTAMD_H
+#define PTAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTAMD_OK 0
+#define PTAMD_ERR_BAD_SHAPE (-1)  /* non-positive or unsupported size                      */
+#define PTAMD_ERR_TOO_LONG (-2)   /* L exceeds what the kernel's LDS staging supports      */
+#define PTAMD_ERR_WORKSPACE (-3)  /* workspace pointer NULL or too small                   */
+#define PTAMD_ERR_HIP (-4)        /* a HIP runtime call failed (see ptamd_last_hip_error)  */
+#define PTAMD_ERR_ALIGN (-5)      /* pointer / leading dimension not 16-byte aligned       */
+
+/* device status bits (int32 word, OR-ed by kernels) */
+#define PTAMD_ST_BAD_RESIDUE 1 /* id outside 0..19 before the padding (Sequence.py:50-51 KeyError)   */
+#define PTAMD_ST_TOO_SHORT 2   /* fewer than 2 residues (StructureBuilder.py:58-59 StopIteration)    */
+#define PTAMD_ST_BAD_THETA 4   /* bond angle outside [-pi, pi] (Structure.py:42 AssertionError)      */
+#define PTAMD_ST_NONFINITE 8   /* NaN/inf loss (log.py:182-185 exits the process)                    */
+
+#define PTAMD_PAD_ID 20
+#define PTAMD_NUM_ANGLES 12
+#define PTAMD_NUM_SLOTS 14
+
+const char *ptamd_version(void);
+const char *ptamd_last_hip_error(void);
+/* number of side-chain atoms of residue type r (0..19); -1 if r is out of range */
+int ptamd_sidechain_atoms(int residue);
+
+/* ------------------------------------------------------------------ angles
+ * inverse_trig_transform (losses.py:26-36): sincos[n,2] = (cos, sin) -> ang[n] = atan2(sin, cos). */
+int ptamd_angles_fwd(const float *sincos, float *ang, int64_t n, void *stream);
+/* d(ang)/d(cos, sin): dsincos[n,2] = dang[n] * (-sin, cos) / (cos^2 + sin^2)   */
+int ptamd_angles_bwd(const float *sincos, const float *dang, float *dsincos, int64_t n, void *stream);
+
+/* ------------------------------------------------------------------ NeRF
+ * generate_coords / StructureBuilder.build / ResidueBuilder.build_bb,build_sc / nerf
+ * (protein/Structure.py:12-65, protein/StructureBuilder.py:55-92,147-236).
+ *   ang [B,L,12] radians; seq [B,L] int64 residue ids with trailing PTAMD_PAD_ID;
+ *   crd [B,L*14,3] out (unused slots and padded residues = 0); status: int32[1], OR-ed. */
+size_t ptamd_nerf_workspace_bytes(int B, int L);
+int ptamd_nerf_fwd(const float *ang, const int64_t *seq, int B, int L, float *crd, int32_t *status,
+                   void *stream);
+/* adjoint of the build: dcrd [B,L*14,3] -> dang [B,L,12] (overwritten). Reproduces the
+ * reference's graph: first residue's C is detached (StructureBuilder.py:185-187). */
+int ptamd_nerf_bwd(const float *ang, const int64_t *seq, const float *crd, const float *dcrd, int B, int L,
+                   float *dang, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------ dRMSD
+ * drmsd_work's loss part for a whole batch (losses.py:63-92,233-278; structure_utils.py:19-32).
+ *   pred_crd, true_crd [B,L*14,3]; NaN in true_crd = atom absent.
+ *   stats [B,8] out: {drmsd, drmsd/n, bb_drmsd, bb_drmsd/n_bb, n, n_bb, 0, 0}
+ *   dcrd [B,L*14,3] out or NULL: d(drmsd/n)/d(pred_crd)  (the reference always
+ *   differentiates the length-normalised loss, losses.py:80,91-92). */
+size_t ptamd_drmsd_workspace_bytes(int B, int L);
+int ptamd_drmsd_fwd_bwd(const float *pred_crd, const float *true_crd, const int64_t *seq, int B, int L,
+                        float *stats, float *dcrd, void *workspace, size_t workspace_bytes, void *stream);
+
+/* mse_over_angles x3 (losses.py:175-214; train.py:64-66) in one pass.
+ *   pred, truth [T,24]; out[6] = {sum_full, cnt_full, sum_bb, cnt_bb, sum_sc, cnt_sc} (fp32, zeroed inside) */
+int ptamd_mse_angles_fwd(const float *pred, const float *truth, int64_t T, float *out, void *stream);
+/* dpred[T,24] (+)= coef * 2*(pred-truth)/cnt_full on the selected elements; accumulate != 0 adds */
+int ptamd_mse_angles_bwd(const float *pred, const float *truth, int64_t T, const float *sums, float coef,
+                         int accumulate, float *dpred, void *stream);
+
+/* ------------------------------------------------------------------ encoder building blocks
+ * Row-major fp32 GEMM on the f32 MFMA pipe (v_mfma_f32_32x32x2_f32):
+ *     C[M,N] = epilogue( A (*) B )          with reduction length K
+ *   a_kmajor = 0: A is [M,K] (K contiguous, lda);  1: A is stored [K,M] (M contiguous, lda)
+ *   b_kmajor = 0: B is [N,K] (K contiguous, ldb) - the torch.nn.Linear weight layout;
+ *              1: B is stored [K,N] (N contiguous, ldb)
+ * epilogue, in order: + bias[N] (may be NULL); ReLU if (flags & PTAMD_EPI_RELU);
+ *   dropout(p, seed, stream_id) if p > 0;  + residual[M,N] (ldr; may be NULL);
+ *   tanh if (flags & PTAMD_EPI_TANH).
+ * Replaces torch.nn.Linear (Attention.py:49,69; Sublayers.py:34; encoder_only.py:39)
+ * and their autograd backward GEMMs. */
+#define PTAMD_EPI_RELU 1
+#define PTAMD_EPI_TANH 2
+#define PTAMD_EPI_ACCUM 4 /* C += result (used for split reductions) */
+typedef struct {
+  int M, N, K;
+  const float *A; int lda; int a_kmajor;
+  const float *B; int ldb; int b_kmajor;
+  float *C; int ldc;
+  const float *bias;
+  const float *residual; int ldr;
+  int flags;
+  float dropout_p; uint64_t seed; uint32_t stream_id;
+  int split_k;            /* >1: partials go to workspace and are reduced deterministically */
+  void *workspace; size_t workspace_bytes;
+} ptamd_gemm_args;
+size_t ptamd_gemm_workspace_bytes(int M, int N, int split_k);
+int ptamd_gemm(const ptamd_gemm_args *args, void *stream);
+
+/* torch.nn.LayerNorm(D, eps=1e-5) (Sublayers.py:13,17): y = (x-mean)*rstd*gamma+beta; saves mean,rstd [T] */
+int ptamd_layernorm_fwd(const float *x, const float *gamma, const float *beta, int64_t T, int D, float *y,
+                        float *mean, float *rstd, void *stream);
+/* dx [T,D] (overwritten); dgamma, dbeta [D] accumulated (+=) through fixed-order partials in workspace */
+size_t ptamd_layernorm_bwd_workspace_bytes(int D);
+int ptamd_layernorm_bwd(const float *dy, const float *x, const float *gamma, const float *mean, const float *rstd,
+                        int64_t T, int D, float *dx, float *dgamma, float *dbeta, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
+/* Embeddings * sqrt(D) and the doubled positional add of Encoder.py:30 + Sublayers.py:59-62,72:
+ *   x0 = emb[seq]*sqrt(D); out = drop2(x0 + drop1(x0 + pe[pos]))      (eval: 2*x0 + pe) */
+int ptamd_embed_fwd(const int64_t *seq, const float *emb, const float *pe, int B, int L, int D, float dropout_p,
+                    uint64_t seed, float *out, void *stream);
+/* demb [22,D] += scatter of dout with the same dropout masks (fixed-order partial tables in workspace) */
+size_t ptamd_embed_bwd_workspace_bytes(int D);
+int ptamd_embed_bwd(const int64_t *seq, const float *dout, int B, int L, int D, float dropout_p, uint64_t seed,
+                    float *demb, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Fused masked multi-head attention (Attention.py:14-22,55-69), fp32 MFMA, scores never materialised.
+ *   qkv [T,3D]: Q | K | V column blocks, head h at columns h*dk..; key-padding mask from seq != 20;
+ *   softmax(QK^T/sqrt(dk)) with dropout p on the probabilities; out [T,D] heads merged.
+ *   lse [B,H,L] saves log-sum-exp per query row for the backward. dk must be 32 or 64. */
+int ptamd_attention_fwd(const float *qkv, const int64_t *seq, int B, int L, int H, int dk, float dropout_p,
+                        uint64_t seed, uint32_t stream_id, float *out, float *lse, void *stream);
+int ptamd_attention_bwd(const float *qkv, const int64_t *seq, const float *out, const float *dout, const float *lse,
+                        int B, int L, int H, int dk, float dropout_p, uint64_t seed, uint32_t stream_id,
+                        float *dqkv, void *workspace, size_t workspace_bytes, void *stream);
+size_t ptamd_attention_workspace_bytes(int B, int L, int H, int dk);
+
+/* column sums: out[N] (+)= sum_t x[t,N]   (bias gradients) */
+size_t ptamd_colsum_workspace_bytes(int N);
+int ptamd_colsum(const float *x, int64_t T, int N, int ldx, int accumulate, float *out, void *workspace,
+                 size_t workspace_bytes, void *stream);
+/* elementwise backward helpers.
+ *   relu_dropout_bwd: y = dropout(relu(.)) -> dx = dy * (y > 0) / (1-p)   (y > 0 iff active AND kept)
+ *   tanh_bwd:         dx = dy * (1 - y*y)
+ *   dropout_bwd:      dx = dy * mask / (1-p), mask regenerated from (seed, stream_id) exactly as the GEMM
+ *                     epilogue drew it: word (row & 3) of Philox4x32-10(seed, (row >> 2) * cols + col, stream_id) */
+int ptamd_relu_dropout_bwd(const float *dy, const float *y, int64_t n, float dropout_p, float *dx, void *stream);
+int ptamd_tanh_bwd(const float *dy, const float *y, int64_t n, float *dx, void *stream);
+int ptamd_dropout_bwd(const float *dy, int64_t rows, int cols, float dropout_p, uint64_t seed, uint32_t stream_id,
+                      float *dx, void *stream);
+
+/* ------------------------------------------------------------------ optimizer (train.py:41-46,371-381)
+ * clip_grad_norm_(params, max_norm) + SGD(lr, weight_decay) / Adam(betas, eps, weight_decay) over ONE flat
+ * fp32 parameter buffer.  sqnorm: out[0] = sum g^2 (zeroed inside, deterministic two-stage reduction). */
+size_t ptamd_grad_sqnorm_workspace_bytes(void);
+int ptamd_grad_sqnorm(const float *g, int64_t n, float *out, void *workspace, size_t workspace_bytes, void *stream);
+/* clip coefficient = min(1, max_norm / (sqrt(*sqnorm) + 1e-6)) computed on device from sqnorm[0];
+ * max_norm <= 0 disables clipping */
+int ptamd_sgd_step(float *w, const float *g, int64_t n, const float *sqnorm, float max_norm, float lr,
+                   float weight_decay, void *stream);
+int ptamd_adam_step(float *w, const float *g, float *m, float *v, int64_t n, const float *sqnorm, float max_norm,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, int step, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTAMD_H */

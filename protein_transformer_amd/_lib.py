@@ -1,0 +1,127 @@
+"""ctypes binding of libptamd.so (include/ptamd.h).  There is NO fallback: if the
+HIP library is missing or a call fails, this raises."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libptamd.so")
+
+OK = 0
+ERRORS = {-1: "bad shape", -2: "sequence too long for the NeRF LDS staging", -3: "workspace missing or too small",
+          -4: "HIP runtime error", -5: "pointer not 16-byte aligned"}
+ST_BAD_RESIDUE, ST_TOO_SHORT, ST_BAD_THETA, ST_NONFINITE = 1, 2, 4, 8
+
+_p, _i, _i64, _f, _sz, _u64, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_uint64, C.c_uint32
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("M", _i), ("N", _i), ("K", _i),
+                ("A", _p), ("lda", _i), ("a_kmajor", _i),
+                ("B", _p), ("ldb", _i), ("b_kmajor", _i),
+                ("C", _p), ("ldc", _i),
+                ("bias", _p),
+                ("residual", _p), ("ldr", _i),
+                ("flags", _i),
+                ("dropout_p", _f), ("seed", _u64), ("stream_id", _u32),
+                ("split_k", _i),
+                ("workspace", _p), ("workspace_bytes", _sz)]
+
+
+# name -> (restype, argtypes); mirrors include/ptamd.h one to one
+SIGNATURES = {
+    "ptamd_version": (C.c_char_p, []),
+    "ptamd_last_hip_error": (C.c_char_p, []),
+    "ptamd_sidechain_atoms": (_i, [_i]),
+    "ptamd_angles_fwd": (_i, [_p, _p, _i64, _p]),
+    "ptamd_angles_bwd": (_i, [_p, _p, _p, _i64, _p]),
+    "ptamd_nerf_workspace_bytes": (_sz, [_i, _i]),
+    "ptamd_nerf_fwd": (_i, [_p, _p, _i, _i, _p, _p, _p]),
+    "ptamd_nerf_bwd": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _sz, _p]),
+    "ptamd_drmsd_workspace_bytes": (_sz, [_i, _i]),
+    "ptamd_drmsd_fwd_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _sz, _p]),
+    "ptamd_mse_angles_fwd": (_i, [_p, _p, _i64, _p, _p]),
+    "ptamd_mse_angles_bwd": (_i, [_p, _p, _i64, _p, _f, _i, _p, _p]),
+    "ptamd_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ptamd_gemm": (_i, [C.POINTER(GemmArgs), _p]),
+    "ptamd_layernorm_fwd": (_i, [_p, _p, _p, _i64, _i, _p, _p, _p, _p]),
+    "ptamd_layernorm_bwd_workspace_bytes": (_sz, [_i]),
+    "ptamd_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _i64, _i, _p, _p, _p, _p, _sz, _p]),
+    "ptamd_embed_fwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _u64, _p, _p]),
+    "ptamd_embed_bwd_workspace_bytes": (_sz, [_i]),
+    "ptamd_embed_bwd": (_i, [_p, _p, _i, _i, _i, _f, _u64, _p, _p, _sz, _p]),
+    "ptamd_attention_fwd": (_i, [_p, _p, _i, _i, _i, _i, _f, _u64, _u32, _p, _p, _p]),
+    "ptamd_attention_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _u32, _p, _p, _sz, _p]),
+    "ptamd_attention_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "ptamd_colsum_workspace_bytes": (_sz, [_i]),
+    "ptamd_colsum": (_i, [_p, _i64, _i, _i, _i, _p, _p, _sz, _p]),
+    "ptamd_relu_dropout_bwd": (_i, [_p, _p, _i64, _f, _p, _p]),
+    "ptamd_tanh_bwd": (_i, [_p, _p, _i64, _p, _p]),
+    "ptamd_dropout_bwd": (_i, [_p, _i64, _i, _f, _u64, _u32, _p, _p]),
+    "ptamd_grad_sqnorm_workspace_bytes": (_sz, []),
+    "ptamd_grad_sqnorm": (_i, [_p, _i64, _p, _p, _sz, _p]),
+    "ptamd_sgd_step": (_i, [_p, _p, _i64, _p, _f, _f, _f, _p]),
+    "ptamd_adam_step": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _f, _f, _i, _p]),
+}
+
+_lib = None
+MISSING = set()
+
+
+def lib():
+    """The loaded library; raises RuntimeError (never falls back) when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m protein_transformer_amd.build` "
+                "(the MI355X path has no CPU or PyTorch fallback)")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError:
+                MISSING.add(name)       # tests/test_abi.py requires this set to be empty
+                continue
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Tensors must be contiguous where the ABI says so."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(rc, what):
+    if rc != OK:
+        detail = ERRORS.get(rc, f"code {rc}")
+        if rc == -4:
+            detail += ": " + lib().ptamd_last_hip_error().decode()
+        raise RuntimeError(f"libptamd {what}: {detail}")
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("libptamd operates on device tensors only (no CPU path); got a CPU tensor")
+
+
+_workspaces = {}
+
+
+def workspace(tag, nbytes, device):
+    """Per-(tag, device) scratch buffer from the PyTorch caching allocator, grown on demand."""
+    key = (tag, device)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf

@@ -1,0 +1,367 @@
+// Bandwidth-bound pieces of the encoder: embedding + positional encoding, LayerNorm, bias-gradient column
+// sums and the elementwise backward helpers.  All are HBM-bound: 16-byte accesses, one wavefront per row,
+// fixed-order reductions (no float atomics, results are run-to-run deterministic).
+//
+// Reference semantics:
+//   Embeddings * sqrt(D)          /root/reference/protein_transformer/models/transformer/Sublayers.py:65-72
+//   PositionalEncoding (+dropout) .../Sublayers.py:37-62 and the second add + dropout of Encoder.py:30
+//   torch.nn.LayerNorm(D)         .../Sublayers.py:13,17   (eps 1e-5, biased variance, affine)
+//   Dropout / ReLU / tanh backward: autograd of Sublayers.py:17,34 and encoder_only.py:41
+#include "common.h"
+
+namespace {
+
+constexpr uint32_t STREAM_EMB1 = 0xE1u, STREAM_EMB2 = 0xE2u;
+
+// ------------------------------------------------------------------------------------------------ embedding
+__global__ void embed_fwd_kernel(const int64_t *__restrict__ seq, const float *__restrict__ emb,
+                                 const float *__restrict__ pe, int L, int D, int64_t n4, float p, uint64_t seed,
+                                 float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 of one token
+  if (i >= n4) return;
+  const int d4 = D >> 2;
+  const int64_t t = i / d4;
+  const int c = (int)(i - t * d4) * 4;
+  const int l = (int)(t % L);
+  int64_t id = seq[t];
+  if (id < 0 || id > 21) id = 21;
+  const float sq = sqrtf((float)D);
+  const float4 e = *reinterpret_cast<const float4 *>(emb + id * D + c);
+  const float4 q = *reinterpret_cast<const float4 *>(pe + (size_t)l * D + c);
+  float x0[4] = {e.x * sq, e.y * sq, e.z * sq, e.w * sq};
+  const float pv[4] = {q.x, q.y, q.z, q.w};
+  float o[4];
+  if (p > 0.f) {
+    const uint32_t thr = dropout_threshold(p);
+    const float ks = 1.f / (1.f - p);
+    const uint4 r1 = philox4x32(seed, (uint64_t)i, STREAM_EMB1), r2 = philox4x32(seed, (uint64_t)i, STREAM_EMB2);
+    const uint32_t w1[4] = {r1.x, r1.y, r1.z, r1.w}, w2[4] = {r2.x, r2.y, r2.z, r2.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float inner = w1[k] >= thr ? (x0[k] + pv[k]) * ks : 0.f;   // PositionalEncoding's dropout
+      o[k] = w2[k] >= thr ? (x0[k] + inner) * ks : 0.f;                // Encoder.emb_dropout
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = x0[k] + (x0[k] + pv[k]);
+  }
+  *reinterpret_cast<float4 *>(out + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// partial embedding-gradient tables: block (slab of 64 columns, chunk of tokens) -> part[chunk][22][D]
+constexpr int EMB_CHUNKS = 64;
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t *__restrict__ seq,
+                                                        const float *__restrict__ dout, int64_t T, int D, float p,
+                                                        uint64_t seed, float *__restrict__ part) {
+  __shared__ float tab[4][22][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  for (int v = 0; v < 22; ++v) tab[wave][v][lane] = 0.f;
+  const int64_t per = (T + EMB_CHUNKS - 1) / EMB_CHUNKS;
+  const int64_t t0 = blockIdx.y * per, t1 = min(T, t0 + per);
+  const float sq = sqrtf((float)D);
+  const uint32_t thr = dropout_threshold(p);
+  const float ks = 1.f / (1.f - p);
+  if (c < D) {
+    for (int64_t t = t0 + wave; t < t1; t += 4) {
+      int64_t id = seq[t];
+      if (id < 0 || id > 21) id = 21;
+      float g = dout[t * D + c];
+      if (p > 0.f) {
+        const uint64_t i4 = (uint64_t)(t * (D >> 2) + (c >> 2));
+        const uint4 r1 = philox4x32(seed, i4, STREAM_EMB1), r2 = philox4x32(seed, i4, STREAM_EMB2);
+        const int k = c & 3;
+        const uint32_t w1 = k == 0 ? r1.x : k == 1 ? r1.y : k == 2 ? r1.z : r1.w;
+        const uint32_t w2 = k == 0 ? r2.x : k == 1 ? r2.y : k == 2 ? r2.z : r2.w;
+        g = w2 >= thr ? g * ks * (1.f + (w1 >= thr ? ks : 0.f)) : 0.f;
+      } else {
+        g *= 2.f;
+      }
+      tab[wave][id][lane] += g * sq;
+    }
+  }
+  __syncthreads();
+  if (c < D)
+    for (int v = wave; v < 22; v += 4)
+      part[((size_t)blockIdx.y * 22 + v) * D + c] = tab[0][v][lane] + tab[1][v][lane] + tab[2][v][lane] + tab[3][v][lane];
+}
+__global__ void embed_bwd_reduce_kernel(const float *__restrict__ part, int D, float *__restrict__ demb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 22 * D) return;
+  float s = 0.f;
+  for (int ch = 0; ch < EMB_CHUNKS; ++ch) s += part[(size_t)ch * 22 * D + i];
+  demb[i] += s;
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+// one wavefront per row, NV float4 per lane kept in registers
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, int64_t T, int D,
+                                                            float *__restrict__ y, float *__restrict__ mean_out,
+                                                            float *__restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= T) return;
+  const float *xr = x + row * D;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    v[j] = c < D ? *reinterpret_cast<const float4 *>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    if (c < D) {
+      const float a = v[j].x - mean, b = v[j].y - mean, cc = v[j].z - mean, d = v[j].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = 1.f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+  float *yr = y + row * D;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    if (c < D) {
+      const float4 g = *reinterpret_cast<const float4 *>(gamma + c), b = *reinterpret_cast<const float4 *>(beta + c);
+      *reinterpret_cast<float4 *>(yr + c) =
+          make_float4((v[j].x - mean) * rstd * g.x + b.x, (v[j].y - mean) * rstd * g.y + b.y,
+                      (v[j].z - mean) * rstd * g.z + b.z, (v[j].w - mean) * rstd * g.w + b.w);
+    }
+  }
+  if (lane == 0) {
+    mean_out[row] = mean;
+    rstd_out[row] = rstd;
+  }
+}
+
+constexpr int LN_BWD_BLOCKS = 256;  // x 4 waves = 1024 partial rows of (dgamma, dbeta)
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                            const float *__restrict__ gamma,
+                                                            const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                            int64_t T, int D, float *__restrict__ dx,
+                                                            float *__restrict__ part) {
+  const int lane = threadIdx.x & 63, wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  float4 g[NV], dg[NV], db[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    g[j] = c < D ? *reinterpret_cast<const float4 *>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    dg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    db[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int64_t row = wid; row < T; row += LN_BWD_BLOCKS * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float4 xh[NV], gy[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = (j * 64 + lane) * 4;
+      if (c < D) {
+        const float4 xv = *reinterpret_cast<const float4 *>(x + row * D + c);
+        const float4 d = *reinterpret_cast<const float4 *>(dy + row * D + c);
+        xh[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+        gy[j] = make_float4(d.x * g[j].x, d.y * g[j].y, d.z * g[j].z, d.w * g[j].w);
+        s1 += (gy[j].x + gy[j].y) + (gy[j].z + gy[j].w);
+        s2 += (gy[j].x * xh[j].x + gy[j].y * xh[j].y) + (gy[j].z * xh[j].z + gy[j].w * xh[j].w);
+        dg[j].x += d.x * xh[j].x; dg[j].y += d.y * xh[j].y; dg[j].z += d.z * xh[j].z; dg[j].w += d.w * xh[j].w;
+        db[j].x += d.x; db[j].y += d.y; db[j].z += d.z; db[j].w += d.w;
+      }
+    }
+    const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = (j * 64 + lane) * 4;
+      if (c < D)
+        *reinterpret_cast<float4 *>(dx + row * D + c) =
+            make_float4(rs * (gy[j].x - m1 - xh[j].x * m2), rs * (gy[j].y - m1 - xh[j].y * m2),
+                        rs * (gy[j].z - m1 - xh[j].z * m2), rs * (gy[j].w - m1 - xh[j].w * m2));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    if (c < D) {
+      *reinterpret_cast<float4 *>(part + ((size_t)wid * 2) * D + c) = dg[j];
+      *reinterpret_cast<float4 *>(part + ((size_t)wid * 2 + 1) * D + c) = db[j];
+    }
+  }
+}
+__global__ void layernorm_bwd_reduce_kernel(const float *__restrict__ part, int D, float *__restrict__ dgamma,
+                                            float *__restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  float a = 0.f, b = 0.f;
+  for (int w = 0; w < LN_BWD_BLOCKS * 4; ++w) {
+    a += part[((size_t)w * 2) * D + c];
+    b += part[((size_t)w * 2 + 1) * D + c];
+  }
+  dgamma[c] += a;
+  dbeta[c] += b;
+}
+
+// ------------------------------------------------------------------------------------------------ column sums
+constexpr int CS_CHUNKS = 128;
+__global__ void colsum_partial_kernel(const float *__restrict__ x, int64_t T, int N, int ldx, float *__restrict__ part) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  const int64_t per = (T + CS_CHUNKS - 1) / CS_CHUNKS;
+  const int64_t t0 = blockIdx.y * per, t1 = min(T, t0 + per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int64_t t = t0;
+  for (; t + 3 < t1; t += 4) {
+    s0 += x[t * ldx + c];
+    s1 += x[(t + 1) * ldx + c];
+    s2 += x[(t + 2) * ldx + c];
+    s3 += x[(t + 3) * ldx + c];
+  }
+  for (; t < t1; ++t) s0 += x[t * ldx + c];
+  part[(size_t)blockIdx.y * N + c] = (s0 + s1) + (s2 + s3);
+}
+__global__ void colsum_reduce_kernel(const float *__restrict__ part, int N, int accumulate, float *__restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  float s = 0.f;
+  for (int ch = 0; ch < CS_CHUNKS; ++ch) s += part[(size_t)ch * N + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise bwd
+__global__ void relu_dropout_bwd_kernel(const float4 *__restrict__ dy, const float4 *__restrict__ y, int64_t n4,
+                                        float ks, float4 *__restrict__ dx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 d = dy[i], v = y[i];
+  dx[i] = make_float4(v.x > 0.f ? d.x * ks : 0.f, v.y > 0.f ? d.y * ks : 0.f, v.z > 0.f ? d.z * ks : 0.f,
+                      v.w > 0.f ? d.w * ks : 0.f);
+}
+__global__ void tanh_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y, int64_t n,
+                                float *__restrict__ dx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dx[i] = dy[i] * (1.f - y[i] * y[i]);
+}
+// mask(row, col) = word (row & 3) of philox(seed, (row >> 2) * cols + col, stream): the GEMM epilogue's mapping
+__global__ void dropout_bwd_kernel(const float *__restrict__ dy, int64_t rows, int cols, float p, uint64_t seed,
+                                   uint32_t stream_id, float *__restrict__ dx) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t rq = blockIdx.y;
+  if (c >= cols) return;
+  const uint32_t thr = dropout_threshold(p);
+  const float ks = 1.f / (1.f - p);
+  const uint4 r = philox4x32(seed, (uint64_t)rq * cols + c, stream_id);
+  const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int64_t row = rq * 4 + e;
+    if (row < rows) dx[row * cols + c] = w[e] >= thr ? dy[row * cols + c] * ks : 0.f;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptamd_embed_fwd(const int64_t *seq, const float *emb, const float *pe, int B, int L, int D, float dropout_p,
+                    uint64_t seed, float *out, void *stream) {
+  if (B <= 0 || L <= 0 || D <= 0 || (D & 3)) return PTAMD_ERR_BAD_SHAPE;
+  const int64_t n4 = (int64_t)B * L * (D >> 2);
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seq, emb,
+                     pe, L, D, n4, dropout_p, seed, out);
+  return pt_check_launch();
+}
+
+size_t ptamd_embed_bwd_workspace_bytes(int D) { return (size_t)EMB_CHUNKS * 22 * (D > 0 ? D : 0) * sizeof(float); }
+
+int ptamd_embed_bwd(const int64_t *seq, const float *dout, int B, int L, int D, float dropout_p, uint64_t seed,
+                    float *demb, void *workspace, size_t workspace_bytes, void *stream) {
+  if (B <= 0 || L <= 0 || D <= 0 || (D & 3)) return PTAMD_ERR_BAD_SHAPE;
+  if (!workspace || workspace_bytes < ptamd_embed_bwd_workspace_bytes(D)) return PTAMD_ERR_WORKSPACE;
+  float *part = static_cast<float *>(workspace);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((D + 63) / 64, EMB_CHUNKS), dim3(256), 0, st, seq, dout, (int64_t)B * L, D,
+                     dropout_p, seed, part);
+  int rc = pt_check_launch();
+  if (rc) return rc;
+  hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3((22 * D + 255) / 256), dim3(256), 0, st, part, D, demb);
+  return pt_check_launch();
+}
+
+int ptamd_layernorm_fwd(const float *x, const float *gamma, const float *beta, int64_t T, int D, float *y, float *mean,
+                        float *rstd, void *stream) {
+  if (T <= 0 || D <= 0 || (D & 3) || D > 2048) return PTAMD_ERR_BAD_SHAPE;
+  const dim3 grid((unsigned)((T + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (D <= 256) hipLaunchKernelGGL(layernorm_fwd_kernel<1>, grid, block, 0, st, x, gamma, beta, T, D, y, mean, rstd);
+  else if (D <= 512) hipLaunchKernelGGL(layernorm_fwd_kernel<2>, grid, block, 0, st, x, gamma, beta, T, D, y, mean, rstd);
+  else if (D <= 1024) hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, block, 0, st, x, gamma, beta, T, D, y, mean, rstd);
+  else hipLaunchKernelGGL(layernorm_fwd_kernel<8>, grid, block, 0, st, x, gamma, beta, T, D, y, mean, rstd);
+  return pt_check_launch();
+}
+
+size_t ptamd_layernorm_bwd_workspace_bytes(int D) {
+  return (size_t)LN_BWD_BLOCKS * 4 * 2 * (D > 0 ? D : 0) * sizeof(float);
+}
+
+int ptamd_layernorm_bwd(const float *dy, const float *x, const float *gamma, const float *mean, const float *rstd,
+                        int64_t T, int D, float *dx, float *dgamma, float *dbeta, void *workspace,
+                        size_t workspace_bytes, void *stream) {
+  if (T <= 0 || D <= 0 || (D & 3) || D > 2048) return PTAMD_ERR_BAD_SHAPE;
+  if (!workspace || workspace_bytes < ptamd_layernorm_bwd_workspace_bytes(D)) return PTAMD_ERR_WORKSPACE;
+  float *part = static_cast<float *>(workspace);
+  const dim3 grid(LN_BWD_BLOCKS), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (D <= 256) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, block, 0, st, dy, x, gamma, mean, rstd, T, D, dx, part);
+  else if (D <= 512) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, block, 0, st, dy, x, gamma, mean, rstd, T, D, dx, part);
+  else if (D <= 1024) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, st, dy, x, gamma, mean, rstd, T, D, dx, part);
+  else hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, block, 0, st, dy, x, gamma, mean, rstd, T, D, dx, part);
+  int rc = pt_check_launch();
+  if (rc) return rc;
+  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((D + 255) / 256), dim3(256), 0, st, part, D, dgamma, dbeta);
+  return pt_check_launch();
+}
+
+size_t ptamd_colsum_workspace_bytes(int N) { return (size_t)CS_CHUNKS * (N > 0 ? N : 0) * sizeof(float); }
+
+int ptamd_colsum(const float *x, int64_t T, int N, int ldx, int accumulate, float *out, void *workspace,
+                 size_t workspace_bytes, void *stream) {
+  if (T <= 0 || N <= 0 || ldx < N) return PTAMD_ERR_BAD_SHAPE;
+  if (!workspace || workspace_bytes < ptamd_colsum_workspace_bytes(N)) return PTAMD_ERR_WORKSPACE;
+  float *part = static_cast<float *>(workspace);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, CS_CHUNKS), dim3(256), 0, st, x, T, N, ldx, part);
+  int rc = pt_check_launch();
+  if (rc) return rc;
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part, N, accumulate, out);
+  return pt_check_launch();
+}
+
+int ptamd_relu_dropout_bwd(const float *dy, const float *y, int64_t n, float dropout_p, float *dx, void *stream) {
+  if (n <= 0 || (n & 3)) return PTAMD_ERR_BAD_SHAPE;
+  if (!pt_aligned16(dy) || !pt_aligned16(y) || !pt_aligned16(dx)) return PTAMD_ERR_ALIGN;
+  hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4 *>(dy), reinterpret_cast<const float4 *>(y), n / 4,
+                     1.f / (1.f - dropout_p), reinterpret_cast<float4 *>(dx));
+  return pt_check_launch();
+}
+
+int ptamd_tanh_bwd(const float *dy, const float *y, int64_t n, float *dx, void *stream) {
+  if (n <= 0) return PTAMD_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, y, n, dx);
+  return pt_check_launch();
+}
+
+int ptamd_dropout_bwd(const float *dy, int64_t rows, int cols, float dropout_p, uint64_t seed, uint32_t stream_id,
+                      float *dx, void *stream) {
+  if (rows <= 0 || cols <= 0) return PTAMD_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(dropout_bwd_kernel, dim3((cols + 255) / 256, (unsigned)((rows + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, dy, rows, cols, dropout_p, seed, stream_id, dx);
+  return pt_check_launch();
+}
+
+}  // extern "C"

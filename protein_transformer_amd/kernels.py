@@ -1,0 +1,168 @@
+"""Thin Python entry points for the encoder / optimizer kernels of libptamd (include/ptamd.h).
+
+Plumbing only: tensors come from the PyTorch-ROCm caching allocator, kernels are enqueued on the
+current HIP stream through the C ABI.  Everything here requires device tensors; nothing falls back.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import GemmArgs, check, lib, ptr, stream, workspace
+
+EPI_RELU, EPI_TANH, EPI_ACCUM = 1, 2, 4
+
+
+def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, bias=None, residual=None,
+         ldr=0, flags=0, dropout_p=0.0, seed=0, stream_id=0, split_k=1):
+    """C[M,N] = epilogue(A (*) B); operand layouts as documented in ptamd.h."""
+    ws = None
+    nbytes = 0
+    if split_k > 1:
+        nbytes = lib().ptamd_gemm_workspace_bytes(M, N, split_k)
+        ws = workspace("gemm", nbytes, C_out.device)
+    args = GemmArgs(M=M, N=N, K=K, A=A.data_ptr(), lda=lda, a_kmajor=int(a_kmajor), B=B.data_ptr(), ldb=ldb,
+                    b_kmajor=int(b_kmajor), C=C_out.data_ptr(), ldc=ldc,
+                    bias=bias.data_ptr() if bias is not None else None,
+                    residual=residual.data_ptr() if residual is not None else None, ldr=ldr, flags=flags,
+                    dropout_p=float(dropout_p), seed=int(seed) & (2 ** 64 - 1), stream_id=int(stream_id),
+                    split_k=int(split_k), workspace=ws.data_ptr() if ws is not None else None,
+                    workspace_bytes=ws.numel() if ws is not None else 0)
+    check(lib().ptamd_gemm(C.byref(args), stream()), "gemm")
+    return C_out
+
+
+def pick_split_k(M, N, K, target_blocks=512):
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles >= target_blocks // 2 or K <= 512:
+        return 1
+    return max(1, min(K // 256, -(-target_blocks // tiles)))
+
+
+def linear_fwd(x, w, b, out=None, **epi):
+    """y[T,N] = x[T,K] w[N,K]^T + b with a fused epilogue."""
+    T, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(T, N, dtype=torch.float32, device=x.device)
+    return gemm(x, w, out, M=T, N=N, K=K, lda=x.stride(0), ldb=w.stride(0), ldc=out.stride(0), bias=b, **epi)
+
+
+def linear_bwd_input(dy, w, out=None, flags=0):
+    """dx[T,K] = dy[T,N] w[N,K]."""
+    T, N = dy.shape
+    K = w.shape[1]
+    if out is None:
+        out = torch.empty(T, K, dtype=torch.float32, device=dy.device)
+    return gemm(dy, w, out, M=T, N=K, K=N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0), b_kmajor=True,
+                flags=flags)
+
+
+def linear_bwd_weight(dy, x, dw):
+    """dw[N,K] += dy[T,N]^T x[T,K]  (reduction over the T tokens, split across workgroups)."""
+    T, N = dy.shape
+    K = x.shape[1]
+    return gemm(dy, x, dw, M=N, N=K, K=T, lda=dy.stride(0), ldb=x.stride(0), ldc=dw.stride(0), a_kmajor=True,
+                b_kmajor=True, flags=EPI_ACCUM, split_k=pick_split_k(N, K, T))
+
+
+def colsum(x, out, accumulate=True):
+    T, N = x.shape
+    ws = workspace("colsum", lib().ptamd_colsum_workspace_bytes(N), x.device)
+    check(lib().ptamd_colsum(ptr(x), T, N, x.stride(0), int(accumulate), ptr(out), ptr(ws), ws.numel(), stream()),
+          "colsum")
+    return out
+
+
+def layernorm_fwd(x, gamma, beta):
+    T, D = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(T, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(T, dtype=torch.float32, device=x.device)
+    check(lib().ptamd_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), T, D, ptr(y), ptr(mean), ptr(rstd), stream()),
+          "layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta):
+    T, D = x.shape
+    dx = torch.empty_like(x)
+    ws = workspace("ln", lib().ptamd_layernorm_bwd_workspace_bytes(D), x.device)
+    check(lib().ptamd_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), T, D, ptr(dx), ptr(dgamma),
+                                    ptr(dbeta), ptr(ws), ws.numel(), stream()), "layernorm_bwd")
+    return dx
+
+
+def embed_fwd(seq, emb, pe, dropout_p, seed):
+    B, L = seq.shape
+    D = emb.shape[1]
+    out = torch.empty(B * L, D, dtype=torch.float32, device=emb.device)
+    check(lib().ptamd_embed_fwd(ptr(seq), ptr(emb), ptr(pe), B, L, D, float(dropout_p), int(seed), ptr(out), stream()),
+          "embed_fwd")
+    return out
+
+
+def embed_bwd(seq, dout, D, dropout_p, seed, demb):
+    B, L = seq.shape
+    ws = workspace("emb", lib().ptamd_embed_bwd_workspace_bytes(D), dout.device)
+    check(lib().ptamd_embed_bwd(ptr(seq), ptr(dout), B, L, D, float(dropout_p), int(seed), ptr(demb), ptr(ws),
+                                ws.numel(), stream()), "embed_bwd")
+
+
+def attention_fwd(qkv, seq, H, dropout_p, seed, stream_id):
+    B, L = seq.shape
+    D = qkv.shape[1] // 3
+    out = torch.empty(B * L, D, dtype=torch.float32, device=qkv.device)
+    lse = torch.empty(B, H, L, dtype=torch.float32, device=qkv.device)
+    check(lib().ptamd_attention_fwd(ptr(qkv), ptr(seq), B, L, H, D // H, float(dropout_p), int(seed), int(stream_id),
+                                    ptr(out), ptr(lse), stream()), "attention_fwd")
+    return out, lse
+
+
+def attention_bwd(qkv, seq, out, dout, lse, H, dropout_p, seed, stream_id):
+    B, L = seq.shape
+    D = qkv.shape[1] // 3
+    dqkv = torch.empty_like(qkv)
+    ws = workspace("attn", lib().ptamd_attention_workspace_bytes(B, L, H, D // H), qkv.device)
+    check(lib().ptamd_attention_bwd(ptr(qkv), ptr(seq), ptr(out), ptr(dout), ptr(lse), B, L, H, D // H,
+                                    float(dropout_p), int(seed), int(stream_id), ptr(dqkv), ptr(ws), ws.numel(),
+                                    stream()), "attention_bwd")
+    return dqkv
+
+
+def relu_dropout_bwd(dy, y, dropout_p):
+    dx = torch.empty_like(dy)
+    check(lib().ptamd_relu_dropout_bwd(ptr(dy), ptr(y), dy.numel(), float(dropout_p), ptr(dx), stream()),
+          "relu_dropout_bwd")
+    return dx
+
+
+def tanh_bwd(dy, y):
+    dx = torch.empty_like(dy)
+    check(lib().ptamd_tanh_bwd(ptr(dy), ptr(y), dy.numel(), ptr(dx), stream()), "tanh_bwd")
+    return dx
+
+
+def dropout_bwd(dy, dropout_p, seed, stream_id):
+    rows, cols = dy.shape
+    dx = torch.empty_like(dy)
+    check(lib().ptamd_dropout_bwd(ptr(dy), rows, cols, float(dropout_p), int(seed), int(stream_id), ptr(dx), stream()),
+          "dropout_bwd")
+    return dx
+
+
+def grad_sqnorm(g, out):
+    ws = workspace("sqnorm", lib().ptamd_grad_sqnorm_workspace_bytes(), g.device)
+    check(lib().ptamd_grad_sqnorm(ptr(g), g.numel(), ptr(out), ptr(ws), ws.numel(), stream()), "grad_sqnorm")
+    return out
+
+
+def sgd_step(w, g, sqnorm, max_norm, lr, weight_decay):
+    check(lib().ptamd_sgd_step(ptr(w), ptr(g), w.numel(), ptr(sqnorm), float(max_norm or 0.0), float(lr),
+                               float(weight_decay), stream()), "sgd_step")
+
+
+def adam_step(w, g, m, v, sqnorm, max_norm, lr, beta1, beta2, eps, weight_decay, step):
+    check(lib().ptamd_adam_step(ptr(w), ptr(g), ptr(m), ptr(v), w.numel(), ptr(sqnorm), float(max_norm or 0.0),
+                                float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+                                stream()), "adam_step")

@@ -1,0 +1,282 @@
+"""MI355X parity tests for the geometry + loss kernels (NeRF fwd/bwd, atan2, dRMSD, angle MSE).
+
+The HIP path (through the C ABI of libptamd.so) is compared with
+  * the golden vectors captured from the reference (tests/golden/*.npz),
+  * the CPU oracle (oracle/) on seeded inputs,
+  * size-independent properties at the full benchmark size (B=32, L=512).
+Stated fp32 tolerances: coordinates 2e-3 A * max(1, L/128) (two fp32 NeRF chains drift apart like
+that: the reference itself is 8e-4 A (L=128) / 5.9e-3 A (L=512) away from an fp64 run of its own
+formulas); per-protein drmsd rel 1e-4; lndrmsd abs 1e-6; angle gradients
+rel-L2 1e-3.
+"""
+import numpy as np
+import pytest
+import torch
+from pytest import approx
+
+pytestmark = pytest.mark.gpu
+
+AA = "ACDEFGHIKLMNPQRSTVWY"
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def ids(s):
+    return torch.tensor([AA.index(c) for c in s])
+
+
+def coord_tol(L):
+    return 2e-3 * max(1.0, L / 128)
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+# --------------------------------------------------------------------------- NeRF forward
+def test_generate_coords_golden(golden, dev):
+    from protein_transformer_amd.protein.Structure import generate_coords
+    g = golden("g2_coords")
+    worst = 0.0
+    for n in range(int(g["n"])):
+        s = str(g[f"seq{n}"])
+        crd = generate_coords(torch.tensor(g[f"ang{n}"]).to(dev), ids(s).to(dev)).cpu().numpy()
+        assert crd.shape == (len(s) * 14, 3)
+        err = np.abs(crd - g[f"crd{n}"]).max()
+        worst = max(worst, err / coord_tol(len(s)))
+        assert err < coord_tol(len(s)), f"case {n} L={len(s)} err={err}"
+        # unused slots are exactly zero, like stack_coords pads them
+        assert np.array_equal(crd == 0, g[f"crd{n}"] == 0)
+    crd = generate_coords(torch.tensor(g["ka2_ang"]), "GAS").cpu().numpy()
+    assert np.abs(crd - g["ka2_crd"]).max() < 1e-5
+    print("worst coordinate error / tolerance:", worst)
+
+
+def test_generate_coords_errors(dev):
+    from protein_transformer_amd.protein.Structure import generate_coords
+    with pytest.raises(StopIteration):
+        generate_coords(torch.zeros(1, 12), torch.tensor([0]))
+    with pytest.raises(KeyError):
+        generate_coords(torch.zeros(3, 12), torch.tensor([0, 21, 1]))
+    with pytest.raises(AssertionError):
+        a = torch.zeros(3, 12)
+        a[1, 4] = 3.5
+        generate_coords(a, torch.tensor([0, 1, 2]))
+
+
+def test_sidechain_table_matches_oracle():
+    from oracle.geometry import SC_PROGRAM
+    from protein_transformer_amd import _lib
+    for r in range(20):
+        assert _lib.lib().ptamd_sidechain_atoms(r) == len(SC_PROGRAM[r])
+    assert _lib.lib().ptamd_sidechain_atoms(20) == -1
+
+
+# --------------------------------------------------------------------------- NeRF backward
+def test_nerf_backward_vs_oracle_autograd(dev):
+    from oracle import batched
+    from protein_transformer_amd import synthetic
+    from protein_transformer_amd.protein.Structure import nerf_backward, nerf_forward
+    lens = [40, 33, 64, 2, 17, 20]
+    batch = synthetic.make_batch(lens, L_pad=64, seed=5)
+    batch["seq"][5, :20] = ids(AA)              # every residue type once, incl. as first/last
+    ang = batch["start_ang_rad"]
+    seq = batch["seq"]
+    a64 = ang.double().clone().requires_grad_()
+    crd64 = batched.generate_coords_batched(a64, seq, torch.float64)
+    w = torch.from_numpy(np.random.default_rng(0).normal(size=crd64.shape))
+    (crd64 * w).sum().backward()
+    crd, _ = nerf_forward(ang.to(dev), seq.to(dev))
+    assert np.abs(crd.cpu().numpy() - crd64.detach().numpy()).max() < coord_tol(64)
+    dang = nerf_backward(ang.to(dev), seq.to(dev), crd, w.float().to(dev)).cpu().numpy()
+    ref = a64.grad.numpy()
+    for b in range(len(lens)):
+        assert rel_l2(dang[b], ref[b]) < 1e-3, (b, rel_l2(dang[b], ref[b]))
+        assert np.all(dang[b, lens[b]:] == 0)
+    # graph quirks of the reference: first residue's phi and N-CA-C angle get no gradient,
+    # nor do the last residue's omega / CA-C-N / C-N-CA
+    assert np.all(dang[0, 0, [0, 3]] == 0)
+    assert np.all(dang[0, lens[0] - 1, [2, 4, 5]] == 0)
+
+
+# --------------------------------------------------------------------------- dRMSD
+def test_drmsd_golden(golden, dev):
+    from protein_transformer_amd.losses import drmsd
+    g = golden("g3_drmsd")
+    for n in range(int(g["n"])):
+        d = drmsd(torch.tensor(g[f"a{n}"]).float().to(dev), torch.tensor(g[f"b{n}"]).float().to(dev)).item()
+        assert d == approx(float(g[f"drmsd{n}"]), rel=1e-5)
+
+
+def test_drmsd_zero_and_permutation(dev):
+    # reference tests/test_losses.py:153-174
+    from protein_transformer_amd.losses import drmsd
+    a = torch.tensor([[0, 0, 0], [0, 1, 0], [0, 0, 2], [0, 0, 0]], dtype=torch.float)
+    b = torch.tensor([[0, 0, 2], [0, 1, 0], [0, 0, 0], [0, 0, 0]], dtype=torch.float)
+    assert drmsd(a, a).item() == 0
+    assert drmsd(a, b).item() != 0
+
+
+def test_drmsd_equals_lazy_drmsd(dev):
+    # reference tests/test_losses.py:58-89
+    from protein_transformer_amd.losses import drmsd
+    rng = np.random.default_rng(3)
+    for x, y in ((np.array([[0, 0, 0], [3, 5, 2], [2, 9, 3]]), np.array([[0, 0, 0], [9, 3, 1], [4, 7, 8]])),
+                 (rng.random((50, 3)) * 10, rng.random((50, 3)) * 10)):
+        n = len(x)
+        da = [np.linalg.norm(x[i] - x[j]) for i in range(n) for j in range(i + 1, n)]
+        db = [np.linalg.norm(y[i] - y[j]) for i in range(n) for j in range(i + 1, n)]
+        lazy = np.sqrt(np.mean((np.array(da) - np.array(db)) ** 2))
+        assert drmsd(torch.tensor(x).float(), torch.tensor(y).float()).item() == approx(lazy, rel=1e-5)
+
+
+def test_drmsd_gradient_vs_autograd(dev):
+    from oracle import batched
+    from protein_transformer_amd.losses import drmsd
+    rng = np.random.default_rng(11)
+    a = torch.tensor(rng.normal(0, 8, (300, 3)))
+    b = torch.tensor(rng.normal(0, 8, (300, 3)))
+    a64 = a.clone().requires_grad_()
+    batched.drmsd_direct(a64, b).backward()
+    ag = a.float().to(dev).requires_grad_()
+    drmsd(ag, b.float().to(dev)).backward()
+    assert rel_l2(ag.grad.cpu().numpy(), a64.grad.numpy()) < 1e-4
+
+
+def test_drmsd_work_golden(golden, dev):
+    from protein_transformer_amd.losses import drmsd_work
+    g = golden("g4_drmsd_work")
+    for b in range(4):
+        r = drmsd_work(g["pred_ang"][b], g["true_crd"][b], g["seq"][b])
+        vals = g[f"vals{b}"]
+        assert r[1] == approx(vals[0], rel=1e-4)
+        assert r[2] == approx(vals[1], abs=1e-6)
+        assert r[3] == approx(vals[2], rel=1e-4)
+        assert r[4] == approx(vals[3], abs=1e-6)
+        assert rel_l2(r[0].numpy(), g[f"grad{b}"]) < 1e-3
+    r = drmsd_work(torch.tensor(g["ka4_ang"]), torch.tensor(g["ka4_crd"]), torch.tensor(g["ka4_seq"]))
+    assert r[1:] == approx((0.8574336, 0.0571622, 0.9411135, 0.1045682), abs=2e-5)
+    grad = r[0].numpy()
+    assert rel_l2(grad, g["ka4_grad"]) < 1e-3
+    assert np.all(grad[3:] == 0)
+    assert set(np.nonzero(grad[0] == 0)[0]) == {0, 3, 6, 7, 8, 9, 10, 11}
+    assert set(np.nonzero(grad[2] == 0)[0]) == {2, 4, 5, 8, 9, 10, 11}
+
+
+def test_batch_loss_vs_oracle_ragged(dev):
+    """Ragged batch with missing residues: HIP loss path vs the serial CPU oracle."""
+    from oracle import geometry, losses as olosses
+    from protein_transformer_amd import synthetic
+    from protein_transformer_amd.losses import batch_loss
+    lens = [31, 64, 2, 47, 20, 9]
+    build = lambda ang, seq: torch.stack([                                     # noqa: E731
+        torch.cat([geometry.generate_coords(ang[b, :n], seq[b, :n]), torch.zeros((seq.shape[1] - n) * 14, 3)])
+        for b, n in enumerate(lens)])
+    batch = synthetic.make_batch(lens, L_pad=64, seed=21, build_coords=build, frac_missing=0.1)
+    ang, seq, crd = batch["start_ang_rad"], batch["seq"], batch["true_crd"]
+    sincos = torch.stack([torch.cos(ang), torch.sin(ang)], -1).reshape(len(lens), 64, 24) * 0.9
+    stats, grad, status = batch_loss(sincos.to(dev), crd.to(dev), seq.to(dev), do_backward=True)
+    assert int(status.item()) == 0
+    stats = stats.cpu().numpy()
+    for b in range(len(lens)):
+        sc = sincos[b].clone().requires_grad_()
+        a = olosses.inverse_trig_transform(sc[None])[0]
+        a.retain_grad()
+        g, d, ln, dbb, lnbb = olosses.drmsd_work(a.detach().numpy(), crd[b].numpy(), seq[b].numpy())
+        assert stats[b, 0] == approx(d, rel=1e-4), b
+        assert stats[b, 1] == approx(ln, abs=1e-6), b
+        assert stats[b, 2] == approx(dbb, rel=1e-4), b
+        assert stats[b, 3] == approx(lnbb, abs=1e-6), b
+        a.backward(gradient=g)
+        assert rel_l2(grad[b].cpu().numpy(), sc.grad.numpy()) < 1e-3, b
+
+
+# --------------------------------------------------------------------------- full benchmark size
+def test_full_size_properties(dev):
+    """B=32, L=512 (BASELINE config 4): properties that do not need the slow serial oracle, plus
+    the vectorised fp64 oracle for values and gradients."""
+    from oracle import batched
+    from protein_transformer_amd import synthetic
+    from protein_transformer_amd.losses import batch_loss, drmsd_forward_backward
+    from protein_transformer_amd.protein.Structure import nerf_forward
+    B, L = 32, 512
+    hip_build = lambda ang, seq: nerf_forward(ang.to(dev), seq.to(dev))[0]      # noqa: E731
+    batch = synthetic.make_batch([L] * B, seed=synthetic.DEFAULT_SEED, build_coords=hip_build)
+    seq, true_crd = batch["seq"].to(dev), batch["true_crd"].to(dev)
+    crd, status = nerf_forward(batch["true_ang_rad"].to(dev), seq)
+    assert int(status.item()) == 0
+    c = crd.view(B, L, 14, 3)
+    # bond lengths along the chain are the force-field constants (SidechainBuildInfo.py:576-580)
+    assert (c[:, :, 1] - c[:, :, 0]).norm(dim=-1).sub(1.442).abs().max() < 2e-4
+    assert (c[:, :, 2] - c[:, :, 1]).norm(dim=-1).sub(1.498).abs().max() < 2e-4
+    assert (c[:, 1:, 0] - c[:, :-1, 2]).norm(dim=-1).sub(1.379).abs().max() < 2e-4
+    assert (c[:, :, 3] - c[:, :, 2]).norm(dim=-1).sub(1.229).abs().max() < 2e-4
+    # a structure against itself: zero loss
+    stats, _ = drmsd_forward_backward(crd, true_crd, seq, need_grad=False)
+    assert float(stats[:, 0].abs().max()) == 0.0
+    n_expected = synthetic.slot_mask(batch["seq"]).sum(1).float()
+    assert torch.equal(stats[:, 4].cpu(), n_expected)
+    assert torch.equal(stats[:, 5].cpu(), torch.full((B,), 3.0 * L))
+    # rigid motion invariance of the loss: rotate + translate the truth
+    q, _ = torch.linalg.qr(torch.randn(3, 3, dtype=torch.float64))
+    moved = (true_crd.double() @ q.to(dev) + 7.5).float()
+    sincos = torch.stack([torch.cos(batch["start_ang_rad"]), torch.sin(batch["start_ang_rad"])], -1).reshape(B, L, 24)
+    s1, g1, _ = batch_loss(sincos.to(dev), true_crd, seq)
+    s2, g2, _ = batch_loss(sincos.to(dev), moved, seq)
+    assert torch.allclose(s1[:, :4], s2[:, :4], rtol=2e-4, atol=1e-6)
+    # values and gradients against the vectorised fp64 oracle on a 4-protein slice
+    sub = slice(0, 4)
+    st64, crd64, g64 = batched.batch_loss_and_grads(batch["start_ang_rad"][sub], batch["seq"][sub],
+                                                    batch["true_crd"][sub], torch.float64)
+    dang_hip = None
+    from protein_transformer_amd.losses import angles_forward, nerf_backward
+    ang = angles_forward(sincos[sub].to(dev))
+    crd_p, _ = nerf_forward(ang, seq[sub])
+    assert np.abs(crd_p.cpu().numpy() - crd64.numpy()).max() < coord_tol(L)
+    stats_p, dcrd = drmsd_forward_backward(crd_p, true_crd[sub], seq[sub])
+    dang_hip = nerf_backward(ang, seq[sub], crd_p, dcrd).cpu().numpy()
+    for b in range(4):
+        assert float(stats_p[b, 0]) == approx(st64[b][0], rel=1e-4)
+        assert float(stats_p[b, 1]) == approx(st64[b][1], abs=1e-6)
+        assert float(stats_p[b, 2]) == approx(st64[b][2], rel=1e-4)
+        assert rel_l2(dang_hip[b], g64[b].numpy()) < 1e-3
+
+
+# --------------------------------------------------------------------------- angle MSE / atan2
+def test_mse_over_angles_golden(golden, dev):
+    from protein_transformer_amd.losses import inverse_trig_transform, mse_over_angles
+    g = golden("g8_mse")
+    p, t = torch.tensor(g["pred"]).to(dev), torch.tensor(g["true"]).to(dev)
+    assert mse_over_angles(p, t).item() == approx(float(g["full"]), rel=1e-5)
+    assert mse_over_angles(p, t, bb_only=True).item() == approx(float(g["bb"]), rel=1e-5)
+    assert mse_over_angles(p, t, sc_only=True).item() == approx(float(g["sc"]), rel=1e-5)
+    out = inverse_trig_transform(torch.tensor(g["itt_in"]).to(dev)).cpu().numpy()
+    assert np.abs(out - g["itt_out"]).max() < 1e-6
+    # reference tests/test_losses.py:117-120
+    a = torch.zeros(8, 10, 24, device=dev)
+    assert mse_over_angles(a, a - .1).item() == approx(0.01)
+
+
+def test_mse_backward_vs_oracle(golden, dev):
+    from oracle import losses as olosses
+    from protein_transformer_amd.losses import mse_over_angles
+    g = golden("g8_mse")
+    p = torch.tensor(g["pred"]).requires_grad_()
+    olosses.mse_over_angles(p, torch.tensor(g["true"])).backward()
+    pg = torch.tensor(g["pred"]).to(dev).requires_grad_()
+    mse_over_angles(pg, torch.tensor(g["true"]).to(dev)).backward()
+    assert np.allclose(pg.grad.cpu().numpy(), p.grad.numpy(), rtol=1e-5, atol=1e-8)
+
+
+def test_combine_drmsd_mse():
+    # reference tests/test_losses.py:11-19
+    from protein_transformer_amd.losses import combine_drmsd_mse
+    assert combine_drmsd_mse(0.01, 0.3, 0.5, 1, 1, log=False) == 0.155
+    assert combine_drmsd_mse(0.01, 0.6, 0, 1, 1, log=False) == .6
+    assert combine_drmsd_mse(0.02, 0.3, 1, 1, 1, log=False) == 0.02
+    assert combine_drmsd_mse(0.02, 0.3, 1, 0.02, 1, log=False) == 1
