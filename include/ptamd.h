@@ -122,10 +122,11 @@ int ptamd_gemm(const ptamd_gemm_args *args, void *stream);
 /* torch.nn.LayerNorm(D, eps=1e-5) (Sublayers.py:13,17): y = (x-mean)*rstd*gamma+beta; saves mean,rstd [T] */
 int ptamd_layernorm_fwd(const float *x, const float *gamma, const float *beta, int64_t T, int D, float *y,
                         float *mean, float *rstd, void *stream);
-/* dx [T,D] (overwritten); dgamma, dbeta [D] accumulated (+=) through fixed-order partials in workspace */
+/* dx [T,D] = LN'(dy) + dres (dres: gradient of the residual branch, may be NULL; dx may alias dres);
+ * dgamma, dbeta [D] accumulated (+=) through fixed-order partials in workspace */
 size_t ptamd_layernorm_bwd_workspace_bytes(int D);
 int ptamd_layernorm_bwd(const float *dy, const float *x, const float *gamma, const float *mean, const float *rstd,
-                        int64_t T, int D, float *dx, float *dgamma, float *dbeta, void *workspace,
+                        const float *dres, int64_t T, int D, float *dx, float *dgamma, float *dbeta, void *workspace,
                         size_t workspace_bytes, void *stream);
 
 /* Embeddings * sqrt(D) and the doubled positional add of Encoder.py:30 + Sublayers.py:59-62,72:

@@ -47,7 +47,7 @@ SIGNATURES = {
     "ptamd_gemm": (_i, [C.POINTER(GemmArgs), _p]),
     "ptamd_layernorm_fwd": (_i, [_p, _p, _p, _i64, _i, _p, _p, _p, _p]),
     "ptamd_layernorm_bwd_workspace_bytes": (_sz, [_i]),
-    "ptamd_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _i64, _i, _p, _p, _p, _p, _sz, _p]),
+    "ptamd_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _p, _p, _p, _p, _sz, _p]),
     "ptamd_embed_fwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _u64, _p, _p]),
     "ptamd_embed_bwd_workspace_bytes": (_sz, [_i]),
     "ptamd_embed_bwd": (_i, [_p, _p, _i, _i, _i, _f, _u64, _p, _p, _sz, _p]),

@@ -145,8 +145,8 @@ template <int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                             const float *__restrict__ gamma,
                                                             const float *__restrict__ mean, const float *__restrict__ rstd,
-                                                            int64_t T, int D, float *__restrict__ dx,
-                                                            float *__restrict__ part) {
+                                                            const float *__restrict__ dres, int64_t T, int D,
+                                                            float *__restrict__ dx, float *__restrict__ part) {
   const int lane = threadIdx.x & 63, wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   float4 g[NV], dg[NV], db[NV];
 #pragma unroll
@@ -178,10 +178,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int c = (j * 64 + lane) * 4;
-      if (c < D)
-        *reinterpret_cast<float4 *>(dx + row * D + c) =
-            make_float4(rs * (gy[j].x - m1 - xh[j].x * m2), rs * (gy[j].y - m1 - xh[j].y * m2),
-                        rs * (gy[j].z - m1 - xh[j].z * m2), rs * (gy[j].w - m1 - xh[j].w * m2));
+      if (c < D) {
+        float4 o = make_float4(rs * (gy[j].x - m1 - xh[j].x * m2), rs * (gy[j].y - m1 - xh[j].y * m2),
+                               rs * (gy[j].z - m1 - xh[j].z * m2), rs * (gy[j].w - m1 - xh[j].w * m2));
+        if (dres) {  // gradient arriving through the residual connection around the normalised sublayer
+          const float4 r = *reinterpret_cast<const float4 *>(dres + row * D + c);
+          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        *reinterpret_cast<float4 *>(dx + row * D + c) = o;
+      }
     }
   }
 #pragma unroll
@@ -309,17 +314,17 @@ size_t ptamd_layernorm_bwd_workspace_bytes(int D) {
 }
 
 int ptamd_layernorm_bwd(const float *dy, const float *x, const float *gamma, const float *mean, const float *rstd,
-                        int64_t T, int D, float *dx, float *dgamma, float *dbeta, void *workspace,
+                        const float *dres, int64_t T, int D, float *dx, float *dgamma, float *dbeta, void *workspace,
                         size_t workspace_bytes, void *stream) {
   if (T <= 0 || D <= 0 || (D & 3) || D > 2048) return PTAMD_ERR_BAD_SHAPE;
   if (!workspace || workspace_bytes < ptamd_layernorm_bwd_workspace_bytes(D)) return PTAMD_ERR_WORKSPACE;
   float *part = static_cast<float *>(workspace);
   const dim3 grid(LN_BWD_BLOCKS), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (D <= 256) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, block, 0, st, dy, x, gamma, mean, rstd, T, D, dx, part);
-  else if (D <= 512) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, block, 0, st, dy, x, gamma, mean, rstd, T, D, dx, part);
-  else if (D <= 1024) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, st, dy, x, gamma, mean, rstd, T, D, dx, part);
-  else hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, block, 0, st, dy, x, gamma, mean, rstd, T, D, dx, part);
+  if (D <= 256) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, block, 0, st, dy, x, gamma, mean, rstd, dres, T, D, dx, part);
+  else if (D <= 512) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, block, 0, st, dy, x, gamma, mean, rstd, dres, T, D, dx, part);
+  else if (D <= 1024) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, st, dy, x, gamma, mean, rstd, dres, T, D, dx, part);
+  else hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, block, 0, st, dy, x, gamma, mean, rstd, dres, T, D, dx, part);
   int rc = pt_check_launch();
   if (rc) return rc;
   hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((D + 255) / 256), dim3(256), 0, st, part, D, dgamma, dbeta);

@@ -1,0 +1,193 @@
+"""Datasets, length-binned batching and collation with the reference's API and on-disk format.
+
+Mirrors /root/reference/protein_transformer/dataset.py: `paired_collate_fn` :13-23, `collate_fn` :26-54,
+`ProteinDataset` :57-100, `BinnedProteinDataset` :103-158, `SimilarLengthBatchSampler` :161-225,
+`prepare_dataloaders` :228-290.  Input: the `torch.save`d dictionary described in SURVEY.md Appendix D
+(`data[split]["seq"|"ang"|"crd"]`, `data["settings"]["angle_means"|"max_len"]`).
+
+Differences by design: the truncation length is a parameter (`max_seq_len`, default 500 = the
+reference's hard-wired MAX_SEQ_LEN) and batches are pinned so the H2D copy overlaps compute.  The batch
+arithmetic (bins, per-bin batch size = residue budget / bin edge, sampling with replacement, rounding
+to a multiple of the CPU count for dRMSD losses) is reproduced exactly, including the `"ln-drmsd"`
+spelling that never matches `lndrmsd` (dataset.py:250-251).
+"""
+import numpy as np
+import torch
+import torch.utils.data
+
+from .protein.Sequence import VOCAB, ProteinVocabulary
+from .protein.Structure import NUM_PREDICTED_COORDS
+
+VALID_SPLITS = [10, 20, 30, 40, 50, 70, 90]
+MAX_SEQ_LEN = 500
+
+
+def collate_fn(insts, coords=False, sequences=False, max_seq_len=None):
+    """Pad every instance to the longest in the batch (pad id 20 for sequences, zeros otherwise), then
+    truncate to max_seq_len residues (x14 atoms for coordinates)."""
+    longest = max(len(inst) for inst in insts)
+    rows = []
+    for inst in insts:
+        inst = np.asarray(inst)
+        if sequences:
+            pad = np.ones((longest - len(inst))) * VOCAB.pad_id
+        else:
+            pad = np.zeros((longest - len(inst), inst.shape[-1]))
+        rows.append(np.concatenate((inst, pad), axis=0))
+    batch = np.array(rows)
+    batch = batch[:, :max_seq_len * NUM_PREDICTED_COORDS] if coords else batch[:, :max_seq_len]
+    return torch.LongTensor(batch) if sequences else torch.FloatTensor(batch)
+
+
+def make_paired_collate_fn(max_seq_len=MAX_SEQ_LEN):
+    def paired(insts):
+        sequences, angles, coords = list(zip(*insts))
+        return (collate_fn(sequences, sequences=True, max_seq_len=max_seq_len),
+                collate_fn(angles, max_seq_len=max_seq_len),
+                collate_fn(coords, coords=True, max_seq_len=max_seq_len))
+    return paired
+
+
+paired_collate_fn = make_paired_collate_fn(MAX_SEQ_LEN)
+
+
+def _load(seqs, angs, crds, add_sos_eos, skip_missing_residues):
+    assert seqs is not None
+    assert (angs is None) or (len(seqs) == len(angs) and len(angs) == len(crds))
+    s, a, c = [], [], []
+    for i in range(len(seqs)):
+        if skip_missing_residues and np.isnan(angs[i]).all(axis=-1).any():
+            continue
+        s.append(VOCAB.str2ints(seqs[i], add_sos_eos))
+        a.append(angs[i])
+        c.append(crds[i])
+    return s, a, c
+
+
+class ProteinDataset(torch.utils.data.Dataset):
+    """Sequences, angles and coordinates of a split, optionally sorted by length (longest first)."""
+
+    def __init__(self, seqs=None, angs=None, crds=None, add_sos_eos=True, sort_by_length=True, reverse_sort=True,
+                 skip_missing_residues=True):
+        self._seqs, self._angs, self._crds = _load(seqs, angs, crds, add_sos_eos, skip_missing_residues)
+        if sort_by_length:
+            order = [i for i, _ in sorted(enumerate(self._angs), key=lambda x: x[1].shape[0], reverse=reverse_sort)]
+            self._seqs = [self._seqs[i] for i in order]
+            self._angs = [self._angs[i] for i in order]
+            self._crds = [self._crds[i] for i in order]
+
+    @property
+    def n_insts(self):
+        return len(self._seqs)
+
+    def __len__(self):
+        return self.n_insts
+
+    def __getitem__(self, idx):
+        if self._angs is not None:
+            return self._seqs[idx], self._angs[idx], self._crds[idx]
+        return self._seqs[idx]
+
+
+class BinnedProteinDataset(torch.utils.data.Dataset):
+    """Like ProteinDataset, plus a length histogram; assumes the data is sorted shortest to longest."""
+
+    def __init__(self, seqs=None, angs=None, crds=None, add_sos_eos=True, skip_missing_residues=True, bins="auto",
+                 max_seq_len=MAX_SEQ_LEN):
+        self.vocab = ProteinVocabulary()
+        self._seqs, self._angs, self._crds = _load(seqs, angs, crds, add_sos_eos, skip_missing_residues)
+        self.lens = [min(len(x), max_seq_len) for x in self._seqs]
+        self.hist_counts, edges = np.histogram(self.lens, bins=bins)
+        self.hist_bins = edges[1:]                       # right edge of every bin: '( , ]'
+        self.bin_probs = self.hist_counts / self.hist_counts.sum()
+        self.bin_map = {}
+        seq_i = bin_j = 0
+        while seq_i < len(self._seqs):
+            if self.lens[seq_i] <= self.hist_bins[bin_j]:
+                self.bin_map.setdefault(bin_j, []).append(seq_i)
+                seq_i += 1
+            else:
+                bin_j += 1
+
+    @property
+    def n_insts(self):
+        return len(self._seqs)
+
+    def __len__(self):
+        return self.n_insts
+
+    def __getitem__(self, idx):
+        if self._angs is not None:
+            return self._seqs[idx], self._angs[idx], self._crds[idx]
+        return self._seqs[idx]
+
+
+class SimilarLengthBatchSampler(torch.utils.data.Sampler):
+    """Yields index batches drawn (with replacement) from one random length bin at a time; with
+    `dynamic_batch` the batch holds about that many residues."""
+
+    def __init__(self, data_source, batch_size, dynamic_batch, optimize_batch_for_cpus, downsample=None,
+                 use_largest_bin=False, repeat_train=None):
+        self.data_source = data_source
+        self.batch_size = batch_size
+        self.dynamic_batch = dynamic_batch
+        self.optimize_batch_for_cpus = optimize_batch_for_cpus
+        self.cpu_count = torch.multiprocessing.cpu_count()
+        self.downsample = downsample
+        self.use_largest_bin = use_largest_bin
+        self.repeat_train = repeat_train if repeat_train else 1
+
+    def __len__(self):
+        if self.dynamic_batch:
+            numerator, divisor = sum(self.data_source.lens) * self.repeat_train, self.dynamic_batch
+        else:
+            numerator, divisor = len(self.data_source) * self.repeat_train, self.batch_size
+        if self.downsample:
+            numerator *= self.downsample
+        return int(np.ceil(numerator / divisor))
+
+    def __iter__(self):
+        ds = self.data_source
+        for _ in range(len(self)):
+            if self.use_largest_bin:
+                b = len(ds.hist_bins) - 1
+            else:
+                b = np.random.choice(range(len(ds.hist_bins)), p=ds.bin_probs)
+            if self.dynamic_batch:
+                size = int(self.dynamic_batch / ds.hist_bins[b])
+                if self.optimize_batch_for_cpus:
+                    size -= size % self.cpu_count
+                size = max(1, size)
+            else:
+                size = self.batch_size
+            yield np.random.choice(ds.bin_map[b], size=size)
+
+
+def prepare_dataloaders(data, args, max_seq_len, num_workers=1):
+    """train (binned, dynamic batches), train-eval, 7 validation splits and test loaders."""
+    if args.batching_order in ["descending", "ascending"]:
+        raise NotImplementedError("Descending and ascending order have not been reimplemented.")
+    collate = make_paired_collate_fn(max_seq_len)
+    cpu_opt = args.loss in ["combined", "drmsd", "ln-drmsd"]
+    common = dict(num_workers=num_workers, collate_fn=collate, pin_memory=torch.cuda.is_available())
+    train_dataset = BinnedProteinDataset(seqs=data['train']['seq'], crds=data['train']['crd'], angs=data['train']['ang'],
+                                         add_sos_eos=args.add_sos_eos, skip_missing_residues=args.skip_missing_res_train,
+                                         bins=args.bins, max_seq_len=max_seq_len)
+    train_loader = torch.utils.data.DataLoader(
+        train_dataset, batch_sampler=SimilarLengthBatchSampler(
+            train_dataset, args.batch_size, dynamic_batch=args.batch_size * max_seq_len,
+            optimize_batch_for_cpus=cpu_opt, repeat_train=args.repeat_train), **common)
+    train_eval_loader = torch.utils.data.DataLoader(
+        train_dataset, batch_sampler=SimilarLengthBatchSampler(
+            train_dataset, args.batch_size, dynamic_batch=None, optimize_batch_for_cpus=cpu_opt,
+            downsample=args.train_eval_downsample), **common)
+
+    def plain(split):
+        return torch.utils.data.DataLoader(
+            ProteinDataset(seqs=data[split]['seq'], crds=data[split]['crd'], angs=data[split]['ang'],
+                           add_sos_eos=args.add_sos_eos, skip_missing_residues=args.skip_missing_res_train),
+            batch_size=args.batch_size, **common)
+
+    valid_loaders = {split: plain(f'valid-{split}') for split in VALID_SPLITS if f'valid-{split}' in data}
+    test_loader = plain('test') if 'test' in data else None
+    return train_loader, train_eval_loader, valid_loaders, test_loader

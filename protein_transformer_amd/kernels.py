@@ -84,11 +84,12 @@ def layernorm_fwd(x, gamma, beta):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None):
+    """dx = LayerNorm'(dy) (+ dres, the gradient that bypassed the sublayer through the residual add)."""
     T, D = x.shape
     dx = torch.empty_like(x)
     ws = workspace("ln", lib().ptamd_layernorm_bwd_workspace_bytes(D), x.device)
-    check(lib().ptamd_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), T, D, ptr(dx), ptr(dgamma),
+    check(lib().ptamd_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), T, D, ptr(dx), ptr(dgamma),
                                     ptr(dbeta), ptr(ws), ws.numel(), stream()), "layernorm_bwd")
     return dx
 

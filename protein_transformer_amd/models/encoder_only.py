@@ -1,0 +1,330 @@
+"""`-m enc-only`: the encoder-only Transformer of the reference, executed by libptamd kernels.
+
+Drop-in for /root/reference/protein_transformer/models/encoder_only.py:10-45 (constructor signature,
+`.forward(enc_input, dec_input=None)`, `.predict`, `_init_parameters`) with the reference's module tree
+(models/transformer/Encoder.py:8-54, Attention.py:24-69, Sublayers.py:5-72) kept only as a *naming*
+skeleton, so `state_dict()` has exactly the reference's keys and checkpoints load
+either way.  No torch op computes anything here:
+
+  * all parameters are views into ONE flat fp32 buffer (wq|wk|wv adjacent = one fused [3D,D] GEMM operand;
+    the flat buffer is what the fused optimizer and the RCCL gradient all-reduce work on);
+  * forward and backward are one autograd.Function that enqueues the HIP kernels (embedding, LayerNorm,
+    fp32-MFMA GEMMs with fused bias/ReLU/dropout/residual/tanh epilogues, fused masked attention) and
+    writes gradients straight into one flat gradient buffer;
+  * dropout masks are counter-based (seed, site) and regenerated in the backward pass.
+
+Reference quirks reproduced on purpose: the embedding is added twice
+(Encoder.py:30 + Sublayers.py:60), attention-probability dropout is 0.1 regardless of `dropout`
+(Attention.py:31), there is no final LayerNorm, pad id 20 has an ordinary embedding row, and the
+output layer starts as weight 0 / bias arctanh(angle_means) (encoder_only.py:28-34).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import kernels as K
+from ..protein.Structure import NUM_PREDICTED_ANGLES
+
+# dropout sites inside one encoder layer (stream ids = layer * 8 + site)
+_SITE_ATTN, _SITE_ATTN_OUT, _SITE_FFN_HID, _SITE_FFN_OUT = 0, 1, 2, 3
+
+
+class _Holder(nn.Module):
+    """Names parameters like the reference's Linear / LayerNorm / Embedding modules; computes nothing."""
+
+    def __init__(self, **shapes):
+        super().__init__()
+        for name, shape in shapes.items():
+            self.register_parameter(name, nn.Parameter(torch.empty(*shape)))
+
+
+class _AttnHolder(nn.Module):
+    def __init__(self, dm):
+        super().__init__()
+        for nm in ("wq", "wk", "wv", "wo"):
+            setattr(self, nm, _Holder(weight=(dm, dm), bias=(dm,)))
+
+
+class _PwffHolder(nn.Module):
+    def __init__(self, dm, dff):
+        super().__init__()
+        self.layer1 = _Holder(weight=(dff, dm), bias=(dff,))
+        self.layer2 = _Holder(weight=(dm, dff), bias=(dm,))
+
+
+class _SublayerHolder(nn.Module):
+    def __init__(self, dm):
+        super().__init__()
+        self.norm = _Holder(weight=(dm,), bias=(dm,))
+
+
+class _LayerHolder(nn.Module):
+    def __init__(self, dm, dff):
+        super().__init__()
+        self.self_attn = _AttnHolder(dm)
+        self.pwff = _PwffHolder(dm, dff)
+        self.sublayer_connections = nn.ModuleList([_SublayerHolder(dm) for _ in range(2)])
+
+
+class _EmbHolder(nn.Module):
+    def __init__(self, vocab, dm):
+        super().__init__()
+        self.emb = _Holder(weight=(vocab, dm))
+
+
+class _PeHolder(nn.Module):
+    def __init__(self, dm, max_seq_len):
+        super().__init__()
+        # Sublayers.py:48-56
+        pe = torch.zeros(max_seq_len, dm)
+        position = torch.arange(0., max_seq_len).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0., dm, 2) * -(np.log(10000.0) / dm))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_buffer('pe', pe.unsqueeze(0))
+
+
+class _EncoderHolder(nn.Module):
+    def __init__(self, din, dm, dff, n_layers, max_seq_len):
+        super().__init__()
+        self.input_embedding = _EmbHolder(din, dm)
+        self.positional_enc = _PeHolder(dm, max_seq_len)
+        self.enc_layers = nn.ModuleList([_LayerHolder(dm, dff) for _ in range(n_layers)])
+
+
+class EncoderOnlyTransformer(nn.Module):
+    """ A Transformer that only uses Encoder layers (reference: models/encoder_only.py:10). """
+
+    def __init__(self, nlayers, nhead, dmodel, dff, max_seq_len, vocab, angle_means, use_tanh_out, dropout=0.1):
+        super().__init__()
+        assert dmodel % nhead == 0, "The dimension of the model must be evenly divisible by the number of attn heads."
+        if dmodel % 4 or dff % 4 or (dmodel // nhead) not in (8, 16, 32, 64):
+            raise ValueError("libptamd needs d_model, d_ff multiples of 4 and d_model / n_head in {8, 16, 32, 64}")
+        if not use_tanh_out:
+            raise NotImplementedError("use_tanh_out=False is unreachable from the reference CLI (SURVEY.md A-1.7)")
+        self.angle_means = angle_means
+        self.vocab = vocab
+        self.nlayers, self.nhead, self.dmodel, self.dff, self.max_seq_len = nlayers, nhead, dmodel, dff, max_seq_len
+        self.use_tanh_out = use_tanh_out
+        self.dropout = float(dropout)
+        self.attn_dropout = 0.1                      # hard-wired in the reference (Attention.py:31, Encoder.py:47)
+        self.encoder = _EncoderHolder(len(vocab), dmodel, dff, nlayers, max_seq_len)
+        self.output_projection = _Holder(weight=(NUM_PREDICTED_ANGLES * 2, dmodel), bias=(NUM_PREDICTED_ANGLES * 2,))
+        self._flat = None
+        self._flat_grad = None
+        self._layout = self._make_layout()
+        self.dropout_seed = 0x5DEECE66D
+        self._step_counter = 0
+        self.grad_hook = None                        # called with (offset, numel) as soon as a gradient slice is final
+        self._init_parameters()
+
+    # ------------------------------------------------------------------ parameters
+    def _make_layout(self):
+        """name -> (offset, shape) in the flat buffer; every offset is a multiple of 4 floats (16 B)."""
+        order = ["encoder.input_embedding.emb.weight"]
+        for i in range(self.nlayers):
+            b = f"encoder.enc_layers.{i}."
+            order += [b + f"self_attn.{n}.weight" for n in ("wq", "wk", "wv")]
+            order += [b + f"self_attn.{n}.bias" for n in ("wq", "wk", "wv")]
+            order += [b + "self_attn.wo.weight", b + "self_attn.wo.bias",
+                      b + "pwff.layer1.weight", b + "pwff.layer1.bias", b + "pwff.layer2.weight", b + "pwff.layer2.bias",
+                      b + "sublayer_connections.0.norm.weight", b + "sublayer_connections.0.norm.bias",
+                      b + "sublayer_connections.1.norm.weight", b + "sublayer_connections.1.norm.bias"]
+        order += ["output_projection.weight", "output_projection.bias"]
+        params = dict(self.named_parameters())
+        assert set(order) == set(params)
+        layout, off = {}, 0
+        for name in order:
+            shape = tuple(params[name].shape)
+            layout[name] = (off, shape)
+            off += (int(np.prod(shape)) + 3) // 4 * 4
+        self._flat_numel = off
+        return layout
+
+    def _init_parameters(self):
+        # encoder_only.py:24-34: xavier_uniform on every >=2-D parameter, module defaults elsewhere
+        # (nn.Linear bias ~ U(+-1/sqrt(fan_in)), LayerNorm 1 / 0), then the output layer
+        for name, p in self.named_parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+            elif "norm.weight" in name:
+                nn.init.ones_(p)
+            elif "norm.bias" in name:
+                nn.init.zeros_(p)
+            else:
+                fan_in = self.dff if "layer2" in name else self.dmodel
+                nn.init.uniform_(p, -1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
+        am = np.arctanh(np.asarray(self.angle_means, dtype=np.float64))
+        with torch.no_grad():
+            self.output_projection.bias.copy_(torch.tensor(am, dtype=torch.float32))
+            self.output_projection.weight.zero_()
+
+    def _ensure_flat(self):
+        """(Re)build the flat parameter / gradient buffers on the parameters' device and alias every
+        named parameter (and its .grad) into them.  Idempotent; survives .to(device) and load_state_dict."""
+        params = dict(self.named_parameters())
+        dev = next(iter(params.values())).device
+        if dev.type != "cuda":
+            raise RuntimeError("EncoderOnlyTransformer runs on the MI355X only: move it to a cuda device "
+                               "(there is no CPU path; the CPU reference lives in oracle/ for tests)")
+        ok = self._flat is not None and self._flat.device == dev
+        if ok:
+            base = self._flat.data_ptr()
+            ok = all(params[n].data_ptr() == base + 4 * off for n, (off, _) in self._layout.items())
+        if not ok:
+            flat = torch.zeros(self._flat_numel, dtype=torch.float32, device=dev)
+            for n, (off, shape) in self._layout.items():
+                view = flat[off:off + int(np.prod(shape))].view(shape)
+                view.copy_(params[n].data)
+                params[n].data = view
+            self._flat = flat
+            self._flat_grad = torch.zeros_like(flat)
+        gbase = self._flat_grad.data_ptr()
+        for n, (off, shape) in self._layout.items():
+            p = params[n]
+            if p.grad is None or p.grad.data_ptr() != gbase + 4 * off:
+                p.grad = self._flat_grad[off:off + int(np.prod(shape))].view(shape)
+        return self._flat, self._flat_grad
+
+    def flat_parameters(self):
+        """(flat parameter buffer, flat gradient buffer): what the fused optimizer / all-reduce operate on."""
+        return self._ensure_flat()
+
+    def zero_grad(self, set_to_none=False):
+        if self._flat_grad is not None:
+            self._flat_grad.zero_()
+        else:
+            super().zero_grad(set_to_none=set_to_none)
+
+    def _slice(self, buf, name):
+        off, shape = self._layout[name]
+        return buf[off:off + int(np.prod(shape))].view(shape)
+
+    def _qkv(self, buf, i):
+        b = f"encoder.enc_layers.{i}.self_attn."
+        off_w, _ = self._layout[b + "wq.weight"]
+        off_b, _ = self._layout[b + "wq.bias"]
+        D = self.dmodel
+        return buf[off_w:off_w + 3 * D * D].view(3 * D, D), buf[off_b:off_b + 3 * D]
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, enc_input, dec_input=None):
+        flat, _ = self._ensure_flat()
+        if enc_input.shape[1] > self.max_seq_len:
+            raise RuntimeError(f"sequence length {enc_input.shape[1]} exceeds max_seq_len={self.max_seq_len} "
+                               "(the reference's positional table has the same limit, Sublayers.py:48,60)")
+        seq = enc_input.to(flat.device, torch.int64).contiguous()
+        if self.training:
+            self._step_counter += 1
+        seed = (self.dropout_seed + 0x9E3779B97F4A7C15 * self._step_counter) & (2 ** 63 - 1)
+        # the flat buffer is a leaf of the autograd graph only so that backward() reaches _EncoderFn.backward;
+        # gradients are written into the flat gradient buffer directly
+        anchor = flat.detach().requires_grad_(torch.is_grad_enabled())
+        out = _EncoderFn.apply(anchor, seq, self, seed)
+        return out.view(seq.shape[0], seq.shape[1], NUM_PREDICTED_ANGLES * 2)
+
+    def predict(self, enc_input):
+        return self.forward(enc_input)
+
+    def set_dropout(self, p, attn_p=None):
+        """Set every dropout of the model (parity runs use 0 everywhere)."""
+        self.dropout = float(p)
+        self.attn_dropout = float(p if attn_p is None else attn_p)
+
+
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flat, seq, model, seed):
+        m = model
+        B, L = seq.shape
+        D, H, F_ = m.dmodel, m.nhead, m.dff
+        train = m.training
+        p = m.dropout if train else 0.0
+        pa = m.attn_dropout if train else 0.0
+        W = lambda name: m._slice(flat, name)                                      # noqa: E731
+        pe = m.encoder.positional_enc.pe[0]
+        x = K.embed_fwd(seq, W("encoder.input_embedding.emb.weight"), pe, p, seed)
+        saved = []
+        for i in range(m.nlayers):
+            b = f"encoder.enc_layers.{i}."
+            sid = i * 8
+            wqkv, bqkv = m._qkv(flat, i)
+            h1, mean1, rstd1 = K.layernorm_fwd(x, W(b + "sublayer_connections.0.norm.weight"),
+                                               W(b + "sublayer_connections.0.norm.bias"))
+            qkv = K.linear_fwd(h1, wqkv, bqkv)
+            att, lse = K.attention_fwd(qkv, seq, H, pa, seed, sid + _SITE_ATTN)
+            x2 = K.linear_fwd(att, W(b + "self_attn.wo.weight"), W(b + "self_attn.wo.bias"), residual=x, ldr=D,
+                              dropout_p=p, seed=seed, stream_id=sid + _SITE_ATTN_OUT)
+            h2, mean2, rstd2 = K.layernorm_fwd(x2, W(b + "sublayer_connections.1.norm.weight"),
+                                               W(b + "sublayer_connections.1.norm.bias"))
+            f1 = K.linear_fwd(h2, W(b + "pwff.layer1.weight"), W(b + "pwff.layer1.bias"), flags=K.EPI_RELU,
+                              dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_HID)
+            x3 = K.linear_fwd(f1, W(b + "pwff.layer2.weight"), W(b + "pwff.layer2.bias"), residual=x2, ldr=D,
+                              dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_OUT)
+            saved.append((x, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, f1))
+            x = x3
+        pred = K.linear_fwd(x, W("output_projection.weight"), W("output_projection.bias"), flags=K.EPI_TANH)
+        ctx.model, ctx.seed, ctx.seq, ctx.flat = m, seed, seq, flat
+        ctx.p, ctx.pa = p, pa
+        ctx.saved = saved
+        ctx.x_last, ctx.pred = x, pred
+        return pred
+
+    @staticmethod
+    def backward(ctx, dpred):
+        m, seed, seq, flat = ctx.model, ctx.seed, ctx.seq, ctx.flat
+        p, pa = ctx.p, ctx.pa
+        D, H = m.dmodel, m.nhead
+        gflat = m._flat_grad
+        W = lambda name: m._slice(flat, name)                                      # noqa: E731
+        G = lambda name: m._slice(gflat, name)                                     # noqa: E731
+
+        def done(first, last):
+            if m.grad_hook is not None:
+                o0, _ = m._layout[first]
+                o1, s1 = m._layout[last]
+                m.grad_hook(o0, o1 + int(np.prod(s1)) - o0)
+
+        dpred = dpred.contiguous().view(-1, NUM_PREDICTED_ANGLES * 2)
+        dpre = K.tanh_bwd(dpred, ctx.pred)
+        K.linear_bwd_weight(dpre, ctx.x_last, G("output_projection.weight"))
+        K.colsum(dpre, G("output_projection.bias"))
+        dx = K.linear_bwd_input(dpre, W("output_projection.weight"))
+        done("output_projection.weight", "output_projection.bias")
+        for i in reversed(range(m.nlayers)):
+            b = f"encoder.enc_layers.{i}."
+            sid = i * 8
+            x, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, f1 = ctx.saved[i]
+            # x3 = x2 + drop(f1 W2^T + b2)
+            dy2 = K.dropout_bwd(dx, p, seed, sid + _SITE_FFN_OUT) if p > 0 else dx
+            K.linear_bwd_weight(dy2, f1, G(b + "pwff.layer2.weight"))
+            K.colsum(dy2, G(b + "pwff.layer2.bias"))
+            df1 = K.linear_bwd_input(dy2, W(b + "pwff.layer2.weight"))
+            dz1 = K.relu_dropout_bwd(df1, f1, p)
+            K.linear_bwd_weight(dz1, h2, G(b + "pwff.layer1.weight"))
+            K.colsum(dz1, G(b + "pwff.layer1.bias"))
+            dh2 = K.linear_bwd_input(dz1, W(b + "pwff.layer1.weight"))
+            dx2 = K.layernorm_bwd(dh2, x2, W(b + "sublayer_connections.1.norm.weight"), mean2, rstd2,
+                                  G(b + "sublayer_connections.1.norm.weight"), G(b + "sublayer_connections.1.norm.bias"),
+                                  dres=dx)
+            # x2 = x + drop(att Wo^T + bo)
+            dyo = K.dropout_bwd(dx2, p, seed, sid + _SITE_ATTN_OUT) if p > 0 else dx2
+            K.linear_bwd_weight(dyo, att, G(b + "self_attn.wo.weight"))
+            K.colsum(dyo, G(b + "self_attn.wo.bias"))
+            datt = K.linear_bwd_input(dyo, W(b + "self_attn.wo.weight"))
+            dqkv = K.attention_bwd(qkv, seq, att, datt, lse, H, pa, seed, sid + _SITE_ATTN)
+            gw, gb = m._qkv(gflat, i)
+            wqkv, _ = m._qkv(flat, i)
+            K.linear_bwd_weight(dqkv, h1, gw)
+            K.colsum(dqkv, gb)
+            dh1 = K.linear_bwd_input(dqkv, wqkv)
+            dx = K.layernorm_bwd(dh1, x, W(b + "sublayer_connections.0.norm.weight"), mean1, rstd1,
+                                 G(b + "sublayer_connections.0.norm.weight"), G(b + "sublayer_connections.0.norm.bias"),
+                                 dres=dx2)
+            done(b + "self_attn.wq.weight", b + "sublayer_connections.1.norm.bias")
+            ctx.saved[i] = None
+        K.embed_bwd(seq, dx, D, p, seed, G("encoder.input_embedding.emb.weight"))
+        done("encoder.input_embedding.emb.weight", "encoder.input_embedding.emb.weight")
+        return None, None, None, None

@@ -1,0 +1,129 @@
+"""Fused clip + optimizer step over the model's flat parameter buffer.
+
+Replaces `torch.nn.utils.clip_grad_norm_` + `torch.optim.SGD/Adam.step()` as used by the reference
+(/root/reference/protein_transformer/train.py:41-46,371-381) with three kernel launches over one
+flat fp32 buffer (csrc/optim.hip) and no host synchronisation.  Both classes are
+`torch.optim.Optimizer`s, so LR schedulers (ReduceLROnPlateau, the Noam wrapper) and
+`state_dict()` work unchanged; hyper-parameters are read from `param_groups[0]` every step.
+"""
+import numpy as np
+import torch
+
+from . import kernels as K
+
+
+class _FlatOptimizer(torch.optim.Optimizer):
+    def __init__(self, model, defaults):
+        self.model = model
+        super().__init__(list(model.parameters()), defaults)
+        self._sqnorm = None
+        self.max_norm = 0.0
+
+    def zero_grad(self, set_to_none=False):
+        _, g = self.model.flat_parameters()
+        g.zero_()
+
+    def clip_grad_norm_(self, max_norm):
+        """Device-side `clip_grad_norm_`: launches the squared-norm reduction and arms the next `step()`
+        to scale gradients by min(1, max_norm / (norm + 1e-6)).  Returns the 1-element device tensor
+        holding ||g||^2 (no sync; take .sqrt().item() if the value is wanted on the host)."""
+        _, g = self.model.flat_parameters()
+        if self._sqnorm is None or self._sqnorm.device != g.device:
+            self._sqnorm = torch.zeros(1, dtype=torch.float32, device=g.device)
+        K.grad_sqnorm(g, self._sqnorm)
+        self.max_norm = float(max_norm or 0.0)
+        return self._sqnorm
+
+    def _clip_args(self):
+        sq, mx = (self._sqnorm, self.max_norm) if self.max_norm > 0 else (None, 0.0)
+        self.max_norm = 0.0                      # one clip arms one step, like the reference's call order
+        return sq, mx
+
+
+class FusedSGD(_FlatOptimizer):
+    """SGD with L2 weight decay (torch.optim.SGD semantics, train.py:379-381)."""
+
+    def __init__(self, model, lr=1e-4, weight_decay=0.0):
+        super().__init__(model, dict(lr=lr, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        w, g = self.model.flat_parameters()
+        grp = self.param_groups[0]
+        sq, mx = self._clip_args()
+        K.sgd_step(w, g, sq, mx, grp["lr"], grp["weight_decay"])
+
+
+class FusedAdam(_FlatOptimizer):
+    """Adam with L2 weight decay (torch.optim.Adam semantics, train.py:374-378)."""
+
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.0):
+        super().__init__(model, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._m = self._v = None
+        self._t = 0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        w, g = self.model.flat_parameters()
+        if self._m is None or self._m.device != w.device:
+            self._m, self._v = torch.zeros_like(w), torch.zeros_like(w)
+        grp = self.param_groups[0]
+        self._t += 1
+        sq, mx = self._clip_args()
+        K.adam_step(w, g, self._m, self._v, sq, mx, grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"],
+                    grp["weight_decay"], self._t)
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["flat_state"] = dict(step=self._t, exp_avg=self._m, exp_avg_sq=self._v)
+        return sd
+
+    def load_state_dict(self, sd):
+        sd = dict(sd)
+        fs = sd.pop("flat_state", None)
+        super().load_state_dict(sd)
+        if fs is not None:
+            self._t, self._m, self._v = fs["step"], fs["exp_avg"], fs["exp_avg_sq"]
+
+
+class ScheduledOptim():
+    """Noam learning-rate schedule wrapper, API of the reference's
+    models/transformer/Optimizer.py:4-62: lr = d_model^-0.5 * min(step^-0.5, step * warmup^-1.5)."""
+
+    def __init__(self, optimizer, d_model, n_warmup_steps):
+        self._optimizer = optimizer
+        self.n_warmup_steps = n_warmup_steps
+        self.n_current_steps = 0
+        self.init_lr = np.power(d_model, -0.5)
+
+    def step(self):
+        self._update_learning_rate()
+        self._optimizer.step()
+
+    def zero_grad(self):
+        self._optimizer.zero_grad()
+
+    def clip_grad_norm_(self, max_norm):
+        return self._optimizer.clip_grad_norm_(max_norm)
+
+    def _get_lr_scale(self):
+        return np.min([np.power(self.n_current_steps, -0.5),
+                       np.power(self.n_warmup_steps, -1.5) * self.n_current_steps])
+
+    def _update_learning_rate(self):
+        self.n_current_steps += 1
+        lr = self.init_lr * self._get_lr_scale()
+        self.cur_lr = lr
+        for param_group in self._optimizer.param_groups:
+            param_group['lr'] = lr
+
+    @property
+    def param_groups(self):
+        return self._optimizer.param_groups
+
+    def state_dict(self):
+        return (self._optimizer.state_dict(), self.n_warmup_steps, self.n_current_steps, self.init_lr)
+
+    def load_state_dict(self, d):
+        self._optimizer.load_state_dict(d[0])
+        self.n_warmup_steps, self.n_current_steps, self.init_lr = d[1], d[2], d[3]

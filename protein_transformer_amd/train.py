@@ -1,0 +1,380 @@
+"""Training driver for the MI355X hot path; command-line compatible with the reference's train.py.
+
+Mirrors /root/reference/protein_transformer/train.py: `train_epoch` :28-54, `get_losses` :57-111,
+`eval_epoch` :114-135, `train` :138-186, `checkpoint_model` :189-230, `load_model` :233-271,
+`make_model` :274-321, `seed_rngs` :340-357, `init_worker_pool` :360-365,
+`setup_model_optimizer_scheduler` :368-393, `create_parser` :396-529, `main` :553-676.
+Same flags plus a few additions at the bottom of the parser: max sequence
+length, synthetic data, wandb on/off.  One process drives one GPU; under
+`python -m torch.distributed.run` every rank takes a shard of each batch and gradients are
+SUM-all-reduced over RCCL (protein_transformer_amd/dp.py).
+
+What is different by design: the whole step stays on the device (no CPU loss workers, so
+`init_worker_pool` returns None and `--sequential_drmsd_loss` is a no-op), clip + optimizer are one
+fused kernel sequence, wandb / PyMOL are optional.
+"""
+import argparse
+import csv
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+from . import dp
+from .dataset import MAX_SEQ_LEN, prepare_dataloaders
+from .log import (EarlyStoppingCondition, do_eval_batch_logging, do_eval_epoch_logging, do_train_batch_logging,
+                  init_metrics, log_batch, prepare_log_header, reset_metrics_for_epoch, update_loss_trackers,
+                  update_metrics_end_of_epoch)
+from .losses import batch_loss, combine_drmsd_mse, compute_batch_drmsd, mse_over_angles, mse_sums
+from .models.encoder_only import EncoderOnlyTransformer
+from .optim import FusedAdam, FusedSGD, ScheduledOptim
+from .protein.Sequence import VOCAB
+from .protein.Structure import NUM_PREDICTED_ANGLES, raise_for_status
+
+START_EPOCH = 0
+START_TIME = time.time()
+
+
+def train_epoch(model, training_data, validation_datasets, optimizer, device, args, log_writer, metrics, pool=None):
+    """ One complete training epoch (train.py:28-54). """
+    model.train()
+    metrics = reset_metrics_for_epoch(metrics, "train")
+    for step, batch in enumerate(training_data):
+        optimizer.zero_grad()
+        src_seq, tgt_ang, tgt_crds = map(lambda x: x.to(device, non_blocking=True), batch)
+        src_seq, tgt_ang, tgt_crds = dp.shard_batch(src_seq, tgt_ang, tgt_crds)
+        pred = model(src_seq, tgt_ang)
+        losses = get_losses(args, pred, tgt_ang, tgt_crds, src_seq, pool=pool)
+        dp.all_reduce_gradients(model)
+        if args.clip:
+            optimizer.clip_grad_norm_(args.clip)
+        optimizer.step()
+        metrics = do_train_batch_logging(metrics, losses, src_seq, optimizer, args, log_writer, START_TIME, step)
+    metrics = update_metrics_end_of_epoch(metrics, "train")
+    return metrics
+
+
+def get_losses(args, pred, tgt_ang, tgt_crds, src_seq, pool=None, log=True, do_backwards=True, return_rmsd=False,
+               eval_mode=False):
+    """Losses/metrics of a batch (train.py:57-111); `loss` depends on `args.loss`.
+
+    Gradient bookkeeping is the reference's: the dRMSD term back-propagates the SUM
+    over proteins of the length-normalised loss whatever the reported loss is; `combined` adds
+    (1-w)/0.01 * d(mse); `mse` back-propagates the MSE only.  Where the reference runs two backward
+    passes through the model for `combined` (retain_graph), the two gradients are added first and
+    the model is traversed once.
+    """
+    m_loss_full = mse_over_angles(pred, tgt_ang)
+    m_loss_bb = mse_over_angles(pred, tgt_ang, bb_only=True)
+    m_loss_sc = mse_over_angles(pred, tgt_ang, sc_only=True)
+    rmsd_loss = None
+    if args.loss in ["lndrmsd", "drmsd", "combined"] or eval_mode:
+        if args.loss == "combined" and do_backwards:
+            stats, grad, status = batch_loss(pred, tgt_crds, src_seq, do_backward=True)
+            (g_mse,) = torch.autograd.grad(m_loss_full, pred, retain_graph=False)
+            w = args.combined_drmsd_weight
+            pred.backward(gradient=grad.view_as(pred) + ((1 - w) / 0.01) * g_mse)
+            host = stats.cpu().numpy().astype(np.float64)
+            raise_for_status(int(status.item()), theta_is_error=False)
+            d_loss, ln_d_loss, d_bb_loss, d_bb_ln_loss = (np.mean(host[:, k]) for k in range(4))
+        else:
+            ls = compute_batch_drmsd(pred, tgt_crds, src_seq, do_backward=do_backwards, retain_graph=False,
+                                     pool=pool, backbone_only=getattr(args, "backbone_loss", False),
+                                     return_rmsd=return_rmsd)
+            if return_rmsd:
+                d_loss, ln_d_loss, d_bb_loss, d_bb_ln_loss, rmsd_loss = ls
+            else:
+                d_loss, ln_d_loss, d_bb_loss, d_bb_ln_loss = ls
+        c_loss = combine_drmsd_mse(ln_d_loss, m_loss_full.detach(), w=args.combined_drmsd_weight, log=log)
+        if args.loss == "lndrmsd":
+            loss = ln_d_loss
+        elif args.loss == "drmsd":
+            loss = d_loss
+        elif args.loss == "combined":
+            loss = c_loss
+        else:
+            loss = m_loss_full
+    elif args.loss == "mse":
+        d_loss, ln_d_loss, d_bb_loss, d_bb_ln_loss, c_loss = (torch.tensor(0),) * 5
+        loss = m_loss_full
+        if do_backwards:
+            m_loss_full.backward()
+    return {"loss": loss, "drmsd-full": d_loss, "lndrmsd-full": ln_d_loss, "drmsd-bb": d_bb_loss,
+            "lndrmsd-bb": d_bb_ln_loss, "combined-full": c_loss, "mse-full": m_loss_full, "mse-bb": m_loss_bb,
+            "mse-sc": m_loss_sc, "rmsd-full": rmsd_loss}
+
+
+def eval_epoch(model, validation_data, device, args, metrics, mode="valid", pool=None):
+    """ One complete evaluation epoch (train.py:114-135). """
+    model.eval()
+    metrics = reset_metrics_for_epoch(metrics, mode)
+    with torch.no_grad():
+        for batch in validation_data:
+            src_seq, tgt_ang, tgt_crds = map(lambda x: x.to(device), batch)
+            pred = model(src_seq, tgt_ang)
+            losses = get_losses(args, pred, tgt_ang, tgt_crds, src_seq, pool=pool, do_backwards=False,
+                                eval_mode=True, return_rmsd=True)
+            metrics = do_eval_batch_logging(metrics, losses, src_seq, args, mode)
+    do_eval_epoch_logging(metrics, mode)
+    return metrics
+
+
+def train(model, metrics, training_data, train_eval_loader, validation_datasets, test_data, optimizer, device, args,
+          log_writer, scheduler, drmsd_worker_pool):
+    """ Model training control loop (train.py:138-186). """
+    for epoch_i in range(START_EPOCH, args.epochs):
+        if dp.is_main():
+            print(f'[ Epoch {epoch_i} ]')
+        metrics["epoch"] = epoch_i
+        metrics = train_epoch(model, training_data, validation_datasets, optimizer, device, args, log_writer, metrics,
+                              pool=drmsd_worker_pool)
+        if args.eval_train:
+            metrics = eval_epoch(model, train_eval_loader, device, args, metrics, mode="train", pool=drmsd_worker_pool)
+        if not args.train_only:
+            for split, validation_data in validation_datasets.items():
+                metrics = eval_epoch(model, validation_data, device, args, metrics, mode=f"valid-{split}",
+                                     pool=drmsd_worker_pool)
+        if scheduler:
+            scheduler.step(metrics[args.es_mode][f"epoch-{args.es_metric}"])
+        try:
+            metrics = update_loss_trackers(args, epoch_i, metrics)
+        except EarlyStoppingCondition:
+            break
+        if dp.is_main():
+            checkpoint_model(args, optimizer, model, scheduler, epoch_i, metrics["loss_to_compare"],
+                             metrics["losses_to_compare"], metrics)
+    if not args.train_only:
+        metrics = eval_epoch(model, test_data, device, args, metrics, mode="test", pool=drmsd_worker_pool)
+    return metrics
+
+
+def checkpoint_model(args, optimizer, model, scheduler, epoch_i, loss_this_epoch, losses, metrics=None):
+    """Best / periodic checkpoints with the reference's dictionary layout (train.py:189-230)."""
+    state = {'model_state_dict': model.state_dict(), 'settings': args, 'epoch': epoch_i,
+             'optimizer_state_dict': optimizer.state_dict(),
+             'scheduler_state_dict': scheduler.state_dict() if scheduler else None,
+             'loss': loss_this_epoch, 'metrics': metrics, 'elapsed_time': time.time() - START_TIME}
+    better = loss_this_epoch <= min(losses) if len(losses) else True
+    if better:
+        torch.save(state, args.chkpt_path + "_best.chkpt")            # file name quirk of train.py:207
+    interval = getattr(args, "checkpoint_time_interval", 0) * 3600
+    last = metrics.get("last_chkpt_time", START_TIME) if metrics else START_TIME
+    if interval and time.time() - last >= interval:
+        torch.save(state, args.chkpt_path + "_latest.chkpt")
+        metrics["last_chkpt_time"] = time.time()
+
+
+def load_model(model, optimizer, scheduler, args):
+    """Resume from `<chkpt_path>_best.chkpt` unless --restart (train.py:233-271)."""
+    global START_EPOCH, START_TIME
+    path = args.load_chkpt if getattr(args, "load_chkpt", None) else args.chkpt_path + "_best.chkpt"
+    if args.restart or not os.path.exists(path):
+        return model, optimizer, scheduler, False, None
+    checkpoint = torch.load(path, map_location="cpu", weights_only=False)
+    model.load_state_dict(checkpoint['model_state_dict'])
+    if not args.restart_opt:
+        optimizer.load_state_dict(checkpoint['optimizer_state_dict'])
+        if scheduler and checkpoint.get('scheduler_state_dict'):
+            scheduler.load_state_dict(checkpoint['scheduler_state_dict'])
+    START_EPOCH = checkpoint['epoch'] + 1
+    START_TIME -= checkpoint.get('elapsed_time', 0)
+    print(f"[Info] Resuming from {path} at epoch {START_EPOCH}, loss = {checkpoint['loss']:.4f}.")
+    return model, optimizer, scheduler, True, checkpoint['metrics']
+
+
+def make_model(args, device, angle_means):
+    """Requested architecture (train.py:274-321). `enc-only`, and `conv-enc` without convolution layers
+    (which the reference builds as exactly the same network)."""
+    convs = [a for a in [getattr(args, "conv1_size", None), getattr(args, "conv2_size", None),
+                         getattr(args, "conv3_size", None)] if a]
+    if args.model == "enc-only" or ("conv-enc" in args.model and not convs):
+        return EncoderOnlyTransformer(nlayers=args.n_layers, nhead=args.n_head, dmodel=args.d_model,
+                                      dff=args.d_inner_hid, max_seq_len=args.max_seq_len, dropout=args.dropout,
+                                      vocab=VOCAB, angle_means=angle_means, use_tanh_out="linear-out" not in args.model)
+    raise argparse.ArgumentError(None, "Model architecture not implemented on the MI355X path "
+                                       "(enc-dec is deprecated upstream; conv-enc with convolutions is a later row).")
+
+
+def parse_conv_kernel_info_from_model_name(mname):
+    """ "conv-enc|3,7,11|2,2,2" -> ([3, 7, 11], [2.0, 2.0, 2.0])   (train.py:323-338) """
+    try:
+        _, kernel_sizes, dim_reducs = mname.split("|")
+    except ValueError:
+        return [], []
+    return list(map(int, kernel_sizes.split(","))), list(map(float, dim_reducs.split(",")))
+
+
+def seed_rngs(args):
+    """ Seed all necessary random number generators (train.py:340-357). """
+    seed = args.seed
+    random.seed(seed)
+    os.environ['PYTHONHASHSEED'] = str(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def init_worker_pool(args):
+    """The reference spawns cpu_count() loss workers (train.py:360-365); the loss runs on the GPU here."""
+    return None
+
+
+def setup_model_optimizer_scheduler(args, device, angle_means):
+    """train.py:368-393: model, SGD/Adam with weight decay 0.01, Noam or plateau scheduling."""
+    if not hasattr(args, "max_seq_len"):
+        args.max_seq_len = MAX_SEQ_LEN
+    model = make_model(args, device, angle_means).to(device)
+    model.dropout_seed = (args.seed * 0x9E3779B1 + 7919 * dp.rank()) & (2 ** 62 - 1)
+    wd = 10e-3 if args.weight_decay else 0
+    if args.optimizer == "adam":
+        optimizer = FusedAdam(model, betas=(0.9, 0.98), eps=1e-09, lr=args.learning_rate, weight_decay=wd)
+    elif args.optimizer == "sgd":
+        optimizer = FusedSGD(model, lr=args.learning_rate, weight_decay=wd)
+    if args.lr_scheduling == "noam":
+        optimizer = ScheduledOptim(optimizer, args.d_model, args.n_warmup_steps)
+        scheduler = None
+    else:
+        scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, patience=args.patience,
+                                                               threshold=args.early_stopping_threshold)
+    return model, optimizer, scheduler
+
+
+def create_parser():
+    """The reference's argument parser (train.py:396-529), flag for flag."""
+    def my_bool(s):
+        return s != 'False'
+    parser = argparse.ArgumentParser()
+
+    required = parser.add_argument_group("Required Args")
+    required.add_argument('--data', help="Path to training data.", default="../data/proteinnet/casp12_200123_30.pt")
+    required.add_argument("--name", type=str, help="The model name.", default=None)
+
+    training = parser.add_argument_group("Training Args")
+    training.add_argument("-lr", "--learning_rate", type=float, default=1 * (10 ** -4))
+    training.add_argument('-e', '--epochs', type=int, default=10)
+    training.add_argument("-b", '--batch_size', type=int, default=8)
+    training.add_argument('-es', '--early_stopping', type=int, default=20)
+    training.add_argument('-nws', '--n_warmup_steps', type=int, default=10_000)
+    training.add_argument('-cg', '--clip', type=float, default=1)
+    training.add_argument('-l', '--loss', choices=["mse", "drmsd", "lndrmsd", "combined"], default="combined")
+    training.add_argument('--train_only', action='store_true')
+    training.add_argument('--lr_scheduling', type=str, choices=['noam', 'plateau'], default='plateau')
+    training.add_argument('--patience', type=int, default=10)
+    training.add_argument('--early_stopping_threshold', type=float, default=0.001)
+    training.add_argument('-esm', '--early_stopping_metric', type=str, default=None,
+                          help="<train|test|valid-NN>-<mse|drmsd|lndrmsd|combined>")
+    training.add_argument('--without_angle_means', action='store_true')
+    training.add_argument('--eval_train', type=my_bool, default=False)
+    training.add_argument('-opt', '--optimizer', type=str, choices=['adam', 'sgd'], default='sgd')
+    training.add_argument("-fctf", "--fraction_complete_tf", type=float, default=1)
+    training.add_argument("-fsstf", "--fraction_subseq_tf", type=float, default=1)
+    training.add_argument("--skip_missing_res_train", type=my_bool, default=False)
+    training.add_argument("--repeat_train", type=int, default=1)
+    training.add_argument("-s", "--seed", type=int, default=11_731)
+    training.add_argument("--combined_drmsd_weight", type=float, default=0.5)
+    training.add_argument("--batching_order", type=str, choices=["descending", "ascending", "binned-random"],
+                          default="binned-random")
+    training.add_argument('--backbone_loss', action='store_true')
+    training.add_argument('--sequential_drmsd_loss', action="store_true")
+    training.add_argument("--bins", type=int, default=-1)
+    training.add_argument("--train_eval_downsample", type=float, default=.10)
+    training.add_argument("-adbs", "--automatically_determine_batch_size", type=my_bool, default=False)
+
+    model_args = parser.add_argument_group("Model Args")
+    model_args.add_argument('-m', '--model', type=str, default="enc-only")
+    model_args.add_argument('-dm', '--d_model', type=int, default=512)
+    model_args.add_argument('-dih', '--d_inner_hid', type=int, default=2048)
+    model_args.add_argument('-nh', '--n_head', type=int, default=8)
+    model_args.add_argument('-nl', '--n_layers', type=int, default=6)
+    model_args.add_argument('-do', '--dropout', type=float, default=0.1)
+    model_args.add_argument('--postnorm', action='store_true')
+    model_args.add_argument("--weight_decay", type=my_bool, default="True")
+    model_args.add_argument("--conv1_size", type=int, default=None)
+    model_args.add_argument("--conv2_size", type=int, default=None)
+    model_args.add_argument("--conv3_size", type=int, default=None)
+    model_args.add_argument("--conv1_reduc", type=int, default=None)
+    model_args.add_argument("--conv2_reduc", type=int, default=None)
+    model_args.add_argument("--conv3_reduc", type=int, default=None)
+    model_args.add_argument("--use_embedding", type=my_bool, default="True")
+    model_args.add_argument("--conv_out_matches_dm", type=my_bool, default="True")
+
+    saving_args = parser.add_argument_group("Saving Args")
+    saving_args.add_argument('--log_structure_step', type=int, default=10)
+    saving_args.add_argument('-lvs', '--log_val_struct_step', type=int, default=50)
+    saving_args.add_argument('--log_wandb_step', type=int, default=1)
+    saving_args.add_argument("-png", '--save_pngs', type=my_bool, default=True)
+    saving_args.add_argument('--no_cuda', action='store_true')
+    saving_args.add_argument('-c', '--cluster', type=my_bool, default=False)
+    saving_args.add_argument('--restart', action='store_true')
+    saving_args.add_argument('--restart_opt', action='store_true')
+    saving_args.add_argument("--checkpoint_time_interval", type=float, default=0)
+    saving_args.add_argument("--load_chkpt", type=str, default=None)
+
+    new = parser.add_argument_group("MI355X path additions (not in the reference)")
+    new.add_argument("--max_seq_len", type=int, default=MAX_SEQ_LEN,
+                     help="Positional table size / truncation length (the reference hard-wires 500).")
+    new.add_argument("--synthetic", type=str, default=None,
+                     help="'B,L[,n_batches]': train on generated fixed-length batches instead of --data.")
+    new.add_argument("--log_dir", type=str, default="../data/logs")
+    new.add_argument("--chkpt_dir", type=str, default="../data/checkpoints")
+    return parser
+
+
+def main():
+    """train.py:553-676 without the wandb / PyMOL requirements."""
+    global START_TIME
+    parser = create_parser()
+    args = parser.parse_args()
+    if args.no_cuda or not torch.cuda.is_available():
+        sys.exit("protein_transformer_amd runs on the MI355X only; use the reference itself for --no_cuda runs.")
+    assert args.name is None or "_" not in args.name, "Please do not use underscores in experiment names."   # :577
+    args.cuda = True
+    args.es_mode, args.es_metric = (args.early_stopping_metric or f"train-{args.loss}").rsplit("-", 1)
+    args.add_sos_eos = args.model == "enc-dec"
+    args.bins = "auto" if args.bins == -1 else args.bins
+    if "conv-enc" in args.model:
+        ks, rs = parse_conv_kernel_info_from_model_name(args.model)
+        for i, (k, r) in enumerate(zip(ks, rs), 1):
+            setattr(args, f"conv{i}_size", k)
+            setattr(args, f"conv{i}_reduc", r)
+        args.model = args.model.split("|")[0]
+    dp.init_from_env()
+    device = torch.device("cuda", dp.local_rank())
+    torch.cuda.set_device(device)
+    drmsd_worker_pool = init_worker_pool(args)
+    seed_rngs(args)
+
+    if args.synthetic:
+        from .synthetic_data import make_synthetic_dataset
+        data = make_synthetic_dataset(args.synthetic, args.seed, device)
+    else:
+        data = torch.load(args.data, weights_only=False)
+    args.max_len = data["settings"]["max_len"]
+    angle_means = data["settings"]["angle_means"]
+
+    model, optimizer, scheduler = setup_model_optimizer_scheduler(args, device, angle_means)
+    args.name = args.name or time.strftime("run%y%m%d-%H%M%S")
+    os.makedirs(args.log_dir, exist_ok=True)
+    os.makedirs(args.chkpt_dir, exist_ok=True)
+    args.log_file = os.path.join(args.log_dir, args.name + '.train')
+    args.chkpt_path = os.path.join(args.chkpt_dir, args.name)
+    model, optimizer, scheduler, resumed, metrics = load_model(model, optimizer, scheduler, args)
+    log_f = open(args.log_file, 'a' if resumed else 'w', buffering=1) if dp.is_main() else open(os.devnull, "w")
+    log_writer = csv.writer(log_f)
+    if not resumed:
+        log_writer.writerow(prepare_log_header(args).split(","))
+        metrics = init_metrics(args)
+    training_data, training_eval_loader, validation_datasets, test_data = prepare_dataloaders(data, args, args.max_seq_len)
+    START_TIME = time.time()
+    train(model, metrics, training_data, training_eval_loader, validation_datasets, test_data, optimizer, device, args,
+          log_writer, scheduler, drmsd_worker_pool)
+    log_f.close()
+    dp.shutdown()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,208 @@
+"""MI355X parity tests of the model, the loss driver and whole training steps.
+
+Golden vectors G5/G6/G7 were captured from the reference (tests/golden/make_golden.py); larger
+configurations are checked against the CPU oracle on seeded inputs.  All dropout is 0 in parity runs
+(RNG streams cannot match).  Tolerances: predictions abs 1e-5; losses rel 1e-4
+(lndrmsd abs 1e-6); parameter gradients rel-L2 1e-3 (per tensor, against the model-wide largest
+gradient for the tensors that are mathematically zero).
+"""
+import types
+
+import numpy as np
+import pytest
+import torch
+from pytest import approx
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def T(x):
+    return torch.tensor(np.asarray(x))
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def golden_model(g, dev, dropout=0.0):
+    from protein_transformer_amd.models.encoder_only import EncoderOnlyTransformer
+    from protein_transformer_amd.protein.Sequence import VOCAB
+    sd = {k[3:]: T(v) for k, v in g.items() if k.startswith("sd/")}
+    D = sd["encoder.input_embedding.emb.weight"].shape[1]
+    nl = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("encoder.enc_layers."))
+    dff = sd["encoder.enc_layers.0.pwff.layer1.weight"].shape[0]
+    m = EncoderOnlyTransformer(nlayers=nl, nhead=int(g["nhead"]), dmodel=D, dff=dff, max_seq_len=int(g["max_seq_len"]),
+                               vocab=VOCAB, angle_means=g["angle_means"], use_tanh_out=True, dropout=dropout)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert missing == ["encoder.positional_enc.pe"] and not unexpected       # same keys as the reference
+    m.set_dropout(dropout)
+    return m.to(dev), sd
+
+
+def test_state_dict_keys_and_init(dev):
+    from oracle.encoder import init_params
+    from protein_transformer_amd.models.encoder_only import EncoderOnlyTransformer
+    from protein_transformer_amd.protein.Sequence import VOCAB
+    am = np.linspace(-0.9, 0.9, 24)
+    m = EncoderOnlyTransformer(2, 8, 64, 128, 500, VOCAB, am, True)
+    ref = init_params(2, 64, 128, 500, am)
+    assert set(m.state_dict().keys()) == set(ref.keys())
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(ref[k].shape), k
+    assert torch.all(m.output_projection.weight == 0)                          # encoder_only.py:34
+    assert torch.allclose(m.output_projection.bias, torch.tensor(np.arctanh(am), dtype=torch.float32))
+    assert torch.equal(m.state_dict()["encoder.positional_enc.pe"], ref["encoder.positional_enc.pe"])
+    m = m.to(dev)
+    seq = torch.randint(0, 20, (2, 30), device=dev)
+    out = m(seq)
+    # at initialisation every residue predicts the mean angles
+    assert torch.allclose(out.cpu(), torch.tensor(am, dtype=torch.float32).expand(2, 30, 24), atol=1e-6)
+
+
+def test_forward_golden(golden, dev):
+    g = golden("g567_model_step")
+    m, _ = golden_model(g, dev)
+    m.eval()
+    with torch.no_grad():
+        pred = m(T(g["seq"]).to(dev)).cpu().numpy()
+    assert np.abs(pred - g["g6_pred_eval"]).max() < 1e-5
+    m.train()
+    pred = m(T(g["seq"]).to(dev)).detach().cpu().numpy()
+    assert np.abs(pred - g["g6_pred_train"]).max() < 1e-5
+
+
+def test_compute_batch_drmsd_golden(golden, dev):
+    from protein_transformer_amd.losses import compute_batch_drmsd
+    g = golden("g567_model_step")
+    m, _ = golden_model(g, dev)
+    m.train()
+    m.zero_grad()
+    pred = m(T(g["seq"]).to(dev))
+    vals = compute_batch_drmsd(pred, T(g["true_crd"]).to(dev), T(g["seq"]).to(dev), do_backward=True)
+    assert vals[0] == approx(g["g5_vals"][0], rel=1e-4)
+    assert vals[1] == approx(g["g5_vals"][1], abs=1e-6)
+    assert vals[2] == approx(g["g5_vals"][2], rel=1e-4)
+    assert vals[3] == approx(g["g5_vals"][3], abs=1e-6)
+    gmax = max(np.abs(g[k]).max() for k in g if k.startswith("g5_grad/"))
+    for name, p in m.named_parameters():
+        ref = g["g5_grad/" + name]
+        got = p.grad.cpu().numpy()
+        assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-5 * gmax, name
+        if np.abs(ref).max() > 1e-4 * gmax:
+            assert rel_l2(got, ref) < 1e-3, (name, rel_l2(got, ref))
+
+
+@pytest.mark.parametrize("loss,opt", [("drmsd", "sgd"), ("combined", "sgd"), ("mse", "sgd"), ("drmsd", "adam"),
+                                      ("lndrmsd", "sgd")])
+def test_train_step_golden(golden, dev, loss, opt):
+    """One full step (forward, loss, backward, clip, optimizer) against the reference's parameters."""
+    from protein_transformer_amd.optim import FusedAdam, FusedSGD
+    from protein_transformer_amd.train import get_losses
+    g = golden("g567_model_step")
+    tag = f"g7_{loss}_{opt}"
+    m, sd = golden_model(g, dev)
+    m.train()
+    lr = float(g[tag + "/lr"])
+    optimizer = (FusedAdam(m, betas=(0.9, 0.98), eps=1e-9, lr=lr, weight_decay=10e-3) if opt == "adam"
+                 else FusedSGD(m, lr=lr, weight_decay=10e-3))
+    args = types.SimpleNamespace(loss=loss, combined_drmsd_weight=0.5, backbone_loss=False)
+    seq, ang, crd = T(g["seq"]).to(dev), T(g["true_ang"]).to(dev), T(g["true_crd"]).to(dev)
+    optimizer.zero_grad()
+    pred = m(seq, ang)
+    losses = get_losses(args, pred, ang, crd, seq)
+    sq = optimizer.clip_grad_norm_(1.0)
+    assert float(sq.sqrt()) == approx(float(g[tag + "/gradnorm"]), rel=1e-3)
+    optimizer.step()
+    for k in ("loss", "drmsd-full", "lndrmsd-full", "drmsd-bb", "lndrmsd-bb", "combined-full", "mse-full", "mse-bb", "mse-sc"):
+        assert float(losses[k]) == approx(float(g[tag + "/loss/" + k]), rel=1e-4, abs=1e-6), k
+    new = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    dn_max = max(float(g[k]) for k in g if k.startswith(tag + "/dnorm/"))
+    for k in sd:
+        dn = float((new[k] - sd[k]).double().norm())
+        ref = float(g[tag + "/dnorm/" + k])
+        assert dn == approx(ref, rel=2e-3, abs=1e-5 * dn_max), k
+        if tag + "/sd/" + k in g:
+            want = g[tag + "/sd/" + k]
+            delta_ref = want - sd[k].numpy()
+            delta = new[k].numpy() - sd[k].numpy()
+            assert np.abs(delta - delta_ref).max() <= 2e-3 * np.abs(delta_ref).max() + 1e-5 * dn_max, k
+
+
+def test_model_vs_oracle_medium(dev):
+    """d_model=256, 2 layers, 8 heads (dk=32), ragged padded batch: forward and every gradient vs the CPU oracle."""
+    from oracle import encoder as oenc
+    from protein_transformer_amd.models.encoder_only import EncoderOnlyTransformer
+    from protein_transformer_amd.protein.Sequence import VOCAB
+    torch.manual_seed(3)
+    am = np.tanh(np.random.default_rng(0).normal(0, 0.5, 24))
+    params = oenc.init_params(2, 256, 512, 128, am, seed=11)
+    params["output_projection.weight"].normal_(0, 0.05)
+    m = EncoderOnlyTransformer(2, 8, 256, 512, 128, VOCAB, am, True, dropout=0.0)
+    m.load_state_dict(params)
+    m.set_dropout(0.0)
+    m = m.to(dev).train()
+    B, L = 5, 100
+    seq = torch.full((B, L), 20, dtype=torch.int64)
+    for b, n in enumerate([100, 64, 77, 3, 31]):
+        seq[b, :n] = torch.randint(0, 20, (n,))
+    leaf = {k: v.clone().requires_grad_() for k, v in params.items() if not k.endswith(".pe")}
+    ref = oenc.encoder_forward({**leaf, "encoder.positional_enc.pe": params["encoder.positional_enc.pe"]}, seq, 8)
+    w = torch.randn(B, L, 24)
+    (ref * w).sum().backward()
+    m.zero_grad()
+    out = m(seq.to(dev))
+    assert np.abs(out.detach().cpu().numpy() - ref.detach().numpy()).max() < 1e-5
+    (out * w.to(dev)).sum().backward()
+    gmax = max(float(v.grad.abs().max()) for v in leaf.values())
+    for name, p in m.named_parameters():
+        r = leaf[name].grad.numpy()
+        got = p.grad.cpu().numpy()
+        if np.abs(r).max() > 1e-4 * gmax:
+            assert rel_l2(got, r) < 1e-3, (name, rel_l2(got, r))
+        else:
+            assert np.abs(got - r).max() < 1e-5 * gmax, name
+
+
+def test_dropout_training_mode(dev):
+    from protein_transformer_amd.models.encoder_only import EncoderOnlyTransformer
+    from protein_transformer_amd.protein.Sequence import VOCAB
+    am = np.zeros(24) + 0.3
+    m = EncoderOnlyTransformer(2, 4, 128, 256, 64, VOCAB, am, True, dropout=0.1).to(dev)
+    with torch.no_grad():
+        m.output_projection.weight.normal_(0, 0.05)
+    seq = torch.randint(0, 20, (3, 64), device=dev)
+    m.eval()
+    with torch.no_grad():
+        e1, e2 = m(seq), m(seq)
+    assert torch.equal(e1, e2)
+    m.train()
+    t1, t2 = m(seq), m(seq)
+    assert not torch.equal(t1, t2) and not torch.equal(t1.detach(), e1)      # fresh masks every step
+    assert torch.isfinite(t1).all()
+    m.zero_grad()
+    t1.sum().backward()                                                       # masks regenerated in backward
+    _, g = m.flat_parameters()
+    assert torch.isfinite(g).all() and float(g.abs().sum()) > 0
+    # gradient of the dropped network is consistent with a finite difference along a random direction
+    m._step_counter -= 1
+    flat, _ = m.flat_parameters()
+    d = torch.randn_like(flat) * 1e-3
+    base = m(seq).double().sum()
+    m._step_counter -= 1
+    with torch.no_grad():
+        flat += d
+    moved = m(seq).double().sum()
+    m.zero_grad()
+    m._step_counter -= 1
+    with torch.no_grad():
+        flat -= d
+    m(seq).sum().backward()
+    _, g = m.flat_parameters()
+    assert float(moved - base) == approx(float((g.double() * d.double()).sum()), rel=0.05, abs=1e-4)
