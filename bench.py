@@ -1,0 +1,158 @@
+#!/usr/bin/env python
+"""Headline benchmark: train-step residues/s of the enc-only d512 model with the dRMSD loss on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[3], the one its metric is quoted on): `-m enc-only -dm 512 -nl 6 -nh 8
+-dih 2048 -l drmsd`, SGD lr 1e-4 wd 0.01 clip 1, dropout 0.1 ON, 32 synthetic proteins of L=512 per GPU
+(weak scaling: the global batch is 32 x N).  One step = zero_grad, forward, NeRF + dRMSD loss + backward,
+gradient all-reduce, clip, optimizer step (train.train_step = reference train.py:36-46), inputs already
+resident in HBM.  Prints ONE JSON line on rank 0 (contract in the task description) with
+  roofline     - the fp32 MFMA GEMM kernel (dominant: ~80% of the step), timed live with HIP events on
+                 its launch stream during the timed steps: algorithmic FLOP / measured kernel time
+                 against the 157.3 TF/s dense f32 matrix peak;
+  cpu_baseline - the CPU oracle (a port of the reference's --no_cuda path) on a bounded sample of the
+                 same workload, on the host cores of this box.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="proteins per GPU")
+    ap.add_argument("--length", type=int, default=512)
+    ap.add_argument("--d_model", type=int, default=512)
+    ap.add_argument("--n_layers", type=int, default=6)
+    ap.add_argument("--n_head", type=int, default=8)
+    ap.add_argument("--d_ff", type=int, default=2048)
+    ap.add_argument("--loss", default="drmsd")
+    ap.add_argument("--optimizer", default="sgd")
+    ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-proteins", type=int, default=2, help="proteins in the bounded CPU-baseline sample")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(a, batch_cpu, angle_means):
+    """Time ONE step of the CPU oracle on `--cpu-proteins` proteins of the same workload (1 thread, sequential
+    loss, like the reference with --sequential_drmsd_loss; the reference pins torch.set_num_threads(1), train.py:344)."""
+    from oracle import encoder as oenc, step as ostep
+    n = a.cpu_proteins
+    torch.set_num_threads(1)
+    params = oenc.init_params(a.n_layers, a.d_model, a.d_ff, a.length, angle_means, seed=11731)
+    trainer = ostep.CpuTrainer(params, a.n_head, loss=a.loss, optimizer=a.optimizer, lr=1e-4, clip=1.0)
+    seq, ang, crd = (batch_cpu[k][:n] for k in ("seq", "true_ang", "true_crd"))
+    res_per_s, dt = ostep.time_cpu_steps(trainer, (seq, ang, crd), n_steps=1)
+    return {"value": round(res_per_s, 2), "unit": "residues/s", "cores": 1, "kind": "port",
+            "sample": f"1 step of oracle.step.CpuTrainer on {n} of the {a.batch} proteins (L={a.length}, same model, "
+                      f"dropout 0, sequential loss, torch threads=1): {dt:.1f} s"}
+
+
+def main():
+    a = parse()
+    from protein_transformer_amd import dp, kernels, synthetic
+    from protein_transformer_amd.models.encoder_only import EncoderOnlyTransformer
+    from protein_transformer_amd.optim import FusedAdam, FusedSGD
+    from protein_transformer_amd.protein.Sequence import VOCAB
+    from protein_transformer_amd.protein.Structure import nerf_forward
+    from protein_transformer_amd.train import train_step
+
+    dp.init_from_env()
+    world, rank = dp.world_size(), dp.rank()
+    if world != a.gpus:
+        sys.exit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    dev = torch.device("cuda", dp.local_rank())
+    torch.cuda.set_device(dev)
+
+    # ---- synthetic, device-resident batches (two per rank, alternated)
+    build = lambda ang, seq: nerf_forward(ang.to(dev), seq.to(dev))[0]            # noqa: E731
+    batches_cpu = [synthetic.make_batch([a.length] * a.batch, seed=synthetic.DEFAULT_SEED + 97 * rank + i,
+                                        build_coords=build) for i in range(2)]
+    angle_means = synthetic.angle_means(batches_cpu[0]["true_ang"])
+    batches = [tuple(b[k].to(dev) for k in ("seq", "true_ang", "true_crd")) for b in batches_cpu]
+    n_res = int((batches[0][0] != 20).sum())
+
+    torch.manual_seed(synthetic.DEFAULT_SEED)
+    model = EncoderOnlyTransformer(a.n_layers, a.n_head, a.d_model, a.d_ff, a.length, VOCAB, angle_means, True,
+                                   dropout=a.dropout).to(dev).train()
+    model.dropout_seed += 7919 * rank
+    dp.attach(model)
+    opt = (FusedAdam(model, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=10e-3) if a.optimizer == "adam"
+           else FusedSGD(model, lr=1e-4, weight_decay=10e-3))
+    args = types.SimpleNamespace(loss=a.loss, combined_drmsd_weight=0.5, backbone_loss=False, clip=1.0)
+
+    def step(i):
+        return train_step(model, opt, args, *batches[i % 2])
+
+    for i in range(a.warmup):
+        losses = step(i)
+    timing = None if a.no_kernel_timing else []
+    dp.barrier()
+    torch.cuda.synchronize()
+    kernels.GEMM_TIMING = timing
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        losses = step(i)
+    dp.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kernels.GEMM_TIMING = None
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t.item())
+
+    roofline = None
+    if timing:
+        flops = sum(f for f, _, _ in timing)
+        ms = sum(e0.elapsed_time(e1) for _, e0, e1 in timing)
+        achieved = flops / (ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "gemm_f32_mfma_kernel (v_mfma_f32_32x32x2_f32)",
+                    "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": len(timing) // a.steps, "avg_launch_us": round(1e3 * ms / len(timing), 2),
+                    "gflop_per_step": round(flops / a.steps / 1e9, 1),
+                    "share_of_step_time": round(ms / (dt * 1e3), 3)}
+
+    if rank == 0:
+        out = {
+            "metric": "train-step residues/sec (enc-only d512, dRMSD loss)",
+            "value": round(world * n_res * a.steps / dt, 1), "unit": "residues/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"enc-only d_model={a.d_model} n_layers={a.n_layers} n_head={a.n_head} "
+                                   f"d_ff={a.d_ff}, -l {a.loss}, {a.optimizer} lr 1e-4 wd 0.01 clip 1, dropout {a.dropout}, "
+                                   f"{a.batch} proteins x L={a.length} per GPU (BASELINE.json configs[3])",
+                       "global_batch": a.batch * world, "seq_len": a.length, "parallelism": f"dp{world}",
+                       "last_loss": {k: float(losses[k]) for k in ("drmsd-full", "lndrmsd-full")}},
+            "roofline": roofline,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a, batches_cpu[0], angle_means)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    dp.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,6 +12,10 @@ from ._lib import GemmArgs, check, lib, ptr, stream, workspace
 
 EPI_RELU, EPI_TANH, EPI_ACCUM = 1, 2, 4
 
+# bench.py sets this to a list to time every GEMM launch with HIP events recorded on the launch stream:
+# entries are (flops, start_event, end_event).  None (the default) adds no work to the hot path.
+GEMM_TIMING = None
+
 
 def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, bias=None, residual=None,
          ldr=0, flags=0, dropout_p=0.0, seed=0, stream_id=0, split_k=1):
@@ -28,7 +32,14 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False,
                     dropout_p=float(dropout_p), seed=int(seed) & (2 ** 64 - 1), stream_id=int(stream_id),
                     split_k=int(split_k), workspace=ws.data_ptr() if ws is not None else None,
                     workspace_bytes=ws.numel() if ws is not None else 0)
-    check(lib().ptamd_gemm(C.byref(args), stream()), "gemm")
+    if GEMM_TIMING is None:
+        check(lib().ptamd_gemm(C.byref(args), stream()), "gemm")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().ptamd_gemm(C.byref(args), stream()), "gemm")
+        e1.record()
+        GEMM_TIMING.append((2.0 * M * N * K, e0, e1))
     return C_out
 
 

@@ -43,18 +43,25 @@ def train_epoch(model, training_data, validation_datasets, optimizer, device, ar
     model.train()
     metrics = reset_metrics_for_epoch(metrics, "train")
     for step, batch in enumerate(training_data):
-        optimizer.zero_grad()
         src_seq, tgt_ang, tgt_crds = map(lambda x: x.to(device, non_blocking=True), batch)
         src_seq, tgt_ang, tgt_crds = dp.shard_batch(src_seq, tgt_ang, tgt_crds)
-        pred = model(src_seq, tgt_ang)
-        losses = get_losses(args, pred, tgt_ang, tgt_crds, src_seq, pool=pool)
-        dp.all_reduce_gradients(model)
-        if args.clip:
-            optimizer.clip_grad_norm_(args.clip)
-        optimizer.step()
+        losses = train_step(model, optimizer, args, src_seq, tgt_ang, tgt_crds, pool=pool)
         metrics = do_train_batch_logging(metrics, losses, src_seq, optimizer, args, log_writer, START_TIME, step)
     metrics = update_metrics_end_of_epoch(metrics, "train")
     return metrics
+
+
+def train_step(model, optimizer, args, src_seq, tgt_ang, tgt_crds, pool=None):
+    """The body of the reference's training loop (train.py:36-46) for one device-resident batch:
+    zero_grad, forward, losses + backward, (gradient all-reduce), clip, optimizer step."""
+    optimizer.zero_grad()
+    pred = model(src_seq, tgt_ang)
+    losses = get_losses(args, pred, tgt_ang, tgt_crds, src_seq, pool=pool)
+    dp.all_reduce_gradients(model)
+    if args.clip:
+        optimizer.clip_grad_norm_(args.clip)
+    optimizer.step()
+    return losses
 
 
 def get_losses(args, pred, tgt_ang, tgt_crds, src_seq, pool=None, log=True, do_backwards=True, return_rmsd=False,
