@@ -124,7 +124,7 @@ def nerf(a, b, c, l, theta, chi):
     Structure.py:23-65.  l may be a Python float (backbone) or an fp32 tensor
     (side chain); theta/chi are fp32 tensors.
     """
-    assert -math.pi <= float(theta) <= math.pi, "theta must be in [-pi, pi]"   # Structure.py:42
+    assert -math.pi <= float(theta.detach() if torch.is_tensor(theta) else theta) <= math.pi, "theta must be in [-pi, pi]"   # Structure.py:42
     w_hat = _unit(b - a)
     x_hat = _unit(c - b)
     n = torch.linalg.cross(w_hat, x_hat)

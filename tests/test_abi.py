@@ -1,0 +1,88 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads, exports every symbol the header
+declares, the ctypes table covers the header, and the product never falls back to a CPU path."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ptamd.h")
+PKG = os.path.join(ROOT, "protein_transformer_amd")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ptamd_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from protein_transformer_amd import _lib, build
+    build.build()                       # hipcc cross-compiles gfx950 without a GPU
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    handle = ctypes.CDLL(built_lib.LIB_PATH)
+    names = declared_functions()
+    assert len(names) >= 30
+    for name in names:
+        assert hasattr(handle, name), f"{name} is declared in include/ptamd.h but not exported by libptamd.so"
+
+
+def test_ctypes_table_matches_header(built_lib):
+    built_lib.lib()
+    assert not built_lib.MISSING
+    assert sorted(built_lib.SIGNATURES) == declared_functions()
+
+
+def test_no_cuda_symbols_or_hipify_shims():
+    out = subprocess.run(["grep", "-rIl", "-E", "cuda_runtime|__HIP_PLATFORM|hipify|triton", os.path.join(PKG, "csrc")],
+                         capture_output=True, text=True).stdout.strip()
+    assert out == "", out
+
+
+def test_host_only_entry_points(built_lib):
+    lib = built_lib.lib()
+    assert lib.ptamd_version().startswith(b"ptamd")
+    assert [lib.ptamd_sidechain_atoms(r) for r in range(20)] == [1, 2, 4, 5, 7, 0, 6, 4, 5, 4, 4, 4, 3, 5, 7, 2, 3, 3, 10, 8]
+    assert lib.ptamd_sidechain_atoms(20) == -1 and lib.ptamd_sidechain_atoms(-1) == -1
+    assert lib.ptamd_nerf_workspace_bytes(32, 512) == 32 * 512 * 12 * 4
+    assert lib.ptamd_drmsd_workspace_bytes(32, 512) > 32 * 512 * 14 * 52
+    assert lib.ptamd_gemm_workspace_bytes(512, 512, 1) == 0
+    assert lib.ptamd_gemm_workspace_bytes(512, 512, 8) == 8 * 512 * 512 * 4
+    # argument validation happens on the host, before any launch
+    assert lib.ptamd_nerf_fwd(None, None, 0, 5, None, None, None) == -1          # PTAMD_ERR_BAD_SHAPE
+    assert lib.ptamd_nerf_fwd(None, None, 2, 5000, None, None, None) == -2       # PTAMD_ERR_TOO_LONG
+    assert lib.ptamd_drmsd_fwd_bwd(None, None, None, 2, 8, None, None, None, 0, None) == -3   # PTAMD_ERR_WORKSPACE
+    assert lib.ptamd_attention_fwd(None, None, 1, 8, 2, 24, 0.0, 0, 0, None, None, None) == -1
+
+
+def test_product_has_no_cpu_fallback(built_lib):
+    from protein_transformer_amd import losses
+    from protein_transformer_amd.models.encoder_only import EncoderOnlyTransformer
+    from protein_transformer_amd.protein.Sequence import VOCAB
+    with pytest.raises(RuntimeError, match="device tensors only"):
+        losses.inverse_trig_transform(torch.zeros(1, 3, 24))
+    with pytest.raises(RuntimeError, match="device tensors only"):
+        losses.drmsd_forward_backward(torch.zeros(1, 28, 3), torch.zeros(1, 28, 3), torch.zeros(1, 2, dtype=torch.int64))
+    m = EncoderOnlyTransformer(1, 4, 32, 64, 16, VOCAB, [0.1] * 24, True)
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        m(torch.zeros(1, 8, dtype=torch.int64))
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    from protein_transformer_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="is missing"):
+        _lib.lib()
+
+
+def test_product_never_imports_the_oracle():
+    hits = subprocess.run(["grep", "-rIn", "-E", r"^\s*(from|import)\s+oracle", PKG], capture_output=True, text=True).stdout
+    assert hits.strip() == "", hits
