@@ -198,17 +198,32 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
     }
   }
 }
-__global__ void layernorm_bwd_reduce_kernel(const float *__restrict__ part, int D, float *__restrict__ dgamma,
-                                            float *__restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= D) return;
+// 1024 partial rows -> [D]: one block per 64 columns, 16 waves each summing 64 rows (coalesced 256 B reads)
+__global__ __launch_bounds__(1024) void layernorm_bwd_reduce_kernel(const float *__restrict__ part, int D,
+                                                                    float *__restrict__ dgamma,
+                                                                    float *__restrict__ dbeta) {
+  __shared__ float s_a[16][64], s_b[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   float a = 0.f, b = 0.f;
-  for (int w = 0; w < LN_BWD_BLOCKS * 4; ++w) {
-    a += part[((size_t)w * 2) * D + c];
-    b += part[((size_t)w * 2 + 1) * D + c];
+  if (c < D)
+    for (int w = wave; w < LN_BWD_BLOCKS * 4; w += 16) {
+      a += part[((size_t)w * 2) * D + c];
+      b += part[((size_t)w * 2 + 1) * D + c];
+    }
+  s_a[wave][lane] = a;
+  s_b[wave][lane] = b;
+  __syncthreads();
+  if (wave == 0 && c < D) {
+    float ta = 0.f, tb = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      ta += s_a[w][lane];
+      tb += s_b[w][lane];
+    }
+    dgamma[c] += ta;
+    dbeta[c] += tb;
   }
-  dgamma[c] += a;
-  dbeta[c] += b;
 }
 
 // ------------------------------------------------------------------------------------------------ column sums
@@ -327,7 +342,7 @@ int ptamd_layernorm_bwd(const float *dy, const float *x, const float *gamma, con
   else hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, block, 0, st, dy, x, gamma, mean, rstd, dres, T, D, dx, part);
   int rc = pt_check_launch();
   if (rc) return rc;
-  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((D + 255) / 256), dim3(256), 0, st, part, D, dgamma, dbeta);
+  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((D + 63) / 64), dim3(1024), 0, st, part, D, dgamma, dbeta);
   return pt_check_launch();
 }
 

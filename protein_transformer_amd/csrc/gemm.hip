@@ -7,13 +7,18 @@
 //   output_projection + tanh  .../models/encoder_only.py:18,39-41
 //   residual + dropout of SublayerConnection  .../models/transformer/Sublayers.py:16-17
 //
-// Tiling (MI355X-first, wave64): block = 128 x 128 outputs, 4 wavefronts in a 2 x 2 grid, each wavefront
+// Tiling (MI355X-first, wave64): workgroup = 128 x 128 outputs, 4 wavefronts in a 2 x 2 grid, each wavefront
 // owns 64 x 64 = 2 x 2 MFMA tiles of 32 x 32 (64 accumulator VGPRs).  K advances 32 per stage through a
-// double-buffered, k-major LDS image [k][row]: a lane's MFMA operand A[i = lane&31][k = lane>>5] is then a
-// conflict-free ds_read_b32 at row stride 1.  The f32 MFMA needs only ONE operand dword per lane per 64
-// cycles, so LDS bandwidth is irrelevant; the kernel is bound by the MFMA issue rate once the global->LDS
-// staging (register double buffering, one barrier per stage) is hidden.
-// Workgroup ids are remapped so that the tiles of one 128-row panel of A run on the same XCD (shared L2).
+// double-buffered LDS image that keeps each operand's OWN contiguity (16-byte global loads -> 16-byte LDS
+// writes, nothing is transposed): K-contiguous operands sit as [row][32+4] and are read back with one
+// conflict-free ds_read_b128 per four MFMA steps, row-contiguous operands sit as [k][128+4] and are read with
+// ds_read_b32.  The f32 MFMA needs ONE operand dword per lane per 64 cycles, so the k index a lane half feeds to
+// MFMA step (m, j) is free to be k = 8m + 4*(lane>>5) + j for both operands.  Workgroups are persistent
+// (2 per CU) and walk (tile, K-split) items; the next item's first stage is prefetched under the current
+// item's last stage and epilogue.  Item ids are remapped so that the tiles of one 128-row panel of A run on the
+// same XCD (shared L2).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -21,8 +26,8 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
-constexpr int LD_T = 129;  // k-major image filled by transposing K-contiguous rows: odd stride, conflict-free
-constexpr int LD_C = 132;  // k-major image filled by straight 16-byte copies
+constexpr int LD_R = 36;   // [row][k] image of a K-contiguous operand: 32 k + 4 pad floats, conflict-free ds_read_b128
+constexpr int LD_C = 132;  // [k][row] image of a row-contiguous operand: straight 16-byte copies, ds_read_b32
 
 struct GemmParams {
   int M, N, K;
@@ -40,23 +45,26 @@ struct GemmParams {
   uint64_t seed;
   uint32_t stream_id;
   int k_per_split;  // multiple of BK
+  int splits;
   size_t slab;      // M*N when split-K writes partial slabs, else 0
 };
 
-// ---- staging: each thread carries 4 float4 per operand per stage
+// ---- staging: each thread carries 4 float4 per operand per stage; global -> registers -> LDS, no transposition:
+//      the LDS image keeps the operand's own contiguity and the MFMA k-assignment adapts instead
+//      (MFMA step (m, j) of a stage uses k = 8m + 4*(lane>>5) + j for BOTH operands).
 template <bool KMAJOR>
-__device__ __forceinline__ void load_stage(const float *__restrict__ src, int ld, int rows, int r0, int K, int k0,
+__device__ __forceinline__ void load_stage(const float *__restrict__ src, int ld, int rows, int r0, int kend, int k0,
                                            int tid, float4 (&v)[4]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    if (!KMAJOR) {  // src[row][k]: 8 lanes cover 32 consecutive k of one row
+    if (!KMAJOR) {  // src[row][k]: 8 lanes cover the 32 k of one row (128 B)
       const int row = r0 + (tid >> 3) + 32 * i, k = k0 + 4 * (tid & 7);
-      v[i] = (row < rows && k < K) ? *reinterpret_cast<const float4 *>(src + (size_t)row * ld + k)
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-    } else {  // src[k][row]: 32 lanes cover 128 consecutive rows of one k
+      v[i] = (row < rows && k < kend) ? *reinterpret_cast<const float4 *>(src + (size_t)row * ld + k)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {  // src[k][row]: 32 lanes cover 128 consecutive rows of one k (512 B)
       const int k = k0 + (tid >> 5) + 8 * i, row = r0 + 4 * (tid & 31);
-      v[i] = (k < K && row < rows) ? *reinterpret_cast<const float4 *>(src + (size_t)k * ld + row)
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[i] = (k < kend && row < rows) ? *reinterpret_cast<const float4 *>(src + (size_t)k * ld + row)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
 }
@@ -66,14 +74,22 @@ __device__ __forceinline__ void store_stage(float *__restrict__ s, int tid, cons
   for (int i = 0; i < 4; ++i) {
     if (!KMAJOR) {
       const int row = (tid >> 3) + 32 * i, k = 4 * (tid & 7);
-      s[(k + 0) * LD_T + row] = v[i].x;
-      s[(k + 1) * LD_T + row] = v[i].y;
-      s[(k + 2) * LD_T + row] = v[i].z;
-      s[(k + 3) * LD_T + row] = v[i].w;
+      *reinterpret_cast<float4 *>(s + row * LD_R + k) = v[i];
     } else {
       const int k = (tid >> 5) + 8 * i, row = 4 * (tid & 31);
       *reinterpret_cast<float4 *>(s + k * LD_C + row) = v[i];
     }
+  }
+}
+// fragment of rows [r0 + l31] for the 4 MFMA steps of k-group m
+template <bool KMAJOR>
+__device__ __forceinline__ void read_frag(const float *__restrict__ s, int r, int lh, int m, float (&f)[4]) {
+  if (!KMAJOR) {
+    const float4 v = *reinterpret_cast<const float4 *>(s + r * LD_R + 8 * m + 4 * lh);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+  } else {
+    const float *q = s + (8 * m + 4 * lh) * LD_C + r;
+    f[0] = q[0]; f[1] = q[LD_C]; f[2] = q[2 * LD_C]; f[3] = q[3 * LD_C];
   }
 }
 
@@ -90,100 +106,176 @@ __device__ __forceinline__ float epilogue_value(float v, int row, int col, const
   return v;
 }
 
+// Persistent workgroups: a launch has min(#work items, 2 per CU) workgroups, each walking work items
+// (output tile x K split) with stride gridDim.x.  The first K stage of the NEXT item is prefetched into
+// registers/LDS before the epilogue of the current one, so the epilogue's stores overlap the next loads and
+// the matrix pipe does not wait for a cold prologue per tile.
 template <bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(NT, 2) void gemm_f32_mfma_kernel(const GemmParams p) {
-  constexpr int LDA = A_KMAJOR ? LD_C : LD_T, LDB = B_KMAJOR ? LD_C : LD_T;
+  constexpr int SA = A_KMAJOR ? BK * LD_C : BM * LD_R, SB = B_KMAJOR ? BK * LD_C : BN * LD_R;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *const sA0 = smem;                 // two stages of A, then two stages of B
-  float *const sB0 = smem + 2 * BK * LDA;
+  float *const sA0 = smem;  // two stages of A, then two stages of B
+  float *const sB0 = smem + 2 * SA;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
-
-  // XCD-aware, bijective remap of the linear workgroup id: consecutive logical tiles (which share the same
-  // A row panel) land on the same XCD because the dispatcher round-robins workgroup b to XCD b % 8.
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-  const int nwg = tiles_m * tiles_n;
-  int logical;
-  {
-    const int id = blockIdx.x, xcd = id & 7, q = nwg >> 3, r = nwg & 7;
-    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-  }
-  const int bm0 = (logical / tiles_n) * BM, bn0 = (logical % tiles_n) * BN;
-  const int kbeg = blockIdx.z * p.k_per_split, kend = min(p.K, kbeg + p.k_per_split);
+  const int nwork = tiles_m * tiles_n * p.splits;
 
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // XCD-aware, bijective remap: workgroup b runs on XCD b % 8; consecutive logical items (same A row panel,
+  // neighbouring N tiles / K splits) are given to the same XCD so that they share its L2.
+  auto decode = [&](int w, int &bm0, int &bn0, int &z) {
+    const int xcd = w & 7, q = nwork >> 3, r = nwork & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
+    const int tile = logical / p.splits;
+    z = logical - tile * p.splits;
+    bm0 = (tile / tiles_n) * BM;
+    bn0 = (tile % tiles_n) * BN;
+  };
 
   float4 ra[4], rb[4];
+  int w = blockIdx.x, bm0, bn0, z;
+  if (w >= nwork) return;
+  decode(w, bm0, bn0, z);
+  int kbeg = z * p.k_per_split, kend = min(p.K, kbeg + p.k_per_split);
   load_stage<A_KMAJOR>(p.A, p.lda, p.M, bm0, kend, kbeg, tid, ra);
   load_stage<B_KMAJOR>(p.B, p.ldb, p.N, bn0, kend, kbeg, tid, rb);
   store_stage<A_KMAJOR>(sA0, tid, ra);
   store_stage<B_KMAJOR>(sB0, tid, rb);
   __syncthreads();
-
   int cur = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    const bool more = k0 + BK < kend;
-    if (more) {  // next stage's global loads fly under this stage's MFMAs
-      load_stage<A_KMAJOR>(p.A, p.lda, p.M, bm0, kend, k0 + BK, tid, ra);
-      load_stage<B_KMAJOR>(p.B, p.ldb, p.N, bn0, kend, k0 + BK, tid, rb);
-    }
-    const float *a_base = sA0 + cur * (BK * LDA) + lh * LDA + wm * 64 + l31;
-    const float *b_base = sB0 + cur * (BK * LDB) + lh * LDB + wn * 64 + l31;
-#pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      const float a0 = a_base[(2 * kk) * LDA], a1 = a_base[(2 * kk) * LDA + 32];
-      const float b0 = b_base[(2 * kk) * LDB], b1 = b_base[(2 * kk) * LDB + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
-    if (more) {
-      store_stage<A_KMAJOR>(sA0 + (cur ^ 1) * (BK * LDA), tid, ra);
-      store_stage<B_KMAJOR>(sB0 + (cur ^ 1) * (BK * LDB), tid, rb);
-    }
-    __syncthreads();
-    cur ^= 1;
-  }
 
-  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const bool partial = p.slab != 0;
-  float *C = p.C + (partial ? (size_t)blockIdx.z * p.slab : 0);
   const uint32_t thr = dropout_threshold(p.dropout_p);
   const float keep_scale = 1.f / (1.f - p.dropout_p);
+
+  while (true) {
+    f32x16 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = bn0 + wn * 64 + j * 32 + l31;
-      if (col >= p.N) continue;
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int rowq = bm0 + wm * 64 + i * 32 + 8 * g + 4 * lh;  // 4 consecutive rows share one Philox call
-        uint4 rnd = make_uint4(0, 0, 0, 0);
-        if (!partial && p.dropout_p > 0.f) rnd = philox4x32(p.seed, (uint64_t)(rowq >> 2) * p.N + col, p.stream_id);
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wn_next = w + gridDim.x;
+    int nbm0 = 0, nbn0 = 0, nz = 0, nkbeg = 0, nkend = 0;
+    const bool has_next = wn_next < nwork;
+    if (has_next) {
+      decode(wn_next, nbm0, nbn0, nz);
+      nkbeg = nz * p.k_per_split;
+      nkend = min(p.K, nkbeg + p.k_per_split);
+    }
+
+    // Software pipeline over k-groups of 8 (16 MFMAs per wavefront): the fragments of group g+1 are read from
+    // LDS while the MFMAs of group g execute; the next stage is written to the other LDS buffer after group 1
+    // (its global loads were issued at the top of the stage); the ONE barrier of the stage sits before the
+    // MFMAs of the last group, whose operands are already in registers, so those 16 MFMAs (1024 cycles) cover
+    // the barrier skew and the LDS latency of the next stage's first fragments.
+    const int ar = wm * 64 + l31, br = wn * 64 + l31;
+    float a0[4], a1[4], b0[4], b1[4];
+    {
+      const float *sa = sA0 + cur * SA, *sb = sB0 + cur * SB;
+      read_frag<A_KMAJOR>(sa, ar, lh, 0, a0);
+      read_frag<A_KMAJOR>(sa, ar + 32, lh, 0, a1);
+      read_frag<B_KMAJOR>(sb, br, lh, 0, b0);
+      read_frag<B_KMAJOR>(sb, br + 32, lh, 0, b1);
+    }
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      const bool more = k0 + BK < kend;
+      const bool fetch = more || has_next;
+      if (more) {  // next stage of this item
+        load_stage<A_KMAJOR>(p.A, p.lda, p.M, bm0, kend, k0 + BK, tid, ra);
+        load_stage<B_KMAJOR>(p.B, p.ldb, p.N, bn0, kend, k0 + BK, tid, rb);
+      } else if (has_next) {  // first stage of the next item: flies under this item's last stage + epilogue
+        load_stage<A_KMAJOR>(p.A, p.lda, p.M, nbm0, nkend, nkbeg, tid, ra);
+        load_stage<B_KMAJOR>(p.B, p.ldb, p.N, nbn0, nkend, nkbeg, tid, rb);
+      }
+      const float *sa = sA0 + cur * SA, *sb = sB0 + cur * SB;
+      const float *na = sA0 + (cur ^ 1) * SA, *nb = sB0 + (cur ^ 1) * SB;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int row = rowq + e;
-          if (row >= p.M) continue;
-          float v = acc[i][j][g * 4 + e];
-          if (!partial) {
-            v = epilogue_value(v, row, col, p, thr, keep_scale, rnd);
-            if (p.flags & PTAMD_EPI_ACCUM) v += C[(size_t)row * p.ldc + col];
-            C[(size_t)row * p.ldc + col] = v;
-          } else {
-            C[(size_t)row * p.N + col] = v;
+      for (int m = 0; m < 4; ++m) {
+        float c0[4], c1[4], d0[4], d1[4];
+        if (m < 3) {
+          read_frag<A_KMAJOR>(sa, ar, lh, m + 1, c0);
+          read_frag<A_KMAJOR>(sa, ar + 32, lh, m + 1, c1);
+          read_frag<B_KMAJOR>(sb, br, lh, m + 1, d0);
+          read_frag<B_KMAJOR>(sb, br + 32, lh, m + 1, d1);
+        } else {
+          __syncthreads();  // next buffer fully written by every wave; nobody reads `cur` any more
+          if (fetch) {
+            read_frag<A_KMAJOR>(na, ar, lh, 0, c0);
+            read_frag<A_KMAJOR>(na, ar + 32, lh, 0, c1);
+            read_frag<B_KMAJOR>(nb, br, lh, 0, d0);
+            read_frag<B_KMAJOR>(nb, br + 32, lh, 0, d1);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+        }
+        if (m == 1 && fetch) {
+          store_stage<A_KMAJOR>(sA0 + (cur ^ 1) * SA, tid, ra);
+          store_stage<B_KMAJOR>(sB0 + (cur ^ 1) * SB, tid, rb);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          a0[j] = c0[j]; a1[j] = c1[j]; b0[j] = d0[j]; b1[j] = d1[j];
+        }
+      }
+      cur ^= 1;
+    }
+
+    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+    // Per 32x32 tile: the bias (one column per lane) is loaded once and the 16 residual / accumulate operands
+    // are fetched as 16 independent loads BEFORE any arithmetic, so the epilogue pays one memory latency per
+    // tile instead of one per element.
+    float *C = p.C + (partial ? (size_t)z * p.slab : 0);
+    const int ldc = partial ? p.N : p.ldc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = bn0 + wn * 64 + j * 32 + l31;
+        const bool col_ok = col < p.N;
+        const int row_base = bm0 + wm * 64 + i * 32 + 4 * lh;
+        const float bias = (!partial && p.bias && col_ok) ? p.bias[col] : 0.f;
+        float res[16], old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row_base + (r & 3) + 8 * (r >> 2);
+          const bool ok = col_ok && row < p.M;
+          res[r] = (!partial && p.residual && ok) ? p.residual[(size_t)row * p.ldr + col] : 0.f;
+          old[r] = (!partial && (p.flags & PTAMD_EPI_ACCUM) && ok) ? C[(size_t)row * ldc + col] : 0.f;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int rowq = row_base + 8 * g;  // 4 consecutive rows share one Philox call
+          uint4 rnd = make_uint4(0, 0, 0, 0);
+          if (!partial && p.dropout_p > 0.f) rnd = philox4x32(p.seed, (uint64_t)(rowq >> 2) * p.N + col, p.stream_id);
+          const uint32_t rw[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int row = rowq + e, r = g * 4 + e;
+            float v = acc[i][j][r];
+            if (!partial) {
+              v += bias;
+              if (p.flags & PTAMD_EPI_RELU) v = fmaxf(v, 0.f);
+              if (p.dropout_p > 0.f) v = rw[e] >= thr ? v * keep_scale : 0.f;
+              v += res[r];
+              if (p.flags & PTAMD_EPI_TANH) v = tanhf(v);
+              v += old[r];
+            }
+            if (col_ok && row < p.M) C[(size_t)row * ldc + col] = v;
           }
         }
       }
-    }
+    if (!has_next) break;
+    w = wn_next; bm0 = nbm0; bn0 = nbn0; z = nz; kbeg = nkbeg; kend = nkend;
+  }
 }
 
 // split-K: sum the slabs in a fixed order, then the same epilogue
@@ -206,11 +298,25 @@ __global__ void gemm_splitk_reduce_kernel(const GemmParams p, const float *__res
   }
 }
 
+int persistent_grid() {
+  static int slots = 0;
+  if (!slots) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    }
+    slots = 2 * cus;  // 2 workgroups (73.7 KB of LDS each) per CU
+    if (const char *e = getenv("PTAMD_GEMM_WG_PER_CU")) slots = atoi(e) > 0 ? atoi(e) * cus : slots;  // tuning knob
+  }
+  return slots;
+}
+
 template <bool AK, bool BK_>
 int launch(const GemmParams &p, int splits, hipStream_t st) {
-  constexpr int LDA = AK ? LD_C : LD_T, LDB = BK_ ? LD_C : LD_T;
-  const size_t lds = (size_t)2 * BK * (LDA + LDB) * sizeof(float);
-  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  constexpr int SA = AK ? BK * LD_C : BM * LD_R, SB = BK_ ? BK * LD_C : BN * LD_R;
+  const size_t lds = (size_t)2 * (SA + SB) * sizeof(float);
+  const int work = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * splits;
   auto kern = gemm_f32_mfma_kernel<AK, BK_>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -218,7 +324,8 @@ int launch(const GemmParams &p, int splits, hipStream_t st) {
                                    (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(NT), lds, st, p);
+  const int grid = work < persistent_grid() ? work : persistent_grid();
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, p);
   return pt_check_launch();
 }
 
@@ -248,6 +355,7 @@ int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
   p.dropout_p = a->dropout_p; p.seed = a->seed; p.stream_id = a->stream_id;
   p.k_per_split = ((kblocks + splits - 1) / splits) * BK;
   splits = (a->K + p.k_per_split - 1) / p.k_per_split;
+  p.splits = splits;
   p.slab = 0;
   float *user_c = a->C;
   if (splits > 1) {
