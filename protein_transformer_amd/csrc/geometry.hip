@@ -9,9 +9,10 @@
 // and the autograd graph the reference builds over them (losses.py:91-92).
 //
 // Structure of the work (one protein = one dependent chain of 3L backbone placements):
-//   nerf_backbone_*  one wavefront per protein; all lanes stage sin/cos (and, backward, coordinates and
-//                    incoming adjoints) into LDS in parallel, then lane 0 walks the chain out of LDS with
-//                    the next residue's operands prefetched.  Latency-bound by construction.
+//   nerf_backbone_fwd  one wavefront per protein: the chain is a product of rigid transforms, evaluated as a
+//                      parallel prefix scan (chunk per lane + 6 shuffle steps) instead of a 3L-step walk.
+//   nerf_backbone_bwd  one wavefront per protein: gradients of all bond / torsion angles from suffix sums of
+//                      force and torque over the chain atoms (fp64 accumulators), again chunk + wave scan.
 //   nerf_sidechain_* one lane per residue: O plus up to 10 table-driven side-chain placements, per-lane
 //                    atom arrays live in LDS ([slot][xyz][lane], conflict-free) because parent slots are
 //                    data dependent.
@@ -22,7 +23,7 @@ namespace {
 
 constexpr float BL_N_CA = 1.442f, BL_CA_C = 1.498f, BL_C_N = 1.379f, BL_C_O = 1.229f, BA_CA_C_O = 2.0944f;
 constexpr float PI_F = 3.141592653589793f;
-constexpr int MAX_L_CHAIN = 1024;  // LDS staging: 144 B per residue in the backward walk
+constexpr int MAX_L_CHAIN = 2048;  // trig cache of the forward scan: 48 B of LDS per residue
 
 struct V3 {
   float x, y, z;
@@ -131,12 +132,75 @@ __global__ void angles_bwd_kernel(const float2 *__restrict__ sc, const float *__
 }
 
 // ------------------------------------------------------------------------------------------------
-// backbone chain, forward.  grid = B, block = 64.  LDS: trig[L][12] = (sin,cos) of angle columns 0..5
+// Backbone chain, forward, as a PARALLEL SCAN over rigid transforms.
+//
+// Placement k = 3i + a (a = 0: N_i, 1: CA_i, 2: C_i; i >= 1) builds P_k from (P_{k-3}, P_{k-2}, P_{k-1}) with
+// the frame M_k = [x y z] of Structure.py:44-59.  In exact arithmetic the next frame is M_{k+1} = M_k R_k and
+// P_k = P_{k-1} + M_k t_k, with R_k, t_k functions of (l_k, theta_k, chi_k) only:
+//     x' = (-cos th, sin th cos chi, sin th sin chi)      (new bond direction in the old frame; t_k = l_k x')
+//     z' = s (0, -sin chi, cos chi),  s = sign(sin th)    (normal of the plane b, c, d)
+//     y' = z' x x' = s (-sin th, -cos th cos chi, -cos th sin chi)
+// so the chain is a product of 4x4 affine matrices [[R_k, t_k], [0, 1]], which is associative: every lane
+// composes a contiguous chunk of placements, one wave-wide Hillis-Steele scan (6 shuffle steps) combines the 64
+// chunk products, and every lane re-walks its chunk from its prefix.  3L = 1536 dependent placements become
+// ~2 * 24 + 6 dependent compositions.  The rounding differs from the reference's step-by-step fp32 walk (which
+// itself drifts by up to 6e-3 A at L = 512 against fp64); it is covered by the stated coordinate tolerance.
+struct Xf {
+  float r[9];  // rotation, row-major: r[3 * row + col], columns = new x, y, z axes
+  float t[3];
+};
+__device__ __forceinline__ Xf xf_identity() {
+  Xf x;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) x.r[i] = (i % 4 == 0) ? 1.f : 0.f;
+  x.t[0] = x.t[1] = x.t[2] = 0.f;
+  return x;
+}
+// a then b (b expressed in a's frame): R = Ra Rb, t = Ra tb + ta
+__device__ __forceinline__ Xf xf_mul(const Xf &a, const Xf &b) {
+  Xf o;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      o.r[3 * i + j] = a.r[3 * i] * b.r[j] + a.r[3 * i + 1] * b.r[3 + j] + a.r[3 * i + 2] * b.r[6 + j];
+    o.t[i] = a.r[3 * i] * b.t[0] + a.r[3 * i + 1] * b.t[1] + a.r[3 * i + 2] * b.t[2] + a.t[i];
+  }
+  return o;
+}
+__device__ __forceinline__ Xf xf_shfl_up(const Xf &x, int d) {
+  Xf o;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) o.r[i] = __shfl_up(x.r[i], d, 64);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) o.t[i] = __shfl_up(x.t[i], d, 64);
+  return o;
+}
+__device__ __forceinline__ Xf xf_local(float l, float st, float ct, float sx, float cx) {
+  const float s = st < 0.f ? -1.f : 1.f;
+  Xf x;
+  x.r[0] = -ct;      x.r[1] = -s * st;      x.r[2] = 0.f;
+  x.r[3] = st * cx;  x.r[4] = -s * ct * cx; x.r[5] = -s * sx;
+  x.r[6] = st * sx;  x.r[7] = -s * ct * sx; x.r[8] = s * cx;
+  x.t[0] = l * x.r[0]; x.t[1] = l * x.r[3]; x.t[2] = l * x.r[6];
+  return x;
+}
+// (bond length, theta column, chi column, residue offset) of placement p = k - 3
+__device__ __forceinline__ void placement_params(int p, int &res, int &col_th, int &col_chi, float &l, int &slot) {
+  const int i = 1 + p / 3, a = p - (i - 1) * 3;
+  slot = a;
+  if (a == 0) { res = i - 1; col_th = 4; col_chi = 1; l = BL_C_N; }
+  else if (a == 1) { res = i - 1; col_th = 5; col_chi = 2; l = BL_N_CA; }
+  else { res = i; col_th = 3; col_chi = 0; l = BL_CA_C; }
+}
+
+// grid = B, block = 64 (one wavefront per protein). dynamic LDS: chunk * 64 float4 of cached (sin th, cos th, sin chi, cos chi)
 __global__ __launch_bounds__(PT_WAVE) void nerf_backbone_fwd_kernel(const float *__restrict__ ang,
                                                                     const int64_t *__restrict__ seq, int L,
                                                                     float *__restrict__ crd,
                                                                     int32_t *__restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  float4 *trig = reinterpret_cast<float4 *>(lds);
   const int b = blockIdx.x, lane = threadIdx.x;
   ang += (size_t)b * L * 12;
   seq += (size_t)b * L;
@@ -146,56 +210,73 @@ __global__ __launch_bounds__(PT_WAVE) void nerf_backbone_fwd_kernel(const float 
     if (lane == 0) atomicOr(status, PTAMD_ST_TOO_SHORT);
     return;  // the side-chain kernel zero-fills
   }
+  const int K = 3 * (len - 1), chunk = (K + PT_WAVE - 1) / PT_WAVE;
+  const int p0 = lane * chunk, p1 = min(K, p0 + chunk);
+
+  // pass 1: local transforms of my chunk, composed in order
+  Xf q = xf_identity();
   int bad_theta = 0;
-  for (int t = lane; t < len * 6; t += PT_WAVE) {
-    int i = t / 6, k = t - i * 6;
-    float a = ang[i * 12 + k], s, c;
-    sincosf(a, &s, &c);
-    lds[i * 12 + 2 * k] = s;
-    lds[i * 12 + 2 * k + 1] = c;
-    if (k >= 3 && !(fabsf(a) <= PI_F)) bad_theta = 1;  // fp32 pi itself is accepted
+  for (int p = p0; p < p1; ++p) {
+    int res, cth, cchi, slot;
+    float l;
+    placement_params(p, res, cth, cchi, l, slot);
+    const float th = ang[res * 12 + cth], chi = ang[res * 12 + cchi];
+    float st, ct, sx, cx;
+    sincosf(th, &st, &ct);
+    sincosf(chi, &sx, &cx);
+    if (!(fabsf(th) <= PI_F)) bad_theta = 1;  // fp32 pi itself is accepted
+    trig[(p - p0) * PT_WAVE + lane] = make_float4(st, ct, sx, cx);
+    q = xf_mul(q, xf_local(l, st, ct, sx, cx));
+  }
+  {
+    const float a03 = ang[3];
+    if (!(fabsf(a03) <= PI_F)) bad_theta = 1;
   }
   if (__any(bad_theta) && lane == 0) atomicOr(status, PTAMD_ST_BAD_THETA);
-  __syncthreads();
-  if (lane != 0) return;
 
-  // init_bb (StructureBuilder.py:181-191)
-  V3 pN = {0.f, 0.f, 0.001f};
-  V3 pCA = {pN.x + BL_N_CA, pN.y + 0.f, pN.z + 0.f};
-  float a03 = ang[3];
-  V3 pC = {pCA.x + cosf(PI_F - a03) * BL_CA_C, pCA.y + sinf(PI_F - a03) * BL_CA_C, pCA.z + 0.f};
-  st3(crd + 0, pN);
-  st3(crd + 3, pCA);
-  st3(crd + 6, pC);
-  float nrm;
-  V3 W = unit(pCA - pN, nrm);  // x_hat of the (virtual) CA placement = W_hat for the next C-type placement
-  V3 Wn = unit(pC - pCA, nrm);
-  // W for N_1 is unit(CA_0 - N_0); after each placement the new x_hat becomes the W of the next one.
-  const float4 *tr = reinterpret_cast<const float4 *>(lds);
-  float4 p0 = tr[0], p1 = tr[1], p2 = tr[2];  // residue i-1: (s0,c0,s1,c1) (s2,c2,s3,c3) (s4,c4,s5,c5)
-  for (int i = 1; i < len; ++i) {
-    float4 q0 = tr[i * 3], q1 = tr[i * 3 + 1], q2 = tr[i * 3 + 2];
-    V3 xo;
-    // N_i = nerf(N_{i-1}, CA_{i-1}, C_{i-1}; c-n, theta = prev[4], chi = prev[1])
-    V3 N = place_with_w(W, pCA, pC, BL_C_N, p2.x, p2.y, p0.z, p0.w, xo);
-    // CA_i = nerf(CA_{i-1}, C_{i-1}, N_i; n-ca, theta = prev[5], chi = prev[2])
-    V3 Wca = xo;  // = unit(C_{i-1} - CA_{i-1}) recomputed inside the call above as x_hat
-    V3 xo2;
-    V3 CA = place_with_w(Wca, pC, N, BL_N_CA, p2.z, p2.w, p1.x, p1.y, xo2);
-    // C_i = nerf(C_{i-1}, N_i, CA_i; ca-c, theta = cur[3], chi = cur[0])
-    V3 xo3;
-    V3 C = place_with_w(xo2, N, CA, BL_CA_C, q1.z, q1.w, q0.x, q0.y, xo3);
-    st3(crd + i * 42 + 0, N);
-    st3(crd + i * 42 + 3, CA);
-    st3(crd + i * 42 + 6, C);
-    W = xo3;  // unit(CA_i - N_i): W_hat of N_{i+1}
-    pN = N;
-    pCA = CA;
-    pC = C;
-    p0 = q0;
-    p1 = q1;
-    p2 = q2;
-    (void)Wn;
+  // wave-wide inclusive scan of the chunk products, then shift to an exclusive prefix
+#pragma unroll
+  for (int d = 1; d < PT_WAVE; d <<= 1) {
+    const Xf o = xf_shfl_up(q, d);
+    if (lane >= d) q = xf_mul(o, q);
+  }
+  Xf ex = xf_shfl_up(q, 1);
+  if (lane == 0) ex = xf_identity();
+
+  // init_bb (StructureBuilder.py:181-191) and the frame of the first placement (N_1 from N_0, CA_0, C_0)
+  const V3 pN = {0.f, 0.f, 0.001f};
+  const V3 pCA = {pN.x + BL_N_CA, pN.y + 0.f, pN.z + 0.f};
+  const float a03 = ang[3];
+  const V3 pC = {pCA.x + cosf(PI_F - a03) * BL_CA_C, pCA.y + sinf(PI_F - a03) * BL_CA_C, pCA.z + 0.f};
+  Xf g;
+  {
+    float n0, n1, n2;
+    const V3 W = unit(pCA - pN, n0), x = unit(pC - pCA, n1);
+    const V3 z = unit(cross(W, x), n2), y = cross(z, x);
+    g.r[0] = x.x; g.r[1] = y.x; g.r[2] = z.x;
+    g.r[3] = x.y; g.r[4] = y.y; g.r[5] = z.y;
+    g.r[6] = x.z; g.r[7] = y.z; g.r[8] = z.z;
+    g.t[0] = pC.x; g.t[1] = pC.y; g.t[2] = pC.z;
+  }
+  if (lane == 0) {
+    st3(crd + 0, pN);
+    st3(crd + 3, pCA);
+    st3(crd + 6, pC);
+  }
+  g = xf_mul(g, ex);
+
+  // pass 2: walk my chunk from its prefix, emitting the atoms
+  for (int p = p0; p < p1; ++p) {
+    int res, cth, cchi, slot;
+    float l;
+    placement_params(p, res, cth, cchi, l, slot);
+    const float4 tr = trig[(p - p0) * PT_WAVE + lane];
+    g = xf_mul(g, xf_local(l, tr.x, tr.y, tr.z, tr.w));
+    const int i = 1 + p / 3;
+    float *o = crd + (size_t)i * 42 + slot * 3;
+    o[0] = g.t[0];
+    o[1] = g.t[1];
+    o[2] = g.t[2];
   }
 }
 
@@ -388,13 +469,32 @@ __global__ __launch_bounds__(SC_BLOCK) void nerf_sidechain_bwd_kernel(const floa
 }
 
 // ------------------------------------------------------------------------------------------------
-// backbone chain, adjoint.  grid = B, block = 64.  LDS per residue: 3 float4 trig | 3 float4 coords | 3 float4 adj
+// Backbone chain, adjoint, as SUFFIX SUMS of force and torque.
+//
+// With the side chains and O already folded onto the backbone atoms (gbb), let g_j = dL/dP_j for the 3*len chain
+// atoms.  Changing chi_k (theta_k) rotates every atom placed at or after k rigidly about the axis x_k (a_k)
+// through c_k = P_{k-1}, where x_k is the b->c bond direction and a_k = sin(chi) y_k - cos(chi) z_k is the
+// normal of the plane (b, c, d).  Hence, with F_k = sum_{j>=k} g_j and T_k = sum_{j>=k} P_j x g_j,
+//     dL/dchi_k = x_k . (T_k - c_k x F_k)        dL/dtheta_k = a_k . (T_k - c_k x F_k).
+// F and T are plain running sums: each lane reduces a contiguous chunk (fp64), one wave-wide suffix scan joins
+// the chunks, each lane walks its chunk backwards.  This is the exact derivative of the same chain function the
+// reference differentiates with autograd; the graph quirks come for free: P_0..P_2 are constants (first C is
+// detached, StructureBuilder.py:185-187), so only placements k >= 3 receive gradients, and the last residue's
+// omega / CA-C-N / C-N-CA have nothing downstream.
+__device__ __forceinline__ void chain_atom(const float *__restrict__ crd, const float *__restrict__ gbb, int len, int j,
+                                           V3 &P, V3 &g) {
+  const int i = j / 3, a = j - 3 * i;
+  P = ld3(crd + (size_t)i * 42 + a * 3);
+  g = ld3(gbb + (size_t)i * 12 + a * 3);
+  if (a == 2 && i + 1 < len) g = g + ld3(gbb + (size_t)(i + 1) * 12 + 9);  // CB of residue i+1 hangs off C_i
+  if (j == 3) g = g + ld3(gbb + 9);                                        // CB of residue 0 hangs off N_1
+}
+
 __global__ __launch_bounds__(PT_WAVE) void nerf_backbone_bwd_kernel(const float *__restrict__ ang,
                                                                     const int64_t *__restrict__ seq,
                                                                     const float *__restrict__ crd,
                                                                     const float *__restrict__ gbb, int L,
                                                                     float *__restrict__ dang) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int b = blockIdx.x, lane = threadIdx.x;
   ang += (size_t)b * L * 12;
   seq += (size_t)b * L;
@@ -404,58 +504,66 @@ __global__ __launch_bounds__(PT_WAVE) void nerf_backbone_bwd_kernel(const float 
   int32_t dummy = 0;
   const int len = protein_len(seq, L, lane, &dummy);
   if (len < 2) return;
-  float *trig = lds, *xyz = lds + (size_t)len * 12, *adj = lds + (size_t)len * 24;
-  for (int t = lane; t < len * 6; t += PT_WAVE) {
-    int i = t / 6, k = t - i * 6;
-    float s, c;
-    sincosf(ang[i * 12 + k], &s, &c);
-    trig[i * 12 + 2 * k] = s;
-    trig[i * 12 + 2 * k + 1] = c;
-  }
-  for (int t = lane; t < len * 9; t += PT_WAVE) {
-    int i = t / 9, k = t - i * 9;
-    xyz[i * 12 + k] = crd[i * 42 + k];
-  }
-  // d/dpsi_i from O_i, written by the side-chain kernel: staged so the serial walk never waits on HBM
-  for (int t = lane; t < len; t += PT_WAVE) xyz[t * 12 + 9] = dang[t * 12 + 1];
-  for (int t = lane; t < len * 12; t += PT_WAVE) adj[t] = gbb[t];
-  __syncthreads();
-  if (lane != 0) return;
+  const int n = 3 * len, chunk = (n + PT_WAVE - 1) / PT_WAVE;
+  const int j0 = lane * chunk, j1 = min(n, j0 + chunk);
 
-  auto V = [](const float *p) { return V3{p[0], p[1], p[2]}; };
-  const float *G = adj;
-  // window: cur = residue i, prv = residue i-1
-  int i = len - 1;
-  V3 cN = V(G + i * 12), cCA = V(G + i * 12 + 3), cC = V(G + i * 12 + 6);
-  for (; i >= 1; --i) {
-    V3 pN = V(G + (i - 1) * 12), pCA = V(G + (i - 1) * 12 + 3), pC = V(G + (i - 1) * 12 + 6);
-    pC = pC + V(G + i * 12 + 9);                 // CB of residue i hangs off C_{i-1}
-    if (i == 1) cN = cN + V(G + 0 * 12 + 9);     // CB of residue 0 hangs off N_1
-    const float *tq = trig + i * 12, *tp = trig + (i - 1) * 12;
-    V3 xN = V(xyz + i * 12), xCA = V(xyz + i * 12 + 3);
-    V3 yN = V(xyz + (i - 1) * 12), yCA = V(xyz + (i - 1) * 12 + 3), yC = V(xyz + (i - 1) * 12 + 6);
-    float gth, gchi;
-    // C_i = nerf(C_{i-1}, N_i, CA_i; theta = ang[i][3], chi = ang[i][0])
-    gth = gchi = 0.f;
-    place_bwd(yC, xN, xCA, BL_CA_C, tq[6], tq[7], tq[0], tq[1], cC, pC, cN, cCA, gth, gchi);
-    dang[i * 12 + 3] = gth;
-    dang[i * 12 + 0] = gchi;
-    // CA_i = nerf(CA_{i-1}, C_{i-1}, N_i; theta = ang[i-1][5], chi = ang[i-1][2])
-    gth = gchi = 0.f;
-    place_bwd(yCA, yC, xN, BL_N_CA, tp[10], tp[11], tp[4], tp[5], cCA, pCA, pC, cN, gth, gchi);
-    dang[(i - 1) * 12 + 5] = gth;
-    dang[(i - 1) * 12 + 2] = gchi;
-    // N_i = nerf(N_{i-1}, CA_{i-1}, C_{i-1}; theta = ang[i-1][4], chi = ang[i-1][1])
-    gth = gchi = 0.f;
-    place_bwd(yN, yCA, yC, BL_C_N, tp[8], tp[9], tp[2], tp[3], cN, pN, pCA, pC, gth, gchi);
-    dang[(i - 1) * 12 + 4] = gth;
-    dang[(i - 1) * 12 + 1] = xyz[(i - 1) * 12 + 9] + gchi;  // psi_{i-1} also placed O_{i-1}
-    cN = pN;
-    cCA = pCA;
-    cC = pC;
+  double F[3] = {0, 0, 0}, T[3] = {0, 0, 0};
+  for (int j = j0; j < j1; ++j) {
+    V3 P, g;
+    chain_atom(crd, gbb, len, j, P, g);
+    F[0] += g.x; F[1] += g.y; F[2] += g.z;
+    T[0] += (double)P.y * g.z - (double)P.z * g.y;
+    T[1] += (double)P.z * g.x - (double)P.x * g.z;
+    T[2] += (double)P.x * g.y - (double)P.y * g.x;
   }
-  // residue 0: N, CA are constants and C is detached from the graph (StructureBuilder.py:185-187):
-  // the adjoints left in (cN, cCA, cC) are dropped, ang[0][3] and ang[0][0] get no gradient.
+  // inclusive suffix scan over lanes, then shift: (F, T) = contribution of all LATER lanes
+#pragma unroll
+  for (int d = 1; d < PT_WAVE; d <<= 1) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double of = __shfl_down(F[c], d, 64), ot = __shfl_down(T[c], d, 64);
+      if (lane + d < PT_WAVE) {
+        F[c] += of;
+        T[c] += ot;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const double of = __shfl_down(F[c], 1, 64), ot = __shfl_down(T[c], 1, 64);
+    F[c] = lane + 1 < PT_WAVE ? of : 0.0;
+    T[c] = lane + 1 < PT_WAVE ? ot : 0.0;
+  }
+  for (int j = j1 - 1; j >= j0; --j) {
+    V3 P, g;
+    chain_atom(crd, gbb, len, j, P, g);
+    F[0] += g.x; F[1] += g.y; F[2] += g.z;
+    T[0] += (double)P.y * g.z - (double)P.z * g.y;
+    T[1] += (double)P.z * g.x - (double)P.x * g.z;
+    T[2] += (double)P.x * g.y - (double)P.y * g.x;
+    if (j < 3) continue;
+    int res, cth, cchi, slot;
+    float l;
+    placement_params(j - 3, res, cth, cchi, l, slot);
+    const int ia = (j - 3) / 3, ib = (j - 2) / 3, ic = (j - 1) / 3;
+    const V3 pa = ld3(crd + (size_t)ia * 42 + ((j - 3) - 3 * ia) * 3);
+    const V3 pb = ld3(crd + (size_t)ib * 42 + ((j - 2) - 3 * ib) * 3);
+    const V3 pc = ld3(crd + (size_t)ic * 42 + ((j - 1) - 3 * ic) * 3);
+    float n0, n1, n2;
+    const V3 W = unit(pb - pa, n0), x = unit(pc - pb, n1);
+    const V3 z = unit(cross(W, x), n2), y = cross(z, x);
+    float sx, cx;
+    sincosf(ang[res * 12 + cchi], &sx, &cx);
+    const V3 ax = {sx * y.x - cx * z.x, sx * y.y - cx * z.y, sx * y.z - cx * z.z};
+    const double tq0 = T[0] - ((double)pc.y * F[2] - (double)pc.z * F[1]);
+    const double tq1 = T[1] - ((double)pc.z * F[0] - (double)pc.x * F[2]);
+    const double tq2 = T[2] - ((double)pc.x * F[1] - (double)pc.y * F[0]);
+    const float dchi = (float)(x.x * tq0 + x.y * tq1 + x.z * tq2);
+    const float dth = (float)(ax.x * tq0 + ax.y * tq1 + ax.z * tq2);
+    dang[res * 12 + cth] = dth;
+    if (cchi == 1) dang[res * 12 + 1] += dchi;  // psi also placed O (the side-chain kernel wrote that part)
+    else dang[res * 12 + cchi] = dchi;
+  }
 }
 
 }  // namespace
@@ -486,7 +594,7 @@ size_t ptamd_nerf_workspace_bytes(int B, int L) { return (size_t)(B > 0 ? B : 0)
 int ptamd_nerf_fwd(const float *ang, const int64_t *seq, int B, int L, float *crd, int32_t *status, void *stream) {
   if (B <= 0 || L <= 0) return PTAMD_ERR_BAD_SHAPE;
   if (L > MAX_L_CHAIN) return PTAMD_ERR_TOO_LONG;
-  size_t lds = (size_t)L * 12 * sizeof(float);
+  const size_t lds = (size_t)((3 * L + PT_WAVE - 1) / PT_WAVE) * PT_WAVE * sizeof(float4);  // trig cache of the scan
   if (lds > 48 * 1024) {
     PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(nerf_backbone_fwd_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -510,13 +618,8 @@ int ptamd_nerf_bwd(const float *ang, const int64_t *seq, const float *crd, const
                      (hipStream_t)stream, ang, seq, crd, dcrd, L, dang, gbb);
   int rc = pt_check_launch();
   if (rc) return rc;
-  size_t lds = (size_t)L * 36 * sizeof(float);
-  if (lds > 48 * 1024) {
-    PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(nerf_backbone_bwd_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
-  hipLaunchKernelGGL(nerf_backbone_bwd_kernel, dim3(B), dim3(PT_WAVE), lds, (hipStream_t)stream, ang, seq, crd, gbb,
-                     L, dang);
+  hipLaunchKernelGGL(nerf_backbone_bwd_kernel, dim3(B), dim3(PT_WAVE), 0, (hipStream_t)stream, ang, seq, crd, gbb, L,
+                     dang);
   return pt_check_launch();
 }
 
