@@ -93,7 +93,7 @@ __device__ __forceinline__ void load_row_frag(const float *__restrict__ base, in
 
 // =================================================================================================== forward
 template <int DK>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
                                                        int L, int H, float p_drop, uint64_t seed, uint32_t stream_id,
                                                        float *__restrict__ out, float *__restrict__ lse) {
   constexpr int LDK = DK + 1, NS = DK / 2, NDT = (DK + 31) / 32;
@@ -224,30 +224,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float *__restrict__
 }
 
 // =================================================================================================== backward
-// delta[b,h,q] = sum_d dO[q,d] * O[q,d]
-__global__ void attn_delta_kernel(const float *__restrict__ o, const float *__restrict__ d_o, int64_t T, int L, int H,
-                                  int DK, float *__restrict__ delta) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (t, h)
-  if (i >= T * H) return;
-  const int64_t t = i / H;
-  const int h = (int)(i - t * H);
-  const float *a = o + t * (H * DK) + h * DK, *g = d_o + t * (H * DK) + h * DK;
-  float s = 0.f;
-  for (int d = 0; d < DK; d += 4) {
-    const float4 x = *reinterpret_cast<const float4 *>(a + d), y = *reinterpret_cast<const float4 *>(g + d);
-    s += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
-  }
-  const int64_t b = t / L;
-  const int q = (int)(t - b * L);
-  delta[((size_t)b * H + h) * L + q] = s;
-}
-
 // dQ: same decomposition as the forward kernel
 template <int DK>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
-                                                          const float *__restrict__ d_o, const float *__restrict__ lse,
-                                                          const float *__restrict__ delta, int L, int H, float p_drop,
-                                                          uint64_t seed, uint32_t stream_id, float *__restrict__ dqkv) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
+                                                          const float *__restrict__ o_fwd, const float *__restrict__ d_o,
+                                                          const float *__restrict__ lse, float *__restrict__ delta, int L,
+                                                          int H, float p_drop, uint64_t seed, uint32_t stream_id,
+                                                          float *__restrict__ dqkv) {
   constexpr int LDK = DK + 1, NS = DK / 2, NDT = (DK + 31) / 32;
   __shared__ float sK[2][KT * LDK];
   __shared__ float sV[2][KT * LDK];
@@ -266,7 +249,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float *__restric
   load_row_frag<DK>(base, D3, q, q_ok, lh, qf);
   load_row_frag<DK>(d_o + (size_t)b * L * D + h * DK, D, q, q_ok, lh, gf);
   const float my_lse = q_ok ? lse[((size_t)b * H + h) * L + q] : 0.f;
-  const float my_delta = q_ok ? delta[((size_t)b * H + h) * L + q] : 0.f;
+  // delta[q] = sum_d dO[q,d] O[q,d]: each lane half holds every other d of its query's row; published for the
+  // dK/dV kernel, which runs after this one on the same stream
+  float my_delta = 0.f;
+  {
+    float of[NS];
+    load_row_frag<DK>(o_fwd + (size_t)b * L * D + h * DK, D, q, q_ok, lh, of);
+#pragma unroll
+    for (int st = 0; st < NS; ++st) my_delta += gf[st] * of[st];
+    my_delta += __shfl_xor(my_delta, 32, 64);
+    if (q_ok && lh == 0) delta[((size_t)b * H + h) * L + q] = my_delta;
+  }
 
   f32x16 dq[NDT];
 #pragma unroll
@@ -358,7 +351,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float *__restric
 
 // dK, dV: one workgroup = 128 keys of one (protein, head); lane column = key
 template <int DK>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
                                                            const float *__restrict__ d_o, const float *__restrict__ lse,
                                                            const float *__restrict__ delta, int L, int H, float p_drop,
                                                            uint64_t seed, uint32_t stream_id, float *__restrict__ dqkv) {
@@ -485,10 +478,11 @@ int launch_fwd(const float *qkv, const int64_t *seq, int B, int L, int H, float 
   return pt_check_launch();
 }
 template <int DK>
-int launch_bwd(const float *qkv, const int64_t *seq, const float *d_o, const float *lse, const float *delta, int B,
-               int L, int H, float p, uint64_t seed, uint32_t sid, float *dqkv, hipStream_t st) {
+int launch_bwd(const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse, float *delta,
+               int B, int L, int H, float p, uint64_t seed, uint32_t sid, float *dqkv, hipStream_t st) {
   const dim3 grid((L + QB - 1) / QB, H, B);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<DK>, grid, dim3(256), 0, st, qkv, seq, d_o, lse, delta, L, H, p, seed, sid, dqkv);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<DK>, grid, dim3(256), 0, st, qkv, seq, o_fwd, d_o, lse, delta, L, H, p, seed, sid,
+                     dqkv);
   int rc = pt_check_launch();
   if (rc) return rc;
   hipLaunchKernelGGL(attn_bwd_dkv_kernel<DK>, grid, dim3(256), 0, st, qkv, seq, d_o, lse, delta, L, H, p, seed, sid, dqkv);
@@ -529,17 +523,12 @@ int ptamd_attention_bwd(const float *qkv, const int64_t *seq, const float *out, 
   if (!pt_aligned16(qkv) || !pt_aligned16(out) || !pt_aligned16(dout) || !pt_aligned16(dqkv)) return PTAMD_ERR_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   float *delta = static_cast<float *>(workspace);
-  const int64_t T = (int64_t)B * L;
-  if (dk != 8 && dk != 16 && dk != 32 && dk != 64) return PTAMD_ERR_BAD_SHAPE;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((T * H + 255) / 256)), dim3(256), 0, st, out, dout, T, L, H, dk,
-                     delta);
-  int rc = pt_check_launch();
-  if (rc) return rc;
   switch (dk) {
-    case 8: return launch_bwd<8>(qkv, seq, dout, lse, delta, B, L, H, dropout_p, seed, stream_id, dqkv, st);
-    case 16: return launch_bwd<16>(qkv, seq, dout, lse, delta, B, L, H, dropout_p, seed, stream_id, dqkv, st);
-    case 32: return launch_bwd<32>(qkv, seq, dout, lse, delta, B, L, H, dropout_p, seed, stream_id, dqkv, st);
-    default: return launch_bwd<64>(qkv, seq, dout, lse, delta, B, L, H, dropout_p, seed, stream_id, dqkv, st);
+    case 8: return launch_bwd<8>(qkv, seq, out, dout, lse, delta, B, L, H, dropout_p, seed, stream_id, dqkv, st);
+    case 16: return launch_bwd<16>(qkv, seq, out, dout, lse, delta, B, L, H, dropout_p, seed, stream_id, dqkv, st);
+    case 32: return launch_bwd<32>(qkv, seq, out, dout, lse, delta, B, L, H, dropout_p, seed, stream_id, dqkv, st);
+    case 64: return launch_bwd<64>(qkv, seq, out, dout, lse, delta, B, L, H, dropout_p, seed, stream_id, dqkv, st);
+    default: return PTAMD_ERR_BAD_SHAPE;
   }
 }
 

@@ -20,7 +20,8 @@
 
 namespace {
 
-constexpr int CB = 256;  // threads per block in all three kernels
+constexpr int CB = 256;  // threads per block of the compaction / finalize kernels
+constexpr int PB = 128;  // rows (= threads) per block of the pair sweep: ~34 blocks per protein keep 256 CUs balanced
 
 struct Counts {
   int n, n_bb, len, pad;
@@ -92,17 +93,17 @@ __global__ __launch_bounds__(CB) void drmsd_compact_kernel(const float *__restri
 }
 
 template <bool WITH_GRAD>
-__global__ __launch_bounds__(CB) void drmsd_pairs_kernel(const float4 *__restrict__ pred4,
+__global__ __launch_bounds__(PB) void drmsd_pairs_kernel(const float4 *__restrict__ pred4,
                                                          const float4 *__restrict__ true4,
                                                          const Counts *__restrict__ counts, int L, int row_blocks,
                                                          float4 *__restrict__ gcomp, double *__restrict__ partials) {
-  __shared__ float4 s_p[CB], s_t[CB];
-  __shared__ double s_red[2 * (CB / 64)];
+  __shared__ float4 s_p[PB], s_t[PB];
+  __shared__ double s_red[2 * (PB / 64)];
   const int b = blockIdx.y, tid = threadIdx.x;
   const Counts cn = counts[b];
   const int n = cn.n, nbb = cn.n_bb;
   double *part = partials + ((size_t)b * row_blocks + blockIdx.x) * 2;
-  const int row0 = blockIdx.x * CB;
+  const int row0 = blockIdx.x * PB;
   if (row0 >= n) {  // block-uniform
     if (tid == 0) part[0] = part[1] = 0.0;
     return;
@@ -137,14 +138,14 @@ __global__ __launch_bounds__(CB) void drmsd_pairs_kernel(const float4 *__restric
     }
   };
 
-  for (int c0 = 0; c0 < n; c0 += CB) {
+  for (int c0 = 0; c0 < n; c0 += PB) {
     __syncthreads();
     if (c0 + tid < n) {
       s_p[tid] = pred4[c0 + tid];
       s_t[tid] = true4[c0 + tid];
     }
     __syncthreads();
-    const int cnt = min(CB, n - c0);
+    const int cnt = min(PB, n - c0);
     const int ja = max(0, min(cnt, nbb - c0));
     int j = 0;
 #pragma unroll 4
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(CB) void drmsd_pairs_kernel(const float4 *__restric
   __syncthreads();
   if (tid == 0) {
     double a = 0, c = 0;
-    for (int w = 0; w < CB / 64; ++w) {
+    for (int w = 0; w < PB / 64; ++w) {
       a += s_red[w * 2];
       c += s_red[w * 2 + 1];
     }
@@ -230,7 +231,7 @@ struct Layout {
 Layout layout(int B, int L) {
   Layout l;
   const size_t nmax = (size_t)L * 14, BN = (size_t)B * nmax;
-  l.row_blocks = (int)((nmax + CB - 1) / CB);
+  l.row_blocks = (int)((nmax + PB - 1) / PB);
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o = off;
@@ -274,10 +275,10 @@ int ptamd_drmsd_fwd_bwd(const float *pred_crd, const float *true_crd, const int6
   int rc = pt_check_launch();
   if (rc) return rc;
   if (dcrd)
-    hipLaunchKernelGGL(drmsd_pairs_kernel<true>, dim3(l.row_blocks, B), dim3(CB), 0, st, pred4, true4, counts, L,
+    hipLaunchKernelGGL(drmsd_pairs_kernel<true>, dim3(l.row_blocks, B), dim3(PB), 0, st, pred4, true4, counts, L,
                        l.row_blocks, gcomp, partials);
   else
-    hipLaunchKernelGGL(drmsd_pairs_kernel<false>, dim3(l.row_blocks, B), dim3(CB), 0, st, pred4, true4, counts, L,
+    hipLaunchKernelGGL(drmsd_pairs_kernel<false>, dim3(l.row_blocks, B), dim3(PB), 0, st, pred4, true4, counts, L,
                        l.row_blocks, gcomp, partials);
   rc = pt_check_launch();
   if (rc) return rc;
