@@ -121,14 +121,22 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     dt = float(t.item())
 
+    traffic = None          # HBM bytes per GEMM launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    tpath = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
+    if os.path.exists(tpath) and (a.batch, a.length, a.d_model, a.n_layers) == (32, 512, 512, 6):
+        with open(tpath) as f:
+            traffic = round(json.load(f)["hbm_bytes_per_launch"])
     roofline = None
     if timing:
         flops = sum(f for f, _, _ in timing)
+        gemm_bytes = kernels.GEMM_BYTES
         ms = sum(e0.elapsed_time(e1) for _, e0, e1 in timing)
         achieved = flops / (ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "gemm_f32_mfma_kernel (v_mfma_f32_32x32x2_f32)",
                     "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_gemm_hbm_traffic.json)",
+                    "algorithmic_bytes_per_launch": round(sum(b for b in gemm_bytes) / max(len(gemm_bytes), 1)),
                     "launches_per_step": len(timing) // a.steps, "avg_launch_us": round(1e3 * ms / len(timing), 2),
                     "gflop_per_step": round(flops / a.steps / 1e9, 1),
                     "share_of_step_time": round(ms / (dt * 1e3), 3)}

@@ -66,6 +66,12 @@ int ptamd_angles_bwd(const float *sincos, const float *dang, float *dsincos, int
  *   ang [B,L,12] radians; seq [B,L] int64 residue ids with trailing PTAMD_PAD_ID;
  *   crd [B,L*14,3] out (unused slots and padded residues = 0); status: int32[1], OR-ed. */
 size_t ptamd_nerf_workspace_bytes(int B, int L);
+/* nerf (protein/Structure.py:23-65), n independent placements: a, b, c, d [n,3]; l, theta, chi [n] */
+int ptamd_nerf_place(const float *a, const float *b, const float *c, const float *l, const float *theta,
+                     const float *chi, int64_t n, float *d, int32_t *status, void *stream);
+/* pairwise_internal_dist (losses.py:233-253): x [n,dim] -> out [n,n] = sqrt(max(|x_i - x_j|^2, 1e-30)); the
+ * training path never materialises this matrix (ptamd_drmsd_fwd_bwd), it exists for API parity */
+int ptamd_pairwise_dist(const float *x, int n, int dim, float *out, void *stream);
 int ptamd_nerf_fwd(const float *ang, const int64_t *seq, int B, int L, float *crd, int32_t *status,
                    void *stream);
 /* adjoint of the build: dcrd [B,L*14,3] -> dang [B,L,12] (overwritten). Reproduces the

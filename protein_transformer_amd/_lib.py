@@ -37,6 +37,8 @@ SIGNATURES = {
     "ptamd_angles_fwd": (_i, [_p, _p, _i64, _p]),
     "ptamd_angles_bwd": (_i, [_p, _p, _p, _i64, _p]),
     "ptamd_nerf_workspace_bytes": (_sz, [_i, _i]),
+    "ptamd_nerf_place": (_i, [_p, _p, _p, _p, _p, _p, _i64, _p, _p, _p]),
+    "ptamd_pairwise_dist": (_i, [_p, _i, _i, _p, _p]),
     "ptamd_nerf_fwd": (_i, [_p, _p, _i, _i, _p, _p, _p]),
     "ptamd_nerf_bwd": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _sz, _p]),
     "ptamd_drmsd_workspace_bytes": (_sz, [_i, _i]),

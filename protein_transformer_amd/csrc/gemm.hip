@@ -106,8 +106,8 @@ __device__ __forceinline__ float epilogue_value(float v, int row, int col, const
   return v;
 }
 
-// Persistent workgroups: a launch has min(#work items, 2 per CU) workgroups, each walking work items
-// (output tile x K split) with stride gridDim.x.  The first K stage of the NEXT item is prefetched into
+// Persistent workgroups: a launch has min(#work items, 2 per CU) workgroups, each walking a contiguous range of
+// work items (output tile x K split).  The first K stage of the NEXT item is prefetched into
 // registers/LDS before the epilogue of the current one, so the epilogue's stores overlap the next loads and
 // the matrix pipe does not wait for a cold prologue per tile.
 template <bool A_KMAJOR, bool B_KMAJOR>
@@ -122,20 +122,25 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_mfma_kernel(const GemmParams p
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
   const int nwork = tiles_m * tiles_n * p.splits;
 
-  // XCD-aware, bijective remap: workgroup b runs on XCD b % 8; consecutive logical items (same A row panel,
-  // neighbouring N tiles / K splits) are given to the same XCD so that they share its L2.
-  auto decode = [&](int w, int &bm0, int &bn0, int &z) {
-    const int xcd = w & 7, q = nwork >> 3, r = nwork & 7;
-    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
-    const int tile = logical / p.splits;
-    z = logical - tile * p.splits;
+  // Work-item order: logical id = ((z * tiles_m + tm) * tiles_n + tn), i.e. neighbours share the same A panel /
+  // K chunk.  Workgroup b (which the dispatcher places on XCD b % 8) owns the CONTIGUOUS logical range
+  // [slot * per, slot * per + per) with slot = (b % 8) * (G / 8) + b / 8: consecutive items of one workgroup and
+  // the workgroups of one XCD all walk neighbouring tiles, so an A panel is fetched through one L2 and re-read
+  // by the same few CUs instead of being requested by every N tile at once.
+  const int G = gridDim.x, base = nwork / G, rem = nwork - base * G;
+  const int slot = (G & 7) == 0 ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const int w_begin = slot * base + min(slot, rem), w_end = w_begin + base + (slot < rem ? 1 : 0);
+  auto decode = [&](int logical, int &bm0, int &bn0, int &z) {
+    const int ntile = tiles_m * tiles_n;
+    z = logical / ntile;
+    const int tile = logical - z * ntile;
     bm0 = (tile / tiles_n) * BM;
     bn0 = (tile % tiles_n) * BN;
   };
 
   float4 ra[4], rb[4];
-  int w = blockIdx.x, bm0, bn0, z;
-  if (w >= nwork) return;
+  int w = w_begin, bm0, bn0, z;
+  if (w >= w_end) return;
   decode(w, bm0, bn0, z);
   int kbeg = z * p.k_per_split, kend = min(p.K, kbeg + p.k_per_split);
   load_stage<A_KMAJOR>(p.A, p.lda, p.M, bm0, kend, kbeg, tid, ra);
@@ -158,9 +163,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_mfma_kernel(const GemmParams p
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int wn_next = w + gridDim.x;
+    const int wn_next = w + 1;
     int nbm0 = 0, nbn0 = 0, nz = 0, nkbeg = 0, nkend = 0;
-    const bool has_next = wn_next < nwork;
+    const bool has_next = wn_next < w_end;
     if (has_next) {
       decode(wn_next, nbm0, nbn0, nz);
       nkbeg = nz * p.k_per_split;

@@ -566,6 +566,34 @@ __global__ __launch_bounds__(PT_WAVE) void nerf_backbone_bwd_kernel(const float 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// stand-alone helpers of the public API: batched single placements and an explicit distance matrix
+__global__ void nerf_place_kernel(const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ c,
+                                  const float *__restrict__ l, const float *__restrict__ theta,
+                                  const float *__restrict__ chi, int64_t n, float *__restrict__ d,
+                                  int32_t *__restrict__ status) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float th = theta[i];
+  if (!(fabsf(th) <= PI_F)) atomicOr(status, PTAMD_ST_BAD_THETA);
+  float st, ct, sx, cx;
+  sincosf(th, &st, &ct);
+  sincosf(chi[i], &sx, &cx);
+  st3(d + i * 3, place(ld3(a + i * 3), ld3(b + i * 3), ld3(c + i * 3), l[i], st, ct, sx, cx));
+}
+
+// losses.py:233-253 by direct differences: out[i][j] = sqrt(max(|x_i - x_j|^2, 1e-30))
+__global__ void pairwise_dist_kernel(const float *__restrict__ x, int n, int dim, float *__restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < dim; ++k) {
+    const float d = x[(size_t)i * dim + k] - x[(size_t)j * dim + k];
+    s += d * d;
+  }
+  out[(size_t)i * n + j] = sqrtf(fmaxf(s, 1e-30f));
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -586,6 +614,20 @@ int ptamd_angles_bwd(const float *sincos, const float *dang, float *dsincos, int
   if (n == 0) return PTAMD_OK;
   hipLaunchKernelGGL(angles_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const float2 *>(sincos), dang, reinterpret_cast<float2 *>(dsincos), n);
+  return pt_check_launch();
+}
+
+int ptamd_nerf_place(const float *a, const float *b, const float *c, const float *l, const float *theta,
+                     const float *chi, int64_t n, float *d, int32_t *status, void *stream) {
+  if (n <= 0) return PTAMD_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(nerf_place_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, c, l,
+                     theta, chi, n, d, status);
+  return pt_check_launch();
+}
+
+int ptamd_pairwise_dist(const float *x, int n, int dim, float *out, void *stream) {
+  if (n <= 0 || dim <= 0 || n > 65535) return PTAMD_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(pairwise_dist_kernel, dim3((n + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, x, n, dim, out);
   return pt_check_launch();
 }
 

@@ -15,6 +15,7 @@ EPI_RELU, EPI_TANH, EPI_ACCUM = 1, 2, 4
 # bench.py sets this to a list to time every GEMM launch with HIP events recorded on the launch stream:
 # entries are (flops, start_event, end_event).  None (the default) adds no work to the hot path.
 GEMM_TIMING = None
+GEMM_BYTES = []          # algorithmic operand bytes (A + B + C [+ residual, + accumulate]) of every timed launch
 
 
 def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, bias=None, residual=None,
@@ -40,6 +41,7 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False,
         check(lib().ptamd_gemm(C.byref(args), stream()), "gemm")
         e1.record()
         GEMM_TIMING.append((2.0 * M * N * K, e0, e1))
+        GEMM_BYTES.append(4 * (M * K + N * K + M * N * (1 + (residual is not None) + bool(flags & EPI_ACCUM))))
     return C_out
 
 

@@ -103,6 +103,18 @@ def drmsd(a, b):
     return _DrmsdFn.apply(a.to(dev), b.to(dev))
 
 
+def pairwise_internal_dist(x):
+    """All pairwise distances of an [n, d] coordinate tensor -> [n, n] (losses.py:233-253).  API parity only:
+    the loss kernels never build this matrix."""
+    assert len(x.shape) == 2, "Pairwise internal distance method is not implemented for batches."
+    dev = x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    x = x.to(dev, torch.float32).contiguous()
+    out = torch.empty(x.shape[0], x.shape[0], dtype=torch.float32, device=dev)
+    rc = _lib.lib().ptamd_pairwise_dist(_lib.ptr(x), x.shape[0], x.shape[1], _lib.ptr(out), _lib.stream())
+    _lib.check(rc, "pairwise_dist")
+    return out
+
+
 def angles_to_coords(angles, seq, remove_batch_padding=False):
     """Torsional angles -> coordinates (losses.py:101-116)."""
     if remove_batch_padding:

@@ -84,3 +84,22 @@ def generate_coords(angles, input_seq, device=None):
     crd, status = _NerfFn.apply(ang[None], seq[None])
     raise_for_status(int(status.item()))
     return crd[0]
+
+
+def nerf(a, b, c, l, theta, chi):
+    """Natural extension reference frame: place atom d from a, b, c with bond length l, bond angle theta and
+    torsion chi (Structure.py:23-65).  Inputs may be single points ([3] / scalars) or batches ([n,3] / [n])."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    f = lambda t: torch.as_tensor(t, dtype=torch.float32).to(dev)                # noqa: E731
+    a, b, c, l, theta, chi = f(a), f(b), f(c), f(l), f(theta), f(chi)
+    single = a.dim() == 1
+    a, b, c = (t.reshape(-1, 3).contiguous() for t in (a, b, c))
+    n = a.shape[0]
+    l, theta, chi = (t.reshape(-1).expand(n).contiguous() for t in (l, theta, chi))
+    d = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    rc = _lib.lib().ptamd_nerf_place(_lib.ptr(a), _lib.ptr(b), _lib.ptr(c), _lib.ptr(l), _lib.ptr(theta), _lib.ptr(chi),
+                                     n, _lib.ptr(d), _lib.ptr(status), _lib.stream())
+    _lib.check(rc, "nerf_place")
+    raise_for_status(int(status.item()))
+    return d[0] if single else d

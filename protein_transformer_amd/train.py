@@ -140,12 +140,16 @@ def train(model, metrics, training_data, train_eval_loader, validation_datasets,
                               pool=drmsd_worker_pool)
         if args.eval_train:
             metrics = eval_epoch(model, train_eval_loader, device, args, metrics, mode="train", pool=drmsd_worker_pool)
+        if dp.is_main():
+            log_batch(log_writer, metrics, START_TIME, mode="train", end_of_epoch=True)
         if not args.train_only:
             for split, validation_data in validation_datasets.items():
                 metrics = eval_epoch(model, validation_data, device, args, metrics, mode=f"valid-{split}",
                                      pool=drmsd_worker_pool)
+                if dp.is_main():
+                    log_batch(log_writer, metrics, START_TIME, mode=f"valid-{split}", end_of_epoch=True)
         if scheduler:
-            scheduler.step(metrics[args.es_mode][f"epoch-{args.es_metric}"])
+            scheduler.step(metrics[args.es_mode][f"epoch-{args.es_metric}-full"])
         try:
             metrics = update_loss_trackers(args, epoch_i, metrics)
         except EarlyStoppingCondition:
@@ -153,8 +157,10 @@ def train(model, metrics, training_data, train_eval_loader, validation_datasets,
         if dp.is_main():
             checkpoint_model(args, optimizer, model, scheduler, epoch_i, metrics["loss_to_compare"],
                              metrics["losses_to_compare"], metrics)
-    if not args.train_only:
+    if not args.train_only and test_data is not None:
         metrics = eval_epoch(model, test_data, device, args, metrics, mode="test", pool=drmsd_worker_pool)
+        if dp.is_main():
+            log_batch(log_writer, metrics, START_TIME, mode="test", end_of_epoch=True)
     return metrics
 
 
