@@ -25,9 +25,11 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
-constexpr int LD_R = 36;   // [row][k] image of a K-contiguous operand: 32 k + 4 pad floats, conflict-free ds_read_b128
-constexpr int LD_C = 132;  // [k][row] image of a row-contiguous operand: straight 16-byte copies, ds_read_b32
+constexpr int BM = 128, BN = 128, NT = 256;
+// BK (K advance per stage) is a template parameter: 32 (2 workgroups / CU, 73.7 KB LDS each) or 16 (3 per CU).
+// [row][k] image of a K-contiguous operand: BK k + 4 pad floats per row (36 or 20): conflict-free ds_read_b128
+// [k][row] image of a row-contiguous operand: 128 + 4 floats per k: straight 16-byte copies, ds_read_b32
+constexpr int LD_C = 132;
 
 struct GemmParams {
   int M, N, K;
@@ -52,13 +54,14 @@ struct GemmParams {
 // ---- staging: each thread carries 4 float4 per operand per stage; global -> registers -> LDS, no transposition:
 //      the LDS image keeps the operand's own contiguity and the MFMA k-assignment adapts instead
 //      (MFMA step (m, j) of a stage uses k = 8m + 4*(lane>>5) + j for BOTH operands).
-template <bool KMAJOR>
+template <bool KMAJOR, int BK>
 __device__ __forceinline__ void load_stage(const float *__restrict__ src, int ld, int rows, int r0, int kend, int k0,
-                                           int tid, float4 (&v)[4]) {
+                                           int tid, float4 (&v)[BK / 8]) {
+  constexpr int LPR = BK / 4;  // lanes per row of a K-contiguous operand
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (!KMAJOR) {  // src[row][k]: 8 lanes cover the 32 k of one row (128 B)
-      const int row = r0 + (tid >> 3) + 32 * i, k = k0 + 4 * (tid & 7);
+  for (int i = 0; i < BK / 8; ++i) {
+    if (!KMAJOR) {  // src[row][k]: BK/4 lanes cover the BK k of one row
+      const int row = r0 + tid / LPR + (NT / LPR) * i, k = k0 + 4 * (tid % LPR);
       v[i] = (row < rows && k < kend) ? *reinterpret_cast<const float4 *>(src + (size_t)row * ld + k)
                                       : make_float4(0.f, 0.f, 0.f, 0.f);
     } else {  // src[k][row]: 32 lanes cover 128 consecutive rows of one k (512 B)
@@ -68,12 +71,13 @@ __device__ __forceinline__ void load_stage(const float *__restrict__ src, int ld
     }
   }
 }
-template <bool KMAJOR>
-__device__ __forceinline__ void store_stage(float *__restrict__ s, int tid, const float4 (&v)[4]) {
+template <bool KMAJOR, int BK>
+__device__ __forceinline__ void store_stage(float *__restrict__ s, int tid, const float4 (&v)[BK / 8]) {
+  constexpr int LPR = BK / 4, LD_R = BK + 4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < BK / 8; ++i) {
     if (!KMAJOR) {
-      const int row = (tid >> 3) + 32 * i, k = 4 * (tid & 7);
+      const int row = tid / LPR + (NT / LPR) * i, k = 4 * (tid % LPR);
       *reinterpret_cast<float4 *>(s + row * LD_R + k) = v[i];
     } else {
       const int k = (tid >> 5) + 8 * i, row = 4 * (tid & 31);
@@ -82,8 +86,9 @@ __device__ __forceinline__ void store_stage(float *__restrict__ s, int tid, cons
   }
 }
 // fragment of rows [r0 + l31] for the 4 MFMA steps of k-group m
-template <bool KMAJOR>
+template <bool KMAJOR, int BK>
 __device__ __forceinline__ void read_frag(const float *__restrict__ s, int r, int lh, int m, float (&f)[4]) {
+  constexpr int LD_R = BK + 4;
   if (!KMAJOR) {
     const float4 v = *reinterpret_cast<const float4 *>(s + r * LD_R + 8 * m + 4 * lh);
     f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
@@ -110,8 +115,9 @@ __device__ __forceinline__ float epilogue_value(float v, int row, int col, const
 // work items (output tile x K split).  The first K stage of the NEXT item is prefetched into
 // registers/LDS before the epilogue of the current one, so the epilogue's stores overlap the next loads and
 // the matrix pipe does not wait for a cold prologue per tile.
-template <bool A_KMAJOR, bool B_KMAJOR>
+template <bool A_KMAJOR, bool B_KMAJOR, int BK>
 __global__ __launch_bounds__(NT, 2) void gemm_f32_mfma_kernel(const GemmParams p) {
+  constexpr int LD_R = BK + 4, NG = BK / 8;
   constexpr int SA = A_KMAJOR ? BK * LD_C : BM * LD_R, SB = B_KMAJOR ? BK * LD_C : BN * LD_R;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *const sA0 = smem;  // two stages of A, then two stages of B
@@ -138,15 +144,15 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_mfma_kernel(const GemmParams p
     bn0 = (tile % tiles_n) * BN;
   };
 
-  float4 ra[4], rb[4];
+  float4 ra[NG], rb[NG];
   int w = w_begin, bm0, bn0, z;
   if (w >= w_end) return;
   decode(w, bm0, bn0, z);
   int kbeg = z * p.k_per_split, kend = min(p.K, kbeg + p.k_per_split);
-  load_stage<A_KMAJOR>(p.A, p.lda, p.M, bm0, kend, kbeg, tid, ra);
-  load_stage<B_KMAJOR>(p.B, p.ldb, p.N, bn0, kend, kbeg, tid, rb);
-  store_stage<A_KMAJOR>(sA0, tid, ra);
-  store_stage<B_KMAJOR>(sB0, tid, rb);
+  load_stage<A_KMAJOR, BK>(p.A, p.lda, p.M, bm0, kend, kbeg, tid, ra);
+  load_stage<B_KMAJOR, BK>(p.B, p.ldb, p.N, bn0, kend, kbeg, tid, rb);
+  store_stage<A_KMAJOR, BK>(sA0, tid, ra);
+  store_stage<B_KMAJOR, BK>(sB0, tid, rb);
   __syncthreads();
   int cur = 0;
 
@@ -181,38 +187,38 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_mfma_kernel(const GemmParams p
     float a0[4], a1[4], b0[4], b1[4];
     {
       const float *sa = sA0 + cur * SA, *sb = sB0 + cur * SB;
-      read_frag<A_KMAJOR>(sa, ar, lh, 0, a0);
-      read_frag<A_KMAJOR>(sa, ar + 32, lh, 0, a1);
-      read_frag<B_KMAJOR>(sb, br, lh, 0, b0);
-      read_frag<B_KMAJOR>(sb, br + 32, lh, 0, b1);
+      read_frag<A_KMAJOR, BK>(sa, ar, lh, 0, a0);
+      read_frag<A_KMAJOR, BK>(sa, ar + 32, lh, 0, a1);
+      read_frag<B_KMAJOR, BK>(sb, br, lh, 0, b0);
+      read_frag<B_KMAJOR, BK>(sb, br + 32, lh, 0, b1);
     }
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
       const bool more = k0 + BK < kend;
       const bool fetch = more || has_next;
       if (more) {  // next stage of this item
-        load_stage<A_KMAJOR>(p.A, p.lda, p.M, bm0, kend, k0 + BK, tid, ra);
-        load_stage<B_KMAJOR>(p.B, p.ldb, p.N, bn0, kend, k0 + BK, tid, rb);
+        load_stage<A_KMAJOR, BK>(p.A, p.lda, p.M, bm0, kend, k0 + BK, tid, ra);
+        load_stage<B_KMAJOR, BK>(p.B, p.ldb, p.N, bn0, kend, k0 + BK, tid, rb);
       } else if (has_next) {  // first stage of the next item: flies under this item's last stage + epilogue
-        load_stage<A_KMAJOR>(p.A, p.lda, p.M, nbm0, nkend, nkbeg, tid, ra);
-        load_stage<B_KMAJOR>(p.B, p.ldb, p.N, nbn0, nkend, nkbeg, tid, rb);
+        load_stage<A_KMAJOR, BK>(p.A, p.lda, p.M, nbm0, nkend, nkbeg, tid, ra);
+        load_stage<B_KMAJOR, BK>(p.B, p.ldb, p.N, nbn0, nkend, nkbeg, tid, rb);
       }
       const float *sa = sA0 + cur * SA, *sb = sB0 + cur * SB;
       const float *na = sA0 + (cur ^ 1) * SA, *nb = sB0 + (cur ^ 1) * SB;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
+      for (int m = 0; m < NG; ++m) {
         float c0[4], c1[4], d0[4], d1[4];
-        if (m < 3) {
-          read_frag<A_KMAJOR>(sa, ar, lh, m + 1, c0);
-          read_frag<A_KMAJOR>(sa, ar + 32, lh, m + 1, c1);
-          read_frag<B_KMAJOR>(sb, br, lh, m + 1, d0);
-          read_frag<B_KMAJOR>(sb, br + 32, lh, m + 1, d1);
+        if (m < NG - 1) {
+          read_frag<A_KMAJOR, BK>(sa, ar, lh, m + 1, c0);
+          read_frag<A_KMAJOR, BK>(sa, ar + 32, lh, m + 1, c1);
+          read_frag<B_KMAJOR, BK>(sb, br, lh, m + 1, d0);
+          read_frag<B_KMAJOR, BK>(sb, br + 32, lh, m + 1, d1);
         } else {
           __syncthreads();  // next buffer fully written by every wave; nobody reads `cur` any more
           if (fetch) {
-            read_frag<A_KMAJOR>(na, ar, lh, 0, c0);
-            read_frag<A_KMAJOR>(na, ar + 32, lh, 0, c1);
-            read_frag<B_KMAJOR>(nb, br, lh, 0, d0);
-            read_frag<B_KMAJOR>(nb, br + 32, lh, 0, d1);
+            read_frag<A_KMAJOR, BK>(na, ar, lh, 0, c0);
+            read_frag<A_KMAJOR, BK>(na, ar + 32, lh, 0, c1);
+            read_frag<B_KMAJOR, BK>(nb, br, lh, 0, d0);
+            read_frag<B_KMAJOR, BK>(nb, br + 32, lh, 0, d1);
           }
         }
 #pragma unroll
@@ -222,9 +228,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_mfma_kernel(const GemmParams p
           acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
           acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
         }
-        if (m == 1 && fetch) {
-          store_stage<A_KMAJOR>(sA0 + (cur ^ 1) * SA, tid, ra);
-          store_stage<B_KMAJOR>(sB0 + (cur ^ 1) * SB, tid, rb);
+        if (m == (NG >= 4 ? 1 : 0) && fetch) {
+          store_stage<A_KMAJOR, BK>(sA0 + (cur ^ 1) * SA, tid, ra);
+          store_stage<B_KMAJOR, BK>(sB0 + (cur ^ 1) * SB, tid, rb);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -311,25 +317,34 @@ int persistent_grid() {
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     }
-    slots = 2 * cus;  // 2 workgroups (73.7 KB of LDS each) per CU
-    if (const char *e = getenv("PTAMD_GEMM_WG_PER_CU")) slots = atoi(e) > 0 ? atoi(e) * cus : slots;  // tuning knob
+    slots = cus;
   }
   return slots;
 }
+int stage_k() {  // tuning knob: PTAMD_GEMM_BK=16 selects the 3-workgroups-per-CU variant
+  static int bk = 0;
+  if (!bk) {
+    bk = 32;
+    if (const char *e = getenv("PTAMD_GEMM_BK")) bk = atoi(e) == 16 ? 16 : 32;
+  }
+  return bk;
+}
 
-template <bool AK, bool BK_>
+template <bool AK, bool BKM, int BK>
 int launch(const GemmParams &p, int splits, hipStream_t st) {
-  constexpr int SA = AK ? BK * LD_C : BM * LD_R, SB = BK_ ? BK * LD_C : BN * LD_R;
+  constexpr int LD_R = BK + 4;
+  constexpr int SA = AK ? BK * LD_C : BM * LD_R, SB = BKM ? BK * LD_C : BN * LD_R;
   const size_t lds = (size_t)2 * (SA + SB) * sizeof(float);
   const int work = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * splits;
-  auto kern = gemm_f32_mfma_kernel<AK, BK_>;
+  auto kern = gemm_f32_mfma_kernel<AK, BKM, BK>;
   static bool attr_set = false;
   if (!attr_set) {
     PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
     attr_set = true;
   }
-  const int grid = work < persistent_grid() ? work : persistent_grid();
+  const int slots = persistent_grid() * (BK == 16 ? 3 : 2);
+  const int grid = work < slots ? work : slots;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, p);
   return pt_check_launch();
 }
@@ -351,6 +366,7 @@ int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
   if (!pt_aligned16(a->A) || !pt_aligned16(a->B)) return PTAMD_ERR_ALIGN;
   if (a->dropout_p < 0.f || a->dropout_p >= 1.f) return PTAMD_ERR_BAD_SHAPE;
   int splits = a->split_k > 1 ? a->split_k : 1;
+  const int BK = stage_k();
   const int kblocks = (a->K + BK - 1) / BK;
   if (splits > kblocks) splits = kblocks;
   GemmParams p;
@@ -370,10 +386,17 @@ int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
   }
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (!a->a_kmajor && !a->b_kmajor) rc = launch<false, false>(p, splits, st);
-  else if (!a->a_kmajor && a->b_kmajor) rc = launch<false, true>(p, splits, st);
-  else if (a->a_kmajor && !a->b_kmajor) rc = launch<true, false>(p, splits, st);
-  else rc = launch<true, true>(p, splits, st);
+  if (stage_k() == 32) {
+    if (!a->a_kmajor && !a->b_kmajor) rc = launch<false, false, 32>(p, splits, st);
+    else if (!a->a_kmajor && a->b_kmajor) rc = launch<false, true, 32>(p, splits, st);
+    else if (a->a_kmajor && !a->b_kmajor) rc = launch<true, false, 32>(p, splits, st);
+    else rc = launch<true, true, 32>(p, splits, st);
+  } else {
+    if (!a->a_kmajor && !a->b_kmajor) rc = launch<false, false, 16>(p, splits, st);
+    else if (!a->a_kmajor && a->b_kmajor) rc = launch<false, true, 16>(p, splits, st);
+    else if (a->a_kmajor && !a->b_kmajor) rc = launch<true, false, 16>(p, splits, st);
+    else rc = launch<true, true, 16>(p, splits, st);
+  }
   if (rc || splits == 1) return rc;
   const float *slabs = p.C;
   p.C = user_c;
