@@ -169,6 +169,23 @@ int ptamd_tanh_bwd(const float *dy, const float *y, int64_t n, float *dx, void *
 int ptamd_dropout_bwd(const float *dy, int64_t rows, int cols, float dropout_p, uint64_t seed, uint32_t stream_id,
                       float *dx, void *stream);
 
+/* ------------------------------------------------------------------ conv-enc front end
+ * torch.nn.Conv1d(C, Co, k, padding=(k-1)/2) of models/convolutional_encoder.py:92-129 as im2col + ptamd_gemm:
+ *   col [T, k*Cp] = im2col(x [T, C], row stride ldx)   with Cp = C rounded up to 4 (zero padded), k odd
+ *   y   [T, Co]   = col @ W2^T + bias                  W2 [Co, k*Cp] = pack(W [Co, C, k])
+ *   dx = col2im(dy @ W2),  dW += unpack(dy^T @ col),  db += colsum(dy)
+ * Windows never cross a protein boundary (rows are grouped in B proteins of L residues). */
+int ptamd_im2col1d(const float *x, int ldx, int B, int L, int C, int k, float *col, void *stream);
+int ptamd_col2im1d(const float *dcol, int B, int L, int C, int k, float *dx, int lddx, void *stream);
+int ptamd_conv_weight_pack(const float *w, int Co, int C, int k, float *w2, void *stream);
+int ptamd_conv_weight_unpack_add(const float *dw2, int Co, int C, int k, float *dw, void *stream);
+/* x [T, Cp] = one_hot(seq, C) (convolutional_encoder.py:110-111, use_embedding=False) */
+int ptamd_onehot(const int64_t *seq, int64_t T, int C, float *x, void *stream);
+/* y = x + dropout(x + pe[pos]) and its adjoint (convolutional_encoder.py:118-119 with Sublayers.py:59-62) */
+int ptamd_posenc_add_fwd(const float *x, const float *pe, int B, int L, int D, float dropout_p, uint64_t seed, float *y,
+                         void *stream);
+int ptamd_posenc_add_bwd(const float *dy, int64_t n, float dropout_p, uint64_t seed, float *dx, void *stream);
+
 /* ------------------------------------------------------------------ optimizer (train.py:41-46,371-381)
  * clip_grad_norm_(params, max_norm) + SGD(lr, weight_decay) / Adam(betas, eps, weight_decay) over ONE flat
  * fp32 parameter buffer.  sqnorm: out[0] = sum g^2 (zeroed inside, deterministic two-stage reduction). */

@@ -88,13 +88,32 @@ def attention(p, base, x, key_mask, nhead):
 
 
 def encoder_forward(p, seq, nhead, return_hidden=False):
-    """[B,L] int64 -> [B,L,24] tanh'ed (cos,sin) predictions (encoder_only.py:36-42)."""
-    emb = p["encoder.input_embedding.emb.weight"]
-    D = emb.shape[1]
+    """[B,L] int64 -> [B,L,24] tanh'ed (cos,sin) predictions.
+
+    enc-only: encoder_only.py:36-42.  conv-enc (keys `encoder.conv_layers.j.*` present, possibly without an
+    embedding): convolutional_encoder.py:41-47,106-123 - Conv1d stack with no activation between the embedding
+    (or the one-hot input) and the encoder layers; without embedding the positional term is added after the
+    convolutions as out + (out + pe).
+    """
     key_mask = seq != PAD_ID                                   # encoder_only.py:37
-    x0 = emb[seq] * np.sqrt(D)                                 # Sublayers.py:72
     pe = p["encoder.positional_enc.pe"][:, :seq.shape[1]]
-    x = x0 + (x0 + pe)                                         # Encoder.py:30 + Sublayers.py:59-62
+    has_emb = "encoder.input_embedding.emb.weight" in p
+    if has_emb:
+        emb = p["encoder.input_embedding.emb.weight"]
+        x0 = emb[seq] * np.sqrt(emb.shape[1])                  # Sublayers.py:72
+        x = x0 + (x0 + pe)                                     # Encoder.py:30 + Sublayers.py:59-62
+    else:
+        x = F.one_hot(seq, num_classes=VOCAB_SIZE).float()     # convolutional_encoder.py:110-111
+    n_conv = len([k for k in p if k.startswith("encoder.conv_layers.") and k.endswith(".weight")])
+    if n_conv:
+        x = x.transpose(-1, -2)
+        for j in range(n_conv):
+            w = p[f"encoder.conv_layers.{j}.weight"]
+            x = F.conv1d(x, w, p[f"encoder.conv_layers.{j}.bias"], padding=(w.shape[2] - 1) // 2)
+        x = x.transpose(-1, -2)
+    if not has_emb:
+        x = x + (x + pe)                                       # convolutional_encoder.py:118-119
+    D = x.shape[-1]
     for i in range(n_layers_of(p)):
         base = f"encoder.enc_layers.{i}."
         n0w, n0b = p[base + "sublayer_connections.0.norm.weight"], p[base + "sublayer_connections.0.norm.bias"]

@@ -61,6 +61,13 @@ SIGNATURES = {
     "ptamd_relu_dropout_bwd": (_i, [_p, _p, _i64, _f, _p, _p]),
     "ptamd_tanh_bwd": (_i, [_p, _p, _i64, _p, _p]),
     "ptamd_dropout_bwd": (_i, [_p, _i64, _i, _f, _u64, _u32, _p, _p]),
+    "ptamd_im2col1d": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    "ptamd_col2im1d": (_i, [_p, _i, _i, _i, _i, _p, _i, _p]),
+    "ptamd_conv_weight_pack": (_i, [_p, _i, _i, _i, _p, _p]),
+    "ptamd_conv_weight_unpack_add": (_i, [_p, _i, _i, _i, _p, _p]),
+    "ptamd_onehot": (_i, [_p, _i64, _i, _p, _p]),
+    "ptamd_posenc_add_fwd": (_i, [_p, _p, _i, _i, _i, _f, _u64, _p, _p]),
+    "ptamd_posenc_add_bwd": (_i, [_p, _i64, _f, _u64, _p, _p]),
     "ptamd_grad_sqnorm_workspace_bytes": (_sz, []),
     "ptamd_grad_sqnorm": (_i, [_p, _i64, _p, _p, _sz, _p]),
     "ptamd_sgd_step": (_i, [_p, _p, _i64, _p, _f, _f, _f, _p]),

@@ -360,7 +360,8 @@ size_t ptamd_gemm_workspace_bytes(int M, int N, int split_k) {
 
 int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
   if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0) return PTAMD_ERR_BAD_SHAPE;
-  if ((a->K & 3) || (a->lda & 3) || (a->ldb & 3)) return PTAMD_ERR_BAD_SHAPE;
+  if ((a->lda & 3) || (a->ldb & 3)) return PTAMD_ERR_BAD_SHAPE;
+  if ((!a->a_kmajor || !a->b_kmajor) && (a->K & 3)) return PTAMD_ERR_BAD_SHAPE;  // K-contiguous rows are read 16 B at a time
   if (a->a_kmajor && (a->M & 3)) return PTAMD_ERR_BAD_SHAPE;
   if (a->b_kmajor && (a->N & 3)) return PTAMD_ERR_BAD_SHAPE;
   if (!pt_aligned16(a->A) || !pt_aligned16(a->B)) return PTAMD_ERR_ALIGN;

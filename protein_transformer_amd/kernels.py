@@ -180,3 +180,56 @@ def adam_step(w, g, m, v, sqnorm, max_norm, lr, beta1, beta2, eps, weight_decay,
     check(lib().ptamd_adam_step(ptr(w), ptr(g), ptr(m), ptr(v), w.numel(), ptr(sqnorm), float(max_norm or 0.0),
                                 float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
                                 stream()), "adam_step")
+
+
+# ----------------------------------------------------------------------------- conv-enc front end
+def pad4(c):
+    return (c + 3) // 4 * 4
+
+
+def conv1d_fwd(x, B, L, C, w, bias, k):
+    """x [T, pad4(C)] token-major, w [Co, C, k] (torch Conv1d layout) -> y [T, Co]; returns (y, packed weight)."""
+    T, Co, Cp = x.shape[0], w.shape[0], pad4(C)
+    col = torch.empty(T, k * Cp, dtype=torch.float32, device=x.device)
+    check(lib().ptamd_im2col1d(ptr(x), x.stride(0), B, L, Cp, k, ptr(col), stream()), "im2col1d")
+    w2 = torch.empty(Co, k * Cp, dtype=torch.float32, device=x.device)
+    check(lib().ptamd_conv_weight_pack(ptr(w), Co, C, k, ptr(w2), stream()), "conv_weight_pack")
+    y = linear_fwd(col, w2, bias)
+    return y, w2
+
+
+def conv1d_bwd(dy, x, B, L, C, w2, k, dw, dbias, need_dx=True):
+    """Accumulates dw [Co, C, k] and dbias [Co]; returns dx [T, pad4(C)] (or None)."""
+    T, Co, Cp = x.shape[0], dy.shape[1], pad4(C)
+    col = torch.empty(T, k * Cp, dtype=torch.float32, device=x.device)          # recomputed, not stored
+    check(lib().ptamd_im2col1d(ptr(x), x.stride(0), B, L, Cp, k, ptr(col), stream()), "im2col1d")
+    dw2 = torch.zeros(Co, k * Cp, dtype=torch.float32, device=x.device)
+    linear_bwd_weight(dy, col, dw2)
+    check(lib().ptamd_conv_weight_unpack_add(ptr(dw2), Co, C, k, ptr(dw), stream()), "conv_weight_unpack_add")
+    colsum(dy, dbias)
+    if not need_dx:
+        return None
+    dcol = linear_bwd_input(dy, w2)
+    dx = torch.empty(T, Cp, dtype=torch.float32, device=x.device)
+    check(lib().ptamd_col2im1d(ptr(dcol), B, L, Cp, k, ptr(dx), dx.stride(0), stream()), "col2im1d")
+    return dx
+
+
+def onehot(seq, C):
+    T = seq.numel()
+    x = torch.empty(T, pad4(C), dtype=torch.float32, device=seq.device)
+    check(lib().ptamd_onehot(ptr(seq), T, C, ptr(x), stream()), "onehot")
+    return x
+
+
+def posenc_add_fwd(x, pe, B, L, dropout_p, seed):
+    y = torch.empty_like(x)
+    check(lib().ptamd_posenc_add_fwd(ptr(x), ptr(pe), B, L, x.shape[1], float(dropout_p), int(seed), ptr(y), stream()),
+          "posenc_add_fwd")
+    return y
+
+
+def posenc_add_bwd(dy, dropout_p, seed):
+    dx = torch.empty_like(dy)
+    check(lib().ptamd_posenc_add_bwd(ptr(dy), dy.numel(), float(dropout_p), int(seed), ptr(dx), stream()), "posenc_add_bwd")
+    return dx

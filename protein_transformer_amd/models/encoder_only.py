@@ -87,31 +87,60 @@ class _PeHolder(nn.Module):
 
 
 class _EncoderHolder(nn.Module):
-    def __init__(self, din, dm, dff, n_layers, max_seq_len):
+    def __init__(self, din, dm, dlayer, dff, n_layers, max_seq_len, conv_shapes, use_embedding):
         super().__init__()
-        self.input_embedding = _EmbHolder(din, dm)
-        self.positional_enc = _PeHolder(dm, max_seq_len)
-        self.enc_layers = nn.ModuleList([_LayerHolder(dm, dff) for _ in range(n_layers)])
+        if use_embedding:
+            self.input_embedding = _EmbHolder(din, dm)
+            self.positional_enc = _PeHolder(dm, max_seq_len)
+        else:
+            self.positional_enc = _PeHolder(dlayer, max_seq_len)
+        if conv_shapes is not None:      # the reference's conv-enc has this (possibly empty) list, enc-only does not
+            self.conv_layers = nn.ModuleList([_Holder(weight=(co, ci, k), bias=(co,)) for ci, co, k in conv_shapes])
+        self.enc_layers = nn.ModuleList([_LayerHolder(dlayer, dff) for _ in range(n_layers)])
 
 
-class EncoderOnlyTransformer(nn.Module):
-    """ A Transformer that only uses Encoder layers (reference: models/encoder_only.py:10). """
+class _TransformerBase(nn.Module):
+    """Shared implementation of `enc-only` and `conv-enc`: parameter flattening, forward/backward driver."""
 
-    def __init__(self, nlayers, nhead, dmodel, dff, max_seq_len, vocab, angle_means, use_tanh_out, dropout=0.1):
+    def __init__(self, nlayers, nhead, dmodel, dff, max_seq_len, vocab, angle_means, use_tanh_out, dropout=0.1,
+                 conv_kernel_sizes=None, conv_dim_reductions=(), use_embedding=True, conv_out_matches_dm=True):
         super().__init__()
-        assert dmodel % nhead == 0, "The dimension of the model must be evenly divisible by the number of attn heads."
-        if dmodel % 4 or dff % 4 or (dmodel // nhead) not in (8, 16, 32, 64):
-            raise ValueError("libptamd needs d_model, d_ff multiples of 4 and d_model / n_head in {8, 16, 32, 64}")
         if not use_tanh_out:
             raise NotImplementedError("use_tanh_out=False is unreachable from the reference CLI (SURVEY.md A-1.7)")
         self.angle_means = angle_means
         self.vocab = vocab
         self.nlayers, self.nhead, self.dmodel, self.dff, self.max_seq_len = nlayers, nhead, dmodel, dff, max_seq_len
         self.use_tanh_out = use_tanh_out
+        self.use_embedding = bool(use_embedding)
         self.dropout = float(dropout)
         self.attn_dropout = 0.1                      # hard-wired in the reference (Attention.py:31, Encoder.py:47)
-        self.encoder = _EncoderHolder(len(vocab), dmodel, dff, nlayers, max_seq_len)
-        self.output_projection = _Holder(weight=(NUM_PREDICTED_ANGLES * 2, dmodel), bias=(NUM_PREDICTED_ANGLES * 2,))
+        # conv stack geometry (convolutional_encoder.py:85-104)
+        self.conv_shapes = None
+        din = dmodel if self.use_embedding else len(vocab)
+        self.dlayer = dmodel
+        if conv_kernel_sizes is not None:
+            self.conv_shapes = []
+            ks, drs = list(conv_kernel_sizes), list(conv_dim_reductions)
+            for i, (k, dr) in enumerate(zip(ks, drs)):
+                assert k % 2 != 0, "Kernel size must be odd to maintain sequence length."
+                dout = dmodel if (i == len(ks) - 1 and conv_out_matches_dm) else int(din // dr)
+                self.conv_shapes.append((din, dout, k))
+                din = dout
+            if conv_out_matches_dm:
+                self.dlayer = dmodel
+            else:
+                d = dmodel if self.use_embedding else len(vocab)
+                for dr in drs:
+                    d /= dr
+                self.dlayer = int(d)
+        D = self.dlayer
+        assert D % nhead == 0, "The dimension of the model must be evenly divisible by the number of attn heads."
+        widths = [dmodel, D, dff] + [c for _, c, _ in (self.conv_shapes or [])]
+        if any(w % 4 for w in widths) or (D // nhead) not in (8, 16, 32, 64):
+            raise ValueError("libptamd needs channel widths that are multiples of 4 and width / n_head in {8, 16, 32, 64}")
+        self.encoder = _EncoderHolder(len(vocab), dmodel, D, dff, nlayers, max_seq_len, self.conv_shapes,
+                                      self.use_embedding)
+        self.output_projection = _Holder(weight=(NUM_PREDICTED_ANGLES * 2, D), bias=(NUM_PREDICTED_ANGLES * 2,))
         self._flat = None
         self._flat_grad = None
         self._layout = self._make_layout()
@@ -123,7 +152,9 @@ class EncoderOnlyTransformer(nn.Module):
     # ------------------------------------------------------------------ parameters
     def _make_layout(self):
         """name -> (offset, shape) in the flat buffer; every offset is a multiple of 4 floats (16 B)."""
-        order = ["encoder.input_embedding.emb.weight"]
+        order = ["encoder.input_embedding.emb.weight"] if self.use_embedding else []
+        for j in range(len(self.conv_shapes or [])):
+            order += [f"encoder.conv_layers.{j}.weight", f"encoder.conv_layers.{j}.bias"]
         for i in range(self.nlayers):
             b = f"encoder.enc_layers.{i}."
             order += [b + f"self_attn.{n}.weight" for n in ("wq", "wk", "wv")]
@@ -153,8 +184,11 @@ class EncoderOnlyTransformer(nn.Module):
                 nn.init.ones_(p)
             elif "norm.bias" in name:
                 nn.init.zeros_(p)
+            elif "conv_layers" in name:
+                ci, _, k = self.conv_shapes[int(name.split(".")[2])]
+                nn.init.uniform_(p, -1 / math.sqrt(ci * k), 1 / math.sqrt(ci * k))
             else:
-                fan_in = self.dff if "layer2" in name else self.dmodel
+                fan_in = self.dff if "layer2" in name else self.dlayer
                 nn.init.uniform_(p, -1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
         am = np.arctanh(np.asarray(self.angle_means, dtype=np.float64))
         with torch.no_grad():
@@ -206,7 +240,7 @@ class EncoderOnlyTransformer(nn.Module):
         b = f"encoder.enc_layers.{i}.self_attn."
         off_w, _ = self._layout[b + "wq.weight"]
         off_b, _ = self._layout[b + "wq.bias"]
-        D = self.dmodel
+        D = self.dlayer
         return buf[off_w:off_w + 3 * D * D].view(3 * D, D), buf[off_b:off_b + 3 * D]
 
     # ------------------------------------------------------------------ forward
@@ -239,13 +273,26 @@ class _EncoderFn(torch.autograd.Function):
     def forward(ctx, flat, seq, model, seed):
         m = model
         B, L = seq.shape
-        D, H, F_ = m.dmodel, m.nhead, m.dff
+        D, H = m.dlayer, m.nhead
         train = m.training
         p = m.dropout if train else 0.0
         pa = m.attn_dropout if train else 0.0
         W = lambda name: m._slice(flat, name)                                      # noqa: E731
         pe = m.encoder.positional_enc.pe[0]
-        x = K.embed_fwd(seq, W("encoder.input_embedding.emb.weight"), pe, p, seed)
+        # ---- front end: embedding (+ doubled positional add) or one-hot, then the optional Conv1d stack
+        if m.use_embedding:
+            x = K.embed_fwd(seq, W("encoder.input_embedding.emb.weight"), pe, p, seed)
+            cin = m.dmodel
+        else:
+            cin = len(m.vocab)
+            x = K.onehot(seq, cin)
+        conv_saved = []
+        for j, (ci, co, k) in enumerate(m.conv_shapes or []):
+            y, w2 = K.conv1d_fwd(x, B, L, ci, W(f"encoder.conv_layers.{j}.weight"), W(f"encoder.conv_layers.{j}.bias"), k)
+            conv_saved.append((x, w2))
+            x, cin = y, co
+        if not m.use_embedding:
+            x = K.posenc_add_fwd(x, pe, B, L, p, seed)             # enc_output += positional_enc(enc_output)
         saved = []
         for i in range(m.nlayers):
             b = f"encoder.enc_layers.{i}."
@@ -268,7 +315,7 @@ class _EncoderFn(torch.autograd.Function):
         pred = K.linear_fwd(x, W("output_projection.weight"), W("output_projection.bias"), flags=K.EPI_TANH)
         ctx.model, ctx.seed, ctx.seq, ctx.flat = m, seed, seq, flat
         ctx.p, ctx.pa = p, pa
-        ctx.saved = saved
+        ctx.saved, ctx.conv_saved = saved, conv_saved
         ctx.x_last, ctx.pred = x, pred
         return pred
 
@@ -276,7 +323,8 @@ class _EncoderFn(torch.autograd.Function):
     def backward(ctx, dpred):
         m, seed, seq, flat = ctx.model, ctx.seed, ctx.seq, ctx.flat
         p, pa = ctx.p, ctx.pa
-        D, H = m.dmodel, m.nhead
+        B, L = seq.shape
+        D, H = m.dlayer, m.nhead
         gflat = m._flat_grad
         W = lambda name: m._slice(flat, name)                                      # noqa: E731
         G = lambda name: m._slice(gflat, name)                                     # noqa: E731
@@ -325,6 +373,27 @@ class _EncoderFn(torch.autograd.Function):
                                  dres=dx2)
             done(b + "self_attn.wq.weight", b + "sublayer_connections.1.norm.bias")
             ctx.saved[i] = None
-        K.embed_bwd(seq, dx, D, p, seed, G("encoder.input_embedding.emb.weight"))
-        done("encoder.input_embedding.emb.weight", "encoder.input_embedding.emb.weight")
+        # ---- front end
+        if not m.use_embedding:
+            dx = K.posenc_add_bwd(dx, p, seed)
+        convs = m.conv_shapes or []
+        for j in reversed(range(len(convs))):
+            ci, co, k = convs[j]
+            xin, w2 = ctx.conv_saved[j]
+            need_dx = m.use_embedding or j > 0                     # the one-hot input is data, not a parameter
+            dx = K.conv1d_bwd(dx, xin, B, L, ci, w2, k, G(f"encoder.conv_layers.{j}.weight"),
+                              G(f"encoder.conv_layers.{j}.bias"), need_dx=need_dx)
+            ctx.conv_saved[j] = None
+        if convs:
+            done("encoder.conv_layers.0.weight", f"encoder.conv_layers.{len(convs) - 1}.bias")
+        if m.use_embedding:
+            K.embed_bwd(seq, dx, m.dmodel, p, seed, G("encoder.input_embedding.emb.weight"))
+            done("encoder.input_embedding.emb.weight", "encoder.input_embedding.emb.weight")
         return None, None, None, None
+
+
+class EncoderOnlyTransformer(_TransformerBase):
+    """ A Transformer that only uses Encoder layers (reference: models/encoder_only.py:10). """
+
+    def __init__(self, nlayers, nhead, dmodel, dff, max_seq_len, vocab, angle_means, use_tanh_out, dropout=0.1):
+        super().__init__(nlayers, nhead, dmodel, dff, max_seq_len, vocab, angle_means, use_tanh_out, dropout=dropout)

@@ -29,6 +29,7 @@ from .log import (EarlyStoppingCondition, do_eval_batch_logging, do_eval_epoch_l
                   init_metrics, log_batch, prepare_log_header, reset_metrics_for_epoch, update_loss_trackers,
                   update_metrics_end_of_epoch)
 from .losses import batch_loss, combine_drmsd_mse, compute_batch_drmsd, mse_over_angles, mse_sums
+from .models.convolutional_encoder import ConvEncoderOnlyTransformer
 from .models.encoder_only import EncoderOnlyTransformer
 from .optim import FusedAdam, FusedSGD, ScheduledOptim
 from .protein.Sequence import VOCAB
@@ -199,16 +200,24 @@ def load_model(model, optimizer, scheduler, args):
 
 
 def make_model(args, device, angle_means):
-    """Requested architecture (train.py:274-321). `enc-only`, and `conv-enc` without convolution layers
-    (which the reference builds as exactly the same network)."""
-    convs = [a for a in [getattr(args, "conv1_size", None), getattr(args, "conv2_size", None),
-                         getattr(args, "conv3_size", None)] if a]
-    if args.model == "enc-only" or ("conv-enc" in args.model and not convs):
+    """Requested architecture (train.py:274-321): `enc-only` or `conv-enc[|k1,k2,k3|r1,r2,r3]`."""
+    if args.model == "enc-only":
         return EncoderOnlyTransformer(nlayers=args.n_layers, nhead=args.n_head, dmodel=args.d_model,
                                       dff=args.d_inner_hid, max_seq_len=args.max_seq_len, dropout=args.dropout,
                                       vocab=VOCAB, angle_means=angle_means, use_tanh_out="linear-out" not in args.model)
+    if "conv-enc" in args.model:
+        sizes = [a for a in [getattr(args, "conv1_size", None), getattr(args, "conv2_size", None),
+                             getattr(args, "conv3_size", None)] if a]
+        reducs = [a for a in [getattr(args, "conv1_reduc", None), getattr(args, "conv2_reduc", None),
+                              getattr(args, "conv3_reduc", None)] if a]
+        return ConvEncoderOnlyTransformer(nlayers=args.n_layers, nhead=args.n_head, dmodel=args.d_model,
+                                          dff=args.d_inner_hid, max_seq_len=args.max_seq_len, dropout=args.dropout,
+                                          vocab=VOCAB, angle_means=angle_means,
+                                          use_tanh_out="linear-out" not in args.model, conv_kernel_sizes=sizes,
+                                          conv_dim_reductions=reducs, use_embedding=args.use_embedding,
+                                          conv_out_matches_dm=args.conv_out_matches_dm)
     raise argparse.ArgumentError(None, "Model architecture not implemented on the MI355X path "
-                                       "(enc-dec is deprecated upstream; conv-enc with convolutions is a later row).")
+                                       "(enc-dec is deprecated upstream, README.md:49).")
 
 
 def parse_conv_kernel_info_from_model_name(mname):

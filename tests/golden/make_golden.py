@@ -282,6 +282,42 @@ def g567(rng):
     return out
 
 
+def g10(rng):
+    """conv-enc with real Conv1d layers (convolutional_encoder.py), embedding and one-hot variants."""
+    from protein_transformer.models.convolutional_encoder import ConvEncoderOnlyTransformer
+    out = {}
+    lens = [14, 9, 16]
+    seq, _, _, tang = synth_batch(rng, lens, 16)
+    am = np.nanmean(np.concatenate([tang[b, :L] for b, L in enumerate(lens)]), axis=0)
+    out.update(seq=seq, angle_means=am)
+    w = rng.normal(0, 1, (len(lens), 16, 24)).astype(np.float32)
+    out["w"] = w
+    for tag, kw in (("emb", dict(conv_kernel_sizes=[3, 5, 3], conv_dim_reductions=[2, 2, 2], use_embedding=True,
+                                 conv_out_matches_dm=True)),
+                    ("onehot", dict(conv_kernel_sizes=[3, 5], conv_dim_reductions=[0.5, 1], use_embedding=False,
+                                    conv_out_matches_dm=True))):
+        torch.manual_seed(int(rng.integers(0, 2 ** 31)))
+        model = ConvEncoderOnlyTransformer(nlayers=1, nhead=4, dmodel=32, dff=64, max_seq_len=500, vocab=VOCAB,
+                                           angle_means=am, use_tanh_out=True, dropout=0.0, **kw)
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        with torch.no_grad():
+            model.output_projection.weight.normal_(0, 0.05)
+        for k, v in model.state_dict().items():
+            if not k.endswith(".pe"):
+                out[f"{tag}/sd/{k}"] = v.numpy().copy()
+        pred = model(torch.tensor(seq))
+        out[f"{tag}/pred"] = pred.detach().numpy()
+        (pred * torch.tensor(w)).sum().backward()
+        for k, p in model.named_parameters():      # the front end + a sample of the rest (G5 covers the layers)
+            if any(t in k for t in ("conv_layers", "input_embedding", "output_projection", "wq.weight", "norm.bias")):
+                out[f"{tag}/grad/{k}"] = p.grad.numpy().copy()
+        out[f"{tag}/kernels"] = np.array(kw["conv_kernel_sizes"])
+        out[f"{tag}/reducs"] = np.array(kw["conv_dim_reductions"], dtype=np.float64)
+    return out
+
+
 def g8(rng):
     out = {}
     lens = [9, 6, 12]
@@ -342,7 +378,7 @@ def main():
     ns = ap.parse_args()
     torch.set_num_threads(1)
     for name, fn, seed in (("g1_nerf", g1, 1), ("g2_coords", g2, 2), ("g3_drmsd", g3, 3), ("g4_drmsd_work", g4, 4),
-                           ("g567_model_step", g567, 5), ("g8_mse", g8, 8), ("g9_dataset", g9, 9)):
+                           ("g567_model_step", g567, 5), ("g8_mse", g8, 8), ("g9_dataset", g9, 9), ("g10_convenc", g10, 10)):
         data = fn(np.random.default_rng(seed))
         path = os.path.join(ns.out, name + ".npz")
         np.savez_compressed(path, **data)

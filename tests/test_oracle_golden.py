@@ -199,3 +199,22 @@ def test_sidechain_program_consistency():
             if parents:
                 assert all(p < 4 + k for p in parents)
     assert sum(len(p) for p in geometry.SC_PROGRAM.values()) == 87
+
+
+# ---------------------------------------------------------------- G10: conv-enc front end
+@pytest.mark.parametrize("tag", ["emb", "onehot"])
+def test_conv_encoder_golden(golden, tag):
+    g = golden("g10_convenc")
+    pre = tag + "/sd/"
+    sd = {k[len(pre):]: T(v).clone().requires_grad_() for k, v in g.items() if k.startswith(pre)}
+    dl = sd["output_projection.weight"].shape[1]
+    d_pe = sd["encoder.input_embedding.emb.weight"].shape[1] if tag == "emb" else dl
+    params = {**sd, "encoder.positional_enc.pe": encoder.positional_table(500, d_pe)}
+    pred = encoder.encoder_forward(params, T(g["seq"]), 4)
+    assert np.allclose(pred.detach().numpy(), g[tag + "/pred"], atol=2e-6)
+    (pred * T(g["w"])).sum().backward()
+    gmax = max(np.abs(g[k]).max() for k in g if k.startswith(tag + "/grad/"))
+    for k in g:
+        if k.startswith(tag + "/grad/"):
+            name = k[len(tag) + 6:]
+            assert np.allclose(sd[name].grad.numpy(), g[k], rtol=1e-3, atol=1e-5 * gmax), name
