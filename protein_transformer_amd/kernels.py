@@ -15,6 +15,7 @@ EPI_RELU, EPI_TANH, EPI_ACCUM = 1, 2, 4
 # bench.py sets this to a list to time every GEMM launch with HIP events recorded on the launch stream:
 # entries are (flops, start_event, end_event).  None (the default) adds no work to the hot path.
 GEMM_TIMING = None
+GEMM_EVENT_POOL = []
 GEMM_BYTES = []          # algorithmic operand bytes (A + B + C [+ residual, + accumulate]) of every timed launch
 
 
@@ -36,7 +37,8 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False,
     if GEMM_TIMING is None:
         check(lib().ptamd_gemm(C.byref(args), stream()), "gemm")
     else:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # events come from a pool created before the timed region: the hot loop only pays two hipEventRecord calls
+        e0, e1 = GEMM_EVENT_POOL.pop(), GEMM_EVENT_POOL.pop()
         e0.record()
         check(lib().ptamd_gemm(C.byref(args), stream()), "gemm")
         e1.record()

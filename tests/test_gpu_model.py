@@ -236,3 +236,26 @@ def test_dropout_training_mode(dev):
     m(seq).sum().backward()
     _, g = m.flat_parameters()
     assert float(plus - minus) / 2 == approx(float((g.double() * d.double()).sum()), rel=0.03, abs=1e-4)
+
+
+def test_long_sequence_model(dev):
+    """L = 1500 > the reference's hard-wired 500: positional table, attention tiling and key masking at length."""
+    from oracle import encoder as oenc
+    from protein_transformer_amd.models.encoder_only import EncoderOnlyTransformer
+    from protein_transformer_amd.protein.Sequence import VOCAB
+    am = np.tanh(np.random.default_rng(2).normal(0, 0.5, 24))
+    params = oenc.init_params(1, 64, 128, 1500, am, seed=9)
+    params["output_projection.weight"].normal_(0, 0.05)
+    m = EncoderOnlyTransformer(1, 8, 64, 128, 1500, VOCAB, am, True, dropout=0.0)
+    m.load_state_dict(params)
+    m.set_dropout(0.0)
+    m = m.to(dev).eval()
+    seq = torch.full((2, 1500), 20, dtype=torch.int64)
+    seq[0] = torch.randint(0, 20, (1500,))
+    seq[1, :777] = torch.randint(0, 20, (777,))
+    with torch.no_grad():
+        out = m(seq.to(dev)).cpu().numpy()
+        ref = oenc.encoder_forward(params, seq, 8).numpy()
+    assert np.abs(out - ref).max() < 1e-5
+    with pytest.raises(RuntimeError, match="max_seq_len"):
+        m(torch.zeros(1, 1501, dtype=torch.int64, device=dev))
