@@ -34,7 +34,11 @@ def rank():
 
 
 def local_rank():
-    return int(os.environ.get("LOCAL_RANK", "0"))
+    """Device index of this process: LOCAL_RANK, folded onto the visible devices (so that a multi-rank smoke test
+    can oversubscribe a single GPU; on an 8-GPU node it is the identity)."""
+    lr = int(os.environ.get("LOCAL_RANK", "0"))
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    return lr % n if n else lr
 
 
 def is_main():
@@ -45,7 +49,8 @@ def init_from_env(backend=None):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun contract)."""
     if int(os.environ.get("WORLD_SIZE", "1")) <= 1 or is_initialized():
         return
-    backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")     # "nccl" is RCCL on ROCm
+    backend = backend or os.environ.get("PTAMD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    # "nccl" is RCCL on ROCm; gloo is only for tests (CPU, or several ranks sharing one GPU)
     kwargs = {}
     if backend == "nccl":
         torch.cuda.set_device(local_rank())
