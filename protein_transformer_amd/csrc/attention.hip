@@ -27,14 +27,16 @@ constexpr int QB = 128;  // queries (or keys) per workgroup
 constexpr int KT = 64;   // keys per LDS tile in the forward / dQ kernels
 constexpr int QT = 32;   // queries per LDS tile in the dK/dV kernel
 
-// lowbias32 integer hash -> uniform 32-bit word per (row, col) element of one attention matrix
+// lowbias32 integer hash (full-avalanche 32-bit mixer) of a per-(seed, site, protein, head) key and the
+// (query, key) position -> one uniform 32-bit word per element of the attention matrix
 __device__ __forceinline__ uint32_t attn_rand(uint32_t key_lo, uint32_t key_hi, uint32_t row, uint32_t col) {
-  uint32_t x = (row * 0x9E3779B1u) ^ (col + key_lo);
-  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-  x += key_hi ^ (col * 0x85EBCA77u);
+  uint32_t x = (row * 0x9E3779B1u + key_lo) ^ (col * 0x85EBCA77u + key_hi);
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return x;
 }
+// exp(x) for x <= 0 on the transcendental unit: v_exp_f32(x * log2 e).  Relative error <= ~|x| * 2^-23 + 1 ulp,
+// i.e. <= 3e-6 over the range that matters for a softmax (exp(-30) ~ 1e-13 contributes nothing).
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 struct DropKey {
   uint32_t lo, hi, thr;
   float ks;
@@ -162,11 +164,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const float *__restric
       mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
       const float m_new = fmaxf(m_run, mt);
       const float m_safe = m_new == -INFINITY ? 0.f : m_new;
-      const float alpha = expf(m_run - m_safe);
+      const float alpha = fast_exp(m_run - m_safe);
       float ps = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s[r] = expf(s[r] - m_safe);
+        s[r] = fast_exp(s[r] - m_safe);
         ps += s[r];
       }
       l_run = l_run * alpha + ps;
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const float *__rest
       for (int r = 0; r < 16; ++r) {
         const int kk = sub * 32 + crow(r, lh);
         const bool valid = (mask >> kk) & 1ull;
-        const float p = valid ? expf(s[r] * scale - my_lse) : 0.f;
+        const float p = valid ? fast_exp(s[r] * scale - my_lse) : 0.f;
         float g = dp[r];
         if (p_drop > 0.f) {
           const uint32_t w = attn_rand(dk_.lo, dk_.hi, (uint32_t)q, (uint32_t)(k0 + kk));
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float *__res
     for (int r = 0; r < 16; ++r) {
       const int qi = crow(r, lh), qg = qq0 + qi;
       const bool ok = k_valid && qg < L;
-      const float p = ok ? expf(s[r] * scale - sLse[cur][qi]) : 0.f;
+      const float p = ok ? fast_exp(s[r] * scale - sLse[cur][qi]) : 0.f;
       float g = dp[r], pk = p;
       if (p_drop > 0.f) {
         const uint32_t w = attn_rand(dk_.lo, dk_.hi, (uint32_t)qg, (uint32_t)key);
