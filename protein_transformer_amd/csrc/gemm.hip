@@ -49,6 +49,7 @@ struct GemmParams {
   int k_per_split;  // multiple of BK
   int splits;
   size_t slab;      // M*N when split-K writes partial slabs, else 0
+  int vec_epilogue;  // N, ldc, ldr multiples of 4 and 16-byte aligned C / residual: float4 epilogue through LDS
 };
 
 // ---- staging: each thread carries 4 float4 per operand per stage; global -> registers -> LDS, no transposition:
@@ -241,49 +242,100 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_mfma_kernel(const GemmParams p
     }
 
     // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-    // Per 32x32 tile: the bias (one column per lane) is loaded once and the 16 residual / accumulate operands
-    // are fetched as 16 independent loads BEFORE any arithmetic, so the epilogue pays one memory latency per
-    // tile instead of one per element.
     float *C = p.C + (partial ? (size_t)z * p.slab : 0);
     const int ldc = partial ? p.N : p.ldc;
+    if (BK == 32 && p.vec_epilogue) {
+      // Vector path: bias / ReLU / dropout are applied in the MFMA layout (one column per lane, four consecutive
+      // rows per Philox call), then each wavefront transposes its tile through the LDS stage buffer that the last
+      // K stage just released (32 rows x 64 columns at a time) so that residual / accumulate operands are READ and
+      // results are WRITTEN as float4 rows: 16 16-byte stores per lane instead of 64 4-byte ones.
+      float *scratch = (wave < 2 ? sA0 + (cur ^ 1) * SA : sB0 + (cur ^ 1) * SB) + (wave & 1) * 2048;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int col = bn0 + wn * 64 + j * 32 + l31;
-        const bool col_ok = col < p.N;
-        const int row_base = bm0 + wm * 64 + i * 32 + 4 * lh;
-        const float bias = (!partial && p.bias && col_ok) ? p.bias[col] : 0.f;
-        float res[16], old[16];
+        for (int j = 0; j < 2; ++j) {
+          const int col = bn0 + wn * 64 + j * 32 + l31;
+          const float bias = (!partial && p.bias && col < p.N) ? p.bias[col] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = row_base + (r & 3) + 8 * (r >> 2);
-          const bool ok = col_ok && row < p.M;
-          res[r] = (!partial && p.residual && ok) ? p.residual[(size_t)row * p.ldr + col] : 0.f;
-          old[r] = (!partial && (p.flags & PTAMD_EPI_ACCUM) && ok) ? C[(size_t)row * ldc + col] : 0.f;
+          for (int g = 0; g < 4; ++g) {
+            const int rowq = bm0 + wm * 64 + i * 32 + 8 * g + 4 * lh;
+            uint4 rnd = make_uint4(0, 0, 0, 0);
+            if (!partial && p.dropout_p > 0.f) rnd = philox4x32(p.seed, (uint64_t)(rowq >> 2) * p.N + col, p.stream_id);
+            const uint32_t rw[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float v = acc[i][j][g * 4 + e];
+              if (!partial) {
+                v += bias;
+                if (p.flags & PTAMD_EPI_RELU) v = fmaxf(v, 0.f);
+                if (p.dropout_p > 0.f) v = rw[e] >= thr ? v * keep_scale : 0.f;
+              }
+              scratch[(8 * g + 4 * lh + e) * 64 + j * 32 + l31] = v;
+            }
+          }
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int rowq = row_base + 8 * g;  // 4 consecutive rows share one Philox call
-          uint4 rnd = make_uint4(0, 0, 0, 0);
-          if (!partial && p.dropout_p > 0.f) rnd = philox4x32(p.seed, (uint64_t)(rowq >> 2) * p.N + col, p.stream_id);
-          const uint32_t rw[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int row = rowq + e, r = g * 4 + e;
-            float v = acc[i][j][r];
+        for (int t = 0; t < 8; ++t) {
+          const int f = lane + 64 * t, rr = f >> 4, c4 = (f & 15) * 4;
+          const int row = bm0 + wm * 64 + i * 32 + rr, col = bn0 + wn * 64 + c4;
+          float4 v = *reinterpret_cast<const float4 *>(scratch + rr * 64 + c4);
+          if (row < p.M && col < p.N) {
             if (!partial) {
-              v += bias;
-              if (p.flags & PTAMD_EPI_RELU) v = fmaxf(v, 0.f);
-              if (p.dropout_p > 0.f) v = rw[e] >= thr ? v * keep_scale : 0.f;
-              v += res[r];
-              if (p.flags & PTAMD_EPI_TANH) v = tanhf(v);
-              v += old[r];
+              if (p.residual) {
+                const float4 r4 = *reinterpret_cast<const float4 *>(p.residual + (size_t)row * p.ldr + col);
+                v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+              }
+              if (p.flags & PTAMD_EPI_TANH) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+              if (p.flags & PTAMD_EPI_ACCUM) {
+                const float4 o4 = *reinterpret_cast<const float4 *>(C + (size_t)row * ldc + col);
+                v.x += o4.x; v.y += o4.y; v.z += o4.z; v.w += o4.w;
+              }
             }
-            if (col_ok && row < p.M) C[(size_t)row * ldc + col] = v;
+            *reinterpret_cast<float4 *>(C + (size_t)row * ldc + col) = v;
           }
         }
       }
+      if (has_next) __syncthreads();  // the next item's first stage store reuses this LDS buffer
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int col = bn0 + wn * 64 + j * 32 + l31;
+          const bool col_ok = col < p.N;
+          const int row_base = bm0 + wm * 64 + i * 32 + 4 * lh;
+          const float bias = (!partial && p.bias && col_ok) ? p.bias[col] : 0.f;
+          float res[16], old[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = row_base + (r & 3) + 8 * (r >> 2);
+            const bool ok = col_ok && row < p.M;
+            res[r] = (!partial && p.residual && ok) ? p.residual[(size_t)row * p.ldr + col] : 0.f;
+            old[r] = (!partial && (p.flags & PTAMD_EPI_ACCUM) && ok) ? C[(size_t)row * ldc + col] : 0.f;
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int rowq = row_base + 8 * g;  // 4 consecutive rows share one Philox call
+            uint4 rnd = make_uint4(0, 0, 0, 0);
+            if (!partial && p.dropout_p > 0.f) rnd = philox4x32(p.seed, (uint64_t)(rowq >> 2) * p.N + col, p.stream_id);
+            const uint32_t rw[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int row = rowq + e, r = g * 4 + e;
+              float v = acc[i][j][r];
+              if (!partial) {
+                v += bias;
+                if (p.flags & PTAMD_EPI_RELU) v = fmaxf(v, 0.f);
+                if (p.dropout_p > 0.f) v = rw[e] >= thr ? v * keep_scale : 0.f;
+                v += res[r];
+                if (p.flags & PTAMD_EPI_TANH) v = tanhf(v);
+                v += old[r];
+              }
+              if (col_ok && row < p.M) C[(size_t)row * ldc + col] = v;
+            }
+          }
+        }
+    }
     if (!has_next) break;
     w = wn_next; bm0 = nbm0; bn0 = nbn0; z = nz; kbeg = nkbeg; kend = nkend;
   }
@@ -378,6 +430,9 @@ int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
   p.k_per_split = ((kblocks + splits - 1) / splits) * BK;
   splits = (a->K + p.k_per_split - 1) / p.k_per_split;
   p.splits = splits;
+  p.vec_epilogue = !(a->N & 3) && !(a->ldc & 3) && pt_aligned16(a->C) &&
+                   (!a->residual || (!(a->ldr & 3) && pt_aligned16(a->residual))) &&
+                   (splits == 1 || pt_aligned16(a->workspace));
   p.slab = 0;
   float *user_c = a->C;
   if (splits > 1) {

@@ -47,11 +47,13 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False,
     return C_out
 
 
-def pick_split_k(M, N, K, target_blocks=512):
+def pick_split_k(M, N, K, slots=512):
+    """K splits for a reduction-heavy product with few output tiles: as many (tile, split) items as fit in ONE round
+    of the persistent grid (2 workgroups x 256 CUs) - one item more than that would cost a whole second round."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if tiles >= target_blocks // 2 or K <= 512:
+    if tiles >= slots // 2 or K <= 512:
         return 1
-    return max(1, min(K // 256, -(-target_blocks // tiles)))
+    return max(1, min(K // 256, slots // tiles))
 
 
 def linear_fwd(x, w, b, out=None, **epi):
