@@ -121,6 +121,7 @@ typedef struct {
   float dropout_p; uint64_t seed; uint32_t stream_id;
   int split_k;            /* >1: partials go to workspace and are reduced deterministically */
   void *workspace; size_t workspace_bytes;
+  float *colsum;          /* optional, a_kmajor only: colsum[m] += sum_k A[k][m] (the bias gradient of a dW product) */
 } ptamd_gemm_args;
 size_t ptamd_gemm_workspace_bytes(int M, int N, int split_k);
 int ptamd_gemm(const ptamd_gemm_args *args, void *stream);

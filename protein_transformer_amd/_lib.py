@@ -26,7 +26,8 @@ class GemmArgs(C.Structure):
                 ("flags", _i),
                 ("dropout_p", _f), ("seed", _u64), ("stream_id", _u32),
                 ("split_k", _i),
-                ("workspace", _p), ("workspace_bytes", _sz)]
+                ("workspace", _p), ("workspace_bytes", _sz),
+                ("colsum", _p)]
 
 
 # name -> (restype, argtypes); mirrors include/ptamd.h one to one

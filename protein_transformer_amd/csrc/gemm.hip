@@ -50,6 +50,7 @@ struct GemmParams {
   int splits;
   size_t slab;      // M*N when split-K writes partial slabs, else 0
   int vec_epilogue;  // N, ldc, ldr multiples of 4 and 16-byte aligned C / residual: float4 epilogue through LDS
+  float *colsum;     // k-major A only: colsum[m] (+)= sum_k A[k][m]; with split-K a [splits][M] slab, reduced later
 };
 
 // ---- staging: each thread carries 4 float4 per operand per stage; global -> registers -> LDS, no transposition:
@@ -170,6 +171,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_mfma_kernel(const GemmParams p
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    const bool do_colsum = A_KMAJOR && BK == 32 && p.colsum != nullptr && bn0 == 0;
+    float csum = 0.f;
     const int wn_next = w + 1;
     int nbm0 = 0, nbn0 = 0, nz = 0, nkbeg = 0, nkend = 0;
     const bool has_next = wn_next < w_end;
@@ -205,6 +208,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_mfma_kernel(const GemmParams p
       }
       const float *sa = sA0 + cur * SA, *sb = sB0 + cur * SB;
       const float *na = sA0 + (cur ^ 1) * SA, *nb = sB0 + (cur ^ 1) * SB;
+      if (A_KMAJOR && do_colsum) {  // sum over this stage's k of A[k][m]: the bias gradient rides along for free
+        const float *q = sa + (tid >> 7) * (BK / 2) * LD_C + (tid & 127);
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) csum += q[kk * LD_C];
+      }
 #pragma unroll
       for (int m = 0; m < NG; ++m) {
         float c0[4], c1[4], d0[4], d1[4];
@@ -336,15 +344,36 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_mfma_kernel(const GemmParams p
           }
         }
     }
+    if (A_KMAJOR && do_colsum) {  // block-uniform
+      float *spare = sA0 + (cur ^ 1) * SA + 4096;  // 128 floats the wave scratch regions do not use
+      __syncthreads();
+      if (tid >= 128) spare[tid - 128] = csum;
+      __syncthreads();
+      if (tid < 128 && bm0 + tid < p.M) {
+        const float tot = csum + spare[tid];
+        if (partial) p.colsum[(size_t)z * p.M + bm0 + tid] = tot;
+        else p.colsum[bm0 + tid] += tot;
+      }
+      __syncthreads();
+    }
     if (!has_next) break;
     w = wn_next; bm0 = nbm0; bn0 = nbn0; z = nz; kbeg = nkbeg; kend = nkend;
   }
 }
 
 // split-K: sum the slabs in a fixed order, then the same epilogue
-__global__ void gemm_splitk_reduce_kernel(const GemmParams p, const float *__restrict__ slabs, int splits) {
+__global__ void gemm_splitk_reduce_kernel(const GemmParams p, const float *__restrict__ slabs, int splits,
+                                          const float *__restrict__ colsum_slabs, float *__restrict__ colsum_out) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   const int rowq = blockIdx.y * 4;
+  if (colsum_out && blockIdx.x == 0 && threadIdx.x < 4) {  // bias gradient of rows rowq..rowq+3
+    const int row = rowq + threadIdx.x;
+    if (row < p.M) {
+      float v = 0.f;
+      for (int s = 0; s < splits; ++s) v += colsum_slabs[(size_t)s * p.M + row];
+      colsum_out[row] += v;
+    }
+  }
   if (col >= p.N) return;
   const uint32_t thr = dropout_threshold(p.dropout_p);
   const float keep_scale = 1.f / (1.f - p.dropout_p);
@@ -407,7 +436,7 @@ extern "C" {
 
 size_t ptamd_gemm_workspace_bytes(int M, int N, int split_k) {
   if (split_k <= 1 || M <= 0 || N <= 0) return 0;
-  return (size_t)split_k * M * N * sizeof(float);
+  return ((size_t)split_k * M * N + (size_t)split_k * M) * sizeof(float);  // C slabs + column-sum slabs
 }
 
 int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
@@ -434,11 +463,14 @@ int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
                    (!a->residual || (!(a->ldr & 3) && pt_aligned16(a->residual))) &&
                    (splits == 1 || pt_aligned16(a->workspace));
   p.slab = 0;
+  p.colsum = a->colsum;
+  if (a->colsum && (!a->a_kmajor || BK != 32)) return PTAMD_ERR_BAD_SHAPE;
   float *user_c = a->C;
   if (splits > 1) {
-    if (!a->workspace || a->workspace_bytes < (size_t)splits * a->M * a->N * sizeof(float)) return PTAMD_ERR_WORKSPACE;
+    if (!a->workspace || a->workspace_bytes < ptamd_gemm_workspace_bytes(a->M, a->N, splits)) return PTAMD_ERR_WORKSPACE;
     p.slab = (size_t)a->M * a->N;
     p.C = static_cast<float *>(a->workspace);
+    if (a->colsum) p.colsum = p.C + (size_t)splits * p.slab;
   }
   hipStream_t st = (hipStream_t)stream;
   int rc;
@@ -457,7 +489,7 @@ int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
   const float *slabs = p.C;
   p.C = user_c;
   hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((a->N + 255) / 256, (a->M + 3) / 4), dim3(256), 0, st, p, slabs,
-                     splits);
+                     splits, a->colsum ? slabs + (size_t)splits * p.slab : nullptr, a->colsum);
   return pt_check_launch();
 }
 

@@ -20,7 +20,7 @@ GEMM_BYTES = []          # algorithmic operand bytes (A + B + C [+ residual, + a
 
 
 def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, bias=None, residual=None,
-         ldr=0, flags=0, dropout_p=0.0, seed=0, stream_id=0, split_k=1):
+         ldr=0, flags=0, dropout_p=0.0, seed=0, stream_id=0, split_k=1, colsum=None):
     """C[M,N] = epilogue(A (*) B); operand layouts as documented in ptamd.h."""
     ws = None
     nbytes = 0
@@ -33,7 +33,8 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False,
                     residual=residual.data_ptr() if residual is not None else None, ldr=ldr, flags=flags,
                     dropout_p=float(dropout_p), seed=int(seed) & (2 ** 64 - 1), stream_id=int(stream_id),
                     split_k=int(split_k), workspace=ws.data_ptr() if ws is not None else None,
-                    workspace_bytes=ws.numel() if ws is not None else 0)
+                    workspace_bytes=ws.numel() if ws is not None else 0,
+                    colsum=colsum.data_ptr() if colsum is not None else None)
     if GEMM_TIMING is None:
         check(lib().ptamd_gemm(C.byref(args), stream()), "gemm")
     else:
@@ -75,12 +76,13 @@ def linear_bwd_input(dy, w, out=None, flags=0):
                 flags=flags)
 
 
-def linear_bwd_weight(dy, x, dw):
-    """dw[N,K] += dy[T,N]^T x[T,K]  (reduction over the T tokens, split across workgroups)."""
+def linear_bwd_weight(dy, x, dw, dbias=None):
+    """dw[N,K] += dy[T,N]^T x[T,K]  (reduction over the T tokens, split across workgroups) and, fused into the same
+    pass over dy, dbias[N] += sum_t dy[t,N]."""
     T, N = dy.shape
     K = x.shape[1]
     return gemm(dy, x, dw, M=N, N=K, K=T, lda=dy.stride(0), ldb=x.stride(0), ldc=dw.stride(0), a_kmajor=True,
-                b_kmajor=True, flags=EPI_ACCUM, split_k=pick_split_k(N, K, T))
+                b_kmajor=True, flags=EPI_ACCUM, split_k=pick_split_k(N, K, T), colsum=dbias)
 
 
 def colsum(x, out, accumulate=True):

@@ -337,8 +337,7 @@ class _EncoderFn(torch.autograd.Function):
 
         dpred = dpred.contiguous().view(-1, NUM_PREDICTED_ANGLES * 2)
         dpre = K.tanh_bwd(dpred, ctx.pred)
-        K.linear_bwd_weight(dpre, ctx.x_last, G("output_projection.weight"))
-        K.colsum(dpre, G("output_projection.bias"))
+        K.linear_bwd_weight(dpre, ctx.x_last, G("output_projection.weight"), G("output_projection.bias"))
         dx = K.linear_bwd_input(dpre, W("output_projection.weight"))
         done("output_projection.weight", "output_projection.bias")
         for i in reversed(range(m.nlayers)):
@@ -347,26 +346,22 @@ class _EncoderFn(torch.autograd.Function):
             x, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, f1 = ctx.saved[i]
             # x3 = x2 + drop(f1 W2^T + b2)
             dy2 = K.dropout_bwd(dx, p, seed, sid + _SITE_FFN_OUT) if p > 0 else dx
-            K.linear_bwd_weight(dy2, f1, G(b + "pwff.layer2.weight"))
-            K.colsum(dy2, G(b + "pwff.layer2.bias"))
+            K.linear_bwd_weight(dy2, f1, G(b + "pwff.layer2.weight"), G(b + "pwff.layer2.bias"))
             df1 = K.linear_bwd_input(dy2, W(b + "pwff.layer2.weight"))
             dz1 = K.relu_dropout_bwd(df1, f1, p)
-            K.linear_bwd_weight(dz1, h2, G(b + "pwff.layer1.weight"))
-            K.colsum(dz1, G(b + "pwff.layer1.bias"))
+            K.linear_bwd_weight(dz1, h2, G(b + "pwff.layer1.weight"), G(b + "pwff.layer1.bias"))
             dh2 = K.linear_bwd_input(dz1, W(b + "pwff.layer1.weight"))
             dx2 = K.layernorm_bwd(dh2, x2, W(b + "sublayer_connections.1.norm.weight"), mean2, rstd2,
                                   G(b + "sublayer_connections.1.norm.weight"), G(b + "sublayer_connections.1.norm.bias"),
                                   dres=dx)
             # x2 = x + drop(att Wo^T + bo)
             dyo = K.dropout_bwd(dx2, p, seed, sid + _SITE_ATTN_OUT) if p > 0 else dx2
-            K.linear_bwd_weight(dyo, att, G(b + "self_attn.wo.weight"))
-            K.colsum(dyo, G(b + "self_attn.wo.bias"))
+            K.linear_bwd_weight(dyo, att, G(b + "self_attn.wo.weight"), G(b + "self_attn.wo.bias"))
             datt = K.linear_bwd_input(dyo, W(b + "self_attn.wo.weight"))
             dqkv = K.attention_bwd(qkv, seq, att, datt, lse, H, pa, seed, sid + _SITE_ATTN)
             gw, gb = m._qkv(gflat, i)
             wqkv, _ = m._qkv(flat, i)
-            K.linear_bwd_weight(dqkv, h1, gw)
-            K.colsum(dqkv, gb)
+            K.linear_bwd_weight(dqkv, h1, gw, gb)
             dh1 = K.linear_bwd_input(dqkv, wqkv)
             dx = K.layernorm_bwd(dh1, x, W(b + "sublayer_connections.0.norm.weight"), mean1, rstd1,
                                  G(b + "sublayer_connections.0.norm.weight"), G(b + "sublayer_connections.0.norm.bias"),

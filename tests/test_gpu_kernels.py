@@ -72,6 +72,13 @@ def test_gemm_epilogues_and_split(dev):
     dw = torch.ones(N, Kd, device=dev)
     K_.linear_bwd_weight(dy.to(dev), xd, dw)
     assert_close(dw, 1 + dy.double().T @ x.double(), 1e-5, 2e-5, "dW accumulate")
+    # bias gradient fused into the dW product (column sums of dy), unsplit and split-K
+    for rows in (384, 4096):
+        dyl, xl = rnd((rows, N), 70), rnd((rows, Kd), 71)
+        dw, db = torch.zeros(N, Kd, device=dev), torch.full((N,), 2.0, device=dev)
+        K_.linear_bwd_weight(dyl.to(dev), xl.to(dev), dw, db)
+        assert_close(dw, dyl.double().T @ xl.double(), 1e-5, 1e-4, "dW with fused colsum")
+        assert_close(db, 2 + dyl.double().sum(0), 1e-5, 1e-4, "fused bias gradient")
     # explicit split-K equals the unsplit product up to reassociation
     big_t = 4096
     x2, dy2 = rnd((big_t, 256), 8), rnd((big_t, 128), 9)
