@@ -50,7 +50,8 @@ struct GemmParams {
   int splits;
   size_t slab;      // M*N when split-K writes partial slabs, else 0
   int vec_epilogue;  // N, ldc, ldr multiples of 4 and 16-byte aligned C / residual: float4 epilogue through LDS
-  float *colsum;     // k-major A only: colsum[m] (+)= sum_k A[k][m]; with split-K a [splits][M] slab, reduced later
+  float *colsum;     // k-major A only: colsum[m] (+)= sum_k A[k][m]; with split-K a [splits * share][M] slab, reduced later
+  int colsum_share;  // N tiles sharing the column-sum work of one (M tile, split): power of two <= min(tiles_n, 16)
 };
 
 // ---- staging: each thread carries 4 float4 per operand per stage; global -> registers -> LDS, no transposition:
@@ -171,7 +172,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_mfma_kernel(const GemmParams p
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const bool do_colsum = A_KMAJOR && BK == 32 && p.colsum != nullptr && bn0 == 0;
+    // Bias gradient = column sums of the k-major A operand.  With split-K slabs the N tiles of one (M tile, split)
+    // share the work: N tile tn takes every cs_share-th k row starting at tn (cs_share = power of two <= 16), and
+    // the slab reduction adds the shares; without slabs the first N tile does it alone and accumulates in place.
+    const int cs_share = partial ? p.colsum_share : 1, cs_first = (bn0 / BN) & (cs_share - 1);
+    const bool do_colsum = A_KMAJOR && BK == 32 && p.colsum != nullptr && (partial ? bn0 / BN < cs_share : bn0 == 0);
     float csum = 0.f;
     const int wn_next = w + 1;
     int nbm0 = 0, nbn0 = 0, nz = 0, nkbeg = 0, nkend = 0;
@@ -208,10 +213,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_mfma_kernel(const GemmParams p
       }
       const float *sa = sA0 + cur * SA, *sb = sB0 + cur * SB;
       const float *na = sA0 + (cur ^ 1) * SA, *nb = sB0 + (cur ^ 1) * SB;
-      if (A_KMAJOR && do_colsum) {  // sum over this stage's k of A[k][m]: the bias gradient rides along for free
-        const float *q = sa + (tid >> 7) * (BK / 2) * LD_C + (tid & 127);
-#pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) csum += q[kk * LD_C];
+      if (A_KMAJOR && do_colsum) {  // sum over (this workgroup's share of) the stage's k of A[k][m]
+        const float *q = sa + ((tid >> 7) * (BK / 2) + cs_first) * LD_C + (tid & 127);
+        for (int kk = 0; kk < BK / 2; kk += cs_share) csum += q[kk * LD_C];
       }
 #pragma unroll
       for (int m = 0; m < NG; ++m) {
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_mfma_kernel(const GemmParams p
       __syncthreads();
       if (tid < 128 && bm0 + tid < p.M) {
         const float tot = csum + spare[tid];
-        if (partial) p.colsum[(size_t)z * p.M + bm0 + tid] = tot;
+        if (partial) p.colsum[((size_t)z * cs_share + cs_first) * p.M + bm0 + tid] = tot;
         else p.colsum[bm0 + tid] += tot;
       }
       __syncthreads();
@@ -370,7 +374,7 @@ __global__ void gemm_splitk_reduce_kernel(const GemmParams p, const float *__res
     const int row = rowq + threadIdx.x;
     if (row < p.M) {
       float v = 0.f;
-      for (int s = 0; s < splits; ++s) v += colsum_slabs[(size_t)s * p.M + row];
+      for (int s = 0; s < splits * p.colsum_share; ++s) v += colsum_slabs[(size_t)s * p.M + row];
       colsum_out[row] += v;
     }
   }
@@ -436,7 +440,7 @@ extern "C" {
 
 size_t ptamd_gemm_workspace_bytes(int M, int N, int split_k) {
   if (split_k <= 1 || M <= 0 || N <= 0) return 0;
-  return ((size_t)split_k * M * N + (size_t)split_k * M) * sizeof(float);  // C slabs + column-sum slabs
+  return ((size_t)split_k * M * N + (size_t)split_k * 16 * M) * sizeof(float);  // C slabs + column-sum slabs
 }
 
 int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
@@ -464,6 +468,11 @@ int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
                    (splits == 1 || pt_aligned16(a->workspace));
   p.slab = 0;
   p.colsum = a->colsum;
+  p.colsum_share = 1;
+  {
+    const int tiles_n = (a->N + BN - 1) / BN;
+    while (p.colsum_share * 2 <= tiles_n && p.colsum_share < 16) p.colsum_share *= 2;
+  }
   if (a->colsum && (!a->a_kmajor || BK != 32)) return PTAMD_ERR_BAD_SHAPE;
   float *user_c = a->C;
   if (splits > 1) {

@@ -54,7 +54,7 @@ def test_host_only_entry_points(built_lib):
     assert lib.ptamd_nerf_workspace_bytes(32, 512) == 32 * 512 * 12 * 4
     assert lib.ptamd_drmsd_workspace_bytes(32, 512) > 32 * 512 * 14 * 52
     assert lib.ptamd_gemm_workspace_bytes(512, 512, 1) == 0
-    assert lib.ptamd_gemm_workspace_bytes(512, 512, 8) == (8 * 512 * 512 + 8 * 512) * 4   # C slabs + column-sum slabs
+    assert lib.ptamd_gemm_workspace_bytes(512, 512, 8) == (8 * 512 * 512 + 8 * 16 * 512) * 4   # C slabs + column-sum slabs
     # argument validation happens on the host, before any launch
     assert lib.ptamd_nerf_fwd(None, None, 0, 5, None, None, None) == -1          # PTAMD_ERR_BAD_SHAPE
     assert lib.ptamd_nerf_fwd(None, None, 2, 5000, None, None, None) == -2       # PTAMD_ERR_TOO_LONG
