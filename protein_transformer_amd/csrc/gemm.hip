@@ -370,13 +370,15 @@ __global__ void gemm_splitk_reduce_kernel(const GemmParams p, const float *__res
                                           const float *__restrict__ colsum_slabs, float *__restrict__ colsum_out) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   const int rowq = blockIdx.y * 4;
-  if (colsum_out && blockIdx.x == 0 && threadIdx.x < 4) {  // bias gradient of rows rowq..rowq+3
-    const int row = rowq + threadIdx.x;
-    if (row < p.M) {
-      float v = 0.f;
-      for (int s = 0; s < splits * p.colsum_share; ++s) v += colsum_slabs[(size_t)s * p.M + row];
-      colsum_out[row] += v;
-    }
+  if (colsum_out && blockIdx.x == 0 && threadIdx.x < 64) {  // bias gradient of rows rowq..rowq+3: one wavefront,
+    const int e = threadIdx.x & 3, chunk = threadIdx.x >> 2;   // 16 lanes per row, each summing every 16th slab
+    const int row = rowq + e, nslab = splits * p.colsum_share;
+    float v = 0.f;
+    if (row < p.M)
+      for (int s = chunk; s < nslab; s += 16) v += colsum_slabs[(size_t)s * p.M + row];
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    if (chunk == 0 && row < p.M) colsum_out[row] += v;
   }
   if (col >= p.N) return;
   const uint32_t thr = dropout_threshold(p.dropout_p);
