@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Turn raw rocprofv3 output (gpurun_out/...) into the small summaries kept under profiles/.
+
+  python profiles/summarize.py stats  <kernel_stats.csv> <steps_in_run>         -> per-step table on stdout
+  python profiles/summarize.py traffic <fetch_counter_collection.csv> <write_counter_collection.csv> \
+         <algorithmic_bytes_per_launch> <out.json>                              -> HBM bytes per GEMM launch
+
+FETCH_SIZE / WRITE_SIZE are reported in KiB.  On gfx950 FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane
+coalesced reads as 64 bytes (MI355X_MICROARCH.md, HBM section), hence the x2 on the fetch side; WRITE_SIZE is taken
+as is.  The two counters are collected in separate passes (one --pmc each, with --kernel-trace only).
+"""
+import csv
+import json
+import sys
+
+KERNEL = "gemm_f32_mfma_kernel"
+
+
+def stats(path, steps):
+    rows = list(csv.DictReader(open(path)))
+    total = sum(float(r["TotalDurationNs"]) for r in rows)
+    print(f"{'kernel':70s} {'calls/step':>10s} {'avg us':>9s} {'ms/step':>9s} {'%':>6s}")
+    for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:24]:
+        t = float(r["TotalDurationNs"])
+        print(f"{r['Name'][:70]:70s} {int(r['Calls']) / steps:10.1f} {float(r['AverageNs']) / 1e3:9.1f} "
+              f"{t / steps / 1e6:9.3f} {100 * t / total:6.2f}")
+    print(f"{'all kernels':70s} {'':10s} {'':9s} {total / steps / 1e6:9.3f}")
+
+
+def counter_avg(path, name):
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
+            if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == name]
+    return sum(vals) / len(vals), len(vals)
+
+
+def traffic(fetch_csv, write_csv, algorithmic, out):
+    f, n = counter_avg(fetch_csv, "FETCH_SIZE")
+    w, _ = counter_avg(write_csv, "WRITE_SIZE")
+    hbm = (2.0 * f + w) * 1024.0
+    rec = {
+        "kernel": KERNEL, "launches_profiled": n, "fetch_size_kb_avg": f, "write_size_kb_avg": w,
+        "fetch_correction": "x2: on gfx950 FETCH_SIZE tallies 128-B requests as 64 B for 16-B/lane coalesced reads "
+                            "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncorrected",
+        "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": float(algorithmic),
+        "ratio": hbm / float(algorithmic),
+        "note": "counted at the L2's fabric side, so Infinity-Cache hits are included",
+        "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python bench.py --steps 2 --warmup 1 "
+                   "--no-cpu-baseline --no-kernel-timing ; same with --pmc WRITE_SIZE (separate passes)",
+    }
+    json.dump(rec, open(out, "w"), indent=1)
+    print(json.dumps(rec, indent=1))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], int(sys.argv[3]))
+    elif sys.argv[1] == "traffic":
+        traffic(*sys.argv[2:6])
+    else:
+        sys.exit(__doc__)
