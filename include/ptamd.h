@@ -97,7 +97,7 @@ int ptamd_mse_angles_bwd(const float *pred, const float *truth, int64_t T, const
                          int accumulate, float *dpred, void *stream);
 
 /* ------------------------------------------------------------------ encoder building blocks
- * Row-major fp32 GEMM on the f32 MFMA pipe (v_mfma_f32_32x32x2_f32):
+ * Row-major fp32 GEMM on the matrix cores (see ptamd_gemm_set_mode for the arithmetic):
  *     C[M,N] = epilogue( A (*) B )          with reduction length K
  *   a_kmajor = 0: A is [M,K] (K contiguous, lda);  1: A is stored [K,M] (M contiguous, lda)
  *   b_kmajor = 0: B is [N,K] (K contiguous, ldb) - the torch.nn.Linear weight layout;
@@ -125,6 +125,24 @@ typedef struct {
 } ptamd_gemm_args;
 size_t ptamd_gemm_workspace_bytes(int M, int N, int split_k);
 int ptamd_gemm(const ptamd_gemm_args *args, void *stream);
+
+/* Arithmetic of ptamd_gemm (process-wide; default PTAMD_GEMM_BF16X3, or the PTAMD_GEMM_MODE environment variable).
+ * The reference computes its Linear layers in fp32 (torch.nn.Linear on fp32 tensors); all three modes take and
+ * return fp32 and accumulate in fp32:
+ *   PTAMD_GEMM_F32          v_mfma_f32_32x32x2_f32: bit-for-bit an fmaf chain over k (157 TF/s peak).
+ *   PTAMD_GEMM_BF16X3       every f32 operand is split EXACTLY into three bf16 terms x = x1 + x2 + x3 (round to nearest
+ *                           at each level: 3 x 8 significand bits = the 24 of an f32) while it is staged into LDS, and
+ *                           x*y is evaluated on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, f32 accumulate) as the
+ *                           six products x1y1 + x1y2 + x2y1 + x1y3 + x2y2 + x3y1.  The three dropped terms are below
+ *                           2^-23 |x y| and unbiased, so the result is at least as close to the exact dot product as the
+ *                           fp32 fma chain is (asserted against fp64 in tests/test_gpu_kernels.py), at 6/16 of the
+ *                           matrix-pipe cost.
+ *   PTAMD_GEMM_BF16X3_FULL  all nine products. */
+#define PTAMD_GEMM_F32 0
+#define PTAMD_GEMM_BF16X3 1
+#define PTAMD_GEMM_BF16X3_FULL 2
+int ptamd_gemm_set_mode(int mode);
+int ptamd_gemm_get_mode(void);
 
 /* torch.nn.LayerNorm(D, eps=1e-5) (Sublayers.py:13,17): y = (x-mean)*rstd*gamma+beta; saves mean,rstd [T] */
 int ptamd_layernorm_fwd(const float *x, const float *gamma, const float *beta, int64_t T, int D, float *y,

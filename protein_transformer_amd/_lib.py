@@ -48,6 +48,8 @@ SIGNATURES = {
     "ptamd_mse_angles_bwd": (_i, [_p, _p, _i64, _p, _f, _i, _p, _p]),
     "ptamd_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
     "ptamd_gemm": (_i, [C.POINTER(GemmArgs), _p]),
+    "ptamd_gemm_set_mode": (_i, [_i]),
+    "ptamd_gemm_get_mode": (_i, []),
     "ptamd_layernorm_fwd": (_i, [_p, _p, _p, _i64, _i, _p, _p, _p, _p]),
     "ptamd_layernorm_bwd_workspace_bytes": (_sz, [_i]),
     "ptamd_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _p, _p, _p, _p, _sz, _p]),

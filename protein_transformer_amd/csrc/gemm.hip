@@ -19,61 +19,11 @@
 // same XCD (shared L2).
 #include <stdlib.h>
 
-#include "common.h"
+#include "gemm_common.h"
 
+namespace ptgemm {
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BM = 128, BN = 128, NT = 256;
-// BK (K advance per stage) is a template parameter: 32 (2 workgroups / CU, 73.7 KB LDS each) or 16 (3 per CU).
-// [row][k] image of a K-contiguous operand: BK k + 4 pad floats per row (36 or 20): conflict-free ds_read_b128
-// [k][row] image of a row-contiguous operand: 128 + 4 floats per k: straight 16-byte copies, ds_read_b32
-constexpr int LD_C = 132;
-
-struct GemmParams {
-  int M, N, K;
-  const float *A;
-  int lda;
-  const float *B;
-  int ldb;
-  float *C;
-  int ldc;
-  const float *bias;
-  const float *residual;
-  int ldr;
-  int flags;
-  float dropout_p;
-  uint64_t seed;
-  uint32_t stream_id;
-  int k_per_split;  // multiple of BK
-  int splits;
-  size_t slab;      // M*N when split-K writes partial slabs, else 0
-  int vec_epilogue;  // N, ldc, ldr multiples of 4 and 16-byte aligned C / residual: float4 epilogue through LDS
-  float *colsum;     // k-major A only: colsum[m] (+)= sum_k A[k][m]; with split-K a [splits * share][M] slab, reduced later
-  int colsum_share;  // N tiles sharing the column-sum work of one (M tile, split): power of two <= min(tiles_n, 16)
-};
-
-// ---- staging: each thread carries 4 float4 per operand per stage; global -> registers -> LDS, no transposition:
-//      the LDS image keeps the operand's own contiguity and the MFMA k-assignment adapts instead
-//      (MFMA step (m, j) of a stage uses k = 8m + 4*(lane>>5) + j for BOTH operands).
-template <bool KMAJOR, int BK>
-__device__ __forceinline__ void load_stage(const float *__restrict__ src, int ld, int rows, int r0, int kend, int k0,
-                                           int tid, float4 (&v)[BK / 8]) {
-  constexpr int LPR = BK / 4;  // lanes per row of a K-contiguous operand
-#pragma unroll
-  for (int i = 0; i < BK / 8; ++i) {
-    if (!KMAJOR) {  // src[row][k]: BK/4 lanes cover the BK k of one row
-      const int row = r0 + tid / LPR + (NT / LPR) * i, k = k0 + 4 * (tid % LPR);
-      v[i] = (row < rows && k < kend) ? *reinterpret_cast<const float4 *>(src + (size_t)row * ld + k)
-                                      : make_float4(0.f, 0.f, 0.f, 0.f);
-    } else {  // src[k][row]: 32 lanes cover 128 consecutive rows of one k (512 B)
-      const int k = k0 + (tid >> 5) + 8 * i, row = r0 + 4 * (tid & 31);
-      v[i] = (k < kend && row < rows) ? *reinterpret_cast<const float4 *>(src + (size_t)k * ld + row)
-                                      : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-}
 template <bool KMAJOR, int BK>
 __device__ __forceinline__ void store_stage(float *__restrict__ s, int tid, const float4 (&v)[BK / 8]) {
   constexpr int LPR = BK / 4, LD_R = BK + 4;
@@ -101,19 +51,6 @@ __device__ __forceinline__ void read_frag(const float *__restrict__ s, int r, in
   }
 }
 
-__device__ __forceinline__ float epilogue_value(float v, int row, int col, const GemmParams &p, uint32_t thr,
-                                                float keep_scale, const uint4 &rnd) {
-  if (p.bias) v += p.bias[col];
-  if (p.flags & PTAMD_EPI_RELU) v = fmaxf(v, 0.f);
-  if (p.dropout_p > 0.f) {
-    const uint32_t w = (row & 3) == 0 ? rnd.x : (row & 3) == 1 ? rnd.y : (row & 3) == 2 ? rnd.z : rnd.w;
-    v = (w >= thr) ? v * keep_scale : 0.f;
-  }
-  if (p.residual) v += p.residual[(size_t)row * p.ldr + col];
-  if (p.flags & PTAMD_EPI_TANH) v = tanhf(v);
-  return v;
-}
-
 // Persistent workgroups: a launch has min(#work items, 2 per CU) workgroups, each walking a contiguous range of
 // work items (output tile x K split).  The first K stage of the NEXT item is prefetched into
 // registers/LDS before the epilogue of the current one, so the epilogue's stores overlap the next loads and
@@ -128,24 +65,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_mfma_kernel(const GemmParams p
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
-  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-  const int nwork = tiles_m * tiles_n * p.splits;
-
-  // Work-item order: logical id = ((z * tiles_m + tm) * tiles_n + tn), i.e. neighbours share the same A panel /
-  // K chunk.  Workgroup b (which the dispatcher places on XCD b % 8) owns the CONTIGUOUS logical range
-  // [slot * per, slot * per + per) with slot = (b % 8) * (G / 8) + b / 8: consecutive items of one workgroup and
-  // the workgroups of one XCD all walk neighbouring tiles, so an A panel is fetched through one L2 and re-read
-  // by the same few CUs instead of being requested by every N tile at once.
-  const int G = gridDim.x, base = nwork / G, rem = nwork - base * G;
-  const int slot = (G & 7) == 0 ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-  const int w_begin = slot * base + min(slot, rem), w_end = w_begin + base + (slot < rem ? 1 : 0);
-  auto decode = [&](int logical, int &bm0, int &bn0, int &z) {
-    const int ntile = tiles_m * tiles_n;
-    z = logical / ntile;
-    const int tile = logical - z * ntile;
-    bm0 = (tile / tiles_n) * BM;
-    bn0 = (tile % tiles_n) * BN;
-  };
+  const WorkRange work(p);
+  const int w_begin = work.begin, w_end = work.end;
+  auto decode = [&](int logical, int &bm0, int &bn0, int &z) { work.decode(logical, bm0, bn0, z); };
 
   float4 ra[NG], rb[NG];
   int w = w_begin, bm0, bn0, z;
@@ -262,91 +184,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_mfma_kernel(const GemmParams p
       // K stage just released (32 rows x 64 columns at a time) so that residual / accumulate operands are READ and
       // results are WRITTEN as float4 rows: 16 16-byte stores per lane instead of 64 4-byte ones.
       float *scratch = (wave < 2 ? sA0 + (cur ^ 1) * SA : sB0 + (cur ^ 1) * SB) + (wave & 1) * 2048;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int col = bn0 + wn * 64 + j * 32 + l31;
-          const float bias = (!partial && p.bias && col < p.N) ? p.bias[col] : 0.f;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int rowq = bm0 + wm * 64 + i * 32 + 8 * g + 4 * lh;
-            uint4 rnd = make_uint4(0, 0, 0, 0);
-            if (!partial && p.dropout_p > 0.f) rnd = philox4x32(p.seed, (uint64_t)(rowq >> 2) * p.N + col, p.stream_id);
-            const uint32_t rw[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float v = acc[i][j][g * 4 + e];
-              if (!partial) {
-                v += bias;
-                if (p.flags & PTAMD_EPI_RELU) v = fmaxf(v, 0.f);
-                if (p.dropout_p > 0.f) v = rw[e] >= thr ? v * keep_scale : 0.f;
-              }
-              scratch[(8 * g + 4 * lh + e) * 64 + j * 32 + l31] = v;
-            }
-          }
-        }
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const int f = lane + 64 * t, rr = f >> 4, c4 = (f & 15) * 4;
-          const int row = bm0 + wm * 64 + i * 32 + rr, col = bn0 + wn * 64 + c4;
-          float4 v = *reinterpret_cast<const float4 *>(scratch + rr * 64 + c4);
-          if (row < p.M && col < p.N) {
-            if (!partial) {
-              if (p.residual) {
-                const float4 r4 = *reinterpret_cast<const float4 *>(p.residual + (size_t)row * p.ldr + col);
-                v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
-              }
-              if (p.flags & PTAMD_EPI_TANH) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
-              if (p.flags & PTAMD_EPI_ACCUM) {
-                const float4 o4 = *reinterpret_cast<const float4 *>(C + (size_t)row * ldc + col);
-                v.x += o4.x; v.y += o4.y; v.z += o4.z; v.w += o4.w;
-              }
-            }
-            *reinterpret_cast<float4 *>(C + (size_t)row * ldc + col) = v;
-          }
-        }
-      }
+      tile_epilogue_vec(p, acc, C, ldc, partial, bm0, bn0, wm, wn, lane, thr, keep_scale, scratch);
       if (has_next) __syncthreads();  // the next item's first stage store reuses this LDS buffer
     } else {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int col = bn0 + wn * 64 + j * 32 + l31;
-          const bool col_ok = col < p.N;
-          const int row_base = bm0 + wm * 64 + i * 32 + 4 * lh;
-          const float bias = (!partial && p.bias && col_ok) ? p.bias[col] : 0.f;
-          float res[16], old[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = row_base + (r & 3) + 8 * (r >> 2);
-            const bool ok = col_ok && row < p.M;
-            res[r] = (!partial && p.residual && ok) ? p.residual[(size_t)row * p.ldr + col] : 0.f;
-            old[r] = (!partial && (p.flags & PTAMD_EPI_ACCUM) && ok) ? C[(size_t)row * ldc + col] : 0.f;
-          }
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int rowq = row_base + 8 * g;  // 4 consecutive rows share one Philox call
-            uint4 rnd = make_uint4(0, 0, 0, 0);
-            if (!partial && p.dropout_p > 0.f) rnd = philox4x32(p.seed, (uint64_t)(rowq >> 2) * p.N + col, p.stream_id);
-            const uint32_t rw[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int row = rowq + e, r = g * 4 + e;
-              float v = acc[i][j][r];
-              if (!partial) {
-                v += bias;
-                if (p.flags & PTAMD_EPI_RELU) v = fmaxf(v, 0.f);
-                if (p.dropout_p > 0.f) v = rw[e] >= thr ? v * keep_scale : 0.f;
-                v += res[r];
-                if (p.flags & PTAMD_EPI_TANH) v = tanhf(v);
-                v += old[r];
-              }
-              if (col_ok && row < p.M) C[(size_t)row * ldc + col] = v;
-            }
-          }
-        }
+      tile_epilogue_scalar(p, acc, C, ldc, partial, bm0, bn0, wm, wn, lane, thr, keep_scale);
     }
     if (A_KMAJOR && do_colsum) {  // block-uniform
       float *spare = sA0 + (cur ^ 1) * SA + 4096;  // 128 floats the wave scratch regions do not use
@@ -396,6 +237,8 @@ __global__ void gemm_splitk_reduce_kernel(const GemmParams p, const float *__res
   }
 }
 
+}  // namespace
+
 int persistent_grid() {
   static int slots = 0;
   if (!slots) {
@@ -408,18 +251,11 @@ int persistent_grid() {
   }
   return slots;
 }
-int stage_k() {  // tuning knob: PTAMD_GEMM_BK=16 selects the 3-workgroups-per-CU variant
-  static int bk = 0;
-  if (!bk) {
-    bk = 32;
-    if (const char *e = getenv("PTAMD_GEMM_BK")) bk = atoi(e) == 16 ? 16 : 32;
-  }
-  return bk;
-}
 
-template <bool AK, bool BKM, int BK>
+namespace {
+template <bool AK, bool BKM>
 int launch(const GemmParams &p, int splits, hipStream_t st) {
-  constexpr int LD_R = BK + 4;
+  constexpr int BK = 32, LD_R = BK + 4;
   constexpr int SA = AK ? BK * LD_C : BM * LD_R, SB = BKM ? BK * LD_C : BN * LD_R;
   const size_t lds = (size_t)2 * (SA + SB) * sizeof(float);
   const int work = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * splits;
@@ -430,13 +266,36 @@ int launch(const GemmParams &p, int splits, hipStream_t st) {
                                    (int)lds));
     attr_set = true;
   }
-  const int slots = persistent_grid() * (BK == 16 ? 3 : 2);
+  const int slots = persistent_grid() * 2;
   const int grid = work < slots ? work : slots;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, p);
   return pt_check_launch();
 }
-
 }  // namespace
+
+int launch_f32(const GemmParams &p, bool a_kmajor, bool b_kmajor, int splits, hipStream_t st) {
+  if (!a_kmajor && !b_kmajor) return launch<false, false>(p, splits, st);
+  if (!a_kmajor && b_kmajor) return launch<false, true>(p, splits, st);
+  if (a_kmajor && !b_kmajor) return launch<true, false>(p, splits, st);
+  return launch<true, true>(p, splits, st);
+}
+
+// precision mode of ptamd_gemm: see ptamd_gemm_set_mode in include/ptamd.h
+int g_mode = -1;
+int current_mode() {
+  if (g_mode < 0) {
+    g_mode = PTAMD_GEMM_BF16X3;
+    if (const char *e = getenv("PTAMD_GEMM_MODE")) {
+      const int v = atoi(e);
+      if (v == PTAMD_GEMM_F32 || v == PTAMD_GEMM_BF16X3 || v == PTAMD_GEMM_BF16X3_FULL) g_mode = v;
+    }
+  }
+  return g_mode;
+}
+
+}  // namespace ptgemm
+
+using namespace ptgemm;
 
 extern "C" {
 
@@ -444,6 +303,13 @@ size_t ptamd_gemm_workspace_bytes(int M, int N, int split_k) {
   if (split_k <= 1 || M <= 0 || N <= 0) return 0;
   return ((size_t)split_k * M * N + (size_t)split_k * 16 * M) * sizeof(float);  // C slabs + column-sum slabs
 }
+
+int ptamd_gemm_set_mode(int mode) {
+  if (mode != PTAMD_GEMM_F32 && mode != PTAMD_GEMM_BF16X3 && mode != PTAMD_GEMM_BF16X3_FULL) return PTAMD_ERR_BAD_SHAPE;
+  ptgemm::g_mode = mode;
+  return PTAMD_OK;
+}
+int ptamd_gemm_get_mode(void) { return ptgemm::current_mode(); }
 
 int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
   if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0) return PTAMD_ERR_BAD_SHAPE;
@@ -454,7 +320,7 @@ int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
   if (!pt_aligned16(a->A) || !pt_aligned16(a->B)) return PTAMD_ERR_ALIGN;
   if (a->dropout_p < 0.f || a->dropout_p >= 1.f) return PTAMD_ERR_BAD_SHAPE;
   int splits = a->split_k > 1 ? a->split_k : 1;
-  const int BK = stage_k();
+  constexpr int BK = 32;
   const int kblocks = (a->K + BK - 1) / BK;
   if (splits > kblocks) splits = kblocks;
   GemmParams p;
@@ -475,7 +341,7 @@ int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
     const int tiles_n = (a->N + BN - 1) / BN;
     while (p.colsum_share * 2 <= tiles_n && p.colsum_share < 16) p.colsum_share *= 2;
   }
-  if (a->colsum && (!a->a_kmajor || BK != 32)) return PTAMD_ERR_BAD_SHAPE;
+  if (a->colsum && !a->a_kmajor) return PTAMD_ERR_BAD_SHAPE;
   float *user_c = a->C;
   if (splits > 1) {
     if (!a->workspace || a->workspace_bytes < ptamd_gemm_workspace_bytes(a->M, a->N, splits)) return PTAMD_ERR_WORKSPACE;
@@ -484,18 +350,10 @@ int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
     if (a->colsum) p.colsum = p.C + (size_t)splits * p.slab;
   }
   hipStream_t st = (hipStream_t)stream;
-  int rc;
-  if (stage_k() == 32) {
-    if (!a->a_kmajor && !a->b_kmajor) rc = launch<false, false, 32>(p, splits, st);
-    else if (!a->a_kmajor && a->b_kmajor) rc = launch<false, true, 32>(p, splits, st);
-    else if (a->a_kmajor && !a->b_kmajor) rc = launch<true, false, 32>(p, splits, st);
-    else rc = launch<true, true, 32>(p, splits, st);
-  } else {
-    if (!a->a_kmajor && !a->b_kmajor) rc = launch<false, false, 16>(p, splits, st);
-    else if (!a->a_kmajor && a->b_kmajor) rc = launch<false, true, 16>(p, splits, st);
-    else if (a->a_kmajor && !a->b_kmajor) rc = launch<true, false, 16>(p, splits, st);
-    else rc = launch<true, true, 16>(p, splits, st);
-  }
+  const int mode = current_mode();
+  const int rc = mode == PTAMD_GEMM_F32 ? launch_f32(p, a->a_kmajor != 0, a->b_kmajor != 0, splits, st)
+                                        : launch_split(p, a->a_kmajor != 0, a->b_kmajor != 0, splits,
+                                                       mode == PTAMD_GEMM_BF16X3_FULL ? 9 : 6, st);
   if (rc || splits == 1) return rc;
   const float *slabs = p.C;
   p.C = user_c;

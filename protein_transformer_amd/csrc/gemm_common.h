@@ -1,0 +1,208 @@
+// Pieces shared by the two MFMA GEMM kernels of libptamd (gemm.hip: exact f32 MFMA; gemm_split.hip: f32 operands
+// split into three bf16 terms on the bf16 MFMA pipe): launch parameters, the global->register stage loader, the work
+// decomposition of the persistent workgroups and the fused epilogue.
+#pragma once
+#include "common.h"
+
+namespace ptgemm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, NT = 256;  // output tile per workgroup, threads per workgroup
+// BK (K advance per stage) is a template parameter: 32 (2 workgroups / CU, 73.7 KB LDS each) or 16 (3 per CU).
+// [row][k] image of a K-contiguous operand: BK k + 4 pad floats per row (36 or 20): conflict-free ds_read_b128
+// [k][row] image of a row-contiguous operand: 128 + 4 floats per k: straight 16-byte copies, ds_read_b32
+constexpr int LD_C = 132;
+
+struct GemmParams {
+  int M, N, K;
+  const float *A;
+  int lda;
+  const float *B;
+  int ldb;
+  float *C;
+  int ldc;
+  const float *bias;
+  const float *residual;
+  int ldr;
+  int flags;
+  float dropout_p;
+  uint64_t seed;
+  uint32_t stream_id;
+  int k_per_split;  // multiple of BK
+  int splits;
+  size_t slab;      // M*N when split-K writes partial slabs, else 0
+  int vec_epilogue;  // N, ldc, ldr multiples of 4 and 16-byte aligned C / residual: float4 epilogue through LDS
+  float *colsum;     // k-major A only: colsum[m] (+)= sum_k A[k][m]; with split-K a [splits * share][M] slab, reduced later
+  int colsum_share;  // N tiles sharing the column-sum work of one (M tile, split): power of two <= min(tiles_n, 16)
+};
+
+// ---- staging: each thread carries 4 float4 per operand per stage; global -> registers -> LDS, no transposition:
+//      the LDS image keeps the operand's own contiguity and the MFMA k-assignment adapts instead
+//      (MFMA step (m, j) of a stage uses k = 8m + 4*(lane>>5) + j for BOTH operands).
+template <bool KMAJOR, int BK>
+__device__ __forceinline__ void load_stage(const float *__restrict__ src, int ld, int rows, int r0, int kend, int k0,
+                                           int tid, float4 (&v)[BK / 8]) {
+  constexpr int LPR = BK / 4;  // lanes per row of a K-contiguous operand
+#pragma unroll
+  for (int i = 0; i < BK / 8; ++i) {
+    if (!KMAJOR) {  // src[row][k]: BK/4 lanes cover the BK k of one row
+      const int row = r0 + tid / LPR + (NT / LPR) * i, k = k0 + 4 * (tid % LPR);
+      v[i] = (row < rows && k < kend) ? *reinterpret_cast<const float4 *>(src + (size_t)row * ld + k)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {  // src[k][row]: 32 lanes cover 128 consecutive rows of one k (512 B)
+      const int k = k0 + (tid >> 5) + 8 * i, row = r0 + 4 * (tid & 31);
+      v[i] = (k < kend && row < rows) ? *reinterpret_cast<const float4 *>(src + (size_t)k * ld + row)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+__device__ __forceinline__ float epilogue_value(float v, int row, int col, const GemmParams &p, uint32_t thr,
+                                                float keep_scale, const uint4 &rnd) {
+  if (p.bias) v += p.bias[col];
+  if (p.flags & PTAMD_EPI_RELU) v = fmaxf(v, 0.f);
+  if (p.dropout_p > 0.f) {
+    const uint32_t w = (row & 3) == 0 ? rnd.x : (row & 3) == 1 ? rnd.y : (row & 3) == 2 ? rnd.z : rnd.w;
+    v = (w >= thr) ? v * keep_scale : 0.f;
+  }
+  if (p.residual) v += p.residual[(size_t)row * p.ldr + col];
+  if (p.flags & PTAMD_EPI_TANH) v = tanhf(v);
+  return v;
+}
+
+
+// ---- epilogue of one 128 x 128 tile held as 2 x 2 MFMA accumulators per wavefront (wm, wn = wavefront row / column).
+// C/D map of the 32x32 MFMA (same for the f32 and the bf16 instruction): col = lane & 31,
+// row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+//
+// Vector path: bias / ReLU / dropout are applied in the MFMA layout (one column per lane, four consecutive rows per
+// Philox call), then each wavefront transposes its tile through `scratch` (its own 2048 floats of LDS, 32 rows x 64
+// columns at a time) so that residual / accumulate operands are READ and results are WRITTEN as float4 rows:
+// 16 16-byte stores per lane instead of 64 4-byte ones.
+__device__ __forceinline__ void tile_epilogue_vec(const GemmParams &p, const f32x16 (&acc)[2][2], float *C, int ldc,
+                                                  bool partial, int bm0, int bn0, int wm, int wn, int lane, uint32_t thr,
+                                                  float keep_scale, float *scratch) {
+  const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = bn0 + wn * 64 + j * 32 + l31;
+      const float bias = (!partial && p.bias && col < p.N) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int rowq = bm0 + wm * 64 + i * 32 + 8 * g + 4 * lh;
+        uint4 rnd = make_uint4(0, 0, 0, 0);
+        if (!partial && p.dropout_p > 0.f) rnd = philox4x32(p.seed, (uint64_t)(rowq >> 2) * p.N + col, p.stream_id);
+        const uint32_t rw[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[i][j][g * 4 + e];
+          if (!partial) {
+            v += bias;
+            if (p.flags & PTAMD_EPI_RELU) v = fmaxf(v, 0.f);
+            if (p.dropout_p > 0.f) v = rw[e] >= thr ? v * keep_scale : 0.f;
+          }
+          scratch[(8 * g + 4 * lh + e) * 64 + j * 32 + l31] = v;
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int f = lane + 64 * t, rr = f >> 4, c4 = (f & 15) * 4;
+      const int row = bm0 + wm * 64 + i * 32 + rr, col = bn0 + wn * 64 + c4;
+      float4 v = *reinterpret_cast<const float4 *>(scratch + rr * 64 + c4);
+      if (row < p.M && col < p.N) {
+        if (!partial) {
+          if (p.residual) {
+            const float4 r4 = *reinterpret_cast<const float4 *>(p.residual + (size_t)row * p.ldr + col);
+            v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+          }
+          if (p.flags & PTAMD_EPI_TANH) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+          if (p.flags & PTAMD_EPI_ACCUM) {
+            const float4 o4 = *reinterpret_cast<const float4 *>(C + (size_t)row * ldc + col);
+            v.x += o4.x; v.y += o4.y; v.z += o4.z; v.w += o4.w;
+          }
+        }
+        *reinterpret_cast<float4 *>(C + (size_t)row * ldc + col) = v;
+      }
+    }
+  }
+}
+
+// Scalar path (any N / leading dimension): every lane stores its own accumulator elements.
+__device__ __forceinline__ void tile_epilogue_scalar(const GemmParams &p, const f32x16 (&acc)[2][2], float *C, int ldc,
+                                                     bool partial, int bm0, int bn0, int wm, int wn, int lane,
+                                                     uint32_t thr, float keep_scale) {
+  const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = bn0 + wn * 64 + j * 32 + l31;
+        const bool col_ok = col < p.N;
+        const int row_base = bm0 + wm * 64 + i * 32 + 4 * lh;
+        const float bias = (!partial && p.bias && col_ok) ? p.bias[col] : 0.f;
+        float res[16], old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row_base + (r & 3) + 8 * (r >> 2);
+          const bool ok = col_ok && row < p.M;
+          res[r] = (!partial && p.residual && ok) ? p.residual[(size_t)row * p.ldr + col] : 0.f;
+          old[r] = (!partial && (p.flags & PTAMD_EPI_ACCUM) && ok) ? C[(size_t)row * ldc + col] : 0.f;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int rowq = row_base + 8 * g;  // 4 consecutive rows share one Philox call
+          uint4 rnd = make_uint4(0, 0, 0, 0);
+          if (!partial && p.dropout_p > 0.f) rnd = philox4x32(p.seed, (uint64_t)(rowq >> 2) * p.N + col, p.stream_id);
+          const uint32_t rw[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int row = rowq + e, r = g * 4 + e;
+            float v = acc[i][j][r];
+            if (!partial) {
+              v += bias;
+              if (p.flags & PTAMD_EPI_RELU) v = fmaxf(v, 0.f);
+              if (p.dropout_p > 0.f) v = rw[e] >= thr ? v * keep_scale : 0.f;
+              v += res[r];
+              if (p.flags & PTAMD_EPI_TANH) v = tanhf(v);
+              v += old[r];
+            }
+            if (col_ok && row < p.M) C[(size_t)row * ldc + col] = v;
+          }
+        }
+      }
+}
+
+// Work decomposition of a persistent launch: logical id = ((z * tiles_m + tm) * tiles_n + tn), i.e. neighbours share
+// the same A panel / K chunk.  Workgroup b (which the dispatcher places on XCD b % 8) owns the CONTIGUOUS logical
+// range [w_begin, w_end) with slot = (b % 8) * (G / 8) + b / 8: consecutive items of one workgroup and the
+// workgroups of one XCD all walk neighbouring tiles, so an A panel is fetched through one L2 and re-read by the
+// same few CUs instead of being requested by every N tile at once.
+struct WorkRange {
+  int tiles_m, tiles_n, begin, end;
+  __device__ __forceinline__ WorkRange(const GemmParams &p) {
+    tiles_n = (p.N + BN - 1) / BN;
+    tiles_m = (p.M + BM - 1) / BM;
+    const int nwork = tiles_m * tiles_n * p.splits;
+    const int G = gridDim.x, base = nwork / G, rem = nwork - base * G;
+    const int slot = (G & 7) == 0 ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    begin = slot * base + min(slot, rem);
+    end = begin + base + (slot < rem ? 1 : 0);
+  }
+  __device__ __forceinline__ void decode(int logical, int &bm0, int &bn0, int &z) const {
+    const int ntile = tiles_m * tiles_n;
+    z = logical / ntile;
+    const int tile = logical - z * ntile;
+    bm0 = (tile / tiles_n) * BM;
+    bn0 = (tile % tiles_n) * BN;
+  }
+};
+
+int persistent_grid();  // CUs of the current device (gemm.hip)
+// launchers of the two kernels: a_kmajor / b_kmajor select the instantiation
+int launch_f32(const GemmParams &p, bool a_kmajor, bool b_kmajor, int splits, hipStream_t st);
+int launch_split(const GemmParams &p, bool a_kmajor, bool b_kmajor, int splits, int products, hipStream_t st);
+
+}  // namespace ptgemm

@@ -48,6 +48,18 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False,
     return C_out
 
 
+GEMM_F32, GEMM_BF16X3, GEMM_BF16X3_FULL = 0, 1, 2   # ptamd.h: PTAMD_GEMM_*
+
+
+def set_gemm_mode(mode):
+    """Select the arithmetic of every subsequent GEMM (see ptamd_gemm_set_mode in include/ptamd.h)."""
+    check(lib().ptamd_gemm_set_mode(int(mode)), "gemm_set_mode")
+
+
+def get_gemm_mode():
+    return lib().ptamd_gemm_get_mode()
+
+
 def pick_split_k(M, N, K, slots=512):
     """K splits for a reduction-heavy product with few output tiles: as many (tile, split) items as fit in ONE round
     of the persistent grid (2 workgroups x 256 CUs) - one item more than that would cost a whole second round."""
