@@ -184,10 +184,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_mfma_kernel(const GemmParams p
       // K stage just released (32 rows x 64 columns at a time) so that residual / accumulate operands are READ and
       // results are WRITTEN as float4 rows: 16 16-byte stores per lane instead of 64 4-byte ones.
       float *scratch = (wave < 2 ? sA0 + (cur ^ 1) * SA : sB0 + (cur ^ 1) * SB) + (wave & 1) * 2048;
-      tile_epilogue_vec(p, acc, C, ldc, partial, bm0, bn0, wm, wn, lane, thr, keep_scale, scratch);
+      tile_epilogue_vec<2>(p, acc, C, ldc, partial, bm0 + wm * 64, bn0 + wn * 64, lane, thr, keep_scale, scratch);
       if (has_next) __syncthreads();  // the next item's first stage store reuses this LDS buffer
     } else {
-      tile_epilogue_scalar(p, acc, C, ldc, partial, bm0, bn0, wm, wn, lane, thr, keep_scale);
+      tile_epilogue_scalar<2>(p, acc, C, ldc, partial, bm0 + wm * 64, bn0 + wn * 64, lane, thr, keep_scale);
     }
     if (A_KMAJOR && do_colsum) {  // block-uniform
       float *spare = sA0 + (cur ^ 1) * SA + 4096;  // 128 floats the wave scratch regions do not use
@@ -350,7 +350,12 @@ int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
     if (a->colsum) p.colsum = p.C + (size_t)splits * p.slab;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int mode = current_mode();
+  int mode = current_mode();
+  {  // the split kernel addresses an operand with 32-bit byte offsets and starts a K tail 16 k before its end
+    const size_t a_bytes = (size_t)(a->a_kmajor ? a->K : a->M) * a->lda * sizeof(float);
+    const size_t b_bytes = (size_t)(a->b_kmajor ? a->K : a->N) * a->ldb * sizeof(float);
+    if (a->K < 16 || a_bytes >= ((size_t)1 << 32) || b_bytes >= ((size_t)1 << 32)) mode = PTAMD_GEMM_F32;
+  }
   const int rc = mode == PTAMD_GEMM_F32 ? launch_f32(p, a->a_kmajor != 0, a->b_kmajor != 0, splits, st)
                                         : launch_split(p, a->a_kmajor != 0, a->b_kmajor != 0, splits,
                                                        mode == PTAMD_GEMM_BF16X3_FULL ? 9 : 6, st);

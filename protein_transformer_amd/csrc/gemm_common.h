@@ -79,19 +79,22 @@ __device__ __forceinline__ float epilogue_value(float v, int row, int col, const
 // Philox call), then each wavefront transposes its tile through `scratch` (its own 2048 floats of LDS, 32 rows x 64
 // columns at a time) so that residual / accumulate operands are READ and results are WRITTEN as float4 rows:
 // 16 16-byte stores per lane instead of 64 4-byte ones.
-__device__ __forceinline__ void tile_epilogue_vec(const GemmParams &p, const f32x16 (&acc)[2][2], float *C, int ldc,
-                                                  bool partial, int bm0, int bn0, int wm, int wn, int lane, uint32_t thr,
+// (row0, col0) = origin of this wavefront's (32 TI) x 64 block of C.
+// VEC = false: same transposition, but the four elements of a lane are read / written one by one (any N / ldc).
+template <int TI, bool VEC = true>
+__device__ __forceinline__ void tile_epilogue_vec(const GemmParams &p, const f32x16 (&acc)[TI][2], float *C, int ldc,
+                                                  bool partial, int row0, int col0, int lane, uint32_t thr,
                                                   float keep_scale, float *scratch) {
   const int l31 = lane & 31, lh = lane >> 5;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < TI; ++i) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int col = bn0 + wn * 64 + j * 32 + l31;
+      const int col = col0 + j * 32 + l31;
       const float bias = (!partial && p.bias && col < p.N) ? p.bias[col] : 0.f;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int rowq = bm0 + wm * 64 + i * 32 + 8 * g + 4 * lh;
+        const int rowq = row0 + i * 32 + 8 * g + 4 * lh;
         uint4 rnd = make_uint4(0, 0, 0, 0);
         if (!partial && p.dropout_p > 0.f) rnd = philox4x32(p.seed, (uint64_t)(rowq >> 2) * p.N + col, p.stream_id);
         const uint32_t rw[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
@@ -110,47 +113,56 @@ __device__ __forceinline__ void tile_epilogue_vec(const GemmParams &p, const f32
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int f = lane + 64 * t, rr = f >> 4, c4 = (f & 15) * 4;
-      const int row = bm0 + wm * 64 + i * 32 + rr, col = bn0 + wn * 64 + c4;
+      const int row = row0 + i * 32 + rr, col = col0 + c4;
       float4 v = *reinterpret_cast<const float4 *>(scratch + rr * 64 + c4);
-      if (row < p.M && col < p.N) {
-        if (!partial) {
-          if (p.residual) {
-            const float4 r4 = *reinterpret_cast<const float4 *>(p.residual + (size_t)row * p.ldr + col);
-            v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+      if (VEC) {
+        if (row < p.M && col < p.N) {
+          if (!partial) {
+            if (p.residual) {
+              const float4 r4 = *reinterpret_cast<const float4 *>(p.residual + (size_t)row * p.ldr + col);
+              v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+            }
+            if (p.flags & PTAMD_EPI_TANH) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+            if (p.flags & PTAMD_EPI_ACCUM) {
+              const float4 o4 = *reinterpret_cast<const float4 *>(C + (size_t)row * ldc + col);
+              v.x += o4.x; v.y += o4.y; v.z += o4.z; v.w += o4.w;
+            }
           }
-          if (p.flags & PTAMD_EPI_TANH) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
-          if (p.flags & PTAMD_EPI_ACCUM) {
-            const float4 o4 = *reinterpret_cast<const float4 *>(C + (size_t)row * ldc + col);
-            v.x += o4.x; v.y += o4.y; v.z += o4.z; v.w += o4.w;
+          *reinterpret_cast<float4 *>(C + (size_t)row * ldc + col) = v;
+        }
+      } else {
+        const float ve[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (row < p.M && col + e < p.N) {
+            float x = ve[e];
+            if (!partial) {
+              if (p.residual) x += p.residual[(size_t)row * p.ldr + col + e];
+              if (p.flags & PTAMD_EPI_TANH) x = tanhf(x);
+              if (p.flags & PTAMD_EPI_ACCUM) x += C[(size_t)row * ldc + col + e];
+            }
+            C[(size_t)row * ldc + col + e] = x;
           }
         }
-        *reinterpret_cast<float4 *>(C + (size_t)row * ldc + col) = v;
       }
     }
   }
 }
 
 // Scalar path (any N / leading dimension): every lane stores its own accumulator elements.
-__device__ __forceinline__ void tile_epilogue_scalar(const GemmParams &p, const f32x16 (&acc)[2][2], float *C, int ldc,
-                                                     bool partial, int bm0, int bn0, int wm, int wn, int lane,
-                                                     uint32_t thr, float keep_scale) {
+template <int TI>
+__device__ __forceinline__ void tile_epilogue_scalar(const GemmParams &p, const f32x16 (&acc)[TI][2], float *C, int ldc,
+                                                     bool partial, int row0, int col0, int lane, uint32_t thr,
+                                                     float keep_scale) {
   const int l31 = lane & 31, lh = lane >> 5;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int col = bn0 + wn * 64 + j * 32 + l31;
+        const int col = col0 + j * 32 + l31;
         const bool col_ok = col < p.N;
-        const int row_base = bm0 + wm * 64 + i * 32 + 4 * lh;
+        const int row_base = row0 + i * 32 + 4 * lh;
         const float bias = (!partial && p.bias && col_ok) ? p.bias[col] : 0.f;
-        float res[16], old[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = row_base + (r & 3) + 8 * (r >> 2);
-          const bool ok = col_ok && row < p.M;
-          res[r] = (!partial && p.residual && ok) ? p.residual[(size_t)row * p.ldr + col] : 0.f;
-          old[r] = (!partial && (p.flags & PTAMD_EPI_ACCUM) && ok) ? C[(size_t)row * ldc + col] : 0.f;
-        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int rowq = row_base + 8 * g;  // 4 consecutive rows share one Philox call
@@ -165,9 +177,9 @@ __device__ __forceinline__ void tile_epilogue_scalar(const GemmParams &p, const 
               v += bias;
               if (p.flags & PTAMD_EPI_RELU) v = fmaxf(v, 0.f);
               if (p.dropout_p > 0.f) v = rw[e] >= thr ? v * keep_scale : 0.f;
-              v += res[r];
+              if (p.residual && col_ok && row < p.M) v += p.residual[(size_t)row * p.ldr + col];
               if (p.flags & PTAMD_EPI_TANH) v = tanhf(v);
-              v += old[r];
+              if ((p.flags & PTAMD_EPI_ACCUM) && col_ok && row < p.M) v += C[(size_t)row * ldc + col];
             }
             if (col_ok && row < p.M) C[(size_t)row * ldc + col] = v;
           }
@@ -181,10 +193,10 @@ __device__ __forceinline__ void tile_epilogue_scalar(const GemmParams &p, const 
 // workgroups of one XCD all walk neighbouring tiles, so an A panel is fetched through one L2 and re-read by the
 // same few CUs instead of being requested by every N tile at once.
 struct WorkRange {
-  int tiles_m, tiles_n, begin, end;
-  __device__ __forceinline__ WorkRange(const GemmParams &p) {
-    tiles_n = (p.N + BN - 1) / BN;
-    tiles_m = (p.M + BM - 1) / BM;
+  int tiles_m, tiles_n, begin, end, bm, bn;
+  __device__ __forceinline__ WorkRange(const GemmParams &p, int tile_m = BM, int tile_n = BN) : bm(tile_m), bn(tile_n) {
+    tiles_n = (p.N + bn - 1) / bn;
+    tiles_m = (p.M + bm - 1) / bm;
     const int nwork = tiles_m * tiles_n * p.splits;
     const int G = gridDim.x, base = nwork / G, rem = nwork - base * G;
     const int slot = (G & 7) == 0 ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
@@ -195,8 +207,8 @@ struct WorkRange {
     const int ntile = tiles_m * tiles_n;
     z = logical / ntile;
     const int tile = logical - z * ntile;
-    bm0 = (tile / tiles_n) * BM;
-    bn0 = (tile % tiles_n) * BN;
+    bm0 = (tile / tiles_n) * bm;
+    bn0 = (tile % tiles_n) * bn;
   }
 };
 

@@ -12,15 +12,24 @@
 // Six products cost 6/16 of the f32 pipe time; the dropped bracket is below the rounding error the f32 fma chain
 // makes itself over K >= 64 terms (tests/test_gpu_kernels.py compares both with fp64).
 //
-// Tiling: workgroup = 128 x 128 outputs, 4 wavefronts x (2 x 2) MFMA tiles of 32 x 32, K advances 16 (one MFMA k
-// step) per stage, persistent workgroups (2 per CU) over (tile, K-split) items as in gemm.hip.  A stage is fetched as
-// f32 into registers (16-byte coalesced loads, issued TWO stages ahead), split with v_cvt_pk_bf16_f32 and written to
-// the other half of a double-buffered LDS image of 3 planes per operand while the MFMAs of the current stage run:
-//   K-contiguous operand  -> plane [row][16 + 8 pad] bf16, fragment = one conflict-free ds_read_b128 (8 k of a row)
-//   row-contiguous operand -> plane [k][128 + 32 pad] bf16 (no transposition on the way in), fragment = two
+// Structure (MI355X-first): one workgroup per CU = 8 wavefronts, two per SIMD with different jobs.
+//   * wavefronts 0-3 are CONSUMERS: each owns a 128 x 64 block (4 x 2 MFMA tiles of 32 x 32, 128 accumulator VGPRs) of
+//     the workgroup's 256 x 128 output tile and does nothing but ds_read fragments and issue MFMAs (48 per K step
+//     of 16), then the epilogue of the tile through its own LDS scratch;
+//   * wavefronts 4-7 are PRODUCERS: they fetch the f32 operands (16-byte coalesced loads issued two stages ahead,
+//     unconditional, addresses clamped), split them with v_cvt_pk_bf16_f32 and write the three bf16 planes of the
+//     next stage into the other half of a double-buffered LDS image; they also form the fused bias gradient.
+//   The matrix pipe of a SIMD is fed by its consumer while its producer uses the VALU, the LDS write path and the
+//   vector memory path: the two instruction streams overlap because they belong to different wavefronts.  One
+//   s_barrier per stage hands a finished buffer from the producers to the consumers and a consumed one back.
+// The 256 x 128 tile (rather than 128 x 128) cuts the L2 -> CU traffic and the LDS write traffic per MFMA by a
+// quarter - with the 16x faster pipe both are first-order costs (LDS writes run at ~80 B/clk/CU).
+// LDS image of a stage, per operand and plane:
+//   K-contiguous operand   -> [row][16 + 8 pad] bf16, fragment = one conflict-free ds_read_b128 (8 k of a row)
+//   row-contiguous operand -> [k][rows + 32 pad] bf16 (no transposition on the way in), fragment = two
 //                             ds_read_b64_tr_b16 (the LDS transpose read delivers 4 k of one row per lane).
-// One barrier per stage; the stage stream runs across work items, so the first stages of the next tile are fetched,
-// converted and stored under the last MFMAs and the epilogue of the current one.
+// Workgroups are persistent and walk contiguous (tile, K-split) ranges as in gemm.hip; the stage stream runs across
+// work items, so the producers fetch and convert the first stages of the next tile under the epilogue of this one.
 #include <stdlib.h>
 
 #include "gemm_common.h"
@@ -35,86 +44,107 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
+constexpr int TBM = 256, TBN = 128;  // output tile of a workgroup
 constexpr int SBK = 16;              // f32 k per stage = one bf16 MFMA k step
+constexpr int NTHREADS = 512, NPRODUCER = 256;
+constexpr int NSETS = 4;             // register sets of a producer = stages of global loads in flight (even)
 constexpr int LD_RK = 24;            // bf16 per row of a [row][k] plane: 48 B = odd multiple of 16 B
-constexpr int LD_KR = 160;           // bf16 per k of a [k][row] plane: 320 B, 4 consecutive k hit 4 different 64-B bank groups
-constexpr int PLANE = 128 * LD_RK;   // 3072 bf16 per plane per operand (the [k][row] form needs 16 * 160 = 2560)
-constexpr int OPERAND = 3 * PLANE;
-constexpr int STAGE = 2 * OPERAND;   // A planes then B planes: 36864 B, also holds the 32 KB epilogue scratch
-constexpr size_t LDS_BYTES = (size_t)2 * STAGE * sizeof(unsigned short);  // 73728: two workgroups per CU
-static_assert(PLANE >= SBK * LD_KR, "plane must hold either layout");
-static_assert(STAGE * sizeof(unsigned short) >= 4 * 2048 * sizeof(float), "epilogue scratch must fit in one stage buffer");
+constexpr int KR_PAD = 32;           // a [k][rows + 32] plane: 4 consecutive k hit 4 different 64-B bank groups
+constexpr int PLANE_A = TBM * LD_RK, PLANE_B = TBN * LD_RK;   // 6144 / 3072 bf16 (the [k][row] forms are smaller)
+constexpr int STAGE = 3 * (PLANE_A + PLANE_B);                // 27648 bf16 = 55296 B
+constexpr int SCRATCH_FLOATS = 4 * 2048;                      // epilogue transpose scratch of the 4 consumers
+constexpr int COLSUM_FLOATS = 2 * 4 * TBM;                    // two alternating [4 k groups][256 rows] partial sums
+constexpr size_t LDS_BYTES = (size_t)2 * STAGE * sizeof(unsigned short) + (SCRATCH_FLOATS + COLSUM_FLOATS) * sizeof(float);
+static_assert(PLANE_A >= SBK * (TBM + KR_PAD) && PLANE_B >= SBK * (TBN + KR_PAD), "plane must hold either layout");
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget of a CU");
 
-// (x0, x1) -> three packed bf16 pairs with x = t1 + t2 + t3 exactly (round to nearest even at each level)
+// (x0, x1) -> three packed bf16 pairs with x = t1 + t2 + t3 exactly (round to nearest even at each level).
+// The residuals are taken with SCALAR v_sub_f32: left alone the compiler pairs them into v_pk_add_f32, and packed f32
+// VALU instructions stall the matrix pipe of the SIMD they share with a consumer wavefront (MI355X_MICROARCH.md,
+// "price of one filler beside MFMAs"); the empty asm statements keep the two subtractions apart.
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));  // v_cvt_pk_bf16_f32
+}
 __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t &t1, uint32_t &t2, uint32_t &t3) {
-  const f32x2 v = {x0, x1};
-  t1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-  const f32x2 r = {x0 - __uint_as_float(t1 << 16), x1 - __uint_as_float(t1 & 0xffff0000u)};
-  t2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
-  const f32x2 q = {r.x - __uint_as_float(t2 << 16), r.y - __uint_as_float(t2 & 0xffff0000u)};
-  t3 = __builtin_bit_cast(uint32_t, __builtin_convertvector(q, bf16x2));
+  t1 = pack_bf16(x0, x1);
+  float r0 = x0 - __uint_as_float(t1 << 16);
+  asm volatile("" : "+v"(r0));
+  float r1 = x1 - __uint_as_float(t1 & 0xffff0000u);
+  asm volatile("" : "+v"(r1));
+  t2 = pack_bf16(r0, r1);
+  float q0 = r0 - __uint_as_float(t2 << 16);
+  asm volatile("" : "+v"(q0));
+  float q1 = r1 - __uint_as_float(t2 & 0xffff0000u);
+  asm volatile("" : "+v"(q1));
+  t3 = pack_bf16(q0, q1);
 }
 
-// One stage of one operand, global -> registers: 2 float4 per thread.  The loads are UNCONDITIONAL (addresses clamped
-// into the operand) and nothing touches the registers until store_split two stages later: a predicated load becomes
-// a branch, behind which the compiler can no longer count the loads in flight, and a select on the loaded value
-// would wait for it at once - either way the prefetch distance collapses.  Out-of-range ROWS need no masking (they
-// only feed output rows that are never stored); out-of-range K is zeroed in store_split.
-template <bool KMAJOR>
-__device__ __forceinline__ void load_raw(const float *__restrict__ src, int ld, int rows, int r0, int kend, int k0, int tid,
-                                         float4 (&v)[2]) {
+// One stage of one operand (ROWS tile rows x 16 k), global -> registers of the 256 producer threads: ROWS / 64
+// float4 per thread, each from  (scalar base of the stage) + (32-bit per-thread byte offset of the work item),
+// so a stage costs no address arithmetic in the vector unit.  The loads are UNCONDITIONAL and nothing touches the
+// registers until store_split two stages later: a predicated load becomes a branch, behind which the compiler can
+// no longer count the loads in flight, and a select on the loaded value would wait for it at once - either way
+// the prefetch distance collapses.  Rows beyond the operand are clamped (they only feed output rows that are never
+// stored); a K tail is handled by starting the last stage of an item 16 k before its end and zeroing the k that
+// were already consumed (store_split's `kskip`).
+template <bool KMAJOR, int ROWS>
+__device__ __forceinline__ void item_offsets(int ld, int rows, int r0, int pt, uint32_t (&voff)[ROWS / 64]) {
+  constexpr int LPK = ROWS / 4;  // lanes per k of a row-contiguous operand
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    if (!KMAJOR) {  // src[row][k]: 4 lanes cover the 16 k of one row
-      const int row = min(r0 + tid / 4 + 64 * i, rows - 1), k = min(k0 + 4 * (tid % 4), kend - 4);
-      v[i] = *reinterpret_cast<const float4 *>(src + (size_t)row * ld + k);
-    } else {  // src[k][row]: 32 lanes cover 128 consecutive rows of one k (512 B)
-      const int k = min(k0 + (tid >> 5) + 8 * i, kend - 1), row = min(r0 + 4 * (tid & 31), rows - 4);
-      v[i] = *reinterpret_cast<const float4 *>(src + (size_t)k * ld + row);
-    }
+  for (int i = 0; i < ROWS / 64; ++i) {
+    if (!KMAJOR) voff[i] = ((uint32_t)min(r0 + pt / 4 + 64 * i, rows - 1) * (uint32_t)ld + 4 * (pt % 4)) * 4u;
+    else voff[i] = ((uint32_t)(pt / LPK + (NPRODUCER / LPK) * i) * (uint32_t)ld + min(r0 + 4 * (pt % LPK), rows - 4)) * 4u;
   }
 }
-
-// registers of one stage -> the three LDS planes of the operand at `s`; klim = number of valid k in the stage
-template <bool KMAJOR>
-__device__ __forceinline__ void store_split(unsigned short *__restrict__ s, int tid, const float4 (&v)[2], int klim) {
+template <int N>
+__device__ __forceinline__ void load_raw(const float *__restrict__ stage_base, const uint32_t (&voff)[N], float4 (&v)[N]) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const bool ok = (KMAJOR ? (tid >> 5) + 8 * i : 4 * (tid % 4)) < klim;
-    const float4 x = make_float4(ok ? v[i].x : 0.f, ok ? v[i].y : 0.f, ok ? v[i].z : 0.f, ok ? v[i].w : 0.f);
+  for (int i = 0; i < N; ++i)
+    v[i] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(stage_base) + voff[i]);
+}
+
+// registers of one stage -> the three LDS planes of the operand at `s`; the first kskip k of the stage are zeroed
+template <bool KMAJOR, int ROWS>
+__device__ __forceinline__ void store_split(unsigned short *__restrict__ s, int pt, float4 (&v)[ROWS / 64], int kskip) {
+  constexpr int LPK = ROWS / 4, PLANE = ROWS * LD_RK, LD_KR = ROWS + KR_PAD;
+  if (kskip > 0) {  // uniform: only the last stage of an item whose K range is not a multiple of 16
+#pragma unroll
+    for (int i = 0; i < ROWS / 64; ++i) {
+      const int kl = KMAJOR ? pt / LPK + (NPRODUCER / LPK) * i : 4 * (pt % 4);
+      if (kl < kskip) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < ROWS / 64; ++i) {
+    const int kl = KMAJOR ? pt / LPK + (NPRODUCER / LPK) * i : 4 * (pt % 4);
     uint2 t1, t2, t3;
-    split_pair(x.x, x.y, t1.x, t2.x, t3.x);
-    split_pair(x.z, x.w, t1.y, t2.y, t3.y);
-    int off;
-    if (!KMAJOR) off = (tid / 4 + 64 * i) * LD_RK + 4 * (tid % 4);   // 4 consecutive k of one row
-    else off = ((tid >> 5) + 8 * i) * LD_KR + 4 * (tid & 31);        // 4 consecutive rows of one k
+    split_pair(v[i].x, v[i].y, t1.x, t2.x, t3.x);
+    split_pair(v[i].z, v[i].w, t1.y, t2.y, t3.y);
+    const int off = KMAJOR ? kl * LD_KR + 4 * (pt % LPK)          // 4 consecutive rows of one k
+                           : (pt / 4 + 64 * i) * LD_RK + kl;      // 4 consecutive k of one row
     *reinterpret_cast<uint2 *>(s + off) = t1;
     *reinterpret_cast<uint2 *>(s + PLANE + off) = t2;
     *reinterpret_cast<uint2 *>(s + 2 * PLANE + off) = t3;
   }
 }
 
-// MFMA operand of the 32 tile rows starting at r0: lane l holds row r0 + (l & 31), k = 8 (l >> 5) + 0..7 of the
-// stage, for each of the three planes
-template <bool KMAJOR>
-__device__ __forceinline__ void read_frags(const unsigned short *__restrict__ s, int r0, int lane, bf16x8 (&f)[3]) {
+// MFMA operand of the 32 tile rows starting at r0, plane t: lane l holds row r0 + (l & 31), k = 8 (l >> 5) + 0..7
+template <bool KMAJOR, int ROWS>
+__device__ __forceinline__ bf16x8 read_frag(const unsigned short *__restrict__ s, int r0, int lane, int t) {
+  constexpr int PLANE = ROWS * LD_RK, LD_KR = ROWS + KR_PAD;
   if (!KMAJOR) {
-    const unsigned short *q = s + (r0 + (lane & 31)) * LD_RK + 8 * (lane >> 5);
-#pragma unroll
-    for (int t = 0; t < 3; ++t) f[t] = *reinterpret_cast<const bf16x8 *>(q + t * PLANE);
+    return *reinterpret_cast<const bf16x8 *>(s + t * PLANE + (r0 + (lane & 31)) * LD_RK + 8 * (lane >> 5));
   } else {
     // ds_read_b64_tr_b16: within a 16-lane group, lane q supplies the address of 4 contiguous bf16 = columns
     // 4 (q & 3) .. +3 of matrix row (q >> 2) and receives column q of the 4 rows.  Rows = 4 consecutive k,
     // columns = 16 consecutive tile rows.
     const int q16 = lane & 15;
-    const unsigned short *q = s + (8 * (lane >> 5) + (q16 >> 2)) * LD_KR + r0 + (lane & 16) + 4 * (q16 & 3);
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(q + t * PLANE));
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(q + t * PLANE + 4 * LD_KR));
-      const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-      f[t] = __builtin_bit_cast(bf16x8, both);
-    }
+    const unsigned short *q = s + t * PLANE + (8 * (lane >> 5) + (q16 >> 2)) * LD_KR + r0 + (lane & 16) + 4 * (q16 & 3);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)q);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(q + 4 * LD_KR));
+    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, both);
   }
 }
 
@@ -122,13 +152,22 @@ struct Item {  // one (output tile, K split) work item
   int bm0, bn0, z, kbeg, kend;
 };
 
+// Cursor over the stage stream of a workgroup: the stages (16 k each) of its work items, in order.
+struct Cursor {
+  int w, k0;
+  Item it;
+  bool end;  // set once the cursor was asked to step past the last stage (it then stays on that stage)
+};
+
 template <bool A_KMAJOR, bool B_KMAJOR, int NPROD>
-__global__ __launch_bounds__(NT, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16x3_mfma_kernel(const GemmParams p) {
+__global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16x3_mfma_kernel(
+    const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  float *const scratch = reinterpret_cast<float *>(smem + 2 * STAGE);
+  float *const cs_area = scratch + SCRATCH_FLOATS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const WorkRange work(p);
+  const WorkRange work(p, TBM, TBN);
   if (work.begin >= work.end) return;
   auto item_at = [&](int logical) __attribute__((always_inline)) {
     Item it;
@@ -137,155 +176,194 @@ __global__ __launch_bounds__(NT, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     it.kend = min(p.K, it.kbeg + p.k_per_split);
     return it;
   };
-
+  // one step of a cursor; past the last stage of the range it stays on that stage
+  auto advance = [&](Cursor &c) __attribute__((always_inline)) {
+    if (c.k0 + SBK < c.it.kend) {
+      c.k0 += SBK;
+    } else if (c.w + 1 < work.end) {
+      c.it = item_at(++c.w);
+      c.k0 = c.it.kbeg;
+    } else {
+      c.end = true;
+    }
+  };
+  int total_stages = 0;  // barriers must match between the two roles: both count the stages of the range
+  for (int w = work.begin; w < work.end; ++w) {
+    const Item it = item_at(w);
+    total_stages += (it.kend - it.kbeg + SBK - 1) / SBK;
+  }
+  const int padded_stages = (total_stages + NSETS - 1) / NSETS * NSETS;  // both roles run this many barriers (+1)
   const bool partial = p.slab != 0;
-  const uint32_t thr = dropout_threshold(p.dropout_p);
-  const float keep_scale = 1.f / (1.f - p.dropout_p);
-  // Bias gradient = column sums of the k-major A operand, taken from the f32 registers of the stage loader.  With
-  // split-K slabs the N tiles of one (M tile, split) share the work: N tile tn takes every cs_share-th k of a
-  // stage starting at tn; without slabs the first N tile does it alone and accumulates in place.
-  const int cs_share = partial ? p.colsum_share : 1;
-  auto colsum_first = [&](const Item &it) __attribute__((always_inline)) { return (it.bn0 / BN) & (cs_share - 1); };
-  auto colsum_on = [&](const Item &it) __attribute__((always_inline)) {
-    return A_KMAJOR && p.colsum != nullptr && (partial ? it.bn0 / BN < cs_share : it.bn0 == 0);
-  };
-  auto colsum_add = [&](const Item &it, const float4 (&v)[2], int klim, float4 &acc4) __attribute__((always_inline)) {
-    if (colsum_on(it)) {
-      const int first = colsum_first(it);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        if ((((tid >> 5) + 8 * i) & (cs_share - 1)) == first && (tid >> 5) + 8 * i < klim) {
-          acc4.x += v[i].x; acc4.y += v[i].y; acc4.z += v[i].z; acc4.w += v[i].w;
-        }
-    }
-  };
 
-  // ---- the stage stream: a load cursor runs two stages ahead of the compute cursor, across work items
-  int w = work.begin;
-  Item cur = item_at(w);
-  bool has_next = w + 1 < work.end;
-  Item nxt = has_next ? item_at(w + 1) : cur;
-  int lw = w, lk0 = cur.kbeg;
-  Item lit = cur;
-  // (past the last stage of the range the cursor stays put and the stage is fetched again: the loop body has no
-  // branch around its loads and stores, see load_raw)
-  auto issue_load = [&](float4 (&a)[2], float4 (&b)[2], int &klim) __attribute__((always_inline)) {
-    load_raw<A_KMAJOR>(p.A, p.lda, p.M, lit.bm0, lit.kend, lk0, tid, a);
-    load_raw<B_KMAJOR>(p.B, p.ldb, p.N, lit.bn0, lit.kend, lk0, tid, b);
-    klim = lit.kend - lk0;
-    if (lk0 + SBK < lit.kend) {
-      lk0 += SBK;
-    } else if (lw + 1 < work.end) {
-      lit = item_at(++lw);
-      lk0 = lit.kbeg;
-    }
-  };
+  if (wave >= 4) {
+    // ================================================================ producers
+    const int pt = tid - NPRODUCER;
+    // Bias gradient = column sums of the k-major A operand, taken from the f32 registers of the loader.  With
+    // split-K slabs the N tiles of one (M tile, split) share the work: N tile tn takes every cs_share-th k of a
+    // stage starting at tn; without slabs the first N tile does it alone and accumulates in place.
+    const int cs_share = partial ? p.colsum_share : 1;
+    auto colsum_first = [&](const Item &it) __attribute__((always_inline)) { return (it.bn0 / TBN) & (cs_share - 1); };
+    auto colsum_on = [&](const Item &it) __attribute__((always_inline)) {
+      return A_KMAJOR && p.colsum != nullptr && (partial ? it.bn0 / TBN < cs_share : it.bn0 == 0);
+    };
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    int cs_parity = 0, cs_pending = -1, cs_pending_row0 = 0, cs_pending_slab = 0;  // finished sums waiting in cs_area
 
-  // the (A term, B term) pairs, smallest products first
-  constexpr int PA[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0}, PB[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
-
-  f32x16 acc[2][2];
-  auto zero_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  };
-  zero_acc();
-  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f), csum_next = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  float4 r0a[2], r0b[2], r1a[2], r1b[2];
-  int klim0 = 0, klim1 = 0;
-  issue_load(r0a, r0b, klim0);
-  issue_load(r1a, r1b, klim1);
-  colsum_add(cur, r0a, klim0, csum);
-  store_split<A_KMAJOR>(smem, tid, r0a, klim0);
-  store_split<B_KMAJOR>(smem + OPERAND, tid, r0b, klim0);
-  __syncthreads();
-  int cb = 0, ck0 = cur.kbeg;
-  bool done = false;
-
-  // one stage: fetch stage g+2 into (la, lb); MFMAs of stage g from LDS buffer cb; convert + store stage g+1 (held in
-  // (sa, sb)) into the other buffer; barrier; at the end of an item its epilogue.
-  auto stage = [&](float4 (&la)[2], float4 (&lb)[2], int &lklim, const float4 (&sa)[2], const float4 (&sb)[2],
-                   int sklim) __attribute__((always_inline)) {
-    issue_load(la, lb, lklim);
-    const unsigned short *bufA = smem + cb * STAGE, *bufB = bufA + OPERAND;
-    unsigned short *othA = smem + (cb ^ 1) * STAGE, *othB = othA + OPERAND;
-    bf16x8 fa[2][3], fb[2][3];
-    read_frags<A_KMAJOR>(bufA, wm * 64, lane, fa[0]);
-    read_frags<A_KMAJOR>(bufA, wm * 64 + 32, lane, fa[1]);
-    read_frags<B_KMAJOR>(bufB, wn * 64, lane, fb[0]);
-    read_frags<B_KMAJOR>(bufB, wn * 64 + 32, lane, fb[1]);
-#pragma unroll
-    for (int t = 9 - NPROD; t < 9; ++t) {
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][PA[t]], fb[0][PB[t]], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][PA[t]], fb[1][PB[t]], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][PA[t]], fb[0][PB[t]], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][PA[t]], fb[1][PB[t]], acc[1][1], 0, 0, 0);
-    }
-    const bool last = ck0 + SBK >= cur.kend;
-    // stage g+1 belongs to this item or is the first stage of the next one (after the very last stage of the range
-    // the registers hold a re-fetched stage: stored, never read)
-    if (A_KMAJOR) {
-      if (!last) colsum_add(cur, sa, sklim, csum);
-      else if (has_next) colsum_add(nxt, sa, sklim, csum_next);
-    }
-    store_split<A_KMAJOR>(othA, tid, sa, sklim);
-    store_split<B_KMAJOR>(othB, tid, sb, sklim);
-    __syncthreads();  // stage g+1 is complete in LDS; nobody reads buffer cb any more
-    ck0 += SBK;
-    if (last) {
-      float *C = p.C + (partial ? (size_t)cur.z * p.slab : 0);
-      const int ldc = partial ? p.N : p.ldc;
-      float *const fsm = reinterpret_cast<float *>(smem + cb * STAGE);  // the buffer this stage just released
-      if (p.vec_epilogue) {
-        tile_epilogue_vec(p, acc, C, ldc, partial, cur.bm0, cur.bn0, wm, wn, lane, thr, keep_scale, fsm + wave * 2048);
-      } else {
-        tile_epilogue_scalar(p, acc, C, ldc, partial, cur.bm0, cur.bn0, wm, wn, lane, thr, keep_scale);
+    Cursor ld = {work.begin, 0, item_at(work.begin), false};  // next stage to fetch
+    ld.k0 = ld.it.kbeg;
+    Cursor st = ld;                                    // next stage to convert and store
+    uint32_t voa[4], vob[2];                           // per-thread byte offsets of the item under `ld`
+    item_offsets<A_KMAJOR, TBM>(p.lda, p.M, ld.it.bm0, pt, voa);
+    item_offsets<B_KMAJOR, TBN>(p.ldb, p.N, ld.it.bn0, pt, vob);
+    float4 ra[NSETS][4], rb[NSETS][2];                 // NSETS stages in flight (registers)
+    int rskip[NSETS];
+    auto fetch = [&](float4 (&a)[4], float4 (&b)[2], int &kskip) __attribute__((always_inline)) {
+      const int klim = ld.it.kend - ld.k0;
+      const int ks = klim >= SBK ? ld.k0 : ld.it.kend - SBK;  // the last stage of an item may start early
+      kskip = ld.k0 - ks;
+      load_raw(p.A + (A_KMAJOR ? (size_t)ks * p.lda : (size_t)ks), voa, a);
+      load_raw(p.B + (B_KMAJOR ? (size_t)ks * p.ldb : (size_t)ks), vob, b);
+      const int w_before = ld.w;
+      advance(ld);
+      if (ld.w != w_before) {  // uniform, no memory access inside
+        item_offsets<A_KMAJOR, TBM>(p.lda, p.M, ld.it.bm0, pt, voa);
+        item_offsets<B_KMAJOR, TBN>(p.ldb, p.N, ld.it.bn0, pt, vob);
       }
-      if (colsum_on(cur)) {  // block-uniform: add up the 8 k-groups of the loader
-        if (p.vec_epilogue) __syncthreads();
-        reinterpret_cast<float4 *>(fsm)[tid] = csum;  // [k group = tid >> 5][row quad = tid & 31]
+    };
+    // convert + store the stage under `st` into LDS buffer `buf`, then refill the registers two stages ahead
+    auto produce = [&](float4 (&a)[4], float4 (&b)[2], int &kskip, int buf) __attribute__((always_inline)) {
+      unsigned short *sa = smem + buf * STAGE, *sb = sa + 3 * PLANE_A;
+      if (A_KMAJOR && !st.end && colsum_on(st.it)) {  // (past the end the last stage is fetched again: not summed)
+        const int first = colsum_first(st.it);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int kl = pt / 64 + 4 * i;
+          if ((kl & (cs_share - 1)) == first && kl >= kskip) {
+            csum.x += a[i].x; csum.y += a[i].y; csum.z += a[i].z; csum.w += a[i].w;
+          }
+        }
+      }
+      store_split<A_KMAJOR, TBM>(sa, pt, a, kskip);
+      store_split<B_KMAJOR, TBN>(sb, pt, b, kskip);
+      if (A_KMAJOR && !st.end && st.k0 + SBK >= st.it.kend && colsum_on(st.it)) {  // last stage of its item: publish
+        reinterpret_cast<float4 *>(cs_area + cs_parity * 4 * TBM)[pt] = csum;  // [k group = pt / 64][row quad]
+        cs_pending = cs_parity;
+        cs_pending_row0 = st.it.bm0;
+        cs_pending_slab = partial ? st.it.z * cs_share + colsum_first(st.it) : -1;
+        cs_parity ^= 1;
+        csum = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      advance(st);
+      // the refill must not be scheduled above the conversion: old and new contents of the registers would overlap,
+      // the set could not stay in place across the loop and the copies (each waiting for its load) would drain the
+      // prefetch queue every iteration
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(a, b, kskip);
+    };
+    // after a barrier: the sums published before it are complete in LDS
+    auto flush_colsum = [&]() __attribute__((always_inline)) {
+      if (A_KMAJOR && cs_pending >= 0) {
+        const float *q = cs_area + cs_pending * 4 * TBM;
+        const int row = cs_pending_row0 + pt;
+        if (row < p.M) {
+          const float tot = q[pt] + q[TBM + pt] + q[2 * TBM + pt] + q[3 * TBM + pt];
+          if (cs_pending_slab >= 0) p.colsum[(size_t)cs_pending_slab * p.M + row] = tot;
+          else p.colsum[row] += tot;
+        }
+        cs_pending = -1;
+      }
+    };
+
+    // (the scheduling fences keep the ISSUE ORDER of the prologue loads: the scheduler would otherwise sink the later
+    // fetches below the refill to shorten live ranges, and since vmcnt counts in order every later wait for an older
+    // register set would have to drain the newer ones as well)
+#pragma unroll
+    for (int u = 0; u < NSETS; ++u) {
+      fetch(ra[u], rb[u], rskip[u]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    produce(ra[0], rb[0], rskip[0], 0);  // stage 0 -> buffer 0, set 0 <- stage NSETS
+    __syncthreads();
+    for (int g = 0; g < padded_stages; g += NSETS) {  // no exit in the middle: the register sets keep their roles
+#pragma unroll
+      for (int u = 1; u <= NSETS; ++u) {
+        flush_colsum();
+        produce(ra[u % NSETS], rb[u % NSETS], rskip[u % NSETS], u & 1);  // stage g + u -> buffer (g + u) & 1
         __syncthreads();
-        if (tid < 128 && cur.bm0 + tid < p.M) {
-          float tot = 0.f;
-#pragma unroll
-          for (int g = 0; g < 8; ++g) tot += fsm[g * 128 + tid];
-          if (partial) p.colsum[((size_t)cur.z * cs_share + colsum_first(cur)) * p.M + cur.bm0 + tid] = tot;
-          else p.colsum[cur.bm0 + tid] += tot;
-        }
       }
-      if (!has_next) {
-        done = true;
+    }
+    flush_colsum();
+  } else {
+    // ================================================================ consumers
+    const int wm = wave >> 1, wn = wave & 1;
+    const uint32_t thr = dropout_threshold(p.dropout_p);
+    const float keep_scale = 1.f / (1.f - p.dropout_p);
+    f32x16 acc[4][2];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    zero_acc();
+    Cursor cc = {work.begin, 0, item_at(work.begin), false};
+    cc.k0 = cc.it.kbeg;
+
+    __syncthreads();  // stage 0 is in buffer 0
+    for (int g = 0; g < padded_stages; ++g) {
+      if (g >= total_stages) {  // padding stage: the producers' loop runs in groups of NSETS stages
+        __syncthreads();
+        continue;
+      }
+      const unsigned short *sa = smem + (g & 1) * STAGE, *sb = sa + 3 * PLANE_A;
+      bf16x8 fa[4][3], fb[2][3];
+      auto read_a = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i][t] = read_frag<A_KMAJOR, TBM>(sa, wm * 128 + 32 * i, lane, t);
+      };
+      auto read_b = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j][t] = read_frag<B_KMAJOR, TBN>(sb, wn * 64 + 32 * j, lane, t);
+      };
+      auto mul = [&](int ta, int tb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ta], fb[j][tb], acc[i][j], 0, 0, 0);
+      };
+      // smallest products first; fragments are read in the order the products need them
+      if (NPROD == 9) {
+        read_a(2); read_b(2); mul(2, 2);
+        read_b(1); mul(2, 1);
+        read_a(1); mul(1, 2);
+        read_b(0); mul(2, 0);
+        read_a(0); mul(0, 2);
       } else {
-        __syncthreads();  // the released buffer (epilogue scratch) receives stage g+2 in the next stage
-        cur = nxt;
-        ++w;
-        has_next = w + 1 < work.end;
-        if (has_next) nxt = item_at(w + 1);
-        ck0 = cur.kbeg;
-        csum = csum_next;
-        csum_next = make_float4(0.f, 0.f, 0.f, 0.f);
+        read_a(2); read_b(0); mul(2, 0);
+        read_a(0); read_b(2); mul(0, 2);
+        read_a(1); read_b(1);
+      }
+      mul(1, 1); mul(1, 0); mul(0, 1); mul(0, 0);
+      __syncthreads();  // buffer g & 1 is released, buffer (g + 1) & 1 holds stage g + 1
+      if (cc.k0 + SBK >= cc.it.kend) {  // that was the item's last stage
+        float *C = p.C + (partial ? (size_t)cc.it.z * p.slab : 0);
+        const int ldc = partial ? p.N : p.ldc;
+        const int row0 = cc.it.bm0 + wm * 128, col0 = cc.it.bn0 + wn * 64;
+        if (p.vec_epilogue) tile_epilogue_vec<4>(p, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 2048);
+        else tile_epilogue_vec<4, false>(p, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 2048);
         zero_acc();
       }
+      advance(cc);
     }
-    cb ^= 1;
-  };
-
-  while (true) {
-    stage(r0a, r0b, klim0, r1a, r1b, klim1);
-    if (done) break;
-    stage(r1a, r1b, klim1, r0a, r0b, klim0);
-    if (done) break;
   }
 }
 
 template <bool AK, bool BKM, int NPROD>
 int launch(const GemmParams &p, int splits, hipStream_t st) {
-  const int work = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * splits;
+  const int work = ((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN) * splits;
   auto kern = gemm_bf16x3_mfma_kernel<AK, BKM, NPROD>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -293,9 +371,9 @@ int launch(const GemmParams &p, int splits, hipStream_t st) {
                                    (int)LDS_BYTES));
     attr_set = true;
   }
-  const int slots = persistent_grid() * 2;
+  const int slots = persistent_grid();  // one workgroup per CU
   const int grid = work < slots ? work : slots;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), LDS_BYTES, st, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), LDS_BYTES, st, p);
   return pt_check_launch();
 }
 
