@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0        # same table: dense bf16 matrix peak (the marketing figure includes 2:1 sparsity)
 
 
 def parse():
@@ -50,6 +51,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-proteins", type=int, default=2, help="proteins in the bounded CPU-baseline sample")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--gemm-mode", default="bf16x3", choices=["f32", "bf16x3", "bf16x3full"],
+                    help="arithmetic of the encoder GEMMs (include/ptamd.h: ptamd_gemm_set_mode)")
     return ap.parse_args()
 
 
@@ -83,6 +86,7 @@ def main():
         sys.exit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     dev = torch.device("cuda", dp.local_rank())
     torch.cuda.set_device(dev)
+    kernels.set_gemm_mode({"f32": kernels.GEMM_F32, "bf16x3": kernels.GEMM_BF16X3, "bf16x3full": kernels.GEMM_BF16X3_FULL}[a.gemm_mode])
 
     # ---- synthetic, device-resident batches (two per rank, alternated)
     build = lambda ang, seq: nerf_forward(ang.to(dev), seq.to(dev))[0]            # noqa: E731
@@ -145,21 +149,35 @@ def main():
         gemm_bytes = kernels.GEMM_BYTES
         ms = sum(e0.elapsed_time(e1) for _, e0, e1 in timing)
         achieved = flops / (ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "gemm_f32_mfma_kernel (v_mfma_f32_32x32x2_f32)",
-                    "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+        mode = kernels.get_gemm_mode()
+        if mode == kernels.GEMM_F32:
+            kern, peak, products = "gemm_f32_mfma_kernel (v_mfma_f32_32x32x2_f32)", F32_MFMA_PEAK_TFLOPS, 1
+        else:
+            # every f32 product is 6 (mode 1) or 9 (mode 2) bf16 MFMA products: the f32-equivalent ceiling is the dense
+            # bf16 MFMA peak divided by that count
+            products = 6 if mode == kernels.GEMM_BF16X3 else 9
+            kern = f"gemm_bf16x3_mfma_kernel (v_mfma_f32_32x32x16_bf16, {products} bf16 products per f32 product)"
+            peak = BF16_MFMA_PEAK_TFLOPS / products
+        roofline = {"bound": "mfma", "kernel": kern,
+                    "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "achieved_is": "algorithmic fp32 FLOP (2*M*N*K) per second of GEMM kernel time",
+                    "mfma_flops_issued_tflops": round(achieved * products, 1),
+                    "mfma_instruction_peak_tflops": BF16_MFMA_PEAK_TFLOPS if products > 1 else F32_MFMA_PEAK_TFLOPS,
                     "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_gemm_hbm_traffic.json)",
                     "algorithmic_bytes_per_launch": round(sum(b for b in gemm_bytes) / max(len(gemm_bytes), 1)),
                     "launches_per_step": len(timing) // a.steps, "avg_launch_us": round(1e3 * ms / len(timing), 2),
                     "gflop_per_step": round(flops / a.steps / 1e9, 1),
                     "share_of_step_time": round(ms / (dt * 1e3), 3)}
 
+    dtype = "f32" if kernels.get_gemm_mode() == kernels.GEMM_F32 else \
+        "f32 (GEMM operands split exactly into 3 bf16 terms on the bf16 MFMA pipe, f32 accumulate; the rest f32)"
     if rank == 0:
         out = {
             "metric": "train-step residues/sec (enc-only d512, dRMSD loss)",
             "value": round(world * n_res * a.steps / dt, 1), "unit": "residues/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"enc-only d_model={a.d_model} n_layers={a.n_layers} n_head={a.n_head} "
                                    f"d_ff={a.d_ff}, -l {a.loss}, {a.optimizer} lr 1e-4 wd 0.01 clip 1, dropout {a.dropout}, "
                                    f"{a.batch} proteins x L={a.length} per GPU (BASELINE.json configs[3])",

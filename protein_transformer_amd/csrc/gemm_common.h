@@ -81,30 +81,49 @@ __device__ __forceinline__ float epilogue_value(float v, int row, int col, const
 // 16 16-byte stores per lane instead of 64 4-byte ones.
 // (row0, col0) = origin of this wavefront's (32 TI) x 64 block of C.
 // VEC = false: same transposition, but the four elements of a lane are read / written one by one (any N / ldc).
-template <int TI, bool VEC = true>
+// EPI selects how much of the epilogue is compiled in (instruction-cache footprint: Philox alone is most of the
+// code): EPI_PLAIN stores the accumulators as they are, EPI_NODROP has everything but dropout, EPI_FULL everything.
+constexpr int EPI_PLAIN = 0, EPI_NODROP = 1, EPI_FULL = 2;
+template <int TI, bool VEC = true, int EPI = EPI_FULL>
 __device__ __forceinline__ void tile_epilogue_vec(const GemmParams &p, const f32x16 (&acc)[TI][2], float *C, int ldc,
                                                   bool partial, int row0, int col0, int lane, uint32_t thr,
                                                   float keep_scale, float *scratch) {
   const int l31 = lane & 31, lh = lane >> 5;
+  // Dropout keep decisions of the whole block, one bit per accumulator element (bit j * 16 + g * 4 + e of keep[i]),
+  // drawn in a ROLLED loop: one copy of Philox in the instruction stream instead of 8 TI.
+  uint32_t keep[TI];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) keep[i] = 0xffffffffu;
+  if (EPI == EPI_FULL && !partial && p.dropout_p > 0.f) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i) keep[i] = 0u;
+#pragma unroll 4
+    for (int idx = 0; idx < TI * 8; ++idx) {
+      const int i = idx >> 3, j = (idx >> 2) & 1, g = idx & 3;
+      const int rowq = row0 + i * 32 + 8 * g + 4 * lh, col = col0 + j * 32 + l31;
+      const uint4 rnd = philox4x32(p.seed, (uint64_t)(rowq >> 2) * p.N + col, p.stream_id);
+      const uint32_t bits = ((rnd.x >= thr ? 1u : 0u) | (rnd.y >= thr ? 2u : 0u) | (rnd.z >= thr ? 4u : 0u) |
+                             (rnd.w >= thr ? 8u : 0u)) << (j * 16 + g * 4);
+#pragma unroll
+      for (int ii = 0; ii < TI; ++ii) keep[ii] |= ii == i ? bits : 0u;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = col0 + j * 32 + l31;
-      const float bias = (!partial && p.bias && col < p.N) ? p.bias[col] : 0.f;
+      const float bias = (EPI != EPI_PLAIN && !partial && p.bias && col < p.N) ? p.bias[col] : 0.f;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int rowq = row0 + i * 32 + 8 * g + 4 * lh;
-        uint4 rnd = make_uint4(0, 0, 0, 0);
-        if (!partial && p.dropout_p > 0.f) rnd = philox4x32(p.seed, (uint64_t)(rowq >> 2) * p.N + col, p.stream_id);
-        const uint32_t rw[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float v = acc[i][j][g * 4 + e];
-          if (!partial) {
+          if (EPI != EPI_PLAIN && !partial) {
             v += bias;
             if (p.flags & PTAMD_EPI_RELU) v = fmaxf(v, 0.f);
-            if (p.dropout_p > 0.f) v = rw[e] >= thr ? v * keep_scale : 0.f;
+            if (EPI == EPI_FULL && p.dropout_p > 0.f) v = (keep[i] >> (j * 16 + g * 4 + e)) & 1u ? v * keep_scale : 0.f;
           }
           scratch[(8 * g + 4 * lh + e) * 64 + j * 32 + l31] = v;
         }
@@ -117,7 +136,7 @@ __device__ __forceinline__ void tile_epilogue_vec(const GemmParams &p, const f32
       float4 v = *reinterpret_cast<const float4 *>(scratch + rr * 64 + c4);
       if (VEC) {
         if (row < p.M && col < p.N) {
-          if (!partial) {
+          if (EPI != EPI_PLAIN && !partial) {
             if (p.residual) {
               const float4 r4 = *reinterpret_cast<const float4 *>(p.residual + (size_t)row * p.ldr + col);
               v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
@@ -136,7 +155,7 @@ __device__ __forceinline__ void tile_epilogue_vec(const GemmParams &p, const f32
         for (int e = 0; e < 4; ++e) {
           if (row < p.M && col + e < p.N) {
             float x = ve[e];
-            if (!partial) {
+            if (EPI != EPI_PLAIN && !partial) {
               if (p.residual) x += p.residual[(size_t)row * p.ldr + col + e];
               if (p.flags & PTAMD_EPI_TANH) x = tanhf(x);
               if (p.flags & PTAMD_EPI_ACCUM) x += C[(size_t)row * ldc + col + e];

@@ -159,7 +159,7 @@ struct Cursor {
   bool end;  // set once the cursor was asked to step past the last stage (it then stays on that stage)
 };
 
-template <bool A_KMAJOR, bool B_KMAJOR, int NPROD>
+template <bool A_KMAJOR, bool B_KMAJOR, int NPROD, int EPI>
 __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16x3_mfma_kernel(
     const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
@@ -352,8 +352,8 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
         float *C = p.C + (partial ? (size_t)cc.it.z * p.slab : 0);
         const int ldc = partial ? p.N : p.ldc;
         const int row0 = cc.it.bm0 + wm * 128, col0 = cc.it.bn0 + wn * 64;
-        if (p.vec_epilogue) tile_epilogue_vec<4>(p, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 2048);
-        else tile_epilogue_vec<4, false>(p, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 2048);
+        if (p.vec_epilogue) tile_epilogue_vec<4, true, EPI>(p, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 2048);
+        else tile_epilogue_vec<4, false, EPI>(p, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 2048);
         zero_acc();
       }
       advance(cc);
@@ -361,10 +361,10 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
   }
 }
 
-template <bool AK, bool BKM, int NPROD>
+template <bool AK, bool BKM, int NPROD, int EPI>
 int launch(const GemmParams &p, int splits, hipStream_t st) {
   const int work = ((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN) * splits;
-  auto kern = gemm_bf16x3_mfma_kernel<AK, BKM, NPROD>;
+  auto kern = gemm_bf16x3_mfma_kernel<AK, BKM, NPROD, EPI>;
   static bool attr_set = false;
   if (!attr_set) {
     PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -377,19 +377,23 @@ int launch(const GemmParams &p, int splits, hipStream_t st) {
   return pt_check_launch();
 }
 
-template <int NPROD>
+template <int NPROD, int EPI>
 int launch_layout(const GemmParams &p, bool ak, bool bk, int splits, hipStream_t st) {
-  if (!ak && !bk) return launch<false, false, NPROD>(p, splits, st);
-  if (!ak && bk) return launch<false, true, NPROD>(p, splits, st);
-  if (ak && !bk) return launch<true, false, NPROD>(p, splits, st);
-  return launch<true, true, NPROD>(p, splits, st);
+  if (!ak && !bk) return launch<false, false, NPROD, EPI>(p, splits, st);
+  if (!ak && bk) return launch<false, true, NPROD, EPI>(p, splits, st);
+  if (ak && !bk) return launch<true, false, NPROD, EPI>(p, splits, st);
+  return launch<true, true, NPROD, EPI>(p, splits, st);
 }
 
 }  // namespace
 
 int launch_split(const GemmParams &p, bool a_kmajor, bool b_kmajor, int splits, int products, hipStream_t st) {
-  return products == 9 ? launch_layout<9>(p, a_kmajor, b_kmajor, splits, st)
-                       : launch_layout<6>(p, a_kmajor, b_kmajor, splits, st);
+  if (products == 9) return launch_layout<9, EPI_FULL>(p, a_kmajor, b_kmajor, splits, st);
+  // the smallest epilogue that does the job (instruction-cache footprint, see gemm_common.h)
+  const bool plain = p.slab != 0 || (!p.bias && !p.residual && !p.flags && p.dropout_p == 0.f);
+  if (plain) return launch_layout<6, EPI_PLAIN>(p, a_kmajor, b_kmajor, splits, st);
+  if (p.dropout_p == 0.f) return launch_layout<6, EPI_NODROP>(p, a_kmajor, b_kmajor, splits, st);
+  return launch_layout<6, EPI_FULL>(p, a_kmajor, b_kmajor, splits, st);
 }
 
 }  // namespace ptgemm
