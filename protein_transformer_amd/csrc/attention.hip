@@ -19,6 +19,14 @@
 //     backward kernels instead of being stored.
 #include "common.h"
 
+// split-bf16 variants for dk = 64 (attention_split.hip), selected by the matrix arithmetic mode of ptamd_gemm_set_mode
+int pt_attention_fwd_split(const float *qkv, const int64_t *seq, int B, int L, int H, float p, uint64_t seed, uint32_t sid,
+                           float *out, float *lse, hipStream_t st);
+int pt_attention_bwd_split(const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse,
+                           float *delta, int B, int L, int H, float p, uint64_t seed, uint32_t sid, float *dqkv,
+                           hipStream_t st);
+extern "C" int ptamd_gemm_get_mode(void);
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -507,6 +515,8 @@ int ptamd_attention_fwd(const float *qkv, const int64_t *seq, int B, int L, int 
   if (dropout_p < 0.f || dropout_p >= 1.f) return PTAMD_ERR_BAD_SHAPE;
   if (!pt_aligned16(qkv) || !pt_aligned16(out)) return PTAMD_ERR_ALIGN;
   hipStream_t st = (hipStream_t)stream;
+  if (dk == 64 && ptamd_gemm_get_mode() != PTAMD_GEMM_F32)
+    return pt_attention_fwd_split(qkv, seq, B, L, H, dropout_p, seed, stream_id, out, lse, st);
   switch (dk) {
     case 8: return launch_fwd<8>(qkv, seq, B, L, H, dropout_p, seed, stream_id, out, lse, st);
     case 16: return launch_fwd<16>(qkv, seq, B, L, H, dropout_p, seed, stream_id, out, lse, st);
@@ -525,6 +535,8 @@ int ptamd_attention_bwd(const float *qkv, const int64_t *seq, const float *out, 
   if (!pt_aligned16(qkv) || !pt_aligned16(out) || !pt_aligned16(dout) || !pt_aligned16(dqkv)) return PTAMD_ERR_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   float *delta = static_cast<float *>(workspace);
+  if (dk == 64 && ptamd_gemm_get_mode() != PTAMD_GEMM_F32)
+    return pt_attention_bwd_split(qkv, seq, out, dout, lse, delta, B, L, H, dropout_p, seed, stream_id, dqkv, st);
   switch (dk) {
     case 8: return launch_bwd<8>(qkv, seq, out, dout, lse, delta, B, L, H, dropout_p, seed, stream_id, dqkv, st);
     case 16: return launch_bwd<16>(qkv, seq, out, dout, lse, delta, B, L, H, dropout_p, seed, stream_id, dqkv, st);
