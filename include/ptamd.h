@@ -103,13 +103,15 @@ int ptamd_mse_angles_bwd(const float *pred, const float *truth, int64_t T, const
  *   b_kmajor = 0: B is [N,K] (K contiguous, ldb) - the torch.nn.Linear weight layout;
  *              1: B is stored [K,N] (N contiguous, ldb)
  * epilogue, in order: + bias[N] (may be NULL); ReLU if (flags & PTAMD_EPI_RELU);
- *   dropout(p, seed, stream_id) if p > 0;  + residual[M,N] (ldr; may be NULL);
- *   tanh if (flags & PTAMD_EPI_TANH).
+ *   dropout(p, seed, stream_id) if p > 0;  + residual[M,N] (ldr; may be NULL), or the ReLU/dropout gate of
+ *   PTAMD_EPI_GATE;  tanh if (flags & PTAMD_EPI_TANH).
  * Replaces torch.nn.Linear (Attention.py:49,69; Sublayers.py:34; encoder_only.py:39)
  * and their autograd backward GEMMs. */
 #define PTAMD_EPI_RELU 1
 #define PTAMD_EPI_TANH 2
 #define PTAMD_EPI_ACCUM 4 /* C += result (used for split reductions) */
+#define PTAMD_EPI_GATE 8  /* result = residual[m,n] > 0 ? result * gate_scale : 0 - the backward of ReLU + dropout through
+                            the saved activation (Sublayers.py:34), instead of adding `residual` */
 typedef struct {
   int M, N, K;
   const float *A; int lda; int a_kmajor;
@@ -122,6 +124,7 @@ typedef struct {
   int split_k;            /* >1: partials go to workspace and are reduced deterministically */
   void *workspace; size_t workspace_bytes;
   float *colsum;          /* optional, a_kmajor only: colsum[m] += sum_k A[k][m] (the bias gradient of a dW product) */
+  float gate_scale;       /* PTAMD_EPI_GATE: 1 / (1 - p) of the dropout that followed the ReLU */
 } ptamd_gemm_args;
 size_t ptamd_gemm_workspace_bytes(int M, int N, int split_k);
 int ptamd_gemm(const ptamd_gemm_args *args, void *stream);

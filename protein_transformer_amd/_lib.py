@@ -27,7 +27,8 @@ class GemmArgs(C.Structure):
                 ("dropout_p", _f), ("seed", _u64), ("stream_id", _u32),
                 ("split_k", _i),
                 ("workspace", _p), ("workspace_bytes", _sz),
-                ("colsum", _p)]
+                ("colsum", _p),
+                ("gate_scale", _f)]
 
 
 # name -> (restype, argtypes); mirrors include/ptamd.h one to one

@@ -206,6 +206,53 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_mfma_kernel(const GemmParams p
   }
 }
 
+// split-K, plain case (no bias / activation / dropout / residual; optional accumulate) with 16-byte accesses: one
+// thread sums one float4 of one output row over the slabs in a fixed order.  The column-sum slabs (fused bias gradient
+// of a dW product) are reduced by the first wavefronts of the grid.
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_plain_kernel(const GemmParams p, const float *__restrict__ slabs,
+                                                                     int splits, const float *__restrict__ colsum_slabs,
+                                                                     float *__restrict__ colsum_out) {
+  const int n4 = p.N >> 2;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, total = (size_t)p.M * n4;
+  if (colsum_out) {  // M rows, one lane per (row, 16th of the slabs): 16 lanes per row
+    const int nslab = splits * p.colsum_share;
+    const size_t g = i >> 4;
+    if (g < (size_t)p.M) {
+      const int chunk = (int)(i & 15);
+      float v = 0.f;
+      for (int s = chunk; s < nslab; s += 16) v += colsum_slabs[(size_t)s * p.M + g];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+      if (chunk == 0) colsum_out[g] += v;
+    }
+  }
+  if (i >= total) return;
+  const size_t row = i / n4;
+  const int c4 = (int)(i - row * n4) * 4;
+  const float4 *src = reinterpret_cast<const float4 *>(slabs) + i;
+  const size_t stride4 = p.slab >> 2;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int s = 0;
+  for (; s + 4 <= splits; s += 4) {  // four independent loads in flight, summed in slab order
+    const float4 a = src[(size_t)s * stride4], b = src[(size_t)(s + 1) * stride4], c = src[(size_t)(s + 2) * stride4],
+                 d = src[(size_t)(s + 3) * stride4];
+    acc.x = (((acc.x + a.x) + b.x) + c.x) + d.x;
+    acc.y = (((acc.y + a.y) + b.y) + c.y) + d.y;
+    acc.z = (((acc.z + a.z) + b.z) + c.z) + d.z;
+    acc.w = (((acc.w + a.w) + b.w) + c.w) + d.w;
+  }
+  for (; s < splits; ++s) {
+    const float4 a = src[(size_t)s * stride4];
+    acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+  }
+  float4 *dst = reinterpret_cast<float4 *>(p.C + row * p.ldc + c4);
+  if (p.flags & PTAMD_EPI_ACCUM) {
+    const float4 o = *dst;
+    acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+  }
+  *dst = acc;
+}
+
 // split-K: sum the slabs in a fixed order, then the same epilogue
 __global__ void gemm_splitk_reduce_kernel(const GemmParams p, const float *__restrict__ slabs, int splits,
                                           const float *__restrict__ colsum_slabs, float *__restrict__ colsum_out) {
@@ -327,7 +374,7 @@ int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
   p.M = a->M; p.N = a->N; p.K = a->K;
   p.A = a->A; p.lda = a->lda; p.B = a->B; p.ldb = a->ldb; p.C = a->C; p.ldc = a->ldc;
   p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr; p.flags = a->flags;
-  p.dropout_p = a->dropout_p; p.seed = a->seed; p.stream_id = a->stream_id;
+  p.dropout_p = a->dropout_p; p.seed = a->seed; p.stream_id = a->stream_id; p.gate_scale = a->gate_scale;
   p.k_per_split = ((kblocks + splits - 1) / splits) * BK;
   splits = (a->K + p.k_per_split - 1) / p.k_per_split;
   p.splits = splits;
@@ -342,6 +389,7 @@ int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
     while (p.colsum_share * 2 <= tiles_n && p.colsum_share < 16) p.colsum_share *= 2;
   }
   if (a->colsum && !a->a_kmajor) return PTAMD_ERR_BAD_SHAPE;
+  if ((a->flags & PTAMD_EPI_GATE) && !a->residual) return PTAMD_ERR_BAD_SHAPE;
   float *user_c = a->C;
   if (splits > 1) {
     if (!a->workspace || a->workspace_bytes < ptamd_gemm_workspace_bytes(a->M, a->N, splits)) return PTAMD_ERR_WORKSPACE;
@@ -362,8 +410,17 @@ int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
   if (rc || splits == 1) return rc;
   const float *slabs = p.C;
   p.C = user_c;
-  hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((a->N + 255) / 256, (a->M + 3) / 4), dim3(256), 0, st, p, slabs,
-                     splits, a->colsum ? slabs + (size_t)splits * p.slab : nullptr, a->colsum);
+  const float *cs_slabs = a->colsum ? slabs + (size_t)splits * p.slab : nullptr;
+  const bool plain = !a->bias && !a->residual && !(a->flags & (PTAMD_EPI_RELU | PTAMD_EPI_TANH)) && a->dropout_p == 0.f;
+  if (plain && !(a->N & 3) && !(a->ldc & 3) && pt_aligned16(user_c) && pt_aligned16(slabs)) {
+    const size_t work = (size_t)a->M * (a->N >> 2), cs_work = a->colsum ? (size_t)a->M * 16 : 0;
+    const size_t threads = work > cs_work ? work : cs_work;
+    hipLaunchKernelGGL(gemm_splitk_reduce_plain_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p, slabs,
+                       splits, cs_slabs, a->colsum);
+  } else {
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((a->N + 255) / 256, (a->M + 3) / 4), dim3(256), 0, st, p, slabs,
+                       splits, cs_slabs, a->colsum);
+  }
   return pt_check_launch();
 }
 

@@ -7,6 +7,7 @@
 namespace ptgemm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128, NT = 256;  // output tile per workgroup, threads per workgroup
 // BK (K advance per stage) is a template parameter: 32 (2 workgroups / CU, 73.7 KB LDS each) or 16 (3 per CU).
@@ -35,6 +36,7 @@ struct GemmParams {
   int vec_epilogue;  // N, ldc, ldr multiples of 4 and 16-byte aligned C / residual: float4 epilogue through LDS
   float *colsum;     // k-major A only: colsum[m] (+)= sum_k A[k][m]; with split-K a [splits * share][M] slab, reduced later
   int colsum_share;  // N tiles sharing the column-sum work of one (M tile, split): power of two <= min(tiles_n, 16)
+  float gate_scale;  // PTAMD_EPI_GATE
 };
 
 // ---- staging: each thread carries 4 float4 per operand per stage; global -> registers -> LDS, no transposition:
@@ -65,7 +67,10 @@ __device__ __forceinline__ float epilogue_value(float v, int row, int col, const
     const uint32_t w = (row & 3) == 0 ? rnd.x : (row & 3) == 1 ? rnd.y : (row & 3) == 2 ? rnd.z : rnd.w;
     v = (w >= thr) ? v * keep_scale : 0.f;
   }
-  if (p.residual) v += p.residual[(size_t)row * p.ldr + col];
+  if (p.residual) {
+    const float r = p.residual[(size_t)row * p.ldr + col];
+    v = (p.flags & PTAMD_EPI_GATE) ? (r > 0.f ? v * p.gate_scale : 0.f) : v + r;
+  }
   if (p.flags & PTAMD_EPI_TANH) v = tanhf(v);
   return v;
 }
@@ -110,6 +115,19 @@ __device__ __forceinline__ void tile_epilogue_vec(const GemmParams &p, const f32
   }
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
+    // residual / gate / accumulate operands of this 32-row block are requested BEFORE the transposition, so that their
+    // latency runs under the LDS traffic instead of in front of every store
+    f32x4 pre4[8];  // the residual / gate operand if there is one, else the old C of an accumulating product
+    const bool want_res = VEC && EPI != EPI_PLAIN && !partial && p.residual != nullptr;
+    const bool want_old = VEC && EPI != EPI_PLAIN && !partial && (p.flags & PTAMD_EPI_ACCUM) && !want_res;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int f = lane + 64 * t, rr = f >> 4, c4 = (f & 15) * 4;
+      const int row = min(row0 + i * 32 + rr, p.M - 1), col = min(col0 + c4, p.N - 4);
+      const float *src = want_res ? p.residual + (size_t)row * p.ldr + col : C + (size_t)row * ldc + col;
+      pre4[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (want_res || want_old) pre4[t] = *reinterpret_cast<const f32x4 *>(src);
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = col0 + j * 32 + l31;
@@ -138,12 +156,17 @@ __device__ __forceinline__ void tile_epilogue_vec(const GemmParams &p, const f32
         if (row < p.M && col < p.N) {
           if (EPI != EPI_PLAIN && !partial) {
             if (p.residual) {
-              const float4 r4 = *reinterpret_cast<const float4 *>(p.residual + (size_t)row * p.ldr + col);
-              v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+              const f32x4 r4 = pre4[t];
+              if (p.flags & PTAMD_EPI_GATE) {
+                v.x = r4.x > 0.f ? v.x * p.gate_scale : 0.f; v.y = r4.y > 0.f ? v.y * p.gate_scale : 0.f;
+                v.z = r4.z > 0.f ? v.z * p.gate_scale : 0.f; v.w = r4.w > 0.f ? v.w * p.gate_scale : 0.f;
+              } else {
+                v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+              }
             }
             if (p.flags & PTAMD_EPI_TANH) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
             if (p.flags & PTAMD_EPI_ACCUM) {
-              const float4 o4 = *reinterpret_cast<const float4 *>(C + (size_t)row * ldc + col);
+              const f32x4 o4 = want_old ? pre4[t] : *reinterpret_cast<const f32x4 *>(C + (size_t)row * ldc + col);
               v.x += o4.x; v.y += o4.y; v.z += o4.z; v.w += o4.w;
             }
           }
@@ -156,7 +179,10 @@ __device__ __forceinline__ void tile_epilogue_vec(const GemmParams &p, const f32
           if (row < p.M && col + e < p.N) {
             float x = ve[e];
             if (EPI != EPI_PLAIN && !partial) {
-              if (p.residual) x += p.residual[(size_t)row * p.ldr + col + e];
+              if (p.residual) {
+                const float r = p.residual[(size_t)row * p.ldr + col + e];
+                x = (p.flags & PTAMD_EPI_GATE) ? (r > 0.f ? x * p.gate_scale : 0.f) : x + r;
+              }
               if (p.flags & PTAMD_EPI_TANH) x = tanhf(x);
               if (p.flags & PTAMD_EPI_ACCUM) x += C[(size_t)row * ldc + col + e];
             }
@@ -196,7 +222,10 @@ __device__ __forceinline__ void tile_epilogue_scalar(const GemmParams &p, const 
               v += bias;
               if (p.flags & PTAMD_EPI_RELU) v = fmaxf(v, 0.f);
               if (p.dropout_p > 0.f) v = rw[e] >= thr ? v * keep_scale : 0.f;
-              if (p.residual && col_ok && row < p.M) v += p.residual[(size_t)row * p.ldr + col];
+              if (p.residual && col_ok && row < p.M) {
+                const float rr = p.residual[(size_t)row * p.ldr + col];
+                v = (p.flags & PTAMD_EPI_GATE) ? (rr > 0.f ? v * p.gate_scale : 0.f) : v + rr;
+              }
               if (p.flags & PTAMD_EPI_TANH) v = tanhf(v);
               if ((p.flags & PTAMD_EPI_ACCUM) && col_ok && row < p.M) v += C[(size_t)row * ldc + col];
             }

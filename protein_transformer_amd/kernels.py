@@ -10,7 +10,7 @@ import torch
 from . import _lib
 from ._lib import GemmArgs, check, lib, ptr, stream, workspace
 
-EPI_RELU, EPI_TANH, EPI_ACCUM = 1, 2, 4
+EPI_RELU, EPI_TANH, EPI_ACCUM, EPI_GATE = 1, 2, 4, 8
 
 # bench.py sets this to a list to time every GEMM launch with HIP events recorded on the launch stream:
 # entries are (flops, start_event, end_event).  None (the default) adds no work to the hot path.
@@ -20,7 +20,7 @@ GEMM_BYTES = []          # algorithmic operand bytes (A + B + C [+ residual, + a
 
 
 def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, bias=None, residual=None,
-         ldr=0, flags=0, dropout_p=0.0, seed=0, stream_id=0, split_k=1, colsum=None):
+         ldr=0, flags=0, dropout_p=0.0, seed=0, stream_id=0, split_k=1, colsum=None, gate_scale=0.0):
     """C[M,N] = epilogue(A (*) B); operand layouts as documented in ptamd.h."""
     ws = None
     nbytes = 0
@@ -34,7 +34,7 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False,
                     dropout_p=float(dropout_p), seed=int(seed) & (2 ** 64 - 1), stream_id=int(stream_id),
                     split_k=int(split_k), workspace=ws.data_ptr() if ws is not None else None,
                     workspace_bytes=ws.numel() if ws is not None else 0,
-                    colsum=colsum.data_ptr() if colsum is not None else None)
+                    colsum=colsum.data_ptr() if colsum is not None else None, gate_scale=float(gate_scale))
     if GEMM_TIMING is None:
         check(lib().ptamd_gemm(C.byref(args), stream()), "gemm")
     else:
@@ -78,12 +78,16 @@ def linear_fwd(x, w, b, out=None, **epi):
     return gemm(x, w, out, M=T, N=N, K=K, lda=x.stride(0), ldb=w.stride(0), ldc=out.stride(0), bias=b, **epi)
 
 
-def linear_bwd_input(dy, w, out=None, flags=0):
-    """dx[T,K] = dy[T,N] w[N,K]."""
+def linear_bwd_input(dy, w, out=None, flags=0, gate=None, gate_dropout_p=0.0):
+    """dx[T,K] = dy[T,N] w[N,K];  with `gate` (the saved output of a ReLU + dropout layer, [T,K]) the product is passed
+    through the backward of that layer in the epilogue: dx = gate > 0 ? dx / (1 - p) : 0."""
     T, N = dy.shape
     K = w.shape[1]
     if out is None:
         out = torch.empty(T, K, dtype=torch.float32, device=dy.device)
+    if gate is not None:
+        return gemm(dy, w, out, M=T, N=K, K=N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0), b_kmajor=True,
+                    flags=flags | EPI_GATE, residual=gate, ldr=gate.stride(0), gate_scale=1.0 / (1.0 - gate_dropout_p))
     return gemm(dy, w, out, M=T, N=K, K=N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0), b_kmajor=True,
                 flags=flags)
 

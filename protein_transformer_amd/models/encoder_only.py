@@ -347,8 +347,8 @@ class _EncoderFn(torch.autograd.Function):
             # x3 = x2 + drop(f1 W2^T + b2)
             dy2 = K.dropout_bwd(dx, p, seed, sid + _SITE_FFN_OUT) if p > 0 else dx
             K.linear_bwd_weight(dy2, f1, G(b + "pwff.layer2.weight"), G(b + "pwff.layer2.bias"))
-            df1 = K.linear_bwd_input(dy2, W(b + "pwff.layer2.weight"))
-            dz1 = K.relu_dropout_bwd(df1, f1, p)
+            # backward of layer2 and, in its epilogue, of the ReLU + dropout in front of it (gate = saved f1)
+            dz1 = K.linear_bwd_input(dy2, W(b + "pwff.layer2.weight"), gate=f1, gate_dropout_p=p)
             K.linear_bwd_weight(dz1, h2, G(b + "pwff.layer1.weight"), G(b + "pwff.layer1.bias"))
             dh2 = K.linear_bwd_input(dz1, W(b + "pwff.layer1.weight"))
             dx2 = K.layernorm_bwd(dh2, x2, W(b + "sublayer_connections.1.norm.weight"), mean2, rstd2,

@@ -81,6 +81,10 @@ def test_gemm_epilogues_and_split(dev, gemm_mode):
     dy = rnd((T, N), 7)
     dx = K_.linear_bwd_input(dy.to(dev), wd)
     assert_close(dx, dy.double() @ w.double(), 1e-5, 1e-5, "dX")
+    # ... fused with the backward of a ReLU + dropout layer whose saved output is `gate`
+    gate = (rnd((T, Kd), 72) * (rnd((T, Kd), 73) > -0.6)).clamp_min(0)
+    dxg = K_.linear_bwd_input(dy.to(dev), wd, gate=gate.to(dev), gate_dropout_p=0.2)
+    assert_close(dxg, (dy.double() @ w.double()) * (gate > 0).double() / 0.8, 1e-5, 1e-5, "dX through the ReLU/dropout gate")
     dw = torch.ones(N, Kd, device=dev)
     K_.linear_bwd_weight(dy.to(dev), xd, dw)
     assert_close(dw, 1 + dy.double().T @ x.double(), 1e-5, 2e-5, "dW accumulate")
@@ -229,7 +233,8 @@ def ref_attention(qkv, key_ok, H, mask_keep=None, p=0.0):
 
 @pytest.mark.parametrize("B,L,H,dk,lens", [(2, 100, 4, 8, [100, 37]), (2, 64, 2, 16, [64, 5]), (3, 200, 8, 32, [200, 129, 64]),
                                            (2, 512, 8, 64, [512, 300]), (1, 130, 2, 64, [130])])
-def test_attention_forward_backward(dev, B, L, H, dk, lens):
+def test_attention_forward_backward(dev, gemm_mode, B, L, H, dk, lens):
+    # gemm_mode selects the matrix arithmetic: exact f32 MFMA, or (dk = 64) the split-bf16 kernels of attention_split.hip
     from protein_transformer_amd import kernels as K_
     D = H * dk
     seq = torch.full((B, L), 20, dtype=torch.int64)
@@ -248,7 +253,7 @@ def test_attention_forward_backward(dev, B, L, H, dk, lens):
     assert_close(dqkv, ref, 1e-4, 2e-6 * max(1.0, scale), "attention bwd")
 
 
-def test_attention_dropout_consistency(dev):
+def test_attention_dropout_consistency(dev, gemm_mode):
     """Recover the dropout mask from a forward pass with V = I, then check all three gradients against
     dense torch math that uses that mask: forward, dQ and dK/dV kernels must draw identical masks."""
     from protein_transformer_amd import kernels as K_
