@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restr
   }
 }
 
-constexpr int LN_BWD_BLOCKS = 256;  // x 4 waves = 1024 partial rows of (dgamma, dbeta)
+constexpr int LN_BWD_BLOCKS = 512;  // 2 per CU, 4 wavefronts each; one partial row of (dgamma, dbeta) per block
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                             const float *__restrict__ gamma,
@@ -189,16 +189,36 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
       }
     }
   }
+  // the four wavefronts of the block add up their (dgamma, dbeta) in a fixed order: one partial row per block
+  __shared__ float4 s_dg[3][NV * 64], s_db[3][NV * 64];
+  const int wave = threadIdx.x >> 6;
+  if (wave > 0) {
 #pragma unroll
-  for (int j = 0; j < NV; ++j) {
-    const int c = (j * 64 + lane) * 4;
-    if (c < D) {
-      *reinterpret_cast<float4 *>(part + ((size_t)wid * 2) * D + c) = dg[j];
-      *reinterpret_cast<float4 *>(part + ((size_t)wid * 2 + 1) * D + c) = db[j];
+    for (int j = 0; j < NV; ++j) {
+      s_dg[wave - 1][j * 64 + lane] = dg[j];
+      s_db[wave - 1][j * 64 + lane] = db[j];
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = (j * 64 + lane) * 4;
+      if (c < D) {
+        float4 a = dg[j], b = db[j];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          const float4 pa = s_dg[w][j * 64 + lane], pb = s_db[w][j * 64 + lane];
+          a.x += pa.x; a.y += pa.y; a.z += pa.z; a.w += pa.w;
+          b.x += pb.x; b.y += pb.y; b.z += pb.z; b.w += pb.w;
+        }
+        *reinterpret_cast<float4 *>(part + ((size_t)blockIdx.x * 2) * D + c) = a;
+        *reinterpret_cast<float4 *>(part + ((size_t)blockIdx.x * 2 + 1) * D + c) = b;
+      }
     }
   }
 }
-// 1024 partial rows -> [D]: one block per 64 columns, 16 waves each summing 64 rows (coalesced 256 B reads)
+// LN_BWD_BLOCKS partial rows -> [D]: one block per 64 columns, 16 waves each summing every 16th row (256 B reads)
 __global__ __launch_bounds__(1024) void layernorm_bwd_reduce_kernel(const float *__restrict__ part, int D,
                                                                     float *__restrict__ dgamma,
                                                                     float *__restrict__ dbeta) {
@@ -207,7 +227,7 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_reduce_kernel(const float 
   const int c = blockIdx.x * 64 + lane;
   float a = 0.f, b = 0.f;
   if (c < D)
-    for (int w = wave; w < LN_BWD_BLOCKS * 4; w += 16) {
+    for (int w = wave; w < LN_BWD_BLOCKS; w += 16) {
       a += part[((size_t)w * 2) * D + c];
       b += part[((size_t)w * 2 + 1) * D + c];
     }
@@ -325,7 +345,7 @@ int ptamd_layernorm_fwd(const float *x, const float *gamma, const float *beta, i
 }
 
 size_t ptamd_layernorm_bwd_workspace_bytes(int D) {
-  return (size_t)LN_BWD_BLOCKS * 4 * 2 * (D > 0 ? D : 0) * sizeof(float);
+  return (size_t)LN_BWD_BLOCKS * 2 * (D > 0 ? D : 0) * sizeof(float);
 }
 
 int ptamd_layernorm_bwd(const float *dy, const float *x, const float *gamma, const float *mean, const float *rstd,
