@@ -4,8 +4,8 @@ Keeps the metric-dictionary keys, the CSV columns and the speed definition of
 /root/reference/protein_transformer/log.py (`update_loss_trackers` :92-112, `log_batch` :115-130,
 `init_metrics` :359-386, `update_metrics` :389-434 with speed = non-pad residues / time since the
 previous batch :422-430, `reset_metrics_for_epoch` :437-457, `update_metrics_end_of_epoch` :460-485,
-`prepare_log_header` :488-495, `EarlyStoppingCondition` :498-503).  wandb, tqdm status bars and the
-PyMOL/PDB structure dumps are not part of the hot path and are left out.
+`prepare_log_header` :488-495, `EarlyStoppingCondition` :498-503) and the PDB part of its structure dumps
+(`log_structure_and_angs` :310-337, without wandb / PyMOL).  wandb and tqdm status bars are left out.
 """
 import sys
 import time
@@ -134,6 +134,32 @@ def do_train_batch_logging(metrics, losses, src_seq, optimizer, args, log_writer
                   f"rmse {np.sqrt(m['batch-mse-full']):.4f}  comb {m['batch-combined-full']:.4f}  "
                   f"lr {lr:.2e}  {m['speed']:.0f} res/s", flush=True)
     return metrics
+
+
+def log_structure(args, pred_coords, true_coords, src_seq, step, struct_name="train"):
+    """PDB dump of one predicted structure next to its target (log.py:310-337 of the reference without wandb and
+    PyMOL): `<structure_dir>/<struct_name>/<step:05>_pred.pdb` and `true.pdb`.
+
+    pred_coords, true_coords: [L*14, 3] of ONE protein (true may carry NaN / zero rows for missing atoms and batch
+    padding rows, which are dropped like in the reference), src_seq: [L] residue ids without padding.
+    """
+    import os
+
+    import torch
+
+    from .protein.PDB_Creator import PDB_Creator
+    seq = VOCAB.ints2str([int(i) for i in torch.as_tensor(src_seq).cpu().tolist()])
+    path = os.path.join(args.structure_dir, struct_name)
+    os.makedirs(path, exist_ok=True)
+    pred = torch.as_tensor(pred_coords).detach().cpu().float().numpy()[:len(seq) * 14]
+    true = torch.as_tensor(true_coords).detach().cpu().float().clone()[:len(seq) * 14]
+    true[torch.isnan(true)] = 0
+    pred_path = os.path.join(path, f"{step:05}_pred.pdb")
+    PDB_Creator(pred, seq=seq).save_pdb(pred_path, title="pred")
+    true_path = os.path.join(path, "true.pdb")
+    if not os.path.isfile(true_path) or struct_name == "train":
+        PDB_Creator(true.numpy(), seq=seq).save_pdb(true_path, title="true")
+    return pred_path, true_path
 
 
 def do_eval_batch_logging(metrics, losses, src_seq, args, mode):

@@ -48,8 +48,27 @@ def train_epoch(model, training_data, validation_datasets, optimizer, device, ar
         src_seq, tgt_ang, tgt_crds = dp.shard_batch(src_seq, tgt_ang, tgt_crds)
         losses = train_step(model, optimizer, args, src_seq, tgt_ang, tgt_crds, pool=pool)
         metrics = do_train_batch_logging(metrics, losses, src_seq, optimizer, args, log_writer, START_TIME, step)
+        if getattr(args, "structure_dir", None) and dp.is_main() and step % max(1, args.log_structure_step) == 0:
+            dump_structure(model, args, src_seq, tgt_crds, step)
     metrics = update_metrics_end_of_epoch(metrics, "train")
     return metrics
+
+
+def dump_structure(model, args, src_seq, tgt_crds, step, struct_name="train"):
+    """Structure dump of the first protein of a batch (log.py:158,201-206 of the reference): predict its angles again
+    without dropout, build the atoms with the NeRF kernels and write the PDB files."""
+    from .log import log_structure
+    from .losses import inverse_trig_transform
+    from .protein.Structure import generate_coords
+    n = int((src_seq[0] != VOCAB.pad_id).sum().item())
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        pred = model(src_seq[:1], None)
+        ang = inverse_trig_transform(pred)[0, :n]
+        crd = generate_coords(ang, src_seq[0, :n], src_seq.device)
+    model.train(was_training)
+    return log_structure(args, crd, tgt_crds[0, :n * 14], src_seq[0, :n], step, struct_name)
 
 
 def train_step(model, optimizer, args, src_seq, tgt_ang, tgt_crds, pool=None):
@@ -326,6 +345,9 @@ def create_parser():
 
     saving_args = parser.add_argument_group("Saving Args")
     saving_args.add_argument('--log_structure_step', type=int, default=10)
+    saving_args.add_argument('--structure_dir', type=str, default=None,
+                             help='write <step>_pred.pdb / true.pdb of the first protein of a batch there every '
+                                  '--log_structure_step steps (off when not given: it costs a device sync)')
     saving_args.add_argument('-lvs', '--log_val_struct_step', type=int, default=50)
     saving_args.add_argument('--log_wandb_step', type=int, default=1)
     saving_args.add_argument("-png", '--save_pngs', type=my_bool, default=True)

@@ -372,13 +372,39 @@ def g9(rng):
     return out
 
 
+def g11(rng):
+    """PDB_Creator.save_pdb on structures built by the reference's own NeRF builder: inputs + the text it writes."""
+    import tempfile
+    from protein_transformer.protein.PDB_Creator import PDB_Creator
+    from protein_transformer.protein.Structure import generate_coords
+    from protein_transformer.protein.Sequence import VOCAB as RV
+    out = {}
+    seqs = ["ACDEFGHIKLMNPQRSTVWY", "GGAWKPY", "MKV"]
+    for i, s in enumerate(seqs):
+        ids = np.array([RV._char2int[c] for c in s], dtype=np.int64)
+        ang = rng.uniform(-np.pi, np.pi, (len(s), 12)).astype(np.float32)
+        crd = generate_coords(torch.tensor(ang), torch.tensor(ids), torch.device("cpu")).detach().numpy()
+        if i == 1:
+            crd = crd.copy()
+            crd[14 + 2] = np.nan          # a missing backbone atom: skipped, numbering continues
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "x.pdb")
+            PDB_Creator(crd, seq=s).save_pdb(path, title=f"golden {i}")
+            text = open(path).read()
+        out[f"seq{i}"] = np.array(s)
+        out[f"crd{i}"] = crd.astype(np.float32)
+        out[f"pdb{i}"] = np.array(text)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=HERE)
     ns = ap.parse_args()
     torch.set_num_threads(1)
     for name, fn, seed in (("g1_nerf", g1, 1), ("g2_coords", g2, 2), ("g3_drmsd", g3, 3), ("g4_drmsd_work", g4, 4),
-                           ("g567_model_step", g567, 5), ("g8_mse", g8, 8), ("g9_dataset", g9, 9), ("g10_convenc", g10, 10)):
+                           ("g567_model_step", g567, 5), ("g8_mse", g8, 8), ("g9_dataset", g9, 9), ("g10_convenc", g10, 10),
+                           ("g11_pdb", g11, 11)):
         data = fn(np.random.default_rng(seed))
         path = os.path.join(ns.out, name + ".npz")
         np.savez_compressed(path, **data)

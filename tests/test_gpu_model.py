@@ -259,3 +259,38 @@ def test_long_sequence_model(dev):
     assert np.abs(out - ref).max() < 1e-5
     with pytest.raises(RuntimeError, match="max_seq_len"):
         m(torch.zeros(1, 1501, dtype=torch.int64, device=dev))
+
+
+def test_structure_dump_writes_pdb_of_first_protein(dev, tmp_path):
+    """`--structure_dir`: the first protein of a batch is predicted without dropout, built with the NeRF kernels and
+    written as PDB next to its target; the atoms must be the oracle's atoms for the same angles."""
+    import types
+    from oracle import encoder as oenc
+    from oracle import geometry as ogeo
+    from oracle.losses import inverse_trig_transform
+    from protein_transformer_amd.models.encoder_only import EncoderOnlyTransformer
+    from protein_transformer_amd.protein.Sequence import VOCAB
+    from protein_transformer_amd.train import dump_structure
+    am = np.tanh(np.random.default_rng(2).normal(0, 0.5, 24))
+    params = oenc.init_params(1, 32, 64, 64, am, seed=7)
+    params["output_projection.weight"].normal_(0, 0.05)
+    m = EncoderOnlyTransformer(1, 4, 32, 64, 64, VOCAB, am, True, dropout=0.1)
+    m.load_state_dict(params)
+    m = m.to(dev).train()
+    seq = torch.full((2, 12), VOCAB.pad_id, dtype=torch.int64)
+    seq[0, :9] = torch.randint(0, 20, (9,), generator=torch.Generator().manual_seed(1))
+    seq[1, :12] = torch.randint(0, 20, (12,), generator=torch.Generator().manual_seed(2))
+    tgt = torch.randn(2, 12 * 14, 3)
+    args = types.SimpleNamespace(structure_dir=str(tmp_path))
+    pred_path, true_path = dump_structure(m, args, seq.to(dev), tgt.to(dev), 3)
+    assert m.training                                               # the mode is restored
+    lines = [l for l in open(pred_path).read().split("\n") if l.startswith("ATOM")]
+    with torch.no_grad():
+        ang = inverse_trig_transform(oenc.encoder_forward(params, seq[:1], 4))[0, :9]
+    want = ogeo.generate_coords(ang, seq[0, :9]).numpy()
+    names_per_res = [l[17:20] for l in lines]
+    assert names_per_res[0] == VOCAB.int2chars(int(seq[0, 0])) and int(lines[-1][22:26]) == 9
+    got = np.array([[float(l[30:38]), float(l[38:46]), float(l[46:54])] for l in lines])
+    kept = want[(want != 0).any(1)]
+    assert got.shape == kept.shape and np.abs(got - kept).max() < 2e-3      # 3 decimals in the file + fp32 NeRF
+    assert open(true_path).read().startswith("REMARK  true")
