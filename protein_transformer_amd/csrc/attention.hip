@@ -35,15 +35,12 @@ constexpr int QB = 128;  // queries (or keys) per workgroup
 constexpr int KT = 64;   // keys per LDS tile in the forward / dQ kernels
 constexpr int QT = 32;   // queries per LDS tile in the dK/dV kernel
 
-// lowbias32 integer hash (full-avalanche 32-bit mixer) of a per-(seed, site, protein, head) key and the
-// (query, key) position -> one uniform 32-bit word per element of the attention matrix
+// counter hash (pt_mix32 of common.h) of a per-(seed, site, protein, head) key and the (query, key) position ->
+// one uniform 32-bit word per element of the attention matrix
 __device__ __forceinline__ uint32_t attn_rand(uint32_t key_lo, uint32_t key_hi, uint32_t row, uint32_t col) {
-  uint32_t x = (row * 0x9E3779B1u + key_lo) ^ (col * 0x85EBCA77u + key_hi);
-  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-  return x;
+  // (the two products are loop invariant or differ by compile-time constants; the mixer has no multiplies)
+  return pt_mix32((row * 0x9E3779B1u + key_lo) ^ (col * 0x85EBCA77u + key_hi));
 }
-// exp(x) for x <= 0 on the transcendental unit: v_exp_f32(x * log2 e).  Relative error <= ~|x| * 2^-23 + 1 ulp,
-// i.e. <= 3e-6 over the range that matters for a softmax (exp(-30) ~ 1e-13 contributes nothing).
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 struct DropKey {
   uint32_t lo, hi, thr;

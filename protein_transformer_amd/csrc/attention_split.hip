@@ -21,9 +21,8 @@ constexpr int TR = 32;  // rows (keys or queries) of an LDS tile
 typedef Tile64<TR> Tile;
 
 __device__ __forceinline__ uint32_t attn_rand(uint32_t key_lo, uint32_t key_hi, uint32_t row, uint32_t col) {
-  uint32_t x = (row * 0x9E3779B1u + key_lo) ^ (col * 0x85EBCA77u + key_hi);
-  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-  return x;
+  // (the two products are loop invariant or differ by compile-time constants; the mixer has no multiplies)
+  return pt_mix32((row * 0x9E3779B1u + key_lo) ^ (col * 0x85EBCA77u + key_hi));
 }
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 struct DropKey {
@@ -300,7 +299,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_split_kernel(const float *
     for (int r = 0; r < 16; ++r) {
       const int kk = crow(r, lh);
       const bool valid = (mask >> kk) & 1u;
-      const float p = valid ? fast_exp(s[r] * scale - my_lse) : 0.f;
+      // (the mask goes into the ARGUMENT, exp2(-inf) = 0: a select around the exp would become a branch per element)
+      const float p = fast_exp(valid ? s[r] * scale - my_lse : -INFINITY);
       float g = dp[r];
       if (p_drop > 0.f) {
         const uint32_t w = attn_rand(dk_.lo, dk_.hi, (uint32_t)q, (uint32_t)(k0 + kk));
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_split_kernel(const float 
                                                                     const float *__restrict__ delta, int L, int H, float p_drop,
                                                                     uint64_t seed, uint32_t stream_id, float *__restrict__ dqkv) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-  __shared__ float sLse[2][TR], sDel[2][TR];
+  __shared__ __attribute__((aligned(16))) float sLse[2][TR], sDel[2][TR];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * QB + wave * 32;
   const int D = H * DK, D3 = 3 * D;
@@ -413,11 +413,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_split_kernel(const float 
       }
     }
     f32x16 pd;  // dropped probabilities (operand of dV)
+    float4 lse4[4], del4[4];  // log-sum-exp and delta of this lane's 16 query rows: rows 8 g + 4 lh + 0..3
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      lse4[g4] = *reinterpret_cast<const float4 *>(&sLse[cur][8 * g4 + 4 * lh]);
+      del4[g4] = *reinterpret_cast<const float4 *>(&sDel[cur][8 * g4 + 4 * lh]);
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qi = crow(r, lh), qg = qq0 + qi;
       const bool ok = k_valid && qg < L;
-      const float p = ok ? fast_exp(s[r] * scale - sLse[cur][qi]) : 0.f;
+      const float4 l4 = lse4[r >> 2], d4 = del4[r >> 2];
+      const float my_l = (r & 3) == 0 ? l4.x : (r & 3) == 1 ? l4.y : (r & 3) == 2 ? l4.z : l4.w;
+      const float my_d = (r & 3) == 0 ? d4.x : (r & 3) == 1 ? d4.y : (r & 3) == 2 ? d4.z : d4.w;
+      // (the mask goes into the ARGUMENT, exp2(-inf) = 0: a select around the exp would become a branch per element)
+      const float p = fast_exp(ok ? s[r] * scale - my_l : -INFINITY);
       float g = dp[r], pk = p;
       if (p_drop > 0.f) {
         const uint32_t w = attn_rand(dk_.lo, dk_.hi, (uint32_t)qg, (uint32_t)key);
@@ -426,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_split_kernel(const float 
         pk = keep ? p * dk_.ks : 0.f;
       }
       pd[r] = pk;
-      s[r] = p * (g - sDel[cur][qi]) * scale;  // dS[q][key]
+      s[r] = p * (g - my_d) * scale;  // dS[q][key]
     }
 #pragma unroll
     for (int m = 0; m < 2; ++m) {

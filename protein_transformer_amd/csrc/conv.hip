@@ -88,7 +88,7 @@ __global__ void posenc_add_fwd_kernel(const float *__restrict__ x, const float *
   if (p > 0.f) {
     const uint32_t thr = dropout_threshold(p);
     const float ks = 1.f / (1.f - p);
-    const uint4 r = philox4x32(seed, (uint64_t)i, STREAM_POSADD);
+    const uint4 r = pt_rand4(seed, (uint64_t)i, STREAM_POSADD);
     const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = xv[k] + (w[k] >= thr ? (xv[k] + pv[k]) * ks : 0.f);
@@ -107,7 +107,7 @@ __global__ void posenc_add_bwd_kernel(const float *__restrict__ dy, int64_t n4, 
   if (p > 0.f) {
     const uint32_t thr = dropout_threshold(p);
     const float ks = 1.f / (1.f - p);
-    const uint4 r = philox4x32(seed, (uint64_t)i, STREAM_POSADD);
+    const uint4 r = pt_rand4(seed, (uint64_t)i, STREAM_POSADD);
     const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = gv[k] * (1.f + (w[k] >= thr ? ks : 0.f));

@@ -34,7 +34,7 @@ __global__ void embed_fwd_kernel(const int64_t *__restrict__ seq, const float *_
   if (p > 0.f) {
     const uint32_t thr = dropout_threshold(p);
     const float ks = 1.f / (1.f - p);
-    const uint4 r1 = philox4x32(seed, (uint64_t)i, STREAM_EMB1), r2 = philox4x32(seed, (uint64_t)i, STREAM_EMB2);
+    const uint4 r1 = pt_rand4(seed, (uint64_t)i, STREAM_EMB1), r2 = pt_rand4(seed, (uint64_t)i, STREAM_EMB2);
     const uint32_t w1[4] = {r1.x, r1.y, r1.z, r1.w}, w2[4] = {r2.x, r2.y, r2.z, r2.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t *__restric
       float g = dout[t * D + c];
       if (p > 0.f) {
         const uint64_t i4 = (uint64_t)(t * (D >> 2) + (c >> 2));
-        const uint4 r1 = philox4x32(seed, i4, STREAM_EMB1), r2 = philox4x32(seed, i4, STREAM_EMB2);
+        const uint4 r1 = pt_rand4(seed, i4, STREAM_EMB1), r2 = pt_rand4(seed, i4, STREAM_EMB2);
         const int k = c & 3;
         const uint32_t w1 = k == 0 ? r1.x : k == 1 ? r1.y : k == 2 ? r1.z : r1.w;
         const uint32_t w2 = k == 0 ? r2.x : k == 1 ? r2.y : k == 2 ? r2.z : r2.w;
@@ -286,7 +286,7 @@ __global__ void tanh_bwd_kernel(const float *__restrict__ dy, const float *__res
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dx[i] = dy[i] * (1.f - y[i] * y[i]);
 }
-// mask(row, col) = word (row & 3) of philox(seed, (row >> 2) * cols + col, stream): the GEMM epilogue's mapping
+// mask(row, col) = word (row & 3) of pt_rand4(seed, (row >> 2) * cols + col, stream): the GEMM epilogue's mapping
 __global__ void dropout_bwd_kernel(const float *__restrict__ dy, int64_t rows, int cols, float p, uint64_t seed,
                                    uint32_t stream_id, float *__restrict__ dx) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -294,7 +294,7 @@ __global__ void dropout_bwd_kernel(const float *__restrict__ dy, int64_t rows, i
   if (c >= cols) return;
   const uint32_t thr = dropout_threshold(p);
   const float ks = 1.f / (1.f - p);
-  const uint4 r = philox4x32(seed, (uint64_t)rq * cols + c, stream_id);
+  const uint4 r = pt_rand4(seed, (uint64_t)rq * cols + c, stream_id);
   const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
   for (int e = 0; e < 4; ++e) {

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_mfma_kernel(const GemmParams p
     const int ldc = partial ? p.N : p.ldc;
     if (BK == 32 && p.vec_epilogue) {
       // Vector path: bias / ReLU / dropout are applied in the MFMA layout (one column per lane, four consecutive
-      // rows per Philox call), then each wavefront transposes its tile through the LDS stage buffer that the last
+      // rows per generator call), then each wavefront transposes its tile through the LDS stage buffer that the last
       // K stage just released (32 rows x 64 columns at a time) so that residual / accumulate operands are READ and
       // results are WRITTEN as float4 rows: 16 16-byte stores per lane instead of 64 4-byte ones.
       float *scratch = (wave < 2 ? sA0 + (cur ^ 1) * SA : sB0 + (cur ^ 1) * SB) + (wave & 1) * 2048;
@@ -272,7 +272,7 @@ __global__ void gemm_splitk_reduce_kernel(const GemmParams p, const float *__res
   const uint32_t thr = dropout_threshold(p.dropout_p);
   const float keep_scale = 1.f / (1.f - p.dropout_p);
   uint4 rnd = make_uint4(0, 0, 0, 0);
-  if (p.dropout_p > 0.f) rnd = philox4x32(p.seed, (uint64_t)(rowq >> 2) * p.N + col, p.stream_id);
+  if (p.dropout_p > 0.f) rnd = pt_rand4(p.seed, (uint64_t)(rowq >> 2) * p.N + col, p.stream_id);
   for (int e = 0; e < 4; ++e) {
     const int row = rowq + e;
     if (row >= p.M) return;

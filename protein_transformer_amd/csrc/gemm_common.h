@@ -81,12 +81,12 @@ __device__ __forceinline__ float epilogue_value(float v, int row, int col, const
 // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
 //
 // Vector path: bias / ReLU / dropout are applied in the MFMA layout (one column per lane, four consecutive rows per
-// Philox call), then each wavefront transposes its tile through `scratch` (its own 2048 floats of LDS, 32 rows x 64
+// generator call), then each wavefront transposes its tile through `scratch` (its own 2048 floats of LDS, 32 rows x 64
 // columns at a time) so that residual / accumulate operands are READ and results are WRITTEN as float4 rows:
 // 16 16-byte stores per lane instead of 64 4-byte ones.
 // (row0, col0) = origin of this wavefront's (32 TI) x 64 block of C.
 // VEC = false: same transposition, but the four elements of a lane are read / written one by one (any N / ldc).
-// EPI selects how much of the epilogue is compiled in (instruction-cache footprint: Philox alone is most of the
+// EPI selects how much of the epilogue is compiled in (instruction-cache footprint: the generator alone is most of the
 // code): EPI_PLAIN stores the accumulators as they are, EPI_NODROP has everything but dropout, EPI_FULL everything.
 constexpr int EPI_PLAIN = 0, EPI_NODROP = 1, EPI_FULL = 2;
 template <int TI, bool VEC = true, int EPI = EPI_FULL>
@@ -95,7 +95,7 @@ __device__ __forceinline__ void tile_epilogue_vec(const GemmParams &p, const f32
                                                   float keep_scale, float *scratch) {
   const int l31 = lane & 31, lh = lane >> 5;
   // Dropout keep decisions of the whole block, one bit per accumulator element (bit j * 16 + g * 4 + e of keep[i]),
-  // drawn in a ROLLED loop: one copy of Philox in the instruction stream instead of 8 TI.
+  // drawn in a ROLLED loop: one copy of the generator in the instruction stream instead of 8 TI.
   uint32_t keep[TI];
 #pragma unroll
   for (int i = 0; i < TI; ++i) keep[i] = 0xffffffffu;
@@ -106,7 +106,7 @@ __device__ __forceinline__ void tile_epilogue_vec(const GemmParams &p, const f32
     for (int idx = 0; idx < TI * 8; ++idx) {
       const int i = idx >> 3, j = (idx >> 2) & 1, g = idx & 3;
       const int rowq = row0 + i * 32 + 8 * g + 4 * lh, col = col0 + j * 32 + l31;
-      const uint4 rnd = philox4x32(p.seed, (uint64_t)(rowq >> 2) * p.N + col, p.stream_id);
+      const uint4 rnd = pt_rand4(p.seed, (uint64_t)(rowq >> 2) * p.N + col, p.stream_id);
       const uint32_t bits = ((rnd.x >= thr ? 1u : 0u) | (rnd.y >= thr ? 2u : 0u) | (rnd.z >= thr ? 4u : 0u) |
                              (rnd.w >= thr ? 8u : 0u)) << (j * 16 + g * 4);
 #pragma unroll
@@ -210,9 +210,9 @@ __device__ __forceinline__ void tile_epilogue_scalar(const GemmParams &p, const 
         const float bias = (!partial && p.bias && col_ok) ? p.bias[col] : 0.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int rowq = row_base + 8 * g;  // 4 consecutive rows share one Philox call
+          const int rowq = row_base + 8 * g;  // 4 consecutive rows share one generator call
           uint4 rnd = make_uint4(0, 0, 0, 0);
-          if (!partial && p.dropout_p > 0.f) rnd = philox4x32(p.seed, (uint64_t)(rowq >> 2) * p.N + col, p.stream_id);
+          if (!partial && p.dropout_p > 0.f) rnd = pt_rand4(p.seed, (uint64_t)(rowq >> 2) * p.N + col, p.stream_id);
           const uint32_t rw[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {

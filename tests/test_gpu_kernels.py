@@ -120,6 +120,9 @@ def test_gemm_dropout_mask_roundtrip(dev, gemm_mode):
     m = K_.dropout_bwd(torch.ones(T, N, device=dev), p, 1234, 7)
     assert torch.equal(m != 0, kept)
     assert torch.allclose(m[kept], torch.full_like(m[kept], 1 / (1 - p)))
+    # the device generator is the documented one (numpy restatement in tests/test_host_logic.py)
+    from test_host_logic import dropout_mask_restated
+    assert np.array_equal(kept.cpu().numpy(), dropout_mask_restated(T, N, p, 1234, 7))
     # a different stream id draws a different mask
     y2 = K_.linear_fwd(x, w, None, dropout_p=p, seed=1234, stream_id=8)
     assert not torch.equal(y2 != 0, kept)

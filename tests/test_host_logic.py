@@ -93,3 +93,57 @@ def test_synthetic_batch():
     assert am.shape == (24,) and np.all(np.abs(am) <= 1)
     b2 = synthetic.make_batch(lens, seed=3)
     assert torch.equal(b["seq"], b2["seq"])                                   # deterministic
+
+
+# ------------------------------------------------------------------------------------------------ dropout generator
+def _mix32(x):
+    """numpy restatement of pt_mix32 (csrc/common.h)."""
+    x = np.asarray(x).astype(np.uint32)
+    x = (~x + (x << np.uint32(15))).astype(np.uint32)
+    x ^= x >> np.uint32(12)
+    x = (x + (x << np.uint32(2))).astype(np.uint32)
+    x ^= x >> np.uint32(4)
+    x = (x + (x << np.uint32(3)) + (x << np.uint32(11))).astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    return x
+
+
+def rand4_restated(seed, idx, stream):
+    """numpy restatement of pt_rand4 (csrc/common.h): four uint32 arrays."""
+    idx = np.asarray(idx, dtype=np.uint64)
+    h = _mix32((idx & np.uint64(0xffffffff)).astype(np.uint32) ^ np.uint32(seed & 0xffffffff))
+    h = _mix32(h ^ (idx >> np.uint64(32)).astype(np.uint32) ^ np.uint32((seed >> 32) & 0xffffffff)
+               ^ np.uint32((stream * 0x9E3779B9) & 0xffffffff))
+    return [_mix32(h ^ np.uint32(c)) for c in (0x68E31DA4, 0xB5297A4D, 0x1B56C4E9, 0x7F4A7C15)]
+
+
+def dropout_mask_restated(rows, cols, p, seed, stream):
+    """keep mask of the GEMM epilogue / ptamd_dropout_bwd: word (row & 3) of the call (row >> 2) * cols + col."""
+    thr = np.uint32(min(p * 2.0 ** 32, 2.0 ** 32 - 1))
+    rq = np.arange((rows + 3) // 4, dtype=np.uint64)[:, None] * np.uint64(cols) + np.arange(cols, dtype=np.uint64)[None, :]
+    w = rand4_restated(seed, rq, stream)
+    return np.stack([wk >= thr for wk in w], axis=1).reshape(-1, cols)[:rows]
+
+
+def test_dropout_generator_statistics():
+    """The multiply-free counter hash must give masks that look like independent Bernoulli draws."""
+    rows, cols, p = 2048, 512, 0.1
+    mask = dropout_mask_restated(rows, cols, p, 1234567890123, 7)
+    n = mask.size
+    assert abs(mask.mean() - (1 - p)) < 4 * np.sqrt(p * (1 - p) / n)
+    m = mask.astype(np.float64) - mask.mean()
+
+    def corr(a, b):
+        return (a * b).mean() / (a.std() * b.std())
+    for a, b in ((m[:, :-1], m[:, 1:]), (m[:-1], m[1:]), (m[:-4], m[4:]), (m[:-1, :-1], m[1:, 1:])):
+        assert abs(corr(a, b)) < 4 / np.sqrt(n)                      # neighbours, the next call, diagonals
+    assert abs(mask.mean(1).std() / np.sqrt(p * (1 - p) / cols) - 1) < 0.1
+    assert abs(mask.mean(0).std() / np.sqrt(p * (1 - p) / rows) - 1) < 0.15
+    for other in (dropout_mask_restated(rows, cols, p, 1234567890124, 7), dropout_mask_restated(rows, cols, p, 1234567890123, 8)):
+        o = other.astype(np.float64) - other.mean()
+        assert abs(corr(m, o)) < 4 / np.sqrt(n)                      # a different seed / site draws a different mask
+    rq = np.arange(1 << 18, dtype=np.uint64)
+    for w in rand4_restated(99, rq, 3):                              # each word uniform over its top byte
+        hist = np.bincount((w >> np.uint32(24)), minlength=256)
+        e = w.size / 256
+        assert ((hist - e) ** 2 / e).sum() / 255 < 1.3
