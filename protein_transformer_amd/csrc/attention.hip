@@ -17,7 +17,7 @@
 //     deterministic.
 //   * dropout masks come from a counter hash of (seed, protein*head, query, key) and are regenerated in the
 //     backward kernels instead of being stored.
-#include "common.h"
+#include "attn_dropout.h"
 
 // split-bf16 variants for dk = 64 (attention_split.hip), selected by the matrix arithmetic mode of ptamd_gemm_set_mode
 int pt_attention_fwd_split(const float *qkv, const int64_t *seq, int B, int L, int H, float p, uint64_t seed, uint32_t sid,
@@ -35,26 +35,7 @@ constexpr int QB = 128;  // queries (or keys) per workgroup
 constexpr int KT = 64;   // keys per LDS tile in the forward / dQ kernels
 constexpr int QT = 32;   // queries per LDS tile in the dK/dV kernel
 
-// counter hash (pt_mix32 of common.h) of a per-(seed, site, protein, head) key and the (query, key) position ->
-// one uniform 32-bit word per element of the attention matrix
-__device__ __forceinline__ uint32_t attn_rand(uint32_t key_lo, uint32_t key_hi, uint32_t row, uint32_t col) {
-  // (the two products are loop invariant or differ by compile-time constants; the mixer has no multiplies)
-  return pt_mix32((row * 0x9E3779B1u + key_lo) ^ (col * 0x85EBCA77u + key_hi));
-}
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
-struct DropKey {
-  uint32_t lo, hi, thr;
-  float ks;
-};
-__device__ __forceinline__ DropKey make_dropkey(uint64_t seed, uint32_t stream_id, uint32_t bh, float p) {
-  DropKey k;
-  k.lo = (uint32_t)seed ^ (bh * 0xC2B2AE35u);
-  k.hi = (uint32_t)(seed >> 32) ^ (stream_id * 0x27D4EB2Fu) ^ bh;
-  k.thr = dropout_threshold(p);
-  k.ks = 1.f / (1.f - p);
-  return k;
-}
-
 // row index inside a 32x32 MFMA C tile held by (register r, lane half lh)
 __device__ __forceinline__ int crow(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
 
@@ -115,7 +96,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const float *__restric
   const int q = q0 + l31;
   const bool q_ok = q < L;
   const float scale = 1.f / sqrtf((float)DK);
-  const DropKey dk_ = make_dropkey(seed, stream_id, (uint32_t)(b * H + h), p_drop);
+  const AttnDrop dk_ = make_attn_drop(seed, stream_id, (uint32_t)(b * H + h), p_drop);
+  const uint32_t q_part = attn_q_part(dk_, (uint32_t)q);
 
   float qf[NS];
   load_row_frag<DK>(base, D3, q, q_ok, lh, qf);
@@ -183,11 +165,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const float *__restric
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
       if (p_drop > 0.f) {
+        const uint32_t keep = attn_keep_bits_keys_in_rows(dk_, q_part, k0 + sub * 32, lh);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const uint32_t w = attn_rand(dk_.lo, dk_.hi, (uint32_t)q, (uint32_t)(k0 + sub * 32 + crow(r, lh)));
-          s[r] = w >= dk_.thr ? s[r] * dk_.ks : 0.f;
-        }
+        for (int r = 0; r < 16; ++r) s[r] = (keep >> r) & 1u ? s[r] * dk_.ks : 0.f;
       }
       // O^T[d][q] += V^T[d][key] P^T[key][q]
 #pragma unroll
@@ -250,7 +230,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const float *__rest
   const int q = q0 + l31;
   const bool q_ok = q < L;
   const float scale = 1.f / sqrtf((float)DK);
-  const DropKey dk_ = make_dropkey(seed, stream_id, (uint32_t)(b * H + h), p_drop);
+  const AttnDrop dk_ = make_attn_drop(seed, stream_id, (uint32_t)(b * H + h), p_drop);
+  const uint32_t q_part = attn_q_part(dk_, (uint32_t)q);
 
   float qf[NS], gf[NS];
   load_row_frag<DK>(base, D3, q, q_ok, lh, qf);
@@ -308,16 +289,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const float *__rest
         s = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * st], qf[st], s, 0, 0, 0);    // S^T[key][q]
         dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[2 * st], gf[st], dp, 0, 0, 0);  // dP^T[key][q] = V dO^T
       }
+      const uint32_t keep = p_drop > 0.f ? attn_keep_bits_keys_in_rows(dk_, q_part, k0 + sub * 32, lh) : 0xffffu;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int kk = sub * 32 + crow(r, lh);
         const bool valid = (mask >> kk) & 1ull;
         const float p = valid ? fast_exp(s[r] * scale - my_lse) : 0.f;
         float g = dp[r];
-        if (p_drop > 0.f) {
-          const uint32_t w = attn_rand(dk_.lo, dk_.hi, (uint32_t)q, (uint32_t)(k0 + kk));
-          g = w >= dk_.thr ? g * dk_.ks : 0.f;
-        }
+        if (p_drop > 0.f) g = (keep >> r) & 1u ? g * dk_.ks : 0.f;
         s[r] = p * (g - my_delta) * scale;  // dS^T, already carrying the 1/sqrt(dk) of the scores
       }
       // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
@@ -376,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float *__res
   const bool k_ok = key < L;
   const bool k_valid = k_ok && seq[(size_t)b * L + key] != PTAMD_PAD_ID;
   const float scale = 1.f / sqrtf((float)DK);
-  const DropKey dk_ = make_dropkey(seed, stream_id, (uint32_t)(b * H + h), p_drop);
+  const AttnDrop dk_ = make_attn_drop(seed, stream_id, (uint32_t)(b * H + h), p_drop);
 
   float kf[NS], vf[NS];
   load_row_frag<DK>(base + D, D3, key, k_ok, lh, kf);
@@ -424,6 +403,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float *__res
       dp = __builtin_amdgcn_mfma_f32_32x32x2f32(gp[2 * st], vf[st], dp, 0, 0, 0);  // dP[q][key] = dO V^T
     }
     f32x16 pd;  // dropped probabilities (operand of dV)
+    const uint32_t keepbits = p_drop > 0.f ? attn_keep_bits_queries_in_rows(dk_, (uint32_t)key, qq0, lh) : 0xffffu;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qi = crow(r, lh), qg = qq0 + qi;
@@ -431,8 +411,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float *__res
       const float p = ok ? fast_exp(s[r] * scale - sLse[cur][qi]) : 0.f;
       float g = dp[r], pk = p;
       if (p_drop > 0.f) {
-        const uint32_t w = attn_rand(dk_.lo, dk_.hi, (uint32_t)qg, (uint32_t)key);
-        const bool keep = w >= dk_.thr;
+        const bool keep = (keepbits >> r) & 1u;
         g = keep ? g * dk_.ks : 0.f;
         pk = keep ? p * dk_.ks : 0.f;
       }

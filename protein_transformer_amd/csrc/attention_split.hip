@@ -11,6 +11,7 @@
 // MFMA accumulator layout, is split in registers and fed straight back as the B operand of O^T += V^T P^T.
 // K and V tiles of 64 keys are staged once per workgroup as three bf16 planes each in the swizzled LDS format of
 // split_bf16.h, which serves the row-fragment reads (K in QK^T) and the transposed reads (V^T in PV) conflict-free.
+#include "attn_dropout.h"
 #include "split_bf16.h"
 
 namespace ptattn {
@@ -20,23 +21,7 @@ constexpr int DK = 64, QB = 128;
 constexpr int TR = 32;  // rows (keys or queries) of an LDS tile
 typedef Tile64<TR> Tile;
 
-__device__ __forceinline__ uint32_t attn_rand(uint32_t key_lo, uint32_t key_hi, uint32_t row, uint32_t col) {
-  // (the two products are loop invariant or differ by compile-time constants; the mixer has no multiplies)
-  return pt_mix32((row * 0x9E3779B1u + key_lo) ^ (col * 0x85EBCA77u + key_hi));
-}
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
-struct DropKey {
-  uint32_t lo, hi, thr;
-  float ks;
-};
-__device__ __forceinline__ DropKey make_dropkey(uint64_t seed, uint32_t stream_id, uint32_t bh, float p) {
-  DropKey k;
-  k.lo = (uint32_t)seed ^ (bh * 0xC2B2AE35u);
-  k.hi = (uint32_t)(seed >> 32) ^ (stream_id * 0x27D4EB2Fu) ^ bh;
-  k.thr = dropout_threshold(p);
-  k.ks = 1.f / (1.f - p);
-  return k;
-}
 __device__ __forceinline__ int crow(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
 
 // 32 rows x 64 floats of a [*, ld] matrix, global -> registers -> split planes in LDS (256 threads, 2 float4 each).
@@ -93,7 +78,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(const float *__r
   const int q = q0 + l31;
   const bool q_ok = q < L;
   const float scale = 0.125f;  // 1 / sqrt(64)
-  const DropKey dk_ = make_dropkey(seed, stream_id, (uint32_t)(b * H + h), p_drop);
+  const AttnDrop dk_ = make_attn_drop(seed, stream_id, (uint32_t)(b * H + h), p_drop);
+  const uint32_t q_part = attn_q_part(dk_, (uint32_t)q);
 
   bf16x8 qf[4][3];
   load_row_split(base, D3, min(q, L - 1), q_ok, lh, qf);
@@ -145,35 +131,39 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(const float *__r
       stV.store(nK + Tile::ELEMS, k0 + TR, L, tid);
       publish_mask(k0 + TR, cur ^ 1);
     }
+    // masked scores stay UNSCALED here; scale and log2(e) are folded into one fma in front of the exp2:
+    // exp(scale s - m) = exp2(c s - c m / scale) with c = scale log2(e) and m kept in scaled units
+    constexpr float LOG2E = 1.4426950408889634f;
     float mt = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const bool valid = (mask >> crow(r, lh)) & 1u;
-      s[r] = valid ? s[r] * scale : -INFINITY;
+      s[r] = valid ? s[r] : -INFINITY;
       mt = fmaxf(mt, s[r]);
     }
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale;
     const float m_new = fmaxf(m_run, mt);
     const float m_safe = m_new == -INFINITY ? 0.f : m_new;
     const float alpha = fast_exp(m_run - m_safe);
+    const float c = scale * LOG2E, mc = -m_safe * LOG2E;
     float ps = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      s[r] = fast_exp(s[r] - m_safe);
+      s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c, mc));
       ps += s[r];
     }
     l_run = l_run * alpha + ps;
     m_run = m_new;
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {  // wave-uniform: after the first tiles the running maximum rarely moves
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+    }
     if (p_drop > 0.f) {
+      const uint32_t keep = attn_keep_bits_keys_in_rows(dk_, q_part, k0, lh);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const uint32_t w = attn_rand(dk_.lo, dk_.hi, (uint32_t)q, (uint32_t)(k0 + crow(r, lh)));
-        s[r] = w >= dk_.thr ? s[r] * dk_.ks : 0.f;
-      }
+      for (int r = 0; r < 16; ++r) s[r] = (keep >> r) & 1u ? s[r] * dk_.ks : 0.f;
     }
     // O^T[d][q] += V^T[d][key] P^T[key][q]: the accumulator rows of s are already in the k order of frag_cols
 #pragma unroll
@@ -225,7 +215,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_split_kernel(const float *
   const int q = q0 + l31, qc = min(q, L - 1);
   const bool q_ok = q < L;
   const float scale = 0.125f;
-  const DropKey dk_ = make_dropkey(seed, stream_id, (uint32_t)(b * H + h), p_drop);
+  const AttnDrop dk_ = make_attn_drop(seed, stream_id, (uint32_t)(b * H + h), p_drop);
+  const uint32_t q_part = attn_q_part(dk_, (uint32_t)q);
 
   bf16x8 qf[4][3], gf[4][3];
   load_row_split(base, D3, qc, q_ok, lh, qf);
@@ -295,6 +286,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_split_kernel(const float *
       stV.store(nK + Tile::ELEMS, k0 + TR, L, tid);
       publish_mask(k0 + TR, cur ^ 1);
     }
+    const uint32_t keep = p_drop > 0.f ? attn_keep_bits_keys_in_rows(dk_, q_part, k0, lh) : 0xffffu;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int kk = crow(r, lh);
@@ -302,10 +294,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_split_kernel(const float *
       // (the mask goes into the ARGUMENT, exp2(-inf) = 0: a select around the exp would become a branch per element)
       const float p = fast_exp(valid ? s[r] * scale - my_lse : -INFINITY);
       float g = dp[r];
-      if (p_drop > 0.f) {
-        const uint32_t w = attn_rand(dk_.lo, dk_.hi, (uint32_t)q, (uint32_t)(k0 + kk));
-        g = w >= dk_.thr ? g * dk_.ks : 0.f;
-      }
+      if (p_drop > 0.f) g = (keep >> r) & 1u ? g * dk_.ks : 0.f;
       s[r] = p * (g - my_delta) * scale;  // dS^T, already carrying the 1/sqrt(dk) of the scores
     }
     // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
@@ -354,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_split_kernel(const float 
   const bool k_ok = key < L;
   const bool k_valid = k_ok && seq[(size_t)b * L + key] != PTAMD_PAD_ID;
   const float scale = 0.125f;
-  const DropKey dk_ = make_dropkey(seed, stream_id, (uint32_t)(b * H + h), p_drop);
+  const AttnDrop dk_ = make_attn_drop(seed, stream_id, (uint32_t)(b * H + h), p_drop);
 
   bf16x8 kf[4][3], vf[4][3];
   load_row_split(base + D, D3, min(key, L - 1), k_ok, lh, kf);
@@ -413,6 +402,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_split_kernel(const float 
       }
     }
     f32x16 pd;  // dropped probabilities (operand of dV)
+    const uint32_t keepbits = p_drop > 0.f ? attn_keep_bits_queries_in_rows(dk_, (uint32_t)key, qq0, lh) : 0xffffu;
     float4 lse4[4], del4[4];  // log-sum-exp and delta of this lane's 16 query rows: rows 8 g + 4 lh + 0..3
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
@@ -430,8 +420,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_split_kernel(const float 
       const float p = fast_exp(ok ? s[r] * scale - my_l : -INFINITY);
       float g = dp[r], pk = p;
       if (p_drop > 0.f) {
-        const uint32_t w = attn_rand(dk_.lo, dk_.hi, (uint32_t)qg, (uint32_t)key);
-        const bool keep = w >= dk_.thr;
+        const bool keep = (keepbits >> r) & 1u;
         g = keep ? g * dk_.ks : 0.f;
         pk = keep ? p * dk_.ks : 0.f;
       }

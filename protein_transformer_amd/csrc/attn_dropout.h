@@ -1,0 +1,62 @@
+// Dropout on the attention probabilities (Attention.py:16-22 of the reference: nn.Dropout(0.1) on softmax(QK^T)),
+// shared by attention.hip and attention_split.hip so that every kernel of both arithmetic modes draws the same mask.
+//
+// One 32-bit word of the counter hash pt_mix32 (common.h) serves a PAIR of adjacent keys of one query: the even key
+// is decided by its low 16 bits, the odd key by its high 16 bits, against a 16-bit threshold.  The kernels that keep a
+// query per lane hold such pairs in adjacent accumulator registers, so they evaluate the hash once per two elements.
+// The drop probability is therefore quantised to thr16 / 65536 (0.1 -> 0.100006) and the kept probabilities are
+// scaled by exactly 65536 / (65536 - thr16), so the expectation is preserved.  Masks are regenerated in the backward
+// kernels instead of being stored.
+#pragma once
+#include "common.h"
+
+struct AttnDrop {
+  uint32_t lo, hi, thr16;
+  float ks;
+};
+constexpr uint32_t ATTN_C_Q = 0x9E3779B1u, ATTN_C_K = 0x85EBCA77u;
+
+__device__ __forceinline__ AttnDrop make_attn_drop(uint64_t seed, uint32_t stream_id, uint32_t bh, float p) {
+  AttnDrop d;
+  d.lo = (uint32_t)seed ^ (bh * 0xC2B2AE35u);
+  d.hi = (uint32_t)(seed >> 32) ^ (stream_id * 0x27D4EB2Fu) ^ bh;
+  const float t = p * 65536.f + 0.5f;
+  d.thr16 = t >= 65535.f ? 65535u : (uint32_t)t;
+  d.ks = 65536.f / (65536.f - (float)d.thr16);
+  return d;
+}
+// the word of (query q, key pair kp = key >> 1), from its two precomputed halves
+__device__ __forceinline__ uint32_t attn_q_part(const AttnDrop &d, uint32_t q) { return q * ATTN_C_Q + d.lo; }
+__device__ __forceinline__ uint32_t attn_kp_part(const AttnDrop &d, uint32_t kp) { return kp * ATTN_C_K + d.hi; }
+__device__ __forceinline__ uint32_t attn_word(uint32_t q_part, uint32_t kp_part) { return pt_mix32(q_part ^ kp_part); }
+__device__ __forceinline__ bool attn_keep_even(const AttnDrop &d, uint32_t w) { return (w & 0xffffu) >= d.thr16; }
+__device__ __forceinline__ bool attn_keep_odd(const AttnDrop &d, uint32_t w) { return (w >> 16) >= d.thr16; }
+
+// Accumulator layout of a 32 x 32 MFMA tile: register r of lane half lh holds row (r & 3) + 8 (r >> 2) + 4 lh.
+//
+// Queries in lanes, keys in rows (forward and dQ kernels), k0 = first key of the 32-key block (even): registers 2j and
+// 2j + 1 hold the even and the odd key of pair (k0 >> 1) + 2 lh + (j & 1) + 4 (j >> 1).  Returns bit r = keep.
+__device__ __forceinline__ uint32_t attn_keep_bits_keys_in_rows(const AttnDrop &d, uint32_t q_part, int k0, int lh) {
+  const uint32_t base = attn_kp_part(d, (uint32_t)((k0 >> 1) + 2 * lh));
+  uint32_t bits = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t w = attn_word(q_part, base + (uint32_t)((j & 1) + 4 * (j >> 1)) * ATTN_C_K);
+    bits |= (attn_keep_even(d, w) ? 1u : 0u) << (2 * j);
+    bits |= (attn_keep_odd(d, w) ? 2u : 0u) << (2 * j);
+  }
+  return bits;
+}
+// Keys in lanes, queries in rows (dK/dV kernel), q0 = first query of the 32-query block: register r holds query
+// q0 + 4 lh + (r & 3) + 8 (r >> 2); the lane's key selects the half of every word.  Returns bit r = keep.
+__device__ __forceinline__ uint32_t attn_keep_bits_queries_in_rows(const AttnDrop &d, uint32_t key, int q0, int lh) {
+  const uint32_t kp_part = attn_kp_part(d, key >> 1), shift = (key & 1u) * 16u;
+  const uint32_t base = attn_q_part(d, (uint32_t)(q0 + 4 * lh));
+  uint32_t bits = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const uint32_t w = attn_word(base + (uint32_t)((r & 3) + 8 * (r >> 2)) * ATTN_C_Q, kp_part);
+    bits |= (((w >> shift) & 0xffffu) >= d.thr16 ? 1u : 0u) << r;
+  }
+  return bits;
+}
