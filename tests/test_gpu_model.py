@@ -294,3 +294,113 @@ def test_structure_dump_writes_pdb_of_first_protein(dev, tmp_path):
     kept = want[(want != 0).any(1)]
     assert got.shape == kept.shape and np.abs(got - kept).max() < 2e-3      # 3 decimals in the file + fp32 NeRF
     assert open(true_path).read().startswith("REMARK  true")
+
+
+def test_full_size_step_is_additive_over_proteins(dev):
+    """BASELINE config 4 (d512, 6 layers, 8 heads, dff 2048, 32 proteins x L = 512, -l drmsd) at full size, through
+    properties that need no slow oracle: the reference back-propagates the SUM over proteins, so
+
+      * the gradient of the whole batch equals the sum of the gradients of its two halves (what makes the data-parallel
+        SUM all-reduce exact, dp.py), and the per-protein losses of the halves are those of the whole batch;
+      * a protein's loss does not depend on what else is in the batch (no cross-protein leakage through padding,
+        attention masking or the tile decomposition of the kernels);
+      * the exact-f32 MFMA kernels and the default split-bf16 kernels agree on losses and gradients.
+    """
+    import types
+    from protein_transformer_amd import kernels as K_
+    from protein_transformer_amd import synthetic
+    from protein_transformer_amd.models.encoder_only import EncoderOnlyTransformer
+    from protein_transformer_amd.protein.Sequence import VOCAB
+    from protein_transformer_amd.protein.Structure import nerf_forward
+    from protein_transformer_amd.train import get_losses
+    B, L = 32, 512
+    lens = [L] * 24 + [300, 411, 77, 512, 129, 33, 256, 500]           # ragged tail
+    build = lambda ang, seq: nerf_forward(ang.to(dev), seq.to(dev))[0]  # noqa: E731
+    batch = synthetic.make_batch(lens, L_pad=L, seed=11, build_coords=build)
+    seq, ang, crd = (batch[k].to(dev) for k in ("seq", "true_ang", "true_crd"))
+    torch.manual_seed(3)
+    model = EncoderOnlyTransformer(6, 8, 512, 2048, L, VOCAB, synthetic.angle_means(batch["true_ang"]), True,
+                                   dropout=0.0)
+    model.set_dropout(0.0)            # also the attention-probability dropout, which the reference fixes at 0.1
+    model = model.to(dev).train()
+    with torch.no_grad():
+        dict(model.named_parameters())["output_projection.weight"].normal_(0, 0.02)   # off the zero init
+    args = types.SimpleNamespace(loss="drmsd", combined_drmsd_weight=0.5, backbone_loss=False, clip=None)
+
+    def grads(sl, mode):
+        K_.set_gemm_mode(mode)
+        model.zero_grad()
+        losses = get_losses(args, model(seq[sl], ang[sl]), ang[sl], crd[sl], seq[sl])
+        _, g = model.flat_parameters()
+        return g.clone(), float(losses["drmsd-full"]), float(losses["lndrmsd-full"])
+
+    old = K_.get_gemm_mode()
+    try:
+        g_all, d_all, ln_all = grads(slice(0, B), K_.GEMM_BF16X3)
+        g_a, d_a, ln_a = grads(slice(0, B // 2), K_.GEMM_BF16X3)
+        g_b, d_b, ln_b = grads(slice(B // 2, B), K_.GEMM_BF16X3)
+        g_f32, d_f32, ln_f32 = grads(slice(0, B), K_.GEMM_F32)
+    finally:
+        K_.set_gemm_mode(old)
+    norm = g_all.norm().item()
+    assert norm > 0 and torch.isfinite(g_all).all()
+    assert (g_a + g_b - g_all).norm().item() <= 2e-5 * norm                 # fp32 summation order only
+    assert 0.5 * (d_a + d_b) == pytest.approx(d_all, rel=1e-6)              # batch means of per-protein losses
+    assert 0.5 * (ln_a + ln_b) == pytest.approx(ln_all, rel=1e-6)
+    # two fp32-grade arithmetic modes: they differ by rounding, amplified through six layers and the 512-residue NeRF
+    # chains (5.6e-4 measured; each of them is closer than that to an fp64 evaluation, see the next test)
+    assert (g_f32 - g_all).norm().item() <= 2e-3 * norm
+    assert d_f32 == pytest.approx(d_all, rel=1e-5) and ln_f32 == pytest.approx(ln_all, rel=1e-5)
+
+
+def test_arithmetic_modes_against_fp64_step(dev):
+    """One whole training step (encoder -> atan2 -> NeRF -> dRMSD -> backward) of the benchmark model in the exact-f32
+    MFMA mode and in the default split-bf16 mode, against the same step evaluated in fp64 by the oracle on the CPU:
+    both must sit at fp32 rounding level (measured gradient relative L2 error: B = 4, L = 512: 6.7e-5 for f32, 4.2e-5
+    for split, 4.9e-5 with all nine products; B = 3, L = 256: 1.1e-5 / 3.2e-5)."""
+    import types
+    from oracle import batched as obat
+    from oracle import encoder as oenc
+    from protein_transformer_amd import kernels as K_
+    from protein_transformer_amd import synthetic
+    from protein_transformer_amd.models.encoder_only import EncoderOnlyTransformer
+    from protein_transformer_amd.protein.Sequence import VOCAB
+    from protein_transformer_amd.protein.Structure import nerf_forward
+    from protein_transformer_amd.train import get_losses
+    B, L, lens = 3, 256, [256, 200, 256]
+    build = lambda ang, seq: nerf_forward(ang.to(dev), seq.to(dev))[0]  # noqa: E731
+    batch = synthetic.make_batch(lens, L_pad=L, seed=12, build_coords=build)
+    seq, ang, crd = (batch[k].to(dev) for k in ("seq", "true_ang", "true_crd"))
+    torch.manual_seed(4)
+    model = EncoderOnlyTransformer(6, 8, 512, 2048, L, VOCAB, synthetic.angle_means(batch["true_ang"]), True, dropout=0.0)
+    model.set_dropout(0.0)
+    model = model.to(dev).train()
+    with torch.no_grad():
+        dict(model.named_parameters())["output_projection.weight"].normal_(0, 0.02)
+    args = types.SimpleNamespace(loss="drmsd", combined_drmsd_weight=0.5, backbone_loss=False, clip=None)
+    got, old = {}, K_.get_gemm_mode()
+    try:
+        for mode in (K_.GEMM_F32, K_.GEMM_BF16X3):
+            K_.set_gemm_mode(mode)
+            model.zero_grad()
+            losses = get_losses(args, model(seq, ang), ang, crd, seq)
+            got[mode] = ({n: p.grad.detach().cpu().double() for n, p in model.named_parameters()},
+                         float(losses["lndrmsd-full"]))
+    finally:
+        K_.set_gemm_mode(old)
+    params = {k: v.detach().cpu().double() for k, v in model.state_dict().items()}
+    leaf = {k: v.clone().requires_grad_() for k, v in params.items() if not k.endswith(".pe")}
+    pred = oenc.encoder_forward({**leaf, "encoder.positional_enc.pe": params["encoder.positional_enc.pe"]}, seq.cpu(), 8)
+    cs = pred.view(B, L, 12, 2)
+    rad = torch.atan2(cs[..., 1], cs[..., 0])
+    stats, _, dang = obat.batch_loss_and_grads(rad, seq.cpu(), crd.cpu(), dtype=torch.float64)
+    rad.backward(dang)
+    ln64 = float(np.mean([st[1] for st in stats]))
+    nrm = np.sqrt(sum((leaf[n].grad ** 2).sum().item() for n in leaf))
+    err = {m: np.sqrt(sum(((got[m][0][n] - leaf[n].grad) ** 2).sum().item() for n in leaf)) / nrm for m in got}
+    # both an order of magnitude inside the 1e-3 gradient tolerance of DESIGN.md section 4; which of the two is closer
+    # varies with the batch (1.1e-5 vs 3.2e-5 here, 6.7e-5 vs 4.2e-5 at B = 4, L = 512): the error is fp32 rounding of
+    # the whole chain (NeRF, softmax, LayerNorm), not the matrix arithmetic
+    assert err[K_.GEMM_F32] < 2e-4 and err[K_.GEMM_BF16X3] < 2e-4, err
+    for m in got:
+        assert got[m][1] == pytest.approx(ln64, rel=2e-5)
