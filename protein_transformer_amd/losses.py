@@ -141,6 +141,23 @@ def batch_loss(pred_sincos, true_crds, input_seqs, do_backward=True):
     return stats, grad, status
 
 
+_HOST_STATS = {}
+
+
+def _stats_to_host(stats, status):
+    """Asynchronous copy of the per-protein statistics [B,8] and the status word into a (cached) pinned buffer;
+    returns (buffer of B*8 + 1 floats, event recorded behind the copy)."""
+    n = stats.numel()
+    buf = _HOST_STATS.get(n)
+    if buf is None:
+        buf = _HOST_STATS[n] = torch.empty(n + 1, dtype=torch.float32).pin_memory()
+    buf[:n].copy_(stats.reshape(-1), non_blocking=True)
+    buf[n:].copy_(status.float(), non_blocking=True)   # a handful of flag bits: exact in fp32
+    done = torch.cuda.Event()
+    done.record()
+    return buf, done
+
+
 def compute_batch_drmsd(pred_angs, true_crds, input_seqs, device=None, return_rmsd=False,
                         do_backward=False, retain_graph=False, pool=None, backbone_only=False):
     """DRMSD loss of a batch (losses.py:133-172), entirely on the GPU.
@@ -154,10 +171,15 @@ def compute_batch_drmsd(pred_angs, true_crds, input_seqs, device=None, return_rm
         raise NotImplementedError("--backbone_loss is broken in the reference too (SURVEY.md A-4)")
     dev = pred_angs.device
     stats, grad, status = batch_loss(pred_angs, true_crds.to(dev), input_seqs.to(dev), do_backward)
+    # The reference returns host numbers every step.  The copy is enqueued right behind the loss kernels and the host
+    # waits for THAT copy only after the whole backward pass has been enqueued: waiting on the stream instead would
+    # drain the queue at the end of every step and leave the GPU idle while the next launches are being issued.
+    host_buf, copied = _stats_to_host(stats, status)
     if do_backward:
         pred_angs.backward(gradient=grad.view_as(pred_angs), retain_graph=retain_graph)
-    host = stats.cpu().numpy().astype(np.float64)        # the one device->host sync of the loss
-    raise_for_status(int(status.item()), theta_is_error=False)
+    copied.synchronize()
+    host = host_buf[:-1].view(-1, 8).numpy().astype(np.float64)
+    raise_for_status(int(host_buf[-1].item()), theta_is_error=False)
     out = (np.mean(host[:, 0]), np.mean(host[:, 1]), np.mean(host[:, 2]), np.mean(host[:, 3]))
     if return_rmsd:
         from .eval_metrics import batch_rmsd

@@ -28,7 +28,8 @@ from .dataset import MAX_SEQ_LEN, prepare_dataloaders
 from .log import (EarlyStoppingCondition, do_eval_batch_logging, do_eval_epoch_logging, do_train_batch_logging,
                   init_metrics, log_batch, prepare_log_header, reset_metrics_for_epoch, update_loss_trackers,
                   update_metrics_end_of_epoch)
-from .losses import batch_loss, combine_drmsd_mse, compute_batch_drmsd, mse_over_angles, mse_sums
+from .losses import (_stats_to_host, batch_loss, combine_drmsd_mse, compute_batch_drmsd, mse_over_angles,
+                     mse_sums)
 from .models.convolutional_encoder import ConvEncoderOnlyTransformer
 from .models.encoder_only import EncoderOnlyTransformer
 from .optim import FusedAdam, FusedSGD, ScheduledOptim
@@ -101,11 +102,13 @@ def get_losses(args, pred, tgt_ang, tgt_crds, src_seq, pool=None, log=True, do_b
     if args.loss in ["lndrmsd", "drmsd", "combined"] or eval_mode:
         if args.loss == "combined" and do_backwards:
             stats, grad, status = batch_loss(pred, tgt_crds, src_seq, do_backward=True)
+            host_buf, copied = _stats_to_host(stats, status)   # see compute_batch_drmsd: no stream-wide wait
             (g_mse,) = torch.autograd.grad(m_loss_full, pred, retain_graph=False)
             w = args.combined_drmsd_weight
             pred.backward(gradient=grad.view_as(pred) + ((1 - w) / 0.01) * g_mse)
-            host = stats.cpu().numpy().astype(np.float64)
-            raise_for_status(int(status.item()), theta_is_error=False)
+            copied.synchronize()
+            host = host_buf[:-1].view(-1, 8).numpy().astype(np.float64)
+            raise_for_status(int(host_buf[-1].item()), theta_is_error=False)
             d_loss, ln_d_loss, d_bb_loss, d_bb_ln_loss = (np.mean(host[:, k]) for k in range(4))
         else:
             ls = compute_batch_drmsd(pred, tgt_crds, src_seq, do_backward=do_backwards, retain_graph=False,
