@@ -185,8 +185,8 @@ int ptamd_colsum(const float *x, int64_t T, int N, int ldx, int accumulate, floa
  *   relu_dropout_bwd: y = dropout(relu(.)) -> dx = dy * (y > 0) / (1-p)   (y > 0 iff active AND kept)
  *   tanh_bwd:         dx = dy * (1 - y*y)
  *   dropout_bwd:      dx = dy * mask / (1-p), mask regenerated from (seed, stream_id) exactly as the GEMM
- *                     epilogue drew it: word (row & 3) of the counter hash pt_rand4(seed, (row >> 2) * cols + col, stream_id) of
- *                     csrc/common.h */
+ *                     epilogue drew it: 16-bit field drop_field(row) of the counter hash pt_rand4(seed, drop_call_index(row, col,
+ *                     cols), stream_id) of csrc/common.h */
 int ptamd_relu_dropout_bwd(const float *dy, const float *y, int64_t n, float dropout_p, float *dx, void *stream);
 int ptamd_tanh_bwd(const float *dy, const float *y, int64_t n, float *dx, void *stream);
 int ptamd_dropout_bwd(const float *dy, int64_t rows, int cols, float dropout_p, uint64_t seed, uint32_t stream_id,

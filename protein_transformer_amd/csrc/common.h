@@ -68,6 +68,23 @@ __device__ __forceinline__ uint4 pt_rand4(uint64_t seed, uint64_t idx, uint32_t 
   return make_uint4(pt_mix32(h ^ 0x68E31DA4u), pt_mix32(h ^ 0xB5297A4Du), pt_mix32(h ^ 0x1B56C4E9u),
                     pt_mix32(h ^ 0x7F4A7C15u));
 }
+// ---- dropout mask of a [rows, cols] activation (GEMM epilogues, ptamd_dropout_bwd).  One pt_rand4 call serves EIGHT
+// rows of a column - the 16-bit halves of its four words against a 16-bit threshold - namely the rows that one lane of a
+// 32 x 32 MFMA accumulator tile holds in two of its four register groups: row = 32 I + 8 g + 4 h + e (g = 0..3,
+// h = lane half, e = 0..3) belongs to call (I, h, g >> 1) and field (g & 1) * 4 + e of that call.
+__device__ __forceinline__ uint64_t drop_call_index(int64_t row, int col, int cols) {
+  const int64_t call_row = ((row >> 5) << 2) | (((row >> 2) & 1) << 1) | ((row >> 4) & 1);
+  return (uint64_t)call_row * (uint64_t)cols + (uint64_t)col;
+}
+__device__ __forceinline__ int drop_field(int64_t row) { return (int)(((row >> 3) & 1) * 4 + (row & 3)); }
+__device__ __forceinline__ uint32_t drop_field_value(const uint4 &r, int f) {
+  const uint32_t w = (f >> 1) == 0 ? r.x : (f >> 1) == 1 ? r.y : (f >> 1) == 2 ? r.z : r.w;
+  return (f & 1) ? w >> 16 : w & 0xffffu;
+}
+// one element (slow paths: scalar epilogues, split-K reduce); thr16 = dropout_threshold(p) >> 16
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint32_t stream_id, int64_t row, int col, int cols, uint32_t thr16) {
+  return drop_field_value(pt_rand4(seed, drop_call_index(row, col, cols), stream_id), drop_field(row)) >= thr16;
+}
 // keep-threshold on the 32-bit word: keep iff word >= p * 2^32
 __device__ __forceinline__ uint32_t dropout_threshold(float p) {
   double t = (double)p * 4294967296.0;

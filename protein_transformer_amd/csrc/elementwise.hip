@@ -286,20 +286,19 @@ __global__ void tanh_bwd_kernel(const float *__restrict__ dy, const float *__res
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dx[i] = dy[i] * (1.f - y[i] * y[i]);
 }
-// mask(row, col) = word (row & 3) of pt_rand4(seed, (row >> 2) * cols + col, stream): the GEMM epilogue's mapping
+// the GEMM epilogue's mask (common.h: drop_call_index / drop_field): one thread = one call = 8 rows of one column
 __global__ void dropout_bwd_kernel(const float *__restrict__ dy, int64_t rows, int cols, float p, uint64_t seed,
                                    uint32_t stream_id, float *__restrict__ dx) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t rq = blockIdx.y;
+  const int64_t cr = blockIdx.y;  // call row: (I, h, g >> 1) = (cr >> 2, (cr >> 1) & 1, cr & 1)
   if (c >= cols) return;
-  const uint32_t thr = dropout_threshold(p);
+  const uint32_t t16 = dropout_threshold(p) >> 16;
   const float ks = 1.f / (1.f - p);
-  const uint4 r = pt_rand4(seed, (uint64_t)rq * cols + c, stream_id);
-  const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+  const uint4 r = pt_rand4(seed, (uint64_t)cr * cols + c, stream_id);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int64_t row = rq * 4 + e;
-    if (row < rows) dx[row * cols + c] = w[e] >= thr ? dy[row * cols + c] * ks : 0.f;
+  for (int f = 0; f < 8; ++f) {
+    const int64_t row = ((cr >> 2) << 5) + 8 * (2 * (cr & 1) + (f >> 2)) + 4 * ((cr >> 1) & 1) + (f & 3);
+    if (row < rows) dx[row * cols + c] = drop_field_value(r, f) >= t16 ? dy[row * cols + c] * ks : 0.f;
   }
 }
 
@@ -399,7 +398,7 @@ int ptamd_tanh_bwd(const float *dy, const float *y, int64_t n, float *dx, void *
 int ptamd_dropout_bwd(const float *dy, int64_t rows, int cols, float dropout_p, uint64_t seed, uint32_t stream_id,
                       float *dx, void *stream) {
   if (rows <= 0 || cols <= 0) return PTAMD_ERR_BAD_SHAPE;
-  hipLaunchKernelGGL(dropout_bwd_kernel, dim3((cols + 255) / 256, (unsigned)((rows + 3) / 4)), dim3(256), 0,
+  hipLaunchKernelGGL(dropout_bwd_kernel, dim3((cols + 255) / 256, (unsigned)(((rows + 31) / 32) * 4)), dim3(256), 0,
                      (hipStream_t)stream, dy, rows, cols, dropout_p, seed, stream_id, dx);
   return pt_check_launch();
 }

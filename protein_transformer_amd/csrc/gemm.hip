@@ -271,14 +271,12 @@ __global__ void gemm_splitk_reduce_kernel(const GemmParams p, const float *__res
   if (col >= p.N) return;
   const uint32_t thr = dropout_threshold(p.dropout_p);
   const float keep_scale = 1.f / (1.f - p.dropout_p);
-  uint4 rnd = make_uint4(0, 0, 0, 0);
-  if (p.dropout_p > 0.f) rnd = pt_rand4(p.seed, (uint64_t)(rowq >> 2) * p.N + col, p.stream_id);
   for (int e = 0; e < 4; ++e) {
     const int row = rowq + e;
     if (row >= p.M) return;
     float v = 0.f;
     for (int s = 0; s < splits; ++s) v += slabs[(size_t)s * p.slab + (size_t)row * p.N + col];
-    v = epilogue_value(v, row, col, p, thr, keep_scale, rnd);
+    v = epilogue_value(v, row, col, p, thr, keep_scale);
     if (p.flags & PTAMD_EPI_ACCUM) v += p.C[(size_t)row * p.ldc + col];
     p.C[(size_t)row * p.ldc + col] = v;
   }

@@ -60,13 +60,10 @@ __device__ __forceinline__ void load_stage(const float *__restrict__ src, int ld
   }
 }
 __device__ __forceinline__ float epilogue_value(float v, int row, int col, const GemmParams &p, uint32_t thr,
-                                                float keep_scale, const uint4 &rnd) {
+                                                float keep_scale) {
   if (p.bias) v += p.bias[col];
   if (p.flags & PTAMD_EPI_RELU) v = fmaxf(v, 0.f);
-  if (p.dropout_p > 0.f) {
-    const uint32_t w = (row & 3) == 0 ? rnd.x : (row & 3) == 1 ? rnd.y : (row & 3) == 2 ? rnd.z : rnd.w;
-    v = (w >= thr) ? v * keep_scale : 0.f;
-  }
+  if (p.dropout_p > 0.f) v = drop_keep(p.seed, p.stream_id, row, col, p.N, thr >> 16) ? v * keep_scale : 0.f;
   if (p.residual) {
     const float r = p.residual[(size_t)row * p.ldr + col];
     v = (p.flags & PTAMD_EPI_GATE) ? (r > 0.f ? v * p.gate_scale : 0.f) : v + r;
@@ -103,12 +100,15 @@ __device__ __forceinline__ void tile_epilogue_vec(const GemmParams &p, const f32
 #pragma unroll
     for (int i = 0; i < TI; ++i) keep[i] = 0u;
 #pragma unroll 4
-    for (int idx = 0; idx < TI * 8; ++idx) {
-      const int i = idx >> 3, j = (idx >> 2) & 1, g = idx & 3;
-      const int rowq = row0 + i * 32 + 8 * g + 4 * lh, col = col0 + j * 32 + l31;
-      const uint4 rnd = pt_rand4(p.seed, (uint64_t)(rowq >> 2) * p.N + col, p.stream_id);
-      const uint32_t bits = ((rnd.x >= thr ? 1u : 0u) | (rnd.y >= thr ? 2u : 0u) | (rnd.z >= thr ? 4u : 0u) |
-                             (rnd.w >= thr ? 8u : 0u)) << (j * 16 + g * 4);
+    for (int idx = 0; idx < TI * 4; ++idx) {  // one call = the lane's 8 rows of two register groups (common.h)
+      const int i = idx >> 2, j = (idx >> 1) & 1, gp = idx & 1;
+      const int row = row0 + i * 32 + 16 * gp + 4 * lh, col = col0 + j * 32 + l31;
+      const uint4 rnd = pt_rand4(p.seed, drop_call_index(row, col, p.N), p.stream_id);
+      const uint32_t t16 = thr >> 16;
+      uint32_t bits = 0;
+#pragma unroll
+      for (int f = 0; f < 8; ++f)   // field f = (g & 1) * 4 + e -> accumulator register (2 gp + (f >> 2)) * 4 + (f & 3)
+        bits |= (drop_field_value(rnd, f) >= t16 ? 1u : 0u) << (j * 16 + (2 * gp + (f >> 2)) * 4 + (f & 3));
 #pragma unroll
       for (int ii = 0; ii < TI; ++ii) keep[ii] |= ii == i ? bits : 0u;
     }
@@ -211,9 +211,6 @@ __device__ __forceinline__ void tile_epilogue_scalar(const GemmParams &p, const 
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int rowq = row_base + 8 * g;  // 4 consecutive rows share one generator call
-          uint4 rnd = make_uint4(0, 0, 0, 0);
-          if (!partial && p.dropout_p > 0.f) rnd = pt_rand4(p.seed, (uint64_t)(rowq >> 2) * p.N + col, p.stream_id);
-          const uint32_t rw[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int row = rowq + e, r = g * 4 + e;
@@ -221,7 +218,7 @@ __device__ __forceinline__ void tile_epilogue_scalar(const GemmParams &p, const 
             if (!partial) {
               v += bias;
               if (p.flags & PTAMD_EPI_RELU) v = fmaxf(v, 0.f);
-              if (p.dropout_p > 0.f) v = rw[e] >= thr ? v * keep_scale : 0.f;
+              if (p.dropout_p > 0.f) v = drop_keep(p.seed, p.stream_id, row, col, p.N, thr >> 16) ? v * keep_scale : 0.f;
               if (p.residual && col_ok && row < p.M) {
                 const float rr = p.residual[(size_t)row * p.ldr + col];
                 v = (p.flags & PTAMD_EPI_GATE) ? (rr > 0.f ? v * p.gate_scale : 0.f) : v + rr;

@@ -118,11 +118,18 @@ def rand4_restated(seed, idx, stream):
 
 
 def dropout_mask_restated(rows, cols, p, seed, stream):
-    """keep mask of the GEMM epilogue / ptamd_dropout_bwd: word (row & 3) of the call (row >> 2) * cols + col."""
-    thr = np.uint32(min(p * 2.0 ** 32, 2.0 ** 32 - 1))
-    rq = np.arange((rows + 3) // 4, dtype=np.uint64)[:, None] * np.uint64(cols) + np.arange(cols, dtype=np.uint64)[None, :]
-    w = rand4_restated(seed, rq, stream)
-    return np.stack([wk >= thr for wk in w], axis=1).reshape(-1, cols)[:rows]
+    """keep mask of the GEMM epilogue / ptamd_dropout_bwd (csrc/common.h: drop_call_index, drop_field): row
+    32 I + 8 g + 4 h + e uses the 16-bit field (g & 1) * 4 + e of the call (I, h, g >> 1) of its column."""
+    thr16 = np.uint32(np.uint32(min(p * 2.0 ** 32, 2.0 ** 32 - 1)) >> np.uint32(16))
+    row = np.arange(rows, dtype=np.int64)[:, None]
+    col = np.arange(cols, dtype=np.int64)[None, :]
+    call_row = ((row >> 5) << 2) | (((row >> 2) & 1) << 1) | ((row >> 4) & 1)
+    idx = (call_row * cols + col).astype(np.uint64)
+    w = np.stack(rand4_restated(seed, idx, stream))                    # [4, rows, cols]
+    f = (((row >> 3) & 1) * 4 + (row & 3)) + 0 * col                   # [rows, cols]
+    word = np.take_along_axis(w, (f >> 1)[None].astype(np.int64), axis=0)[0]
+    val = np.where(f & 1, word >> np.uint32(16), word & np.uint32(0xffff))
+    return val >= thr16
 
 
 def test_dropout_generator_statistics():
@@ -135,8 +142,8 @@ def test_dropout_generator_statistics():
 
     def corr(a, b):
         return (a * b).mean() / (a.std() * b.std())
-    for a, b in ((m[:, :-1], m[:, 1:]), (m[:-1], m[1:]), (m[:-4], m[4:]), (m[:-1, :-1], m[1:, 1:])):
-        assert abs(corr(a, b)) < 4 / np.sqrt(n)                      # neighbours, the next call, diagonals
+    for a, b in ((m[:, :-1], m[:, 1:]), (m[:-1], m[1:]), (m[:-4], m[4:]), (m[:-8], m[8:]), (m[:-1, :-1], m[1:, 1:])):
+        assert abs(corr(a, b)) < 4 / np.sqrt(n)                      # neighbours, other fields of a call, diagonals
     assert abs(mask.mean(1).std() / np.sqrt(p * (1 - p) / cols) - 1) < 0.1
     assert abs(mask.mean(0).std() / np.sqrt(p * (1 - p) / rows) - 1) < 0.15
     for other in (dropout_mask_restated(rows, cols, p, 1234567890124, 7), dropout_mask_restated(rows, cols, p, 1234567890123, 8)):
