@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const float *__restric
       if (p_drop > 0.f) {
         const uint32_t keep = attn_keep_bits_keys_in_rows(dk_, q_part, k0 + sub * 32, lh);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = (keep >> r) & 1u ? s[r] * dk_.ks : 0.f;
+        for (int r = 0; r < 16; ++r) s[r] = (keep >> r) & 1u ? s[r] : 0.f;  // the 1 / (1 - p) is applied to O at the end
       }
       // O^T[d][q] += V^T[d][key] P^T[key][q]
 #pragma unroll
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const float *__restric
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.f / l_tot;
+  const float inv = (p_drop > 0.f ? dk_.ks : 1.f) / l_tot;  // softmax normalisation and the dropout scale in one factor
   if (q_ok) {
     float *op = out + (size_t)(b * L + q) * D + h * DK;
 #pragma unroll

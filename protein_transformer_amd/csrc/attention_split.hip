@@ -158,12 +158,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(const float *__r
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        for (int r = 0; r < 16; ++r) {  // scalar multiplies, kept apart: packed f32 VALU stalls the matrix pipe
+          float v = o[t][r] * alpha;
+          asm volatile("" : "+v"(v));
+          o[t][r] = v;
+        }
     }
     if (p_drop > 0.f) {
       const uint32_t keep = attn_keep_bits_keys_in_rows(dk_, q_part, k0, lh);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = (keep >> r) & 1u ? s[r] * dk_.ks : 0.f;
+      for (int r = 0; r < 16; ++r) s[r] = (keep >> r) & 1u ? s[r] : 0.f;  // the 1 / (1 - p) is applied to O at the end
     }
     // O^T[d][q] += V^T[d][key] P^T[key][q]: the accumulator rows of s are already in the k order of frag_cols
 #pragma unroll
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(const float *__r
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.f / l_tot;
+  const float inv = (p_drop > 0.f ? dk_.ks : 1.f) / l_tot;  // softmax normalisation and the dropout scale in one factor
   if (q_ok) {
     float *op = out + (size_t)(b * L + q) * D + h * DK;
 #pragma unroll

@@ -53,7 +53,8 @@ constexpr int KR_PAD = 32;           // a [k][rows + 32] plane: 4 consecutive k 
 constexpr int PLANE_A = TBM * LD_RK, PLANE_B = TBN * LD_RK;   // 6144 / 3072 bf16 (the [k][row] forms are smaller)
 constexpr int STAGE = 3 * (PLANE_A + PLANE_B);                // 27648 bf16 = 55296 B
 constexpr int SCRATCH_FLOATS = 4 * 2048;                      // epilogue transpose scratch of the 4 consumers
-constexpr int COLSUM_FLOATS = 2 * 4 * TBM;                    // two alternating [4 k groups][256 rows] partial sums
+constexpr int COLSUM_AREAS = 3;                               // see the producers' publish / the consumers' read below
+constexpr int COLSUM_FLOATS = COLSUM_AREAS * 4 * TBM;         // rotating [4 k groups][256 rows] partial sums
 constexpr size_t LDS_BYTES = (size_t)2 * STAGE * sizeof(unsigned short) + (SCRATCH_FLOATS + COLSUM_FLOATS) * sizeof(float);
 static_assert(PLANE_A >= SBK * (TBM + KR_PAD) && PLANE_B >= SBK * (TBN + KR_PAD), "plane must hold either layout");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget of a CU");
@@ -104,17 +105,22 @@ __device__ __forceinline__ void load_raw(const float *__restrict__ stage_base, c
     v[i] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(stage_base) + voff[i]);
 }
 
-// registers of one stage -> the three LDS planes of the operand at `s`; the first kskip k of the stage are zeroed
+// the first kskip k of a stage are zeroed (only the last stage of an item whose K range is not a multiple of 16)
 template <bool KMAJOR, int ROWS>
-__device__ __forceinline__ void store_split(unsigned short *__restrict__ s, int pt, float4 (&v)[ROWS / 64], int kskip) {
-  constexpr int LPK = ROWS / 4, PLANE = ROWS * LD_RK, LD_KR = ROWS + KR_PAD;
-  if (kskip > 0) {  // uniform: only the last stage of an item whose K range is not a multiple of 16
+__device__ __forceinline__ void mask_tail(int pt, float4 (&v)[ROWS / 64], int kskip) {
+  constexpr int LPK = ROWS / 4;
+  if (kskip > 0) {  // uniform
 #pragma unroll
     for (int i = 0; i < ROWS / 64; ++i) {
       const int kl = KMAJOR ? pt / LPK + (NPRODUCER / LPK) * i : 4 * (pt % 4);
       if (kl < kskip) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
+}
+// registers of one stage -> the three LDS planes of the operand at `s`
+template <bool KMAJOR, int ROWS>
+__device__ __forceinline__ void store_split(unsigned short *__restrict__ s, int pt, const float4 (&v)[ROWS / 64]) {
+  constexpr int LPK = ROWS / 4, PLANE = ROWS * LD_RK, LD_KR = ROWS + KR_PAD;
 #pragma unroll
   for (int i = 0; i < ROWS / 64; ++i) {
     const int kl = KMAJOR ? pt / LPK + (NPRODUCER / LPK) * i : 4 * (pt % 4);
@@ -194,24 +200,35 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
   }
   const int padded_stages = (total_stages + NSETS - 1) / NSETS * NSETS;  // both roles run this many barriers (+1)
   const bool partial = p.slab != 0;
+  // Bias gradient = column sums of the k-major A operand.  The producers add up the f32 registers of their loader
+  // (weights 0 / 1 per k row, no branch and no memory access in their loop) and publish one partial row per k group in
+  // LDS at the end of an item; the consumers write it out with the tile.  With split-K slabs the N tiles of one
+  // (M tile, split) share the work: N tile tn takes every cs_share-th k of a stage starting at tn; without slabs the
+  // first N tile does it alone and accumulates in place.
+  const bool has_colsum = A_KMAJOR && p.colsum != nullptr;
+  const int cs_share = partial ? p.colsum_share : 1;
+  auto colsum_first = [&](const Item &it) __attribute__((always_inline)) { return (it.bn0 / TBN) & (cs_share - 1); };
+  auto colsum_on = [&](const Item &it) __attribute__((always_inline)) {
+    return has_colsum && (partial ? it.bn0 / TBN < cs_share : it.bn0 == 0);
+  };
 
   if (wave >= 4) {
     // ================================================================ producers
     const int pt = tid - NPRODUCER;
-    // Bias gradient = column sums of the k-major A operand, taken from the f32 registers of the loader.  With
-    // split-K slabs the N tiles of one (M tile, split) share the work: N tile tn takes every cs_share-th k of a
-    // stage starting at tn; without slabs the first N tile does it alone and accumulates in place.
-    const int cs_share = partial ? p.colsum_share : 1;
-    auto colsum_first = [&](const Item &it) __attribute__((always_inline)) { return (it.bn0 / TBN) & (cs_share - 1); };
-    auto colsum_on = [&](const Item &it) __attribute__((always_inline)) {
-      return A_KMAJOR && p.colsum != nullptr && (partial ? it.bn0 / TBN < cs_share : it.bn0 == 0);
-    };
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
-    int cs_parity = 0, cs_pending = -1, cs_pending_row0 = 0, cs_pending_slab = 0;  // finished sums waiting in cs_area
+    float cs_w[4] = {0.f, 0.f, 0.f, 0.f};  // weight of this thread's k rows (pt / 64 + 4 i) for the item under `st`
+    int cs_parity = 0;
+    auto colsum_weights = [&](const Item &it) __attribute__((always_inline)) {
+      const bool on = colsum_on(it);
+      const int first = colsum_first(it);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cs_w[i] = (on && ((pt / 64 + 4 * i) & (cs_share - 1)) == first) ? 1.f : 0.f;
+    };
 
     Cursor ld = {work.begin, 0, item_at(work.begin), false};  // next stage to fetch
     ld.k0 = ld.it.kbeg;
     Cursor st = ld;                                    // next stage to convert and store
+    colsum_weights(st.it);
     uint32_t voa[4], vob[2];                           // per-thread byte offsets of the item under `ld`
     item_offsets<A_KMAJOR, TBM>(p.lda, p.M, ld.it.bm0, pt, voa);
     item_offsets<B_KMAJOR, TBN>(p.ldb, p.N, ld.it.bn0, pt, vob);
@@ -233,47 +250,42 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
     // convert + store the stage under `st` into LDS buffer `buf`, then refill the registers two stages ahead
     auto produce = [&](float4 (&a)[4], float4 (&b)[2], int &kskip, int buf) __attribute__((always_inline)) {
       unsigned short *sa = smem + buf * STAGE, *sb = sa + 3 * PLANE_A;
-      if (A_KMAJOR && !st.end && colsum_on(st.it)) {  // (past the end the last stage is fetched again: not summed)
-        const int first = colsum_first(st.it);
+      mask_tail<A_KMAJOR, TBM>(pt, a, kskip);
+      mask_tail<B_KMAJOR, TBN>(pt, b, kskip);
+      if (has_colsum) {  // kernel-uniform; the weights are zero where this workgroup has nothing to add
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int kl = pt / 64 + 4 * i;
-          if ((kl & (cs_share - 1)) == first && kl >= kskip) {
-            csum.x += a[i].x; csum.y += a[i].y; csum.z += a[i].z; csum.w += a[i].w;
-          }
+        for (int i = 0; i < 4; ++i) {  // scalar fmas, kept apart: a v_pk_fma_f32 beside the consumer's MFMAs stalls the pipe
+          csum.x = fmaf(cs_w[i], a[i].x, csum.x); asm volatile("" : "+v"(csum.x));
+          csum.y = fmaf(cs_w[i], a[i].y, csum.y); asm volatile("" : "+v"(csum.y));
+          csum.z = fmaf(cs_w[i], a[i].z, csum.z); asm volatile("" : "+v"(csum.z));
+          csum.w = fmaf(cs_w[i], a[i].w, csum.w); asm volatile("" : "+v"(csum.w));
         }
       }
-      store_split<A_KMAJOR, TBM>(sa, pt, a, kskip);
-      store_split<B_KMAJOR, TBN>(sb, pt, b, kskip);
-      if (A_KMAJOR && !st.end && st.k0 + SBK >= st.it.kend && colsum_on(st.it)) {  // last stage of its item: publish
-        reinterpret_cast<float4 *>(cs_area + cs_parity * 4 * TBM)[pt] = csum;  // [k group = pt / 64][row quad]
-        cs_pending = cs_parity;
-        cs_pending_row0 = st.it.bm0;
-        cs_pending_slab = partial ? st.it.z * cs_share + colsum_first(st.it) : -1;
-        cs_parity ^= 1;
+      store_split<A_KMAJOR, TBM>(sa, pt, a);
+      store_split<B_KMAJOR, TBN>(sb, pt, b);
+      if (has_colsum && !st.end && st.k0 + SBK >= st.it.kend) {  // last stage of its item: publish (LDS only)
+        if (colsum_on(st.it)) {
+          // Three rotating areas: an item's sums are published one stage before the consumers finish the item and read
+          // by them after the barrier of its last stage; with items of a single stage the writer of item I + 2 may
+          // already run while the reader of item I is still in its epilogue, the writer of item I + 3 may not.
+          reinterpret_cast<float4 *>(cs_area + cs_parity * 4 * TBM)[pt] = csum;  // [k group = pt / 64][row quad]
+          cs_parity = cs_parity == COLSUM_AREAS - 1 ? 0 : cs_parity + 1;
+        }
         csum = make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      advance(st);
+      {
+        const int w_before = st.w;
+        const bool was_end = st.end;
+        advance(st);
+        if (st.w != w_before) colsum_weights(st.it);
+        if (st.end && !was_end) cs_w[0] = cs_w[1] = cs_w[2] = cs_w[3] = 0.f;  // past the end the last stage is re-fetched
+      }
       // the refill must not be scheduled above the conversion: old and new contents of the registers would overlap,
       // the set could not stay in place across the loop and the copies (each waiting for its load) would drain the
       // prefetch queue every iteration
       __builtin_amdgcn_sched_barrier(0);
       fetch(a, b, kskip);
     };
-    // after a barrier: the sums published before it are complete in LDS
-    auto flush_colsum = [&]() __attribute__((always_inline)) {
-      if (A_KMAJOR && cs_pending >= 0) {
-        const float *q = cs_area + cs_pending * 4 * TBM;
-        const int row = cs_pending_row0 + pt;
-        if (row < p.M) {
-          const float tot = q[pt] + q[TBM + pt] + q[2 * TBM + pt] + q[3 * TBM + pt];
-          if (cs_pending_slab >= 0) p.colsum[(size_t)cs_pending_slab * p.M + row] = tot;
-          else p.colsum[row] += tot;
-        }
-        cs_pending = -1;
-      }
-    };
-
     // (the scheduling fences keep the ISSUE ORDER of the prologue loads: the scheduler would otherwise sink the later
     // fetches below the refill to shorten live ranges, and since vmcnt counts in order every later wait for an older
     // register set would have to drain the newer ones as well)
@@ -287,12 +299,10 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
     for (int g = 0; g < padded_stages; g += NSETS) {  // no exit in the middle: the register sets keep their roles
 #pragma unroll
       for (int u = 1; u <= NSETS; ++u) {
-        flush_colsum();
         produce(ra[u % NSETS], rb[u % NSETS], rskip[u % NSETS], u & 1);  // stage g + u -> buffer (g + u) & 1
         __syncthreads();
       }
     }
-    flush_colsum();
   } else {
     // ================================================================ consumers
     const int wm = wave >> 1, wn = wave & 1;
@@ -310,6 +320,7 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
     zero_acc();
     Cursor cc = {work.begin, 0, item_at(work.begin), false};
     cc.k0 = cc.it.kbeg;
+    int cs_parity = 0;  // which of the published column-sum areas belongs to the current item
 
     __syncthreads();  // stage 0 is in buffer 0
     for (int g = 0; g < padded_stages; ++g) {
@@ -355,6 +366,16 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
         if (p.vec_epilogue) tile_epilogue_vec<4, true, EPI>(p, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 2048);
         else tile_epilogue_vec<4, false, EPI>(p, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 2048);
         zero_acc();
+        if (colsum_on(cc.it)) {  // the producers published this item's sums before the barrier above: one row per lane
+          const float *q = cs_area + cs_parity * 4 * TBM;
+          const int row = cc.it.bm0 + tid;
+          if (row < p.M) {
+            const float tot = q[tid] + q[TBM + tid] + q[2 * TBM + tid] + q[3 * TBM + tid];
+            if (partial) p.colsum[((size_t)cc.it.z * cs_share + colsum_first(cc.it)) * p.M + row] = tot;
+            else p.colsum[row] += tot;
+          }
+          cs_parity = cs_parity == COLSUM_AREAS - 1 ? 0 : cs_parity + 1;
+        }
       }
       advance(cc);
     }
