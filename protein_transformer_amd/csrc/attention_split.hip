@@ -407,19 +407,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_split_kernel(const float 
     }
     f32x16 pd;  // dropped probabilities (operand of dV)
     const uint32_t keepbits = p_drop > 0.f ? attn_keep_bits_queries_in_rows(dk_, (uint32_t)key, qq0, lh) : 0xffffu;
-    float4 lse4[4], del4[4];  // log-sum-exp and delta of this lane's 16 query rows: rows 8 g + 4 lh + 0..3
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      lse4[g4] = *reinterpret_cast<const float4 *>(&sLse[cur][8 * g4 + 4 * lh]);
-      del4[g4] = *reinterpret_cast<const float4 *>(&sDel[cur][8 * g4 + 4 * lh]);
-    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qi = crow(r, lh), qg = qq0 + qi;
       const bool ok = k_valid && qg < L;
-      const float4 l4 = lse4[r >> 2], d4 = del4[r >> 2];
-      const float my_l = (r & 3) == 0 ? l4.x : (r & 3) == 1 ? l4.y : (r & 3) == 2 ? l4.z : l4.w;
-      const float my_d = (r & 3) == 0 ? d4.x : (r & 3) == 1 ? d4.y : (r & 3) == 2 ? d4.z : d4.w;
+      const float my_l = sLse[cur][qi], my_d = sDel[cur][qi];  // (LDS broadcast reads: registers are the scarce resource here)
       // (the mask goes into the ARGUMENT, exp2(-inf) = 0: a select around the exp would become a branch per element)
       const float p = fast_exp(ok ? s[r] * scale - my_l : -INFINITY);
       float g = dp[r], pk = p;
