@@ -178,16 +178,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_mfma_kernel(const GemmParams p
     // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
     float *C = p.C + (partial ? (size_t)z * p.slab : 0);
     const int ldc = partial ? p.N : p.ldc;
-    if (BK == 32 && p.vec_epilogue) {
-      // Vector path: bias / ReLU / dropout are applied in the MFMA layout (one column per lane, four consecutive
-      // rows per generator call), then each wavefront transposes its tile through the LDS stage buffer that the last
-      // K stage just released (32 rows x 64 columns at a time) so that residual / accumulate operands are READ and
-      // results are WRITTEN as float4 rows: 16 16-byte stores per lane instead of 64 4-byte ones.
+    {
+      // Bias / ReLU / dropout are applied in the MFMA layout (one column per lane), then each wavefront transposes its
+      // tile through the LDS stage buffer that the last K stage just released (32 rows x 64 columns at a time) so
+      // that residual / accumulate operands are READ and results are WRITTEN as float4 rows: 16 16-byte stores per
+      // lane instead of 64 4-byte ones (element by element when N or a leading dimension is not a multiple of 4).
       float *scratch = (wave < 2 ? sA0 + (cur ^ 1) * SA : sB0 + (cur ^ 1) * SB) + (wave & 1) * 2048;
-      tile_epilogue_vec<2>(p, acc, C, ldc, partial, bm0 + wm * 64, bn0 + wn * 64, lane, thr, keep_scale, scratch);
+      if (p.vec_epilogue)
+        tile_epilogue_vec<2, true>(p, acc, C, ldc, partial, bm0 + wm * 64, bn0 + wn * 64, lane, thr, keep_scale, scratch);
+      else
+        tile_epilogue_vec<2, false>(p, acc, C, ldc, partial, bm0 + wm * 64, bn0 + wn * 64, lane, thr, keep_scale, scratch);
       if (has_next) __syncthreads();  // the next item's first stage store reuses this LDS buffer
-    } else {
-      tile_epilogue_scalar<2>(p, acc, C, ldc, partial, bm0 + wm * 64, bn0 + wn * 64, lane, thr, keep_scale);
     }
     if (A_KMAJOR && do_colsum) {  // block-uniform
       float *spare = sA0 + (cur ^ 1) * SA + 4096;  // 128 floats the wave scratch regions do not use

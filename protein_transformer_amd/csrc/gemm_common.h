@@ -194,44 +194,6 @@ __device__ __forceinline__ void tile_epilogue_vec(const GemmParams &p, const f32
   }
 }
 
-// Scalar path (any N / leading dimension): every lane stores its own accumulator elements.
-template <int TI>
-__device__ __forceinline__ void tile_epilogue_scalar(const GemmParams &p, const f32x16 (&acc)[TI][2], float *C, int ldc,
-                                                     bool partial, int row0, int col0, int lane, uint32_t thr,
-                                                     float keep_scale) {
-  const int l31 = lane & 31, lh = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int col = col0 + j * 32 + l31;
-        const bool col_ok = col < p.N;
-        const int row_base = row0 + i * 32 + 4 * lh;
-        const float bias = (!partial && p.bias && col_ok) ? p.bias[col] : 0.f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int rowq = row_base + 8 * g;  // 4 consecutive rows share one generator call
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int row = rowq + e, r = g * 4 + e;
-            float v = acc[i][j][r];
-            if (!partial) {
-              v += bias;
-              if (p.flags & PTAMD_EPI_RELU) v = fmaxf(v, 0.f);
-              if (p.dropout_p > 0.f) v = drop_keep(p.seed, p.stream_id, row, col, p.N, thr >> 16) ? v * keep_scale : 0.f;
-              if (p.residual && col_ok && row < p.M) {
-                const float rr = p.residual[(size_t)row * p.ldr + col];
-                v = (p.flags & PTAMD_EPI_GATE) ? (rr > 0.f ? v * p.gate_scale : 0.f) : v + rr;
-              }
-              if (p.flags & PTAMD_EPI_TANH) v = tanhf(v);
-              if ((p.flags & PTAMD_EPI_ACCUM) && col_ok && row < p.M) v += C[(size_t)row * ldc + col];
-            }
-            if (col_ok && row < p.M) C[(size_t)row * ldc + col] = v;
-          }
-        }
-      }
-}
-
 // Work decomposition of a persistent launch: logical id = ((z * tiles_m + tm) * tiles_n + tn), i.e. neighbours share
 // the same A panel / K chunk.  Workgroup b (which the dispatcher places on XCD b % 8) owns the CONTIGUOUS logical
 // range [w_begin, w_end) with slot = (b % 8) * (G / 8) + b / 8: consecutive items of one workgroup and the
