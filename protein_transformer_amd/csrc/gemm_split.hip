@@ -16,9 +16,11 @@
 //   * wavefronts 0-3 are CONSUMERS: each owns a 128 x 64 block (4 x 2 MFMA tiles of 32 x 32, 128 accumulator VGPRs) of
 //     the workgroup's 256 x 128 output tile and does nothing but ds_read fragments and issue MFMAs (48 per K step
 //     of 16), then the epilogue of the tile through its own LDS scratch;
-//   * wavefronts 4-7 are PRODUCERS: they fetch the f32 operands (16-byte coalesced loads issued two stages ahead,
-//     unconditional, addresses clamped), split them with v_cvt_pk_bf16_f32 and write the three bf16 planes of the
-//     next stage into the other half of a double-buffered LDS image; they also form the fused bias gradient.
+//   * wavefronts 4-7 are PRODUCERS: they fetch the f32 operands (16-byte coalesced loads from a scalar stage base + a
+//     32-bit lane offset, NSETS = 4 stages in flight, unconditional), split them with v_cvt_pk_bf16_f32 and scalar
+//     subtractions and write the three bf16 planes of the next stage into the other half of a double-buffered LDS
+//     image; they also add up the fused bias gradient (no branch, no memory access and no packed f32 instruction
+//     in their loop: each of the three was measured to cost 10-30 %).
 //   The matrix pipe of a SIMD is fed by its consumer while its producer uses the VALU, the LDS write path and the
 //   vector memory path: the two instruction streams overlap because they belong to different wavefronts.  One
 //   s_barrier per stage hands a finished buffer from the producers to the consumers and a consumed one back.

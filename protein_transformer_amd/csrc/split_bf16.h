@@ -10,6 +10,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
@@ -40,7 +41,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 (&f)[3]) {
   for (int i = 0; i < 4; ++i) split_pair(x[2 * i], x[2 * i + 1], t[0][i], t[1][i], t[2][i]);
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const uint4 u = make_uint4(t[k][0], t[k][1], t[k][2], t[k][3]);
+    const u32x4 u = {t[k][0], t[k][1], t[k][2], t[k][3]};  // (a register vector, so the packs land in place)
     f[k] = __builtin_bit_cast(bf16x8, u);
   }
 }
