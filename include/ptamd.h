@@ -90,8 +90,11 @@ int ptamd_drmsd_fwd_bwd(const float *pred_crd, const float *true_crd, const int6
                         float *stats, float *dcrd, void *workspace, size_t workspace_bytes, void *stream);
 
 /* mse_over_angles x3 (losses.py:175-214; train.py:64-66) in one pass.
- *   pred, truth [T,24]; out[6] = {sum_full, cnt_full, sum_bb, cnt_bb, sum_sc, cnt_sc} (fp32, zeroed inside) */
-int ptamd_mse_angles_fwd(const float *pred, const float *truth, int64_t T, float *out, void *stream);
+ *   pred, truth [T,24]; out[6] = {sum_full, cnt_full, sum_bb, cnt_bb, sum_sc, cnt_sc} (fp32); the workspace holds
+ *   the fp64 partial sums of the first pass */
+size_t ptamd_mse_angles_workspace_bytes(void);
+int ptamd_mse_angles_fwd(const float *pred, const float *truth, int64_t T, float *out, void *workspace,
+                         size_t workspace_bytes, void *stream);
 /* dpred[T,24] (+)= coef * 2*(pred-truth)/cnt_full on the selected elements; accumulate != 0 adds */
 int ptamd_mse_angles_bwd(const float *pred, const float *truth, int64_t T, const float *sums, float coef,
                          int accumulate, float *dpred, void *stream);

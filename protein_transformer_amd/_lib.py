@@ -45,7 +45,8 @@ SIGNATURES = {
     "ptamd_nerf_bwd": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _sz, _p]),
     "ptamd_drmsd_workspace_bytes": (_sz, [_i, _i]),
     "ptamd_drmsd_fwd_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _sz, _p]),
-    "ptamd_mse_angles_fwd": (_i, [_p, _p, _i64, _p, _p]),
+    "ptamd_mse_angles_workspace_bytes": (_sz, []),
+    "ptamd_mse_angles_fwd": (_i, [_p, _p, _i64, _p, _p, _sz, _p]),
     "ptamd_mse_angles_bwd": (_i, [_p, _p, _i64, _p, _f, _i, _p, _p]),
     "ptamd_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
     "ptamd_gemm": (_i, [C.POINTER(GemmArgs), _p]),

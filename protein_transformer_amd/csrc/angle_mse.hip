@@ -8,14 +8,16 @@
 
 namespace {
 
-constexpr int MB = 1024;
+constexpr int MB = 256;    // threads per block
+constexpr int NBLK = 128;  // blocks of the first pass: one fp64 partial row of 6 sums each
 
-__global__ __launch_bounds__(MB) void mse_angles_fwd_kernel(const float *__restrict__ pred,
-                                                            const float *__restrict__ truth, int64_t T,
-                                                            float *__restrict__ out) {
+// pass 1: every block strides over the rows and leaves its 6 partial sums (fp64) in part[block][6]
+__global__ __launch_bounds__(MB) void mse_angles_partial_kernel(const float *__restrict__ pred,
+                                                                const float *__restrict__ truth, int64_t T,
+                                                                double *__restrict__ part) {
   __shared__ double s_red[MB / 64][6];
   double acc[6] = {0, 0, 0, 0, 0, 0};
-  for (int64_t t = threadIdx.x; t < T; t += MB) {
+  for (int64_t t = (int64_t)blockIdx.x * MB + threadIdx.x; t < T; t += (int64_t)NBLK * MB) {
     const float4 *tp = reinterpret_cast<const float4 *>(truth + t * 24);
     const float4 *pp = reinterpret_cast<const float4 *>(pred + t * 24);
     float tv[24], pv[24];
@@ -52,6 +54,14 @@ __global__ __launch_bounds__(MB) void mse_angles_fwd_kernel(const float *__restr
   if (threadIdx.x < 6) {
     double v = 0;
     for (int w = 0; w < MB / 64; ++w) v += s_red[w][threadIdx.x];
+    part[(size_t)blockIdx.x * 6 + threadIdx.x] = v;
+  }
+}
+// pass 2: the partial rows in a fixed order
+__global__ void mse_angles_final_kernel(const double *__restrict__ part, float *__restrict__ out) {
+  if (threadIdx.x < 6) {
+    double v = 0;
+    for (int b = 0; b < NBLK; ++b) v += part[(size_t)b * 6 + threadIdx.x];
     out[threadIdx.x] = (float)v;
   }
 }
@@ -77,10 +87,18 @@ __global__ void mse_angles_bwd_kernel(const float *__restrict__ pred, const floa
 
 extern "C" {
 
-int ptamd_mse_angles_fwd(const float *pred, const float *truth, int64_t T, float *out, void *stream) {
+size_t ptamd_mse_angles_workspace_bytes(void) { return (size_t)NBLK * 6 * sizeof(double); }
+
+int ptamd_mse_angles_fwd(const float *pred, const float *truth, int64_t T, float *out, void *workspace,
+                         size_t workspace_bytes, void *stream) {
   if (T <= 0) return PTAMD_ERR_BAD_SHAPE;
   if (!pt_aligned16(pred) || !pt_aligned16(truth)) return PTAMD_ERR_ALIGN;
-  hipLaunchKernelGGL(mse_angles_fwd_kernel, dim3(1), dim3(MB), 0, (hipStream_t)stream, pred, truth, T, out);
+  if (!workspace || workspace_bytes < ptamd_mse_angles_workspace_bytes()) return PTAMD_ERR_WORKSPACE;
+  double *part = static_cast<double *>(workspace);
+  hipLaunchKernelGGL(mse_angles_partial_kernel, dim3(NBLK), dim3(MB), 0, (hipStream_t)stream, pred, truth, T, part);
+  int rc = pt_check_launch();
+  if (rc) return rc;
+  hipLaunchKernelGGL(mse_angles_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part, out);
   return pt_check_launch();
 }
 

@@ -221,8 +221,10 @@ def mse_sums(pred, true):
         return _mse_cache[3]
     T = pred.shape[0] * pred.shape[1]
     out = torch.empty(6, dtype=torch.float32, device=pred.device)
+    ws = _lib.workspace("mse_angles", _lib.lib().ptamd_mse_angles_workspace_bytes(), pred.device)
     rc = _lib.lib().ptamd_mse_angles_fwd(_lib.ptr(pred.detach().float().contiguous()),
-                                         _lib.ptr(true.float().contiguous()), T, _lib.ptr(out), _lib.stream())
+                                         _lib.ptr(true.float().contiguous()), T, _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                                         _lib.stream())
     _lib.check(rc, "mse_angles_fwd")
     _mse_cache = (key, pred, true, out)
     return out
