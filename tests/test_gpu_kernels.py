@@ -132,6 +132,69 @@ def test_gemm_dropout_mask_roundtrip(dev, gemm_mode):
     assert torch.equal(g != 0, h > 0)
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_gemm_randomised(dev, seed):
+    """40 random (shape, operand layout, epilogue, split-K, fused bias gradient, arithmetic mode) combinations per
+    seed against fp64: every code path of ptamd_gemm meets the same bound, 2e-6 * (sum |a||b| + 1)."""
+    from protein_transformer_amd import kernels as K_
+    rng = np.random.default_rng(seed)
+    old = K_.get_gemm_mode()
+    try:
+        for _ in range(40):
+            mode = int(rng.integers(0, 3))
+            a_km, b_km = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+            M, N, Kd = (int(rng.integers(1, 700)) for _ in range(3))
+            if a_km:
+                M = max(4, M // 4 * 4)
+            if b_km:
+                N = max(4, N // 4 * 4)
+            if rng.integers(0, 4) == 0:
+                Kd = int(rng.choice([16, 20, 36, 512, 4096 + 16 * int(rng.integers(0, 3))]))
+            if not (a_km and b_km):
+                Kd = max(4, Kd // 4 * 4)
+            split = int(rng.choice([1, 1, 2, 5, 16])) if Kd >= 64 else 1
+            use_bias, use_res, relu, tanh_, accum = (bool(rng.integers(0, 2)) for _ in range(5))
+            colsum = a_km and bool(rng.integers(0, 2))
+            gate = (not use_res) and bool(rng.integers(0, 4) == 0)
+            a = torch.tensor(rng.normal(0, 1, (M, Kd)), dtype=torch.float32)
+            b = torch.tensor(rng.normal(0, 1, (N, Kd)), dtype=torch.float32)
+            bias = torch.tensor(rng.normal(0, 1, N), dtype=torch.float32) if use_bias else None
+            res = torch.tensor(rng.normal(0, 1, (M, N)), dtype=torch.float32) if (use_res or gate) else None
+            c0 = torch.tensor(rng.normal(0, 1, (M, N)), dtype=torch.float32)
+            cs0 = torch.tensor(rng.normal(0, 1, M), dtype=torch.float32)
+            ref = a.double() @ b.double().T
+            if use_bias:
+                ref = ref + bias.double()
+            if relu:
+                ref = ref.clamp_min(0)
+            if use_res:
+                ref = ref + res.double()
+            if gate:
+                ref = torch.where(res.double() > 0, ref * 1.25, torch.zeros_like(ref))
+            if tanh_:
+                ref = torch.tanh(ref)
+            if accum:
+                ref = ref + c0.double()
+            flags = ((K_.EPI_RELU if relu else 0) | (K_.EPI_TANH if tanh_ else 0) | (K_.EPI_ACCUM if accum else 0)
+                     | (K_.EPI_GATE if gate else 0))
+            K_.set_gemm_mode(mode)
+            A = (a.T if a_km else a).contiguous().to(dev)
+            B = (b.T if b_km else b).contiguous().to(dev)
+            C, cs = c0.clone().to(dev), cs0.clone().to(dev)
+            K_.gemm(A, B, C, M=M, N=N, K=Kd, lda=A.stride(0), ldb=B.stride(0), ldc=N, a_kmajor=a_km, b_kmajor=b_km,
+                    bias=bias.to(dev) if use_bias else None, residual=res.to(dev) if res is not None else None, ldr=N,
+                    flags=flags, split_k=split, colsum=cs if colsum else None, gate_scale=1.25)
+            what = dict(mode=mode, M=M, N=N, K=Kd, a_km=a_km, b_km=b_km, split=split, bias=use_bias, res=use_res,
+                        relu=relu, tanh=tanh_, accum=accum, colsum=colsum, gate=gate)
+            scale = (a.abs().double() @ b.abs().double().T) + 1.0
+            assert ((C.cpu().double() - ref).abs() / scale).max().item() < 2e-6, what
+            if colsum:
+                cref = cs0.double() + a.double().sum(1)
+                assert ((cs.cpu().double() - cref).abs() / (a.abs().double().sum(1) + 1)).max().item() < 2e-6, what
+    finally:
+        K_.set_gemm_mode(old)
+
+
 def test_gemm_split_bf16_is_fp32_grade(dev):
     """The default arithmetic (three-term bf16 split, six MFMA products) against fp64, next to the exact-f32 MFMA.
 
