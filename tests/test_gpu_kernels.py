@@ -319,6 +319,31 @@ def test_attention_forward_backward(dev, gemm_mode, B, L, H, dk, lens):
     assert_close(dqkv, ref, 1e-4, 2e-6 * max(1.0, scale), "attention bwd")
 
 
+def test_attention_randomised(dev, gemm_mode):
+    """25 random (batch, heads, length, padding) cases with dk = 64 - the head size of the split-bf16 kernels -
+    forward and backward against dense fp64 attention."""
+    from protein_transformer_amd import kernels as K_
+    rng = np.random.default_rng(5 + gemm_mode)
+    for _ in range(25):
+        B, H, dk, L = int(rng.integers(1, 4)), int(rng.choice([1, 2, 4])), 64, int(rng.integers(2, 600))
+        D = H * dk
+        seq = torch.full((B, L), 20, dtype=torch.int64)
+        for b in range(B):
+            n = int(rng.integers(1, L + 1)) if b else L
+            seq[b, :n] = torch.tensor(rng.integers(0, 20, n))
+        qkv = torch.tensor(rng.normal(0, 1.2, (B, L, 3 * D)), dtype=torch.float32).double().requires_grad_()
+        out, _ = ref_attention(qkv, seq != 20, H)
+        dout = torch.tensor(rng.normal(0, 1, (B, L, D)), dtype=torch.float64)
+        out.backward(dout)
+        qd = qkv.detach().float().view(B * L, 3 * D).to(dev)
+        o, lse = K_.attention_fwd(qd, seq.to(dev), H, 0.0, 0, 0)
+        what = f"B={B} H={H} L={L} lens={(seq != 20).sum(1).tolist()}"
+        assert_close(o.view(B, L, D), out, 1e-5, 2e-6, "attention fwd " + what)
+        dqkv = K_.attention_bwd(qd, seq.to(dev), o, dout.float().view(B * L, D).to(dev), lse, H, 0.0, 0, 0)
+        ref = qkv.grad.view(B * L, 3 * D)
+        assert_close(dqkv, ref, 1e-4, 2e-6 * max(1.0, ref.abs().max().item()), "attention bwd " + what)
+
+
 def test_attention_dropout_consistency(dev, gemm_mode):
     """Recover the dropout mask from a forward pass with V = I, then check all three gradients against
     dense torch math that uses that mask: forward, dQ and dK/dV kernels must draw identical masks."""
