@@ -147,10 +147,18 @@ __global__ __launch_bounds__(PB) void drmsd_pairs_kernel(const float4 *__restric
     __syncthreads();
     const int cnt = min(PB, n - c0);
     const int ja = max(0, min(cnt, nbb - c0));
+    // two pairs per iteration, written out by hand (the optimizer declines to unroll this loop by itself): the loop
+    // bookkeeping is shared and the second pair's LDS reads are in flight under the first pair's arithmetic
     int j = 0;
-#pragma unroll 4
+    for (; j + 1 < ja; j += 2) {
+      pair(j, accA);
+      pair(j + 1, accA);
+    }
     for (; j < ja; ++j) pair(j, accA);
-#pragma unroll 4
+    for (; j + 1 < cnt; j += 2) {
+      pair(j, accB);
+      pair(j + 1, accB);
+    }
     for (; j < cnt; ++j) pair(j, accB);
   }
   if (WITH_GRAD && live) gcomp[(size_t)b * nmax + i] = make_float4(gx, gy, gz, 0.f);
