@@ -147,17 +147,21 @@ __global__ __launch_bounds__(PB) void drmsd_pairs_kernel(const float4 *__restric
     __syncthreads();
     const int cnt = min(PB, n - c0);
     const int ja = max(0, min(cnt, nbb - c0));
-    // two pairs per iteration, written out by hand (the optimizer declines to unroll this loop by itself): the loop
-    // bookkeeping is shared and the second pair's LDS reads are in flight under the first pair's arithmetic
+    // four pairs per iteration, written out by hand (the optimizer declines to unroll this loop by itself): the loop
+    // bookkeeping is shared and the next pairs' LDS reads are in flight under the current pair's arithmetic
     int j = 0;
-    for (; j + 1 < ja; j += 2) {
+    for (; j + 3 < ja; j += 4) {
       pair(j, accA);
       pair(j + 1, accA);
+      pair(j + 2, accA);
+      pair(j + 3, accA);
     }
     for (; j < ja; ++j) pair(j, accA);
-    for (; j + 1 < cnt; j += 2) {
+    for (; j + 3 < cnt; j += 4) {
       pair(j, accB);
       pair(j + 1, accB);
+      pair(j + 2, accB);
+      pair(j + 3, accB);
     }
     for (; j < cnt; ++j) pair(j, accB);
   }
