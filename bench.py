@@ -174,12 +174,12 @@ def main():
         "f32 (GEMM operands split exactly into 3 bf16 terms on the bf16 MFMA pipe, f32 accumulate; the rest f32)"
     # the stored line of the same bench in the exact-f32 MFMA mode (python bench.py --gemm-mode f32), for comparison
     f32_ref = None
-    fpath = os.path.join(ROOT, "profiles", "r01_v6_bench_gemm_mode_f32.json")
+    fpath = os.path.join(ROOT, "profiles", "r01_v7_bench_gemm_mode_f32.json")
     if roofline is not None and kernels.get_gemm_mode() != kernels.GEMM_F32 and os.path.exists(fpath):
         with open(fpath) as f:
             r = json.load(f)
         f32_ref = {"ms_per_step": r["ms_per_step"], "residues_per_s": r["value"], "gemm_tflops": r["roofline"]["achieved"],
-                   "gemm_frac_of_f32_mfma_peak": r["roofline"]["frac"], "source": "profiles/r01_v6_bench_gemm_mode_f32.json"}
+                   "gemm_frac_of_f32_mfma_peak": r["roofline"]["frac"], "source": "profiles/r01_v7_bench_gemm_mode_f32.json"}
     if roofline is not None:
         roofline["exact_f32_mfma_mode_reference"] = f32_ref
     if rank == 0:
