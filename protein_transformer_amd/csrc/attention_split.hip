@@ -6,10 +6,11 @@
 // v_mfma_f32_32x32x16_bf16 products of exactly split operands (see gemm_split.hip / split_bf16.h): 6/16 of the matrix
 // pipe time of the f32 MFMA at the same accuracy.  Selected by ptamd_gemm_set_mode like the GEMMs.
 //
-// Decomposition as in attention.hip: one workgroup = (protein, head, 128 queries), 4 wavefronts x 32 queries, scores
+// Decomposition as in attention.hip but with 8 wavefronts: one workgroup = (protein, head, 256 queries), 32 per
+// wavefront (a staged tile is converted once per 256 queries: -10 % against 4-wavefront workgroups), scores
 // computed TRANSPOSED (S^T[key][q]) so a softmax row is lane-local and the probability block, still sitting in the
 // MFMA accumulator layout, is split in registers and fed straight back as the B operand of O^T += V^T P^T.
-// K and V tiles of 64 keys are staged once per workgroup as three bf16 planes each in the swizzled LDS format of
+// K and V tiles of 32 keys are staged once per workgroup as three bf16 planes each in the swizzled LDS format of
 // split_bf16.h, which serves the row-fragment reads (K in QK^T) and the transposed reads (V^T in PV) conflict-free.
 #include "attn_dropout.h"
 #include "split_bf16.h"
@@ -17,28 +18,30 @@
 namespace ptattn {
 using namespace ptsplit;
 
-constexpr int DK = 64, QB = 128;
+constexpr int DK = 64;
+constexpr int NTHR = 512;        // 8 wavefronts: a staged tile is converted once for 256 queries (keys) instead of 128
+constexpr int QB = NTHR / 2;     // queries (or keys) per workgroup: 32 per wavefront
 constexpr int TR = 32;  // rows (keys or queries) of an LDS tile
 typedef Tile64<TR> Tile;
 
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 __device__ __forceinline__ int crow(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
 
-// 32 rows x 64 floats of a [*, ld] matrix, global -> registers -> split planes in LDS (256 threads, 2 float4 each).
+// 32 rows x 64 floats of a [*, ld] matrix, global -> registers -> split planes in LDS (512 threads, 1 float4 each).
 // The loads are unconditional (row clamped); rows beyond nrows are zeroed when they are stored.
 struct Stage32 {
-  float4 v[2];
+  float4 v[512 / NTHR];
   __device__ __forceinline__ void load(const float *__restrict__ base, int ld, int row0, int nrows, int tid) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int f = tid + 256 * i, row = min(row0 + f / 16, nrows - 1);
+    for (int i = 0; i < 512 / NTHR; ++i) {
+      const int f = tid + NTHR * i, row = min(row0 + f / 16, nrows - 1);
       v[i] = *reinterpret_cast<const float4 *>(base + (size_t)row * ld + (f % 16) * 4);
     }
   }
   __device__ __forceinline__ void store(unsigned short *__restrict__ s, int row0, int nrows, int tid) const {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int f = tid + 256 * i, row = f / 16;
+    for (int i = 0; i < 512 / NTHR; ++i) {
+      const int f = tid + NTHR * i, row = f / 16;
       const bool ok = row0 + row < nrows;
       const float4 x = make_float4(ok ? v[i].x : 0.f, ok ? v[i].y : 0.f, ok ? v[i].z : 0.f, ok ? v[i].w : 0.f);
       Tile::store4(s, row, (f % 16) * 4, x);
@@ -60,12 +63,13 @@ __device__ __forceinline__ void load_row_split(const float *__restrict__ base, i
 }
 
 // =================================================================================================== forward
-// LDS: two buffers of {K tile, V tile} (32 keys each), 73.7 KB: two workgroups per CU.  One barrier per tile: the
+// LDS: two buffers of {K tile, V tile} (32 keys each), 73.7 KB; one 8-wavefront workgroup per CU (two wavefronts per
+// SIMD, 256 VGPRs each).  One barrier per tile: the
 // next tile is fetched at the top of the iteration, converted and stored into the other buffer after the scores.
 constexpr int BUF = 2 * Tile::ELEMS;  // bf16 elements of one {K, V} buffer
 constexpr size_t ATTN_LDS = (size_t)2 * BUF * sizeof(unsigned short);
 
-__global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
+__global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_split_kernel(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
                                                                 int L, int H, float p_drop, uint64_t seed, uint32_t stream_id,
                                                                 float *__restrict__ out, float *__restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(const float *__r
 // =================================================================================================== backward
 // dQ: same decomposition as the forward kernel.  Also computes delta[q] = sum_d dO[q,d] O[q,d] and publishes it for the
 // dK/dV kernel, which runs after this one on the same stream.
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_split_kernel(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
+__global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq_split_kernel(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
                                                                    const float *__restrict__ o_fwd, const float *__restrict__ d_o,
                                                                    const float *__restrict__ lse, float *__restrict__ delta,
                                                                    int L, int H, float p_drop, uint64_t seed, uint32_t stream_id,
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_split_kernel(const float *
 // dK, dV: one workgroup = 128 keys of one (protein, head); lane column = key.  The split K and V rows of a lane's key
 // stay in registers as B operands; Q and dO tiles of 32 queries stream through LDS and serve both as row fragments
 // (S = Q K^T, dP = dO V^T) and as transposed fragments (dK^T += Q^T dS, dV^T += dO^T Pd).
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_split_kernel(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
+__global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv_split_kernel(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
                                                                     const float *__restrict__ d_o, const float *__restrict__ lse,
                                                                     const float *__restrict__ delta, int L, int H, float p_drop,
                                                                     uint64_t seed, uint32_t stream_id, float *__restrict__ dqkv) {
@@ -471,7 +475,7 @@ int pt_attention_fwd_split(const float *qkv, const int64_t *seq, int B, int L, i
     if (int rc = set_lds(attn_fwd_split_kernel)) return rc;
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn_fwd_split_kernel, dim3((L + QB - 1) / QB, H, B), dim3(256), ATTN_LDS, st, qkv, seq, L, H, p, seed,
+  hipLaunchKernelGGL(attn_fwd_split_kernel, dim3((L + QB - 1) / QB, H, B), dim3(NTHR), ATTN_LDS, st, qkv, seq, L, H, p, seed,
                      sid, out, lse);
   return pt_check_launch();
 }
@@ -487,10 +491,10 @@ int pt_attention_bwd_split(const float *qkv, const int64_t *seq, const float *o_
     attr_set = true;
   }
   const dim3 grid((L + QB - 1) / QB, H, B);
-  hipLaunchKernelGGL(attn_bwd_dq_split_kernel, grid, dim3(256), ATTN_LDS, st, qkv, seq, o_fwd, d_o, lse, delta, L, H, p, seed,
+  hipLaunchKernelGGL(attn_bwd_dq_split_kernel, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, o_fwd, d_o, lse, delta, L, H, p, seed,
                      sid, dqkv);
   if (int rc = pt_check_launch()) return rc;
-  hipLaunchKernelGGL(attn_bwd_dkv_split_kernel, grid, dim3(256), ATTN_LDS, st, qkv, seq, d_o, lse, delta, L, H, p, seed, sid,
+  hipLaunchKernelGGL(attn_bwd_dkv_split_kernel, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, d_o, lse, delta, L, H, p, seed, sid,
                      dqkv);
   return pt_check_launch();
 }
