@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-proteins", type=int, default=2, help="proteins in the bounded CPU-baseline sample")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--gemm-mode", default="bf16x3", choices=["f32", "bf16x3", "bf16x3full"],
+    ap.add_argument("--gemm-mode", default="bf16x3", choices=["f32", "bf16x3", "bf16x3full", "f16x2"],
                     help="arithmetic of the encoder GEMMs (include/ptamd.h: ptamd_gemm_set_mode)")
     return ap.parse_args()
 
@@ -86,7 +86,8 @@ def main():
         sys.exit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     dev = torch.device("cuda", dp.local_rank())
     torch.cuda.set_device(dev)
-    kernels.set_gemm_mode({"f32": kernels.GEMM_F32, "bf16x3": kernels.GEMM_BF16X3, "bf16x3full": kernels.GEMM_BF16X3_FULL}[a.gemm_mode])
+    kernels.set_gemm_mode({"f32": kernels.GEMM_F32, "bf16x3": kernels.GEMM_BF16X3, "bf16x3full": kernels.GEMM_BF16X3_FULL,
+                           "f16x2": kernels.GEMM_F16X2}[a.gemm_mode])
 
     # ---- synthetic, device-resident batches (two per rank, alternated)
     build = lambda ang, seq: nerf_forward(ang.to(dev), seq.to(dev))[0]            # noqa: E731
@@ -152,6 +153,11 @@ def main():
         mode = kernels.get_gemm_mode()
         if mode == kernels.GEMM_F32:
             kern, peak, products = "gemm_f32_mfma_kernel (v_mfma_f32_32x32x2_f32)", F32_MFMA_PEAK_TFLOPS, 1
+        elif mode == kernels.GEMM_F16X2:
+            # every f32 product is 3 f16 MFMA products (same dense peak as bf16); the launch time includes the row-scale pass
+            products = 3
+            kern = "gemm_bf16x3_mfma_kernel<NPROD=3> (v_mfma_f32_32x32x16_f16, 3 f16 products per f32 product) + gemm_row_scale_kernel"
+            peak = BF16_MFMA_PEAK_TFLOPS / products
         else:
             # every f32 product is 6 (mode 1) or 9 (mode 2) bf16 MFMA products: the f32-equivalent ceiling is the dense
             # bf16 MFMA peak divided by that count
@@ -170,8 +176,11 @@ def main():
                     "gflop_per_step": round(flops / a.steps / 1e9, 1),
                     "share_of_step_time": round(ms / (dt * 1e3), 3)}
 
-    dtype = "f32" if kernels.get_gemm_mode() == kernels.GEMM_F32 else \
-        "f32 (GEMM operands split exactly into 3 bf16 terms on the bf16 MFMA pipe, f32 accumulate; the rest f32)"
+    dtype = {kernels.GEMM_F32: "f32",
+             kernels.GEMM_F16X2: "f32 (GEMM operands row-scaled and split into 2 f16 terms on the f16 MFMA pipe, f32 accumulate; "
+                                 "attention operands split into 3 bf16 terms; the rest f32)"}.get(
+        kernels.get_gemm_mode(),
+        "f32 (GEMM operands split exactly into 3 bf16 terms on the bf16 MFMA pipe, f32 accumulate; the rest f32)")
     # the stored line of the same bench in the exact-f32 MFMA mode (python bench.py --gemm-mode f32), for comparison
     f32_ref = None
     fpath = os.path.join(ROOT, "profiles", "r01_v7_bench_gemm_mode_f32.json")

@@ -133,7 +133,7 @@ size_t ptamd_gemm_workspace_bytes(int M, int N, int split_k);
 int ptamd_gemm(const ptamd_gemm_args *args, void *stream);
 
 /* Arithmetic of ptamd_gemm (process-wide; default PTAMD_GEMM_BF16X3, or the PTAMD_GEMM_MODE environment variable).
- * The reference computes its Linear layers in fp32 (torch.nn.Linear on fp32 tensors); all three modes take and
+ * The reference computes its Linear layers in fp32 (torch.nn.Linear on fp32 tensors); all modes take and
  * return fp32 and accumulate in fp32:
  *   PTAMD_GEMM_F32          v_mfma_f32_32x32x2_f32: bit-for-bit an fmaf chain over k (157 TF/s peak).
  *   PTAMD_GEMM_BF16X3       every f32 operand is split EXACTLY into three bf16 terms x = x1 + x2 + x3 (round to nearest
@@ -143,10 +143,25 @@ int ptamd_gemm(const ptamd_gemm_args *args, void *stream);
  *                           2^-23 |x y| and unbiased, so the result is at least as close to the exact dot product as the
  *                           fp32 fma chain is (asserted against fp64 in tests/test_gpu_kernels.py), at 6/16 of the
  *                           matrix-pipe cost.
- *   PTAMD_GEMM_BF16X3_FULL  all nine products. */
+ *   PTAMD_GEMM_BF16X3_FULL  all nine products.
+ *   PTAMD_GEMM_F16X2        every operand row (A: per m, B: per n) is scaled by the power of two that takes its largest
+ *                           |x| into [2^14, 2^15) - found by a pass over the operands in front of the product, kept in
+ *                           the workspace - and split into TWO f16 terms (2 x 11 significand bits); x*y is the three
+ *                           products x1y1 + x1y2 + x2y1 on v_mfma_f32_32x32x16_f16 and the scales are taken out of the
+ *                           f32 accumulators before the epilogue.  Half the matrix-pipe work of BF16X3.  The error is
+ *                           fp32-grade in the NORM-WISE sense: an element keeps 22 bits down to 2^-18 of its row's
+ *                           maximum and an absolute 2^-39 of that maximum below, so
+ *                               |error| <= 2^-20 sum|x||y| + 2^-36 K max|x_row| max|y_col|     (worst case)
+ *                           - on the tensors of the training step (rows spanning a few binades) it measures slightly
+ *                           BELOW the fp32 fma chain (4e-7 vs 6e-7 max, 4e-8 vs 7e-8 rms in units of sum|x||y|), for
+ *                           rows spanning 40 binades it does not (tests/test_gpu_kernels.py shows both).  A row of
+ *                           subnormals only is flushed to zero.  Needs the workspace also when split_k <= 1.
+ *                           Opt-in: the pass over the operands currently costs what the halved matrix work saves
+ *                           (DESIGN.md section 6). */
 #define PTAMD_GEMM_F32 0
 #define PTAMD_GEMM_BF16X3 1
 #define PTAMD_GEMM_BF16X3_FULL 2
+#define PTAMD_GEMM_F16X2 3
 int ptamd_gemm_set_mode(int mode);
 int ptamd_gemm_get_mode(void);
 

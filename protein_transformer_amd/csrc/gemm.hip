@@ -333,7 +333,7 @@ int current_mode() {
     g_mode = PTAMD_GEMM_BF16X3;
     if (const char *e = getenv("PTAMD_GEMM_MODE")) {
       const int v = atoi(e);
-      if (v == PTAMD_GEMM_F32 || v == PTAMD_GEMM_BF16X3 || v == PTAMD_GEMM_BF16X3_FULL) g_mode = v;
+      if (v == PTAMD_GEMM_F32 || v == PTAMD_GEMM_BF16X3 || v == PTAMD_GEMM_BF16X3_FULL || v == PTAMD_GEMM_F16X2) g_mode = v;
     }
   }
   return g_mode;
@@ -345,13 +345,22 @@ using namespace ptgemm;
 
 extern "C" {
 
+namespace {
+size_t slab_bytes(int M, int N, int split_k) {  // C slabs + column-sum slabs of a split-K product, rounded to 16 bytes
+  if (split_k <= 1) return 0;
+  return (((size_t)split_k * M * N + (size_t)split_k * 16 * M) * sizeof(float) + 15) & ~(size_t)15;
+}
+int round4(int n) { return (n + 3) & ~3; }
+}  // namespace
+
 size_t ptamd_gemm_workspace_bytes(int M, int N, int split_k) {
-  if (split_k <= 1 || M <= 0 || N <= 0) return 0;
-  return ((size_t)split_k * M * N + (size_t)split_k * 16 * M) * sizeof(float);  // C slabs + column-sum slabs
+  if (M <= 0 || N <= 0) return 0;
+  return slab_bytes(M, N, split_k) + (size_t)(round4(M) + round4(N)) * sizeof(uint32_t);  // + row scales (f16x2 arithmetic)
 }
 
 int ptamd_gemm_set_mode(int mode) {
-  if (mode != PTAMD_GEMM_F32 && mode != PTAMD_GEMM_BF16X3 && mode != PTAMD_GEMM_BF16X3_FULL) return PTAMD_ERR_BAD_SHAPE;
+  if (mode != PTAMD_GEMM_F32 && mode != PTAMD_GEMM_BF16X3 && mode != PTAMD_GEMM_BF16X3_FULL && mode != PTAMD_GEMM_F16X2)
+    return PTAMD_ERR_BAD_SHAPE;
   ptgemm::g_mode = mode;
   return PTAMD_OK;
 }
@@ -391,7 +400,7 @@ int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
   if ((a->flags & PTAMD_EPI_GATE) && !a->residual) return PTAMD_ERR_BAD_SHAPE;
   float *user_c = a->C;
   if (splits > 1) {
-    if (!a->workspace || a->workspace_bytes < ptamd_gemm_workspace_bytes(a->M, a->N, splits)) return PTAMD_ERR_WORKSPACE;
+    if (!a->workspace || a->workspace_bytes < slab_bytes(a->M, a->N, splits)) return PTAMD_ERR_WORKSPACE;
     p.slab = (size_t)a->M * a->N;
     p.C = static_cast<float *>(a->workspace);
     if (a->colsum) p.colsum = p.C + (size_t)splits * p.slab;
@@ -403,9 +412,19 @@ int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
     const size_t b_bytes = (size_t)(a->b_kmajor ? a->K : a->N) * a->ldb * sizeof(float);
     if (a->K < 16 || a_bytes >= ((size_t)1 << 32) || b_bytes >= ((size_t)1 << 32)) mode = PTAMD_GEMM_F32;
   }
+  p.scale_a = p.scale_b = nullptr;
+  if (mode == PTAMD_GEMM_F16X2) {  // the row scales live behind the split-K slabs
+    if (!a->workspace || !pt_aligned16(a->workspace) || a->workspace_bytes < ptamd_gemm_workspace_bytes(a->M, a->N, splits))
+      return PTAMD_ERR_WORKSPACE;
+    uint32_t *sa = reinterpret_cast<uint32_t *>(static_cast<char *>(a->workspace) + slab_bytes(a->M, a->N, splits));
+    uint32_t *sb = sa + round4(a->M);
+    if (const int rs = launch_row_scales(p, a->a_kmajor != 0, a->b_kmajor != 0, sa, sb, st)) return rs;
+    p.scale_a = sa;
+    p.scale_b = sb;
+  }
+  const int products = mode == PTAMD_GEMM_BF16X3_FULL ? 9 : mode == PTAMD_GEMM_F16X2 ? 3 : 6;
   const int rc = mode == PTAMD_GEMM_F32 ? launch_f32(p, a->a_kmajor != 0, a->b_kmajor != 0, splits, st)
-                                        : launch_split(p, a->a_kmajor != 0, a->b_kmajor != 0, splits,
-                                                       mode == PTAMD_GEMM_BF16X3_FULL ? 9 : 6, st);
+                                        : launch_split(p, a->a_kmajor != 0, a->b_kmajor != 0, splits, products, st);
   if (rc || splits == 1) return rc;
   const float *slabs = p.C;
   p.C = user_c;

@@ -37,6 +37,7 @@ struct GemmParams {
   float *colsum;     // k-major A only: colsum[m] (+)= sum_k A[k][m]; with split-K a [splits * share][M] slab, reduced later
   int colsum_share;  // N tiles sharing the column-sum work of one (M tile, split): power of two <= min(tiles_n, 16)
   float gate_scale;  // PTAMD_EPI_GATE
+  const uint32_t *scale_a, *scale_b;  // f16x2 arithmetic only: power-of-two scale (bits) per row of A / column of B
 };
 
 // ---- staging: each thread carries 4 float4 per operand per stage; global -> registers -> LDS, no transposition:
@@ -223,5 +224,7 @@ int persistent_grid();  // CUs of the current device (gemm.hip)
 // launchers of the two kernels: a_kmajor / b_kmajor select the instantiation
 int launch_f32(const GemmParams &p, bool a_kmajor, bool b_kmajor, int splits, hipStream_t st);
 int launch_split(const GemmParams &p, bool a_kmajor, bool b_kmajor, int splits, int products, hipStream_t st);
+// f16x2 arithmetic: fills scale_a[M] / scale_b[N] (device, uint32 bits of powers of two) from the operands of p
+int launch_row_scales(const GemmParams &p, bool a_kmajor, bool b_kmajor, uint32_t *scale_a, uint32_t *scale_b, hipStream_t st);
 
 }  // namespace ptgemm

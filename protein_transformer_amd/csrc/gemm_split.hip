@@ -111,6 +111,49 @@ __device__ __forceinline__ void store_split(unsigned short *__restrict__ s, int 
   }
 }
 
+// ---- f16x2 arithmetic (NPROD == 3): every operand row carries a power-of-two scale (gemm_row_scale_kernel below);
+// the producers load it with the stage (unconditionally, like the operand itself), multiply and split into TWO f16
+// planes, and the consumers undo the two scales on the accumulators before the epilogue.
+template <bool KMAJOR, int ROWS>
+__device__ __forceinline__ void scale_offsets(int rows, int r0, int pt, uint32_t (&soff)[4]) {
+  constexpr int LPK = ROWS / 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (!KMAJOR) soff[i] = (uint32_t)min(r0 + pt / 4 + 64 * (i < ROWS / 64 ? i : 0), rows - 1) * 4u;  // the row of v[i]
+    else soff[i] = (uint32_t)min(r0 + 4 * (pt % LPK), rows - 4) * 4u;                                  // the 4 rows of every v[i]
+  }
+}
+template <bool KMAJOR, int ROWS>
+__device__ __forceinline__ void load_scales(const uint32_t *__restrict__ scale, const uint32_t (&soff)[4], float (&sc)[4]) {
+  const char *base = reinterpret_cast<const char *>(scale);
+  if (!KMAJOR) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 64; ++i) sc[i] = *reinterpret_cast<const float *>(base + soff[i]);
+  } else {
+    const float4 v = *reinterpret_cast<const float4 *>(base + soff[0]);
+    sc[0] = v.x; sc[1] = v.y; sc[2] = v.z; sc[3] = v.w;
+  }
+}
+template <bool KMAJOR, int ROWS>
+__device__ __forceinline__ void store_split_f16(unsigned short *__restrict__ s, int pt, const float4 (&v)[ROWS / 64],
+                                                const float (&sc)[4]) {
+  constexpr int LPK = ROWS / 4, PLANE = ROWS * LD_RK, LD_KR = ROWS + KR_PAD;
+#pragma unroll
+  for (int i = 0; i < ROWS / 64; ++i) {
+    const int kl = KMAJOR ? pt / LPK + (NPRODUCER / LPK) * i : 4 * (pt % 4);
+    uint2 t1, t2;
+    split_pair_f16(v[i].x, v[i].y, KMAJOR ? sc[0] : sc[i], KMAJOR ? sc[1] : sc[i], t1.x, t2.x);
+    split_pair_f16(v[i].z, v[i].w, KMAJOR ? sc[2] : sc[i], KMAJOR ? sc[3] : sc[i], t1.y, t2.y);
+    const int off = KMAJOR ? kl * LD_KR + 4 * (pt % LPK) : (pt / 4 + 64 * i) * LD_RK + kl;
+    *reinterpret_cast<uint2 *>(s + off) = t1;
+    *reinterpret_cast<uint2 *>(s + PLANE + off) = t2;
+  }
+}
+// scale (bits of a power of two) of a row whose largest |x| has the bits `amax`: max |x| * scale in [2^14, 2^15);
+// rows of zeros / subnormals get the largest finite power.  A larger maximum gives a SMALLER scale (atomicMin).
+__device__ __forceinline__ uint32_t row_scale_bits(uint32_t amax) { return min(268u - (amax >> 23), 254u) << 23; }
+__device__ __forceinline__ float inverse_scale(uint32_t scale_bits) { return __uint_as_float((254u << 23) - scale_bits); }
+
 // MFMA operand of the 32 tile rows starting at r0, plane t: lane l holds row r0 + (l & 31), k = 8 (l >> 5) + 0..7
 template <bool KMAJOR, int ROWS>
 __device__ __forceinline__ bf16x8 read_frag(const unsigned short *__restrict__ s, int r0, int lane, int t) {
@@ -148,6 +191,7 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
   float *const scratch = reinterpret_cast<float *>(smem + 2 * STAGE);
   float *const cs_area = scratch + SCRATCH_FLOATS;
 
+  constexpr bool F16 = NPROD == 3;  // two scaled f16 terms and three products instead of three bf16 terms and six
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const WorkRange work(p, TBM, TBN);
   if (work.begin >= work.end) return;
@@ -209,22 +253,36 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
     item_offsets<A_KMAJOR, TBM>(p.lda, p.M, ld.it.bm0, pt, voa);
     item_offsets<B_KMAJOR, TBN>(p.ldb, p.N, ld.it.bn0, pt, vob);
     float4 ra[NSETS][4], rb[NSETS][2];                 // NSETS stages in flight (registers)
+    float rsa[NSETS][4], rsb[NSETS][4];                // f16x2 only: the row scales that go with them
+    uint32_t soa[4], sob[4];
+    if (F16) {
+      scale_offsets<A_KMAJOR, TBM>(p.M, ld.it.bm0, pt, soa);
+      scale_offsets<B_KMAJOR, TBN>(p.N, ld.it.bn0, pt, sob);
+    }
     int rskip[NSETS];
-    auto fetch = [&](float4 (&a)[4], float4 (&b)[2], int &kskip) __attribute__((always_inline)) {
+    auto fetch = [&](float4 (&a)[4], float4 (&b)[2], int &kskip, float (&sa_)[4], float (&sb_)[4]) __attribute__((always_inline)) {
       const int klim = ld.it.kend - ld.k0;
       const int ks = klim >= SBK ? ld.k0 : ld.it.kend - SBK;  // the last stage of an item may start early
       kskip = ld.k0 - ks;
       load_raw(p.A + (A_KMAJOR ? (size_t)ks * p.lda : (size_t)ks), voa, a);
       load_raw(p.B + (B_KMAJOR ? (size_t)ks * p.ldb : (size_t)ks), vob, b);
+      if (F16) {
+        load_scales<A_KMAJOR, TBM>(p.scale_a, soa, sa_);
+        load_scales<B_KMAJOR, TBN>(p.scale_b, sob, sb_);
+      }
       const int w_before = ld.w;
       advance(ld);
       if (ld.w != w_before) {  // uniform, no memory access inside
         item_offsets<A_KMAJOR, TBM>(p.lda, p.M, ld.it.bm0, pt, voa);
         item_offsets<B_KMAJOR, TBN>(p.ldb, p.N, ld.it.bn0, pt, vob);
+        if (F16) {
+          scale_offsets<A_KMAJOR, TBM>(p.M, ld.it.bm0, pt, soa);
+          scale_offsets<B_KMAJOR, TBN>(p.N, ld.it.bn0, pt, sob);
+        }
       }
     };
     // convert + store the stage under `st` into LDS buffer `buf`, then refill the registers two stages ahead
-    auto produce = [&](float4 (&a)[4], float4 (&b)[2], int &kskip, int buf) __attribute__((always_inline)) {
+    auto produce = [&](float4 (&a)[4], float4 (&b)[2], int &kskip, float (&sa_)[4], float (&sb_)[4], int buf) __attribute__((always_inline)) {
       unsigned short *sa = smem + buf * STAGE, *sb = sa + 3 * PLANE_A;
       mask_tail<A_KMAJOR, TBM>(pt, a, kskip);
       mask_tail<B_KMAJOR, TBN>(pt, b, kskip);
@@ -237,8 +295,13 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
           csum.w = fmaf(cs_w[i], a[i].w, csum.w); asm volatile("" : "+v"(csum.w));
         }
       }
-      store_split<A_KMAJOR, TBM>(sa, pt, a);
-      store_split<B_KMAJOR, TBN>(sb, pt, b);
+      if (F16) {
+        store_split_f16<A_KMAJOR, TBM>(sa, pt, a, sa_);
+        store_split_f16<B_KMAJOR, TBN>(sb, pt, b, sb_);
+      } else {
+        store_split<A_KMAJOR, TBM>(sa, pt, a);
+        store_split<B_KMAJOR, TBN>(sb, pt, b);
+      }
       if (has_colsum && !st.end && st.k0 + SBK >= st.it.kend) {  // last stage of its item: publish (LDS only)
         if (colsum_on(st.it)) {
           // Three rotating areas: an item's sums are published one stage before the consumers finish the item and read
@@ -260,22 +323,22 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
       // the set could not stay in place across the loop and the copies (each waiting for its load) would drain the
       // prefetch queue every iteration
       __builtin_amdgcn_sched_barrier(0);
-      fetch(a, b, kskip);
+      fetch(a, b, kskip, sa_, sb_);
     };
     // (the scheduling fences keep the ISSUE ORDER of the prologue loads: the scheduler would otherwise sink the later
     // fetches below the refill to shorten live ranges, and since vmcnt counts in order every later wait for an older
     // register set would have to drain the newer ones as well)
 #pragma unroll
     for (int u = 0; u < NSETS; ++u) {
-      fetch(ra[u], rb[u], rskip[u]);
+      fetch(ra[u], rb[u], rskip[u], rsa[u], rsb[u]);
       __builtin_amdgcn_sched_barrier(0);
     }
-    produce(ra[0], rb[0], rskip[0], 0);  // stage 0 -> buffer 0, set 0 <- stage NSETS
+    produce(ra[0], rb[0], rskip[0], rsa[0], rsb[0], 0);  // stage 0 -> buffer 0, set 0 <- stage NSETS
     __syncthreads();
     for (int g = 0; g < padded_stages; g += NSETS) {  // no exit in the middle: the register sets keep their roles
 #pragma unroll
       for (int u = 1; u <= NSETS; ++u) {
-        produce(ra[u % NSETS], rb[u % NSETS], rskip[u % NSETS], u & 1);  // stage g + u -> buffer (g + u) & 1
+        produce(ra[u % NSETS], rb[u % NSETS], rskip[u % NSETS], rsa[u % NSETS], rsb[u % NSETS], u & 1);  // stage g + u -> buffer (g + u) & 1
         __syncthreads();
       }
     }
@@ -319,10 +382,16 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ta], fb[j][tb], acc[i][j], 0, 0, 0);
+            acc[i][j] = F16 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][ta]),
+                                                                     __builtin_bit_cast(f16x8, fb[j][tb]), acc[i][j], 0, 0, 0)
+                            : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ta], fb[j][tb], acc[i][j], 0, 0, 0);
       };
       // smallest products first; fragments are read in the order the products need them
-      if (NPROD == 9) {
+      if (NPROD == 3) {
+        read_a(1); read_b(0); mul(1, 0);
+        read_a(0); read_b(1); mul(0, 1);
+        mul(0, 0);
+      } else if (NPROD == 9) {
         read_a(2); read_b(2); mul(2, 2);
         read_b(1); mul(2, 1);
         read_a(1); mul(1, 2);
@@ -333,12 +402,28 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
         read_a(0); read_b(2); mul(0, 2);
         read_a(1); read_b(1);
       }
-      mul(1, 1); mul(1, 0); mul(0, 1); mul(0, 0);
+      if (NPROD != 3) { mul(1, 1); mul(1, 0); mul(0, 1); mul(0, 0); }
       __syncthreads();  // buffer g & 1 is released, buffer (g + 1) & 1 holds stage g + 1
       if (cc.k0 + SBK >= cc.it.kend) {  // that was the item's last stage
         float *C = p.C + (partial ? (size_t)cc.it.z * p.slab : 0);
         const int ldc = partial ? p.N : p.ldc;
         const int row0 = cc.it.bm0 + wm * 128, col0 = cc.it.bn0 + wn * 64;
+        if (F16) {  // back from the scaled operands: acc / (scale_a[row] scale_b[col]), exact (powers of two)
+          const int l31 = lane & 31, lh = lane >> 5;
+          float ib[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) ib[j] = inverse_scale(p.scale_b[min(col0 + j * 32 + l31, p.N - 1)]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float ia = inverse_scale(p.scale_a[min(row0 + i * 32 + 8 * g + 4 * lh + e, p.M - 1)]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j][g * 4 + e] = acc[i][j][g * 4 + e] * ia * ib[j];
+              }
+        }
         if (p.vec_epilogue) tile_epilogue_vec<4, true, EPI>(p, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 2048);
         else tile_epilogue_vec<4, false, EPI>(p, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 2048);
         zero_acc();
@@ -354,6 +439,76 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
         }
       }
       advance(cc);
+    }
+  }
+}
+
+// ---- row scales of the f16x2 arithmetic: scale[r] = the power of two that takes max_k |x[r][k]| into [2^14, 2^15).
+// One launch covers both operands (blocks [0, ja.blocks) work on A, the rest on B).
+//   K-contiguous operand [rows][K]: a wavefront reduces 8 rows at a time (8 independent 16-byte loads per lane in flight)
+//                                   and stores the scale;
+//   row-contiguous operand [K][rows]: a block takes 256 rows x a chunk of RS_KCHUNK k, its threads 4 consecutive rows
+//                                   each, and the chunks meet in an atomicMin on the scale bits (a larger maximum is a
+//                                   smaller scale; the array is preset to the largest scale by the launcher).
+struct ScaleJob {
+  const float *x;
+  int ld, rows, K, kmajor;
+  uint32_t *scale;
+  int blocks;
+};
+constexpr int RS_THREADS = 256, RS_ROWS = 32, RS_KCHUNK = 128;
+
+__device__ __forceinline__ float absmax4(float m, const float4 v) {
+  return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+
+__global__ __launch_bounds__(RS_THREADS) void gemm_row_scale_kernel(const ScaleJob ja, const ScaleJob jb) {
+  const bool second = (int)blockIdx.x >= ja.blocks;
+  const ScaleJob j = second ? jb : ja;
+  const int b = (int)blockIdx.x - (second ? ja.blocks : 0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (!j.kmajor) {
+    const int r0 = b * RS_ROWS + wave * 8;
+    float m[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) m[r] = 0.f;
+    for (int k = lane * 4; k < j.K; k += 256) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r)  // (rows past the end repeat the last one: same value, same store)
+        m[r] = absmax4(m[r], *reinterpret_cast<const float4 *>(j.x + (size_t)min(r0 + r, j.rows - 1) * j.ld + k));
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+#pragma unroll
+      for (int o = 32; o; o >>= 1) m[r] = fmaxf(m[r], __shfl_xor(m[r], o));
+      if (lane == 0) j.scale[min(r0 + r, j.rows - 1)] = row_scale_bits(__float_as_uint(m[r]));
+    }
+  } else {
+    __shared__ float4 red[RS_THREADS];
+    const int groups = (j.rows + 255) / 256;
+    const int grp = b % groups, chunk = b / groups;
+    const int r4 = grp * 256 + lane * 4;
+    const int kbeg = chunk * RS_KCHUNK, kend = min(j.K, kbeg + RS_KCHUNK);
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r4 < j.rows) {
+#pragma unroll 8
+      for (int k = kbeg + wave; k < kend; k += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(j.x + (size_t)k * j.ld + r4);
+        m.x = fmaxf(m.x, fabsf(v.x)); m.y = fmaxf(m.y, fabsf(v.y)); m.z = fmaxf(m.z, fabsf(v.z)); m.w = fmaxf(m.w, fabsf(v.w));
+      }
+    }
+    red[tid] = m;
+    __syncthreads();
+    if (wave == 0 && r4 < j.rows) {
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const float4 o = red[tid + 64 * w];
+        m.x = fmaxf(m.x, o.x); m.y = fmaxf(m.y, o.y); m.z = fmaxf(m.z, o.z); m.w = fmaxf(m.w, o.w);
+      }
+      atomicMin(j.scale + r4 + 0, row_scale_bits(__float_as_uint(m.x)));
+      atomicMin(j.scale + r4 + 1, row_scale_bits(__float_as_uint(m.y)));
+      atomicMin(j.scale + r4 + 2, row_scale_bits(__float_as_uint(m.z)));
+      atomicMin(j.scale + r4 + 3, row_scale_bits(__float_as_uint(m.w)));
     }
   }
 }
@@ -384,8 +539,27 @@ int launch_layout(const GemmParams &p, bool ak, bool bk, int splits, hipStream_t
 
 }  // namespace
 
+int launch_row_scales(const GemmParams &p, bool a_kmajor, bool b_kmajor, uint32_t *scale_a, uint32_t *scale_b, hipStream_t st) {
+  auto job = [](const float *x, int ld, int rows, int K, bool kmajor, uint32_t *scale) {
+    ScaleJob j = {x, ld, rows, K, kmajor ? 1 : 0, scale, 0};
+    j.blocks = kmajor ? ((rows + 255) / 256) * ((K + RS_KCHUNK - 1) / RS_KCHUNK) : (rows + RS_ROWS - 1) / RS_ROWS;
+    return j;
+  };
+  const ScaleJob ja = job(p.A, p.lda, p.M, p.K, a_kmajor, scale_a), jb = job(p.B, p.ldb, p.N, p.K, b_kmajor, scale_b);
+  if (a_kmajor) PT_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scale_a), (int)(254u << 23), (size_t)p.M, st));
+  if (b_kmajor) PT_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scale_b), (int)(254u << 23), (size_t)p.N, st));
+  hipLaunchKernelGGL(gemm_row_scale_kernel, dim3(ja.blocks + jb.blocks), dim3(RS_THREADS), 0, st, ja, jb);
+  return pt_check_launch();
+}
+
 int launch_split(const GemmParams &p, bool a_kmajor, bool b_kmajor, int splits, int products, hipStream_t st) {
   if (products == 9) return launch_layout<9, EPI_FULL>(p, a_kmajor, b_kmajor, splits, st);
+  if (products == 3) {
+    const bool plain3 = p.slab != 0 || (!p.bias && !p.residual && !p.flags && p.dropout_p == 0.f);
+    if (plain3) return launch_layout<3, EPI_PLAIN>(p, a_kmajor, b_kmajor, splits, st);
+    if (p.dropout_p == 0.f) return launch_layout<3, EPI_NODROP>(p, a_kmajor, b_kmajor, splits, st);
+    return launch_layout<3, EPI_FULL>(p, a_kmajor, b_kmajor, splits, st);
+  }
   // the smallest epilogue that does the job (instruction-cache footprint, see gemm_common.h)
   const bool plain = p.slab != 0 || (!p.bias && !p.residual && !p.flags && p.dropout_p == 0.f);
   if (plain) return launch_layout<6, EPI_PLAIN>(p, a_kmajor, b_kmajor, splits, st);

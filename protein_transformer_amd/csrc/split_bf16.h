@@ -7,6 +7,8 @@ namespace ptsplit {
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -33,6 +35,23 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t &t1, uin
   float q1 = r1 - __uint_as_float(t2 & 0xffff0000u);
   asm volatile("" : "+v"(q1));
   t3 = pack_bf16(q0, q1);
+}
+
+// Two f16 terms of the SCALED value: x s = h1 + h2 + e with |e| <= 2^-22 |x s| (2^-24 absolute where h2 is subnormal).
+// s is a power of two that takes the largest |x| of the operand row into [2^14, 2^15), so x s is exact, h1 cannot
+// overflow and the residual x s - h1 (one fma, exact) stays a normal f16 for values down to 2^-18 of the row maximum.
+// Scalar operations for the reason given above (v_pk_mul_f32 / v_pk_fma_f32 beside MFMAs).
+__device__ __forceinline__ void split_pair_f16(float x0, float x1, float s0, float s1, uint32_t &t1, uint32_t &t2) {
+  float a0 = x0 * s0, a1 = x1 * s1;
+  asm volatile("" : "+v"(a0));
+  asm volatile("" : "+v"(a1));
+  const f16x2 h = __builtin_convertvector((f32x2){a0, a1}, f16x2);  // v_cvt_pk_f16_f32, round to nearest even
+  float r0 = fmaf(x0, s0, -(float)h[0]), r1 = fmaf(x1, s1, -(float)h[1]);  // v_fma_mix_f32
+  asm volatile("" : "+v"(r0));
+  asm volatile("" : "+v"(r1));
+  const f16x2 g = __builtin_convertvector((f32x2){r0, r1}, f16x2);
+  t1 = __builtin_bit_cast(uint32_t, h);
+  t2 = __builtin_bit_cast(uint32_t, g);
 }
 // eight f32 -> the three bf16x8 MFMA operands
 __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 (&f)[3]) {

@@ -22,11 +22,8 @@ GEMM_BYTES = []          # algorithmic operand bytes (A + B + C [+ residual, + a
 def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, bias=None, residual=None,
          ldr=0, flags=0, dropout_p=0.0, seed=0, stream_id=0, split_k=1, colsum=None, gate_scale=0.0):
     """C[M,N] = epilogue(A (*) B); operand layouts as documented in ptamd.h."""
-    ws = None
-    nbytes = 0
-    if split_k > 1:
-        nbytes = lib().ptamd_gemm_workspace_bytes(M, N, split_k)
-        ws = workspace("gemm", nbytes, C_out.device)
+    # split-K slabs and, for the f16x2 arithmetic, the row scales of the two operands
+    ws = workspace("gemm", lib().ptamd_gemm_workspace_bytes(M, N, split_k), C_out.device)
     args = GemmArgs(M=M, N=N, K=K, A=A.data_ptr(), lda=lda, a_kmajor=int(a_kmajor), B=B.data_ptr(), ldb=ldb,
                     b_kmajor=int(b_kmajor), C=C_out.data_ptr(), ldc=ldc,
                     bias=bias.data_ptr() if bias is not None else None,
@@ -48,7 +45,7 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False,
     return C_out
 
 
-GEMM_F32, GEMM_BF16X3, GEMM_BF16X3_FULL = 0, 1, 2   # ptamd.h: PTAMD_GEMM_*
+GEMM_F32, GEMM_BF16X3, GEMM_BF16X3_FULL, GEMM_F16X2 = 0, 1, 2, 3   # ptamd.h: PTAMD_GEMM_*
 
 
 def set_gemm_mode(mode):

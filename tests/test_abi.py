@@ -53,8 +53,9 @@ def test_host_only_entry_points(built_lib):
     assert lib.ptamd_sidechain_atoms(20) == -1 and lib.ptamd_sidechain_atoms(-1) == -1
     assert lib.ptamd_nerf_workspace_bytes(32, 512) == 32 * 512 * 12 * 4
     assert lib.ptamd_drmsd_workspace_bytes(32, 512) > 32 * 512 * 14 * 52
-    assert lib.ptamd_gemm_workspace_bytes(512, 512, 1) == 0
-    assert lib.ptamd_gemm_workspace_bytes(512, 512, 8) == (8 * 512 * 512 + 8 * 16 * 512) * 4   # C slabs + column-sum slabs
+    assert lib.ptamd_gemm_workspace_bytes(512, 512, 1) == (512 + 512) * 4    # row scales of the f16x2 arithmetic
+    assert lib.ptamd_gemm_workspace_bytes(512, 512, 8) == (8 * 512 * 512 + 8 * 16 * 512) * 4 + (512 + 512) * 4   # + C / column-sum slabs
+    assert lib.ptamd_gemm_workspace_bytes(510, 30, 1) == (512 + 32) * 4
     # argument validation happens on the host, before any launch
     assert lib.ptamd_nerf_fwd(None, None, 0, 5, None, None, None) == -1          # PTAMD_ERR_BAD_SHAPE
     assert lib.ptamd_nerf_fwd(None, None, 2, 5000, None, None, None) == -2       # PTAMD_ERR_TOO_LONG

@@ -32,10 +32,10 @@ def assert_close(got, ref, rtol, atol, what=""):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-GEMM_MODES = [0, 1, 2]   # PTAMD_GEMM_F32 (exact f32 MFMA), PTAMD_GEMM_BF16X3 (default), PTAMD_GEMM_BF16X3_FULL
+GEMM_MODES = [0, 1, 2, 3]   # PTAMD_GEMM_F32 (exact f32 MFMA), _BF16X3 (default), _BF16X3_FULL, _F16X2 (row-scaled f16 pairs)
 
 
-@pytest.fixture(params=GEMM_MODES, ids=["f32", "bf16x3", "bf16x3full"])
+@pytest.fixture(params=GEMM_MODES, ids=["f32", "bf16x3", "bf16x3full", "f16x2"])
 def gemm_mode(request):
     from protein_transformer_amd import kernels as K_
     old = K_.get_gemm_mode()
@@ -141,7 +141,7 @@ def test_gemm_randomised(dev, seed):
     old = K_.get_gemm_mode()
     try:
         for _ in range(40):
-            mode = int(rng.integers(0, 3))
+            mode = int(rng.integers(0, 4))
             a_km, b_km = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
             M, N, Kd = (int(rng.integers(1, 700)) for _ in range(3))
             if a_km:
@@ -229,6 +229,64 @@ def test_gemm_split_bf16_is_fp32_grade(dev):
                 assert mx <= 1.5 * f32_max + 2e-8, (M, N, Kd, mode, errs)
                 assert mx <= 2e-6, (M, N, Kd, mode, errs)          # absolute, in units of sum |a||b|
             print(f"K={Kd}: rel err (max, rms) f32 {errs[0]}, bf16x3 {errs[1]}, bf16x3full {errs[2]}")
+    finally:
+        K_.set_gemm_mode(old)
+
+
+def test_gemm_f16x2_error_model(dev):
+    """PTAMD_GEMM_F16X2 (row-scaled f16 pairs, three products) against fp64: what include/ptamd.h states.
+
+    (1) operands whose rows span a moderate range - every tensor of the training step: activations, gradients with
+        per-token magnitudes from 1e-9 to 1e3, weights - meet the fp32 bound, in units of sum |a||b|;
+    (2) rows spanning more than 18 binades only meet the norm-wise bound 2^-20 sum|a||b| + 2^-36 K max|a_row| max|b_col|;
+    (3) zero rows, single-element rows, huge and tiny magnitudes do not overflow, underflow or produce NaN.
+    """
+    from protein_transformer_amd import kernels as K_
+    old = K_.get_gemm_mode()
+
+    def run(a, b, mode, a_km=False, b_km=False, split=1):
+        K_.set_gemm_mode(mode)
+        M, N, Kd = a.shape[0], b.shape[0], a.shape[1]
+        A = (a.T if a_km else a).contiguous().to(dev)
+        B = (b.T if b_km else b).contiguous().to(dev)
+        c = torch.empty(M, N, device=dev)
+        K_.gemm(A, B, c, M=M, N=N, K=Kd, lda=A.stride(0), ldb=B.stride(0), ldc=N, a_kmajor=a_km, b_kmajor=b_km, split_k=split)
+        return c.cpu().double()
+    try:
+        g = torch.Generator().manual_seed(11)
+        # (1) per-row magnitudes over 12 decades, a few binades inside a row
+        for (M, N, Kd, a_km, b_km, split) in [(512, 256, 512, False, False, 1), (384, 512, 2048, False, True, 1),
+                                              (256, 128, 8192, True, True, 8), (260, 132, 516, True, False, 1)]:
+            a = torch.randn(M, Kd, generator=g) * torch.exp(torch.empty(M, 1).uniform_(-20, 7, generator=g))
+            b = torch.randn(N, Kd, generator=g) * torch.exp(torch.empty(N, 1).uniform_(-8, 2, generator=g))
+            a[:, ::7] *= 64.0
+            ref, unit = a.double() @ b.double().T, a.abs().double() @ b.abs().double().T
+            e16 = ((run(a, b, K_.GEMM_F16X2, a_km, b_km, split) - ref).abs() / unit)
+            e32 = ((run(a, b, K_.GEMM_F32, a_km, b_km, split) - ref).abs() / unit)
+            print(f"K={Kd}: rel err (max, rms) f16x2 {e16.max():.2e} {e16.pow(2).mean().sqrt():.2e}  "
+                  f"f32 {e32.max():.2e} {e32.pow(2).mean().sqrt():.2e}")
+            assert e16.max().item() < 1e-6, (M, N, Kd)
+            assert e16.pow(2).mean().sqrt().item() < 1.5 * e32.pow(2).mean().sqrt().item() + 2e-8, (M, N, Kd)
+        # (2) 40 binades inside every row: the norm-wise bound holds, the component-wise one need not
+        M, N, Kd = 256, 256, 512
+        a = torch.randn(M, Kd, generator=g) * torch.exp(4 * torch.randn(M, Kd, generator=g))
+        b = torch.randn(N, Kd, generator=g) * torch.exp(4 * torch.randn(N, Kd, generator=g))
+        ref, unit = a.double() @ b.double().T, a.abs().double() @ b.abs().double().T
+        norm = 2.0 ** -20 * unit + 2.0 ** -36 * Kd * a.abs().amax(1, keepdim=True).double() * b.abs().amax(1).double()
+        err = (run(a, b, K_.GEMM_F16X2) - ref).abs()
+        assert bool((err <= norm).all()), (err / norm).max()
+        assert (err / unit).max().item() > 1e-5          # ... and the fp32 bound is indeed missed here
+        # (3) degenerate rows and extreme magnitudes
+        a = torch.randn(64, 256, generator=g)
+        b = torch.randn(64, 256, generator=g)
+        a[0] = 0.0; a[1] = 0.0; a[1, 5] = 3.0; a[2] *= 1e25; a[3] *= 1e-30; a[4] *= 1e-42   # row 4: subnormals only
+        b[0] = 0.0; b[2] *= 1e-25; b[3] *= 1e8
+        ref, unit = a.double() @ b.double().T, a.abs().double() @ b.abs().double().T
+        c = run(a, b, K_.GEMM_F16X2)
+        assert bool(torch.isfinite(c).all())
+        keep = torch.ones(64, dtype=torch.bool); keep[4] = False          # (a row of subnormals is flushed to zero)
+        assert bool(((c - ref).abs() <= 1e-6 * unit + 1e-37)[keep].all())       # (1e-37: products below the f32 range)
+        assert bool((c[4] == 0).all()) and bool((c[0] == 0).all()) and bool((c[:, 0] == 0).all())
     finally:
         K_.set_gemm_mode(old)
 
