@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-proteins", type=int, default=2, help="proteins in the bounded CPU-baseline sample")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--gemm-mode", default="bf16x3", choices=["f32", "bf16x3", "bf16x3full", "f16x2"],
+    ap.add_argument("--gemm-mode", default="auto", choices=["f32", "bf16x3", "bf16x3full", "f16x2", "auto"],
                     help="arithmetic of the encoder GEMMs (include/ptamd.h: ptamd_gemm_set_mode)")
     return ap.parse_args()
 
@@ -87,7 +87,7 @@ def main():
     dev = torch.device("cuda", dp.local_rank())
     torch.cuda.set_device(dev)
     kernels.set_gemm_mode({"f32": kernels.GEMM_F32, "bf16x3": kernels.GEMM_BF16X3, "bf16x3full": kernels.GEMM_BF16X3_FULL,
-                           "f16x2": kernels.GEMM_F16X2}[a.gemm_mode])
+                           "f16x2": kernels.GEMM_F16X2, "auto": kernels.GEMM_AUTO}[a.gemm_mode])
 
     # ---- synthetic, device-resident batches (two per rank, alternated)
     build = lambda ang, seq: nerf_forward(ang.to(dev), seq.to(dev))[0]            # noqa: E731
@@ -146,30 +146,38 @@ def main():
             traffic = round(json.load(f)["hbm_bytes_per_launch"])
     roofline = None
     if timing:
-        flops = sum(f for f, _, _ in timing)
+        flops = sum(t[0] for t in timing)
         gemm_bytes = kernels.GEMM_BYTES
-        ms = sum(e0.elapsed_time(e1) for _, e0, e1 in timing)
+        ms = sum(t[1].elapsed_time(t[2]) for t in timing)
         achieved = flops / (ms * 1e-3) / 1e12
-        mode = kernels.get_gemm_mode()
-        if mode == kernels.GEMM_F32:
-            kern, peak, products = "gemm_f32_mfma_kernel (v_mfma_f32_32x32x2_f32)", F32_MFMA_PEAK_TFLOPS, 1
-        elif mode == kernels.GEMM_F16X2:
-            # every f32 product is 3 f16 MFMA products (same dense peak as bf16); the launch time includes the row-scale pass
-            products = 3
-            kern = "gemm_bf16x3_mfma_kernel<NPROD=3> (v_mfma_f32_32x32x16_f16, 3 f16 products per f32 product) + gemm_row_scale_kernel"
-            peak = BF16_MFMA_PEAK_TFLOPS / products
-        else:
-            # every f32 product is 6 (mode 1) or 9 (mode 2) bf16 MFMA products: the f32-equivalent ceiling is the dense
-            # bf16 MFMA peak divided by that count
-            products = 6 if mode == kernels.GEMM_BF16X3 else 9
-            kern = f"gemm_bf16x3_mfma_kernel (v_mfma_f32_32x32x16_bf16, {products} bf16 products per f32 product)"
-            peak = BF16_MFMA_PEAK_TFLOPS / products
+        # Every launch runs one fp32 product as `products` matrix-pipe products (1: f32 MFMA; 3: two f16 terms; 6 / 9:
+        # three bf16 terms).  The f32-equivalent ceiling of the launch mix is the rate at which the mix would run with
+        # the matrix pipe at its dense peak throughout: sum(flop) / sum(flop_i * products_i / pipe peak_i).
+        pipe_time = sum(t[0] * t[3] / ((F32_MFMA_PEAK_TFLOPS if t[3] == 1 else BF16_MFMA_PEAK_TFLOPS) * 1e12) for t in timing)
+        peak = flops / pipe_time / 1e12
+        issued = sum(t[0] * t[3] for t in timing) / (ms * 1e-3) / 1e12
+        by_products = {}
+        for t in timing:
+            e = by_products.setdefault(t[3], [0, 0.0, 0.0])
+            e[0] += 1; e[1] += t[0]; e[2] += t[1].elapsed_time(t[2])
+        names = {1: "gemm_f32_mfma_kernel (v_mfma_f32_32x32x2_f32)",
+                 3: "gemm_bf16x3_mfma_kernel<NPROD=3> (two row-scaled f16 terms, 3 x v_mfma_f32_32x32x16_f16 per fp32 product; "
+                    "time includes gemm_row_scale_kernel)",
+                 6: "gemm_bf16x3_mfma_kernel<NPROD=6> (three bf16 terms, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product)",
+                 9: "gemm_bf16x3_mfma_kernel<NPROD=9> (three bf16 terms, all 9 products)"}
+        mix = {names[k]: {"launches_per_step": v[0] // a.steps, "tflops_f32_equivalent": round(v[1] / (v[2] * 1e-3) / 1e12, 1),
+                          "peak_f32_equivalent": round((F32_MFMA_PEAK_TFLOPS if k == 1 else BF16_MFMA_PEAK_TFLOPS) / k, 1),
+                          "ms_per_step": round(v[2] / a.steps, 3)} for k, v in sorted(by_products.items())}
+        kern = "ptamd_gemm: " + " + ".join(f"{v[0] // a.steps} x NPROD={k}" for k, v in sorted(by_products.items()))
+        products = issued / achieved
         roofline = {"bound": "mfma", "kernel": kern,
                     "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
                     "achieved_is": "algorithmic fp32 FLOP (2*M*N*K) per second of GEMM kernel time",
-                    "mfma_flops_issued_tflops": round(achieved * products, 1),
+                    "peak_is": "f32-equivalent ceiling of the launch mix: sum(flop) / sum(flop_i * products_i / dense MFMA peak_i)",
+                    "mfma_flops_issued_tflops": round(issued, 1),
                     "mfma_instruction_peak_tflops": BF16_MFMA_PEAK_TFLOPS if products > 1 else F32_MFMA_PEAK_TFLOPS,
+                    "launch_mix": mix,
                     "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_gemm_hbm_traffic.json)",
                     "algorithmic_bytes_per_launch": round(sum(b for b in gemm_bytes) / max(len(gemm_bytes), 1)),
                     "launches_per_step": len(timing) // a.steps, "avg_launch_us": round(1e3 * ms / len(timing), 2),
@@ -178,17 +186,20 @@ def main():
 
     dtype = {kernels.GEMM_F32: "f32",
              kernels.GEMM_F16X2: "f32 (GEMM operands row-scaled and split into 2 f16 terms on the f16 MFMA pipe, f32 accumulate; "
-                                 "attention operands split into 3 bf16 terms; the rest f32)"}.get(
+                                 "attention operands split into 3 bf16 terms; the rest f32)",
+             kernels.GEMM_AUTO: "f32 (GEMM operands split into 2 row-scaled f16 terms [activation x weight products] or exactly "
+                                "into 3 bf16 terms [weight-gradient products, attention] on the f16 / bf16 MFMA pipe, f32 "
+                                "accumulate; the rest f32)"}.get(
         kernels.get_gemm_mode(),
         "f32 (GEMM operands split exactly into 3 bf16 terms on the bf16 MFMA pipe, f32 accumulate; the rest f32)")
     # the stored line of the same bench in the exact-f32 MFMA mode (python bench.py --gemm-mode f32), for comparison
     f32_ref = None
-    fpath = os.path.join(ROOT, "profiles", "r01_v7_bench_gemm_mode_f32.json")
+    fpath = os.path.join(ROOT, "profiles", "r01_v9_bench_gemm_mode_f32.json")
     if roofline is not None and kernels.get_gemm_mode() != kernels.GEMM_F32 and os.path.exists(fpath):
         with open(fpath) as f:
             r = json.load(f)
         f32_ref = {"ms_per_step": r["ms_per_step"], "residues_per_s": r["value"], "gemm_tflops": r["roofline"]["achieved"],
-                   "gemm_frac_of_f32_mfma_peak": r["roofline"]["frac"], "source": "profiles/r01_v7_bench_gemm_mode_f32.json"}
+                   "gemm_frac_of_f32_mfma_peak": r["roofline"]["frac"], "source": "profiles/r01_v9_bench_gemm_mode_f32.json"}
     if roofline is not None:
         roofline["exact_f32_mfma_mode_reference"] = f32_ref
     if rank == 0:

@@ -132,7 +132,7 @@ typedef struct {
 size_t ptamd_gemm_workspace_bytes(int M, int N, int split_k);
 int ptamd_gemm(const ptamd_gemm_args *args, void *stream);
 
-/* Arithmetic of ptamd_gemm (process-wide; default PTAMD_GEMM_BF16X3, or the PTAMD_GEMM_MODE environment variable).
+/* Arithmetic of ptamd_gemm (process-wide; default PTAMD_GEMM_AUTO, or the PTAMD_GEMM_MODE environment variable).
  * The reference computes its Linear layers in fp32 (torch.nn.Linear on fp32 tensors); all modes take and
  * return fp32 and accumulate in fp32:
  *   PTAMD_GEMM_F32          v_mfma_f32_32x32x2_f32: bit-for-bit an fmaf chain over k (157 TF/s peak).
@@ -156,14 +156,23 @@ int ptamd_gemm(const ptamd_gemm_args *args, void *stream);
  *                           BELOW the fp32 fma chain (4e-7 vs 6e-7 max, 4e-8 vs 7e-8 rms in units of sum|x||y|), for
  *                           rows spanning 40 binades it does not (tests/test_gpu_kernels.py shows both).  A row of
  *                           subnormals only is flushed to zero.  Needs the workspace also when split_k <= 1.
- *                           Opt-in: the pass over the operands currently costs what the halved matrix work saves
- *                           (DESIGN.md section 6). */
+ *   PTAMD_GEMM_AUTO         per call: F16X2 when A is K-contiguous (activations / per-token gradients x weights: the
+ *                           pass over the operands is cheap next to the product), BF16X3 when A is k-major (the
+ *                           weight-gradient reductions over all tokens, where that pass would read both big operands
+ *                           once more).  Measured on the benchmark step: 15.0 ms against 15.75 (all BF16X3) and 15.3
+ *                           (all F16X2); gradients of a whole step against fp64: same level in every mode
+ *                           (tests/test_gpu_model.py).
+ * Whatever the mode, products with K < 16 or an operand of 4 GiB or more run in PTAMD_GEMM_F32. */
 #define PTAMD_GEMM_F32 0
 #define PTAMD_GEMM_BF16X3 1
 #define PTAMD_GEMM_BF16X3_FULL 2
 #define PTAMD_GEMM_F16X2 3
+#define PTAMD_GEMM_AUTO 4
 int ptamd_gemm_set_mode(int mode);
 int ptamd_gemm_get_mode(void);
+/* matrix-pipe products per fp32 product that ptamd_gemm would use for these arguments in the current mode:
+ * 1 (F32), 3 (F16X2), 6 (BF16X3), 9 (BF16X3_FULL); host only, nothing is launched */
+int ptamd_gemm_products(const ptamd_gemm_args *args);
 
 /* torch.nn.LayerNorm(D, eps=1e-5) (Sublayers.py:13,17): y = (x-mean)*rstd*gamma+beta; saves mean,rstd [T] */
 int ptamd_layernorm_fwd(const float *x, const float *gamma, const float *beta, int64_t T, int D, float *y,

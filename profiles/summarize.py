@@ -13,7 +13,7 @@ import csv
 import json
 import sys
 
-KERNEL = "_mfma_kernel"     # gemm_bf16x3_mfma_kernel (default arithmetic) or gemm_f32_mfma_kernel (PTAMD_GEMM_MODE=0)
+KERNEL = "_mfma_kernel"     # gemm_bf16x3_mfma_kernel<.., NPROD, ..> (NPROD = 3: f16x2, 6: bf16x3) or gemm_f32_mfma_kernel (PTAMD_GEMM_MODE=0)
 
 
 def stats(path, steps):
@@ -27,22 +27,28 @@ def stats(path, steps):
     print(f"{'all kernels':70s} {'':10s} {'':9s} {total / steps / 1e6:9.3f}")
 
 
-def counter_avg(path, name):
+def counter_avg(path, name, kernel=KERNEL):
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-            if "gemm_" in r["Kernel_Name"] and KERNEL in r["Kernel_Name"] and r["Counter_Name"] == name]
-    return sum(vals) / len(vals), len(vals)
+            if "gemm_" in r["Kernel_Name"] and kernel in r["Kernel_Name"] and r["Counter_Name"] == name]
+    return (sum(vals) / len(vals), len(vals)) if vals else (0.0, 0)
 
 
 def traffic(fetch_csv, write_csv, algorithmic, out):
     f, n = counter_avg(fetch_csv, "FETCH_SIZE")
     w, _ = counter_avg(write_csv, "WRITE_SIZE")
     hbm = (2.0 * f + w) * 1024.0
+    # the pass in front of an f16x2 product (row scales of both operands): its traffic per GEMM launch that has one
+    fs, ns = counter_avg(fetch_csv, "FETCH_SIZE", "row_scale_kernel")
+    ws, _ = counter_avg(write_csv, "WRITE_SIZE", "row_scale_kernel")
     rec = {
         "kernel": "gemm_*" + KERNEL, "launches_profiled": n, "fetch_size_kb_avg": f, "write_size_kb_avg": w,
         "fetch_correction": "x2: on gfx950 FETCH_SIZE tallies 128-B requests as 64 B for 16-B/lane coalesced reads "
                             "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncorrected",
         "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": float(algorithmic),
         "ratio": hbm / float(algorithmic),
+        "row_scale_pass": {"kernel": "gemm_row_scale_kernel", "launches_profiled": ns,
+                           "hbm_bytes_per_launch": (2.0 * fs + ws) * 1024.0,
+                           "note": "reads both operands of an f16x2 product once more; not part of hbm_bytes_per_launch"},
         "note": "counted at the L2's fabric side, so Infinity-Cache hits are included",
         "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python bench.py --steps 2 --warmup 1 "
                    "--no-cpu-baseline --no-kernel-timing ; same with --pmc WRITE_SIZE (separate passes)",

@@ -52,6 +52,7 @@ SIGNATURES = {
     "ptamd_gemm": (_i, [C.POINTER(GemmArgs), _p]),
     "ptamd_gemm_set_mode": (_i, [_i]),
     "ptamd_gemm_get_mode": (_i, []),
+    "ptamd_gemm_products": (_i, [C.POINTER(GemmArgs)]),
     "ptamd_layernorm_fwd": (_i, [_p, _p, _p, _i64, _i, _p, _p, _p, _p]),
     "ptamd_layernorm_bwd_workspace_bytes": (_sz, [_i]),
     "ptamd_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _p, _p, _p, _p, _sz, _p]),

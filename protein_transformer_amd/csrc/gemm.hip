@@ -330,10 +330,10 @@ int launch_f32(const GemmParams &p, bool a_kmajor, bool b_kmajor, int splits, hi
 int g_mode = -1;
 int current_mode() {
   if (g_mode < 0) {
-    g_mode = PTAMD_GEMM_BF16X3;
+    g_mode = PTAMD_GEMM_AUTO;
     if (const char *e = getenv("PTAMD_GEMM_MODE")) {
       const int v = atoi(e);
-      if (v == PTAMD_GEMM_F32 || v == PTAMD_GEMM_BF16X3 || v == PTAMD_GEMM_BF16X3_FULL || v == PTAMD_GEMM_F16X2) g_mode = v;
+      if (v == PTAMD_GEMM_F32 || v == PTAMD_GEMM_BF16X3 || v == PTAMD_GEMM_BF16X3_FULL || v == PTAMD_GEMM_F16X2 || v == PTAMD_GEMM_AUTO) g_mode = v;
     }
   }
   return g_mode;
@@ -359,12 +359,35 @@ size_t ptamd_gemm_workspace_bytes(int M, int N, int split_k) {
 }
 
 int ptamd_gemm_set_mode(int mode) {
-  if (mode != PTAMD_GEMM_F32 && mode != PTAMD_GEMM_BF16X3 && mode != PTAMD_GEMM_BF16X3_FULL && mode != PTAMD_GEMM_F16X2)
+  if (mode != PTAMD_GEMM_F32 && mode != PTAMD_GEMM_BF16X3 && mode != PTAMD_GEMM_BF16X3_FULL && mode != PTAMD_GEMM_F16X2 &&
+      mode != PTAMD_GEMM_AUTO)
     return PTAMD_ERR_BAD_SHAPE;
   ptgemm::g_mode = mode;
   return PTAMD_OK;
 }
 int ptamd_gemm_get_mode(void) { return ptgemm::current_mode(); }
+
+namespace {
+// the arithmetic one call runs in: the process-wide mode, AUTO resolved by operand layout, and the exact-f32 kernel
+// for what the split kernels do not take (they address an operand with 32-bit byte offsets and start a K tail 16 k
+// before its end)
+int resolve_mode(const ptamd_gemm_args *a) {
+  int mode = current_mode();
+  // AUTO: f16x2 where the pass over the operands is cheap next to the product (K-contiguous A: activations x weights),
+  // bf16x3 for the long token reductions of the weight gradients (both operands are read whole by that pass)
+  if (mode == PTAMD_GEMM_AUTO) mode = a->a_kmajor ? PTAMD_GEMM_BF16X3 : PTAMD_GEMM_F16X2;
+  const size_t a_bytes = (size_t)(a->a_kmajor ? a->K : a->M) * a->lda * sizeof(float);
+  const size_t b_bytes = (size_t)(a->b_kmajor ? a->K : a->N) * a->ldb * sizeof(float);
+  if (a->K < 16 || a_bytes >= ((size_t)1 << 32) || b_bytes >= ((size_t)1 << 32)) mode = PTAMD_GEMM_F32;
+  return mode;
+}
+}  // namespace
+
+int ptamd_gemm_products(const ptamd_gemm_args *a) {
+  if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0) return PTAMD_ERR_BAD_SHAPE;
+  const int mode = resolve_mode(a);
+  return mode == PTAMD_GEMM_F32 ? 1 : mode == PTAMD_GEMM_F16X2 ? 3 : mode == PTAMD_GEMM_BF16X3_FULL ? 9 : 6;
+}
 
 int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
   if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0) return PTAMD_ERR_BAD_SHAPE;
@@ -406,12 +429,7 @@ int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
     if (a->colsum) p.colsum = p.C + (size_t)splits * p.slab;
   }
   hipStream_t st = (hipStream_t)stream;
-  int mode = current_mode();
-  {  // the split kernel addresses an operand with 32-bit byte offsets and starts a K tail 16 k before its end
-    const size_t a_bytes = (size_t)(a->a_kmajor ? a->K : a->M) * a->lda * sizeof(float);
-    const size_t b_bytes = (size_t)(a->b_kmajor ? a->K : a->N) * a->ldb * sizeof(float);
-    if (a->K < 16 || a_bytes >= ((size_t)1 << 32) || b_bytes >= ((size_t)1 << 32)) mode = PTAMD_GEMM_F32;
-  }
+  const int mode = resolve_mode(a);
   p.scale_a = p.scale_b = nullptr;
   if (mode == PTAMD_GEMM_F16X2) {  // the row scales live behind the split-K slabs
     if (!a->workspace || !pt_aligned16(a->workspace) || a->workspace_bytes < ptamd_gemm_workspace_bytes(a->M, a->N, splits))

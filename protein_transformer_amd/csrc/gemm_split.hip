@@ -445,8 +445,7 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
 
 // ---- row scales of the f16x2 arithmetic: scale[r] = the power of two that takes max_k |x[r][k]| into [2^14, 2^15).
 // One launch covers both operands (blocks [0, ja.blocks) work on A, the rest on B).
-//   K-contiguous operand [rows][K]: a wavefront reduces 8 rows at a time (8 independent 16-byte loads per lane in flight)
-//                                   and stores the scale;
+//   K-contiguous operand [rows][K]: a wavefront reduces two rows (RS_ROWS = 8 per block) and stores their scales;
 //   row-contiguous operand [K][rows]: a block takes 256 rows x a chunk of RS_KCHUNK k, its threads 4 consecutive rows
 //                                   each, and the chunks meet in an atomicMin on the scale bits (a larger maximum is a
 //                                   smaller scale; the array is preset to the largest scale by the launcher).
@@ -456,7 +455,7 @@ struct ScaleJob {
   uint32_t *scale;
   int blocks;
 };
-constexpr int RS_THREADS = 256, RS_ROWS = 32, RS_KCHUNK = 128;
+constexpr int RS_THREADS = 256, RS_ROWS = 8, RS_KCHUNK = 128;
 
 __device__ __forceinline__ float absmax4(float m, const float4 v) {
   return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
@@ -468,20 +467,27 @@ __global__ __launch_bounds__(RS_THREADS) void gemm_row_scale_kernel(const ScaleJ
   const int b = (int)blockIdx.x - (second ? ja.blocks : 0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (!j.kmajor) {
-    const int r0 = b * RS_ROWS + wave * 8;
-    float m[8];
+    // RS_ROWS / 4 rows per wavefront, two at a time: many small wavefronts (this pass is latency-bound otherwise)
+    for (int rr = 0; rr < RS_ROWS / 4; rr += 2) {
+      const int r0 = b * RS_ROWS + wave * (RS_ROWS / 4) + rr;
+      if (r0 >= j.rows) break;  // wavefront-uniform
+      const int r1 = min(r0 + 1, j.rows - 1);  // (past the end: the last row again, same value, same store)
+      const float *p0 = j.x + (size_t)r0 * j.ld, *p1 = j.x + (size_t)r1 * j.ld;
+      float m0 = 0.f, m1 = 0.f;
+#pragma unroll 2
+      for (int k = lane * 4; k < j.K; k += 256) {
+        m0 = absmax4(m0, *reinterpret_cast<const float4 *>(p0 + k));
+        m1 = absmax4(m1, *reinterpret_cast<const float4 *>(p1 + k));
+      }
 #pragma unroll
-    for (int r = 0; r < 8; ++r) m[r] = 0.f;
-    for (int k = lane * 4; k < j.K; k += 256) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r)  // (rows past the end repeat the last one: same value, same store)
-        m[r] = absmax4(m[r], *reinterpret_cast<const float4 *>(j.x + (size_t)min(r0 + r, j.rows - 1) * j.ld + k));
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-#pragma unroll
-      for (int o = 32; o; o >>= 1) m[r] = fmaxf(m[r], __shfl_xor(m[r], o));
-      if (lane == 0) j.scale[min(r0 + r, j.rows - 1)] = row_scale_bits(__float_as_uint(m[r]));
+      for (int o = 32; o; o >>= 1) {
+        m0 = fmaxf(m0, __shfl_xor(m0, o));
+        m1 = fmaxf(m1, __shfl_xor(m1, o));
+      }
+      if (lane == 0) {
+        j.scale[r0] = row_scale_bits(__float_as_uint(m0));
+        j.scale[r1] = row_scale_bits(__float_as_uint(m1));
+      }
     }
   } else {
     __shared__ float4 red[RS_THREADS];

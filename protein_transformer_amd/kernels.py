@@ -40,12 +40,13 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False,
         e0.record()
         check(lib().ptamd_gemm(C.byref(args), stream()), "gemm")
         e1.record()
-        GEMM_TIMING.append((2.0 * M * N * K, e0, e1))
+        # (flops, events, matrix-pipe products per fp32 product of the arithmetic this call ran in)
+        GEMM_TIMING.append((2.0 * M * N * K, e0, e1, lib().ptamd_gemm_products(C.byref(args))))
         GEMM_BYTES.append(4 * (M * K + N * K + M * N * (1 + (residual is not None) + bool(flags & EPI_ACCUM))))
     return C_out
 
 
-GEMM_F32, GEMM_BF16X3, GEMM_BF16X3_FULL, GEMM_F16X2 = 0, 1, 2, 3   # ptamd.h: PTAMD_GEMM_*
+GEMM_F32, GEMM_BF16X3, GEMM_BF16X3_FULL, GEMM_F16X2, GEMM_AUTO = 0, 1, 2, 3, 4   # ptamd.h: PTAMD_GEMM_*
 
 
 def set_gemm_mode(mode):

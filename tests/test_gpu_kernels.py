@@ -32,7 +32,7 @@ def assert_close(got, ref, rtol, atol, what=""):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-GEMM_MODES = [0, 1, 2, 3]   # PTAMD_GEMM_F32 (exact f32 MFMA), _BF16X3 (default), _BF16X3_FULL, _F16X2 (row-scaled f16 pairs)
+GEMM_MODES = [0, 1, 2, 3]   # PTAMD_GEMM_F32 (exact f32 MFMA), _BF16X3, _BF16X3_FULL, _F16X2 (row-scaled f16 pairs); AUTO = 3 or 1
 
 
 @pytest.fixture(params=GEMM_MODES, ids=["f32", "bf16x3", "bf16x3full", "f16x2"])
@@ -141,7 +141,7 @@ def test_gemm_randomised(dev, seed):
     old = K_.get_gemm_mode()
     try:
         for _ in range(40):
-            mode = int(rng.integers(0, 4))
+            mode = int(rng.integers(0, 5))
             a_km, b_km = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
             M, N, Kd = (int(rng.integers(1, 700)) for _ in range(3))
             if a_km:
