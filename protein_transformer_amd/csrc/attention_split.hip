@@ -3,7 +3,7 @@
 // Same operator, interface, masking, dropout hash and outputs as attention.hip
 //   /root/reference/protein_transformer/models/transformer/Attention.py:14-22,55-68
 // but every f32 matrix product (QK^T, PV and the five products of the backward pass) is evaluated as six
-// v_mfma_f32_32x32x16_bf16 products of exactly split operands (see gemm_split.hip / split_bf16.h): 6/16 of the matrix
+// v_mfma_f32_32x32x16_bf16 products of exactly split operands (see gemm_split_kernel.h / split_bf16.h): 6/16 of the matrix
 // pipe time of the f32 MFMA at the same accuracy.  Selected by ptamd_gemm_set_mode like the GEMMs.
 //
 // Decomposition as in attention.hip but with 8 wavefronts: one workgroup = (protein, head, 256 queries), 32 per

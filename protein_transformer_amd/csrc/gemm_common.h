@@ -1,4 +1,4 @@
-// Pieces shared by the two MFMA GEMM kernels of libptamd (gemm.hip: exact f32 MFMA; gemm_split.hip: f32 operands
+// Pieces shared by the two MFMA GEMM kernels of libptamd (gemm.hip: exact f32 MFMA; gemm_split_kernel.h: f32 operands
 // split into three bf16 terms on the bf16 MFMA pipe): launch parameters, the global->register stage loader, the work
 // decomposition of the persistent workgroups and the fused epilogue.
 #pragma once
@@ -224,6 +224,7 @@ int persistent_grid();  // CUs of the current device (gemm.hip)
 // launchers of the two kernels: a_kmajor / b_kmajor select the instantiation
 int launch_f32(const GemmParams &p, bool a_kmajor, bool b_kmajor, int splits, hipStream_t st);
 int launch_split(const GemmParams &p, bool a_kmajor, bool b_kmajor, int splits, int products, hipStream_t st);
+int launch_split_f16x2(const GemmParams &p, bool a_kmajor, bool b_kmajor, int splits, hipStream_t st);
 // f16x2 arithmetic: fills scale_a[M] / scale_b[N] (device, uint32 bits of powers of two) from the operands of p
 int launch_row_scales(const GemmParams &p, bool a_kmajor, bool b_kmajor, uint32_t *scale_a, uint32_t *scale_b, hipStream_t st);
 

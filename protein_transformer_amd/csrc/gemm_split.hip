@@ -1,571 +1,11 @@
-// fp32 GEMM on the CDNA4 bf16 matrix pipe: each f32 operand is split exactly into three bf16 terms while it is
-// staged into LDS, and the product is evaluated as 6 (or 9) v_mfma_f32_32x32x16_bf16 products with f32 accumulation.
-//
-// Same role, interface and epilogues as gemm.hip (every torch.nn.Linear of the reference encoder and the backward
-// GEMMs: Attention.py:38-41,49,69; Sublayers.py:28-34; encoder_only.py:18,39-41) - see ptamd_gemm_set_mode.
-//
-// Why: on MI355X the f32-input MFMA runs at the vector rate (157 TF/s) while the bf16 MFMA is 16x faster.  An f32
-// has 24 significand bits = 3 x the 8 of a bf16 and the same exponent range, so with round-to-nearest at each level
-//     x = x1 + x2 + x3  exactly,  |x2| <= 2^-8 |x|,  |x3| <= 2^-16 |x|,
-// every bf16 x bf16 product is exact in the f32 accumulator, and
-//     x*y = x1y1 + (x1y2 + x2y1) + (x1y3 + x2y2 + x3y1) + [x2y3 + x3y2 + x3y3],   [..] <= 2^-23 |x y|.
-// Six products cost 6/16 of the f32 pipe time; the dropped bracket is below the rounding error the f32 fma chain
-// makes itself over K >= 64 terms (tests/test_gpu_kernels.py compares both with fp64).
-//
-// Structure (MI355X-first): one workgroup per CU = 8 wavefronts, two per SIMD with different jobs.
-//   * wavefronts 0-3 are CONSUMERS: each owns a 128 x 64 block (4 x 2 MFMA tiles of 32 x 32, 128 accumulator VGPRs) of
-//     the workgroup's 256 x 128 output tile and does nothing but ds_read fragments and issue MFMAs (48 per K step
-//     of 16), then the epilogue of the tile through its own LDS scratch;
-//   * wavefronts 4-7 are PRODUCERS: they fetch the f32 operands (16-byte coalesced loads from a scalar stage base + a
-//     32-bit lane offset, NSETS = 4 stages in flight, unconditional), split them with v_cvt_pk_bf16_f32 and scalar
-//     subtractions and write the three bf16 planes of the next stage into the other half of a double-buffered LDS
-//     image; they also add up the fused bias gradient (no branch, no memory access and no packed f32 instruction
-//     in their loop: each of the three was measured to cost 10-30 %).
-//   The matrix pipe of a SIMD is fed by its consumer while its producer uses the VALU, the LDS write path and the
-//   vector memory path: the two instruction streams overlap because they belong to different wavefronts.  One
-//   s_barrier per stage hands a finished buffer from the producers to the consumers and a consumed one back.
-// The 256 x 128 tile (rather than 128 x 128) cuts the L2 -> CU traffic and the LDS write traffic per MFMA by a
-// quarter - with the 16x faster pipe both are first-order costs (LDS writes run at ~80 B/clk/CU).
-// LDS image of a stage, per operand and plane:
-//   K-contiguous operand   -> [row][16 + 8 pad] bf16, fragment = one conflict-free ds_read_b128 (8 k of a row)
-//   row-contiguous operand -> [k][rows + 32 pad] bf16 (no transposition on the way in), fragment = two
-//                             ds_read_b64_tr_b16 (the LDS transpose read delivers 4 k of one row per lane).
-// Workgroups are persistent and walk contiguous (tile, K-split) ranges as in gemm.hip; the stage stream runs across
-// work items, so the producers fetch and convert the first stages of the next tile under the epilogue of this one.
-#include <stdlib.h>
-
-#include "gemm_common.h"
-#include "split_bf16.h"
+// ptamd_gemm in bf16x3 arithmetic: the 6- and 9-product instantiations of gemm_split_kernel.h (kernel description there).
+#include "gemm_split_kernel.h"
 
 namespace ptgemm {
-namespace {
-
-using namespace ptsplit;  // bf16x8, split_pair (x = t1 + t2 + t3 exactly, scalar subtractions), LDS transpose-read types
-
-constexpr int TBM = 256, TBN = 128;  // output tile of a workgroup
-constexpr int SBK = 16;              // f32 k per stage = one bf16 MFMA k step
-constexpr int NTHREADS = 512, NPRODUCER = 256;
-constexpr int NSETS = 4;             // register sets of a producer = stages of global loads in flight (even)
-constexpr int LD_RK = 24;            // bf16 per row of a [row][k] plane: 48 B = odd multiple of 16 B
-constexpr int KR_PAD = 32;           // a [k][rows + 32] plane: 4 consecutive k hit 4 different 64-B bank groups
-constexpr int PLANE_A = TBM * LD_RK, PLANE_B = TBN * LD_RK;   // 6144 / 3072 bf16 (the [k][row] forms are smaller)
-constexpr int STAGE = 3 * (PLANE_A + PLANE_B);                // 27648 bf16 = 55296 B
-constexpr int SCRATCH_FLOATS = 4 * 2048;                      // epilogue transpose scratch of the 4 consumers
-constexpr int COLSUM_AREAS = 3;                               // see the producers' publish / the consumers' read below
-constexpr int COLSUM_FLOATS = COLSUM_AREAS * 4 * TBM;         // rotating [4 k groups][256 rows] partial sums
-constexpr size_t LDS_BYTES = (size_t)2 * STAGE * sizeof(unsigned short) + (SCRATCH_FLOATS + COLSUM_FLOATS) * sizeof(float);
-static_assert(PLANE_A >= SBK * (TBM + KR_PAD) && PLANE_B >= SBK * (TBN + KR_PAD), "plane must hold either layout");
-static_assert(LDS_BYTES <= 160 * 1024, "LDS budget of a CU");
-
-// One stage of one operand (ROWS tile rows x 16 k), global -> registers of the 256 producer threads: ROWS / 64
-// float4 per thread, each from  (scalar base of the stage) + (32-bit per-thread byte offset of the work item),
-// so a stage costs no address arithmetic in the vector unit.  The loads are UNCONDITIONAL and nothing touches the
-// registers until store_split two stages later: a predicated load becomes a branch, behind which the compiler can
-// no longer count the loads in flight, and a select on the loaded value would wait for it at once - either way
-// the prefetch distance collapses.  Rows beyond the operand are clamped (they only feed output rows that are never
-// stored); a K tail is handled by starting the last stage of an item 16 k before its end and zeroing the k that
-// were already consumed (store_split's `kskip`).
-template <bool KMAJOR, int ROWS>
-__device__ __forceinline__ void item_offsets(int ld, int rows, int r0, int pt, uint32_t (&voff)[ROWS / 64]) {
-  constexpr int LPK = ROWS / 4;  // lanes per k of a row-contiguous operand
-#pragma unroll
-  for (int i = 0; i < ROWS / 64; ++i) {
-    if (!KMAJOR) voff[i] = ((uint32_t)min(r0 + pt / 4 + 64 * i, rows - 1) * (uint32_t)ld + 4 * (pt % 4)) * 4u;
-    else voff[i] = ((uint32_t)(pt / LPK + (NPRODUCER / LPK) * i) * (uint32_t)ld + min(r0 + 4 * (pt % LPK), rows - 4)) * 4u;
-  }
-}
-template <int N>
-__device__ __forceinline__ void load_raw(const float *__restrict__ stage_base, const uint32_t (&voff)[N], float4 (&v)[N]) {
-#pragma unroll
-  for (int i = 0; i < N; ++i)
-    v[i] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(stage_base) + voff[i]);
-}
-
-// the first kskip k of a stage are zeroed (only the last stage of an item whose K range is not a multiple of 16)
-template <bool KMAJOR, int ROWS>
-__device__ __forceinline__ void mask_tail(int pt, float4 (&v)[ROWS / 64], int kskip) {
-  constexpr int LPK = ROWS / 4;
-  if (kskip > 0) {  // uniform
-#pragma unroll
-    for (int i = 0; i < ROWS / 64; ++i) {
-      const int kl = KMAJOR ? pt / LPK + (NPRODUCER / LPK) * i : 4 * (pt % 4);
-      if (kl < kskip) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-}
-// registers of one stage -> the three LDS planes of the operand at `s`
-template <bool KMAJOR, int ROWS>
-__device__ __forceinline__ void store_split(unsigned short *__restrict__ s, int pt, const float4 (&v)[ROWS / 64]) {
-  constexpr int LPK = ROWS / 4, PLANE = ROWS * LD_RK, LD_KR = ROWS + KR_PAD;
-#pragma unroll
-  for (int i = 0; i < ROWS / 64; ++i) {
-    const int kl = KMAJOR ? pt / LPK + (NPRODUCER / LPK) * i : 4 * (pt % 4);
-    uint2 t1, t2, t3;
-    split_pair(v[i].x, v[i].y, t1.x, t2.x, t3.x);
-    split_pair(v[i].z, v[i].w, t1.y, t2.y, t3.y);
-    const int off = KMAJOR ? kl * LD_KR + 4 * (pt % LPK)          // 4 consecutive rows of one k
-                           : (pt / 4 + 64 * i) * LD_RK + kl;      // 4 consecutive k of one row
-    *reinterpret_cast<uint2 *>(s + off) = t1;
-    *reinterpret_cast<uint2 *>(s + PLANE + off) = t2;
-    *reinterpret_cast<uint2 *>(s + 2 * PLANE + off) = t3;
-  }
-}
-
-// ---- f16x2 arithmetic (NPROD == 3): every operand row carries a power-of-two scale (gemm_row_scale_kernel below);
-// the producers load it with the stage (unconditionally, like the operand itself), multiply and split into TWO f16
-// planes, and the consumers undo the two scales on the accumulators before the epilogue.
-template <bool KMAJOR, int ROWS>
-__device__ __forceinline__ void scale_offsets(int rows, int r0, int pt, uint32_t (&soff)[4]) {
-  constexpr int LPK = ROWS / 4;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (!KMAJOR) soff[i] = (uint32_t)min(r0 + pt / 4 + 64 * (i < ROWS / 64 ? i : 0), rows - 1) * 4u;  // the row of v[i]
-    else soff[i] = (uint32_t)min(r0 + 4 * (pt % LPK), rows - 4) * 4u;                                  // the 4 rows of every v[i]
-  }
-}
-template <bool KMAJOR, int ROWS>
-__device__ __forceinline__ void load_scales(const uint32_t *__restrict__ scale, const uint32_t (&soff)[4], float (&sc)[4]) {
-  const char *base = reinterpret_cast<const char *>(scale);
-  if (!KMAJOR) {
-#pragma unroll
-    for (int i = 0; i < ROWS / 64; ++i) sc[i] = *reinterpret_cast<const float *>(base + soff[i]);
-  } else {
-    const float4 v = *reinterpret_cast<const float4 *>(base + soff[0]);
-    sc[0] = v.x; sc[1] = v.y; sc[2] = v.z; sc[3] = v.w;
-  }
-}
-template <bool KMAJOR, int ROWS>
-__device__ __forceinline__ void store_split_f16(unsigned short *__restrict__ s, int pt, const float4 (&v)[ROWS / 64],
-                                                const float (&sc)[4]) {
-  constexpr int LPK = ROWS / 4, PLANE = ROWS * LD_RK, LD_KR = ROWS + KR_PAD;
-#pragma unroll
-  for (int i = 0; i < ROWS / 64; ++i) {
-    const int kl = KMAJOR ? pt / LPK + (NPRODUCER / LPK) * i : 4 * (pt % 4);
-    uint2 t1, t2;
-    split_pair_f16(v[i].x, v[i].y, KMAJOR ? sc[0] : sc[i], KMAJOR ? sc[1] : sc[i], t1.x, t2.x);
-    split_pair_f16(v[i].z, v[i].w, KMAJOR ? sc[2] : sc[i], KMAJOR ? sc[3] : sc[i], t1.y, t2.y);
-    const int off = KMAJOR ? kl * LD_KR + 4 * (pt % LPK) : (pt / 4 + 64 * i) * LD_RK + kl;
-    *reinterpret_cast<uint2 *>(s + off) = t1;
-    *reinterpret_cast<uint2 *>(s + PLANE + off) = t2;
-  }
-}
-// scale (bits of a power of two) of a row whose largest |x| has the bits `amax`: max |x| * scale in [2^14, 2^15);
-// rows of zeros / subnormals get the largest finite power.  A larger maximum gives a SMALLER scale (atomicMin).
-__device__ __forceinline__ uint32_t row_scale_bits(uint32_t amax) { return min(268u - (amax >> 23), 254u) << 23; }
-__device__ __forceinline__ float inverse_scale(uint32_t scale_bits) { return __uint_as_float((254u << 23) - scale_bits); }
-
-// MFMA operand of the 32 tile rows starting at r0, plane t: lane l holds row r0 + (l & 31), k = 8 (l >> 5) + 0..7
-template <bool KMAJOR, int ROWS>
-__device__ __forceinline__ bf16x8 read_frag(const unsigned short *__restrict__ s, int r0, int lane, int t) {
-  constexpr int PLANE = ROWS * LD_RK, LD_KR = ROWS + KR_PAD;
-  if (!KMAJOR) {
-    return *reinterpret_cast<const bf16x8 *>(s + t * PLANE + (r0 + (lane & 31)) * LD_RK + 8 * (lane >> 5));
-  } else {
-    // ds_read_b64_tr_b16: within a 16-lane group, lane q supplies the address of 4 contiguous bf16 = columns
-    // 4 (q & 3) .. +3 of matrix row (q >> 2) and receives column q of the 4 rows.  Rows = 4 consecutive k,
-    // columns = 16 consecutive tile rows.
-    const int q16 = lane & 15;
-    const unsigned short *q = s + t * PLANE + (8 * (lane >> 5) + (q16 >> 2)) * LD_KR + r0 + (lane & 16) + 4 * (q16 & 3);
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)q);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(q + 4 * LD_KR));
-    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, both);
-  }
-}
-
-struct Item {  // one (output tile, K split) work item
-  int bm0, bn0, z, kbeg, kend;
-};
-
-// Cursor over the stage stream of a workgroup: the stages (16 k each) of its work items, in order.
-struct Cursor {
-  int w, k0;
-  Item it;
-  bool end;  // set once the cursor was asked to step past the last stage (it then stays on that stage)
-};
-
-template <bool A_KMAJOR, bool B_KMAJOR, int NPROD, int EPI>
-__global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16x3_mfma_kernel(
-    const GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-  float *const scratch = reinterpret_cast<float *>(smem + 2 * STAGE);
-  float *const cs_area = scratch + SCRATCH_FLOATS;
-
-  constexpr bool F16 = NPROD == 3;  // two scaled f16 terms and three products instead of three bf16 terms and six
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const WorkRange work(p, TBM, TBN);
-  if (work.begin >= work.end) return;
-  auto item_at = [&](int logical) __attribute__((always_inline)) {
-    Item it;
-    work.decode(logical, it.bm0, it.bn0, it.z);
-    it.kbeg = it.z * p.k_per_split;
-    it.kend = min(p.K, it.kbeg + p.k_per_split);
-    return it;
-  };
-  // one step of a cursor; past the last stage of the range it stays on that stage
-  auto advance = [&](Cursor &c) __attribute__((always_inline)) {
-    if (c.k0 + SBK < c.it.kend) {
-      c.k0 += SBK;
-    } else if (c.w + 1 < work.end) {
-      c.it = item_at(++c.w);
-      c.k0 = c.it.kbeg;
-    } else {
-      c.end = true;
-    }
-  };
-  int total_stages = 0;  // barriers must match between the two roles: both count the stages of the range
-  for (int w = work.begin; w < work.end; ++w) {
-    const Item it = item_at(w);
-    total_stages += (it.kend - it.kbeg + SBK - 1) / SBK;
-  }
-  const int padded_stages = (total_stages + NSETS - 1) / NSETS * NSETS;  // both roles run this many barriers (+1)
-  const bool partial = p.slab != 0;
-  // Bias gradient = column sums of the k-major A operand.  The producers add up the f32 registers of their loader
-  // (weights 0 / 1 per k row, no branch and no memory access in their loop) and publish one partial row per k group in
-  // LDS at the end of an item; the consumers write it out with the tile.  With split-K slabs the N tiles of one
-  // (M tile, split) share the work: N tile tn takes every cs_share-th k of a stage starting at tn; without slabs the
-  // first N tile does it alone and accumulates in place.
-  const bool has_colsum = A_KMAJOR && p.colsum != nullptr;
-  const int cs_share = partial ? p.colsum_share : 1;
-  auto colsum_first = [&](const Item &it) __attribute__((always_inline)) { return (it.bn0 / TBN) & (cs_share - 1); };
-  auto colsum_on = [&](const Item &it) __attribute__((always_inline)) {
-    return has_colsum && (partial ? it.bn0 / TBN < cs_share : it.bn0 == 0);
-  };
-
-  if (wave >= 4) {
-    // ================================================================ producers
-    const int pt = tid - NPRODUCER;
-    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
-    float cs_w[4] = {0.f, 0.f, 0.f, 0.f};  // weight of this thread's k rows (pt / 64 + 4 i) for the item under `st`
-    int cs_parity = 0;
-    auto colsum_weights = [&](const Item &it) __attribute__((always_inline)) {
-      const bool on = colsum_on(it);
-      const int first = colsum_first(it);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) cs_w[i] = (on && ((pt / 64 + 4 * i) & (cs_share - 1)) == first) ? 1.f : 0.f;
-    };
-
-    Cursor ld = {work.begin, 0, item_at(work.begin), false};  // next stage to fetch
-    ld.k0 = ld.it.kbeg;
-    Cursor st = ld;                                    // next stage to convert and store
-    colsum_weights(st.it);
-    uint32_t voa[4], vob[2];                           // per-thread byte offsets of the item under `ld`
-    item_offsets<A_KMAJOR, TBM>(p.lda, p.M, ld.it.bm0, pt, voa);
-    item_offsets<B_KMAJOR, TBN>(p.ldb, p.N, ld.it.bn0, pt, vob);
-    float4 ra[NSETS][4], rb[NSETS][2];                 // NSETS stages in flight (registers)
-    float rsa[NSETS][4], rsb[NSETS][4];                // f16x2 only: the row scales that go with them
-    uint32_t soa[4], sob[4];
-    if (F16) {
-      scale_offsets<A_KMAJOR, TBM>(p.M, ld.it.bm0, pt, soa);
-      scale_offsets<B_KMAJOR, TBN>(p.N, ld.it.bn0, pt, sob);
-    }
-    int rskip[NSETS];
-    auto fetch = [&](float4 (&a)[4], float4 (&b)[2], int &kskip, float (&sa_)[4], float (&sb_)[4]) __attribute__((always_inline)) {
-      const int klim = ld.it.kend - ld.k0;
-      const int ks = klim >= SBK ? ld.k0 : ld.it.kend - SBK;  // the last stage of an item may start early
-      kskip = ld.k0 - ks;
-      load_raw(p.A + (A_KMAJOR ? (size_t)ks * p.lda : (size_t)ks), voa, a);
-      load_raw(p.B + (B_KMAJOR ? (size_t)ks * p.ldb : (size_t)ks), vob, b);
-      if (F16) {
-        load_scales<A_KMAJOR, TBM>(p.scale_a, soa, sa_);
-        load_scales<B_KMAJOR, TBN>(p.scale_b, sob, sb_);
-      }
-      const int w_before = ld.w;
-      advance(ld);
-      if (ld.w != w_before) {  // uniform, no memory access inside
-        item_offsets<A_KMAJOR, TBM>(p.lda, p.M, ld.it.bm0, pt, voa);
-        item_offsets<B_KMAJOR, TBN>(p.ldb, p.N, ld.it.bn0, pt, vob);
-        if (F16) {
-          scale_offsets<A_KMAJOR, TBM>(p.M, ld.it.bm0, pt, soa);
-          scale_offsets<B_KMAJOR, TBN>(p.N, ld.it.bn0, pt, sob);
-        }
-      }
-    };
-    // convert + store the stage under `st` into LDS buffer `buf`, then refill the registers two stages ahead
-    auto produce = [&](float4 (&a)[4], float4 (&b)[2], int &kskip, float (&sa_)[4], float (&sb_)[4], int buf) __attribute__((always_inline)) {
-      unsigned short *sa = smem + buf * STAGE, *sb = sa + 3 * PLANE_A;
-      mask_tail<A_KMAJOR, TBM>(pt, a, kskip);
-      mask_tail<B_KMAJOR, TBN>(pt, b, kskip);
-      if (has_colsum) {  // kernel-uniform; the weights are zero where this workgroup has nothing to add
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {  // scalar fmas, kept apart: a v_pk_fma_f32 beside the consumer's MFMAs stalls the pipe
-          csum.x = fmaf(cs_w[i], a[i].x, csum.x); asm volatile("" : "+v"(csum.x));
-          csum.y = fmaf(cs_w[i], a[i].y, csum.y); asm volatile("" : "+v"(csum.y));
-          csum.z = fmaf(cs_w[i], a[i].z, csum.z); asm volatile("" : "+v"(csum.z));
-          csum.w = fmaf(cs_w[i], a[i].w, csum.w); asm volatile("" : "+v"(csum.w));
-        }
-      }
-      if (F16) {
-        store_split_f16<A_KMAJOR, TBM>(sa, pt, a, sa_);
-        store_split_f16<B_KMAJOR, TBN>(sb, pt, b, sb_);
-      } else {
-        store_split<A_KMAJOR, TBM>(sa, pt, a);
-        store_split<B_KMAJOR, TBN>(sb, pt, b);
-      }
-      if (has_colsum && !st.end && st.k0 + SBK >= st.it.kend) {  // last stage of its item: publish (LDS only)
-        if (colsum_on(st.it)) {
-          // Three rotating areas: an item's sums are published one stage before the consumers finish the item and read
-          // by them after the barrier of its last stage; with items of a single stage the writer of item I + 2 may
-          // already run while the reader of item I is still in its epilogue, the writer of item I + 3 may not.
-          reinterpret_cast<float4 *>(cs_area + cs_parity * 4 * TBM)[pt] = csum;  // [k group = pt / 64][row quad]
-          cs_parity = cs_parity == COLSUM_AREAS - 1 ? 0 : cs_parity + 1;
-        }
-        csum = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      {
-        const int w_before = st.w;
-        const bool was_end = st.end;
-        advance(st);
-        if (st.w != w_before) colsum_weights(st.it);
-        if (st.end && !was_end) cs_w[0] = cs_w[1] = cs_w[2] = cs_w[3] = 0.f;  // past the end the last stage is re-fetched
-      }
-      // the refill must not be scheduled above the conversion: old and new contents of the registers would overlap,
-      // the set could not stay in place across the loop and the copies (each waiting for its load) would drain the
-      // prefetch queue every iteration
-      __builtin_amdgcn_sched_barrier(0);
-      fetch(a, b, kskip, sa_, sb_);
-    };
-    // (the scheduling fences keep the ISSUE ORDER of the prologue loads: the scheduler would otherwise sink the later
-    // fetches below the refill to shorten live ranges, and since vmcnt counts in order every later wait for an older
-    // register set would have to drain the newer ones as well)
-#pragma unroll
-    for (int u = 0; u < NSETS; ++u) {
-      fetch(ra[u], rb[u], rskip[u], rsa[u], rsb[u]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    produce(ra[0], rb[0], rskip[0], rsa[0], rsb[0], 0);  // stage 0 -> buffer 0, set 0 <- stage NSETS
-    __syncthreads();
-    for (int g = 0; g < padded_stages; g += NSETS) {  // no exit in the middle: the register sets keep their roles
-#pragma unroll
-      for (int u = 1; u <= NSETS; ++u) {
-        produce(ra[u % NSETS], rb[u % NSETS], rskip[u % NSETS], rsa[u % NSETS], rsb[u % NSETS], u & 1);  // stage g + u -> buffer (g + u) & 1
-        __syncthreads();
-      }
-    }
-  } else {
-    // ================================================================ consumers
-    const int wm = wave >> 1, wn = wave & 1;
-    const uint32_t thr = dropout_threshold(p.dropout_p);
-    const float keep_scale = 1.f / (1.f - p.dropout_p);
-    f32x16 acc[4][2];
-    auto zero_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    };
-    zero_acc();
-    Cursor cc = {work.begin, 0, item_at(work.begin), false};
-    cc.k0 = cc.it.kbeg;
-    int cs_parity = 0;  // which of the published column-sum areas belongs to the current item
-
-    __syncthreads();  // stage 0 is in buffer 0
-    for (int g = 0; g < padded_stages; ++g) {
-      if (g >= total_stages) {  // padding stage: the producers' loop runs in groups of NSETS stages
-        __syncthreads();
-        continue;
-      }
-      const unsigned short *sa = smem + (g & 1) * STAGE, *sb = sa + 3 * PLANE_A;
-      bf16x8 fa[4][3], fb[2][3];
-      auto read_a = [&](int t) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i][t] = read_frag<A_KMAJOR, TBM>(sa, wm * 128 + 32 * i, lane, t);
-      };
-      auto read_b = [&](int t) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) fb[j][t] = read_frag<B_KMAJOR, TBN>(sb, wn * 64 + 32 * j, lane, t);
-      };
-      auto mul = [&](int ta, int tb) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = F16 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][ta]),
-                                                                     __builtin_bit_cast(f16x8, fb[j][tb]), acc[i][j], 0, 0, 0)
-                            : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ta], fb[j][tb], acc[i][j], 0, 0, 0);
-      };
-      // smallest products first; fragments are read in the order the products need them
-      if (NPROD == 3) {
-        read_a(1); read_b(0); mul(1, 0);
-        read_a(0); read_b(1); mul(0, 1);
-        mul(0, 0);
-      } else if (NPROD == 9) {
-        read_a(2); read_b(2); mul(2, 2);
-        read_b(1); mul(2, 1);
-        read_a(1); mul(1, 2);
-        read_b(0); mul(2, 0);
-        read_a(0); mul(0, 2);
-      } else {
-        read_a(2); read_b(0); mul(2, 0);
-        read_a(0); read_b(2); mul(0, 2);
-        read_a(1); read_b(1);
-      }
-      if (NPROD != 3) { mul(1, 1); mul(1, 0); mul(0, 1); mul(0, 0); }
-      __syncthreads();  // buffer g & 1 is released, buffer (g + 1) & 1 holds stage g + 1
-      if (cc.k0 + SBK >= cc.it.kend) {  // that was the item's last stage
-        float *C = p.C + (partial ? (size_t)cc.it.z * p.slab : 0);
-        const int ldc = partial ? p.N : p.ldc;
-        const int row0 = cc.it.bm0 + wm * 128, col0 = cc.it.bn0 + wn * 64;
-        if (F16) {  // back from the scaled operands: acc / (scale_a[row] scale_b[col]), exact (powers of two)
-          const int l31 = lane & 31, lh = lane >> 5;
-          float ib[2];
-#pragma unroll
-          for (int j = 0; j < 2; ++j) ib[j] = inverse_scale(p.scale_b[min(col0 + j * 32 + l31, p.N - 1)]);
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float ia = inverse_scale(p.scale_a[min(row0 + i * 32 + 8 * g + 4 * lh + e, p.M - 1)]);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j][g * 4 + e] = acc[i][j][g * 4 + e] * ia * ib[j];
-              }
-        }
-        if (p.vec_epilogue) tile_epilogue_vec<4, true, EPI>(p, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 2048);
-        else tile_epilogue_vec<4, false, EPI>(p, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 2048);
-        zero_acc();
-        if (colsum_on(cc.it)) {  // the producers published this item's sums before the barrier above: one row per lane
-          const float *q = cs_area + cs_parity * 4 * TBM;
-          const int row = cc.it.bm0 + tid;
-          if (row < p.M) {
-            const float tot = q[tid] + q[TBM + tid] + q[2 * TBM + tid] + q[3 * TBM + tid];
-            if (partial) p.colsum[((size_t)cc.it.z * cs_share + colsum_first(cc.it)) * p.M + row] = tot;
-            else p.colsum[row] += tot;
-          }
-          cs_parity = cs_parity == COLSUM_AREAS - 1 ? 0 : cs_parity + 1;
-        }
-      }
-      advance(cc);
-    }
-  }
-}
-
-// ---- row scales of the f16x2 arithmetic: scale[r] = the power of two that takes max_k |x[r][k]| into [2^14, 2^15).
-// One launch covers both operands (blocks [0, ja.blocks) work on A, the rest on B).
-//   K-contiguous operand [rows][K]: a wavefront reduces two rows (RS_ROWS = 8 per block) and stores their scales;
-//   row-contiguous operand [K][rows]: a block takes 256 rows x a chunk of RS_KCHUNK k, its threads 4 consecutive rows
-//                                   each, and the chunks meet in an atomicMin on the scale bits (a larger maximum is a
-//                                   smaller scale; the array is preset to the largest scale by the launcher).
-struct ScaleJob {
-  const float *x;
-  int ld, rows, K, kmajor;
-  uint32_t *scale;
-  int blocks;
-};
-constexpr int RS_THREADS = 256, RS_ROWS = 8, RS_KCHUNK = 128;
-
-__device__ __forceinline__ float absmax4(float m, const float4 v) {
-  return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-}
-
-__global__ __launch_bounds__(RS_THREADS) void gemm_row_scale_kernel(const ScaleJob ja, const ScaleJob jb) {
-  const bool second = (int)blockIdx.x >= ja.blocks;
-  const ScaleJob j = second ? jb : ja;
-  const int b = (int)blockIdx.x - (second ? ja.blocks : 0);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (!j.kmajor) {
-    // RS_ROWS / 4 rows per wavefront, two at a time: many small wavefronts (this pass is latency-bound otherwise)
-    for (int rr = 0; rr < RS_ROWS / 4; rr += 2) {
-      const int r0 = b * RS_ROWS + wave * (RS_ROWS / 4) + rr;
-      if (r0 >= j.rows) break;  // wavefront-uniform
-      const int r1 = min(r0 + 1, j.rows - 1);  // (past the end: the last row again, same value, same store)
-      const float *p0 = j.x + (size_t)r0 * j.ld, *p1 = j.x + (size_t)r1 * j.ld;
-      float m0 = 0.f, m1 = 0.f;
-#pragma unroll 2
-      for (int k = lane * 4; k < j.K; k += 256) {
-        m0 = absmax4(m0, *reinterpret_cast<const float4 *>(p0 + k));
-        m1 = absmax4(m1, *reinterpret_cast<const float4 *>(p1 + k));
-      }
-#pragma unroll
-      for (int o = 32; o; o >>= 1) {
-        m0 = fmaxf(m0, __shfl_xor(m0, o));
-        m1 = fmaxf(m1, __shfl_xor(m1, o));
-      }
-      if (lane == 0) {
-        j.scale[r0] = row_scale_bits(__float_as_uint(m0));
-        j.scale[r1] = row_scale_bits(__float_as_uint(m1));
-      }
-    }
-  } else {
-    __shared__ float4 red[RS_THREADS];
-    const int groups = (j.rows + 255) / 256;
-    const int grp = b % groups, chunk = b / groups;
-    const int r4 = grp * 256 + lane * 4;
-    const int kbeg = chunk * RS_KCHUNK, kend = min(j.K, kbeg + RS_KCHUNK);
-    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r4 < j.rows) {
-#pragma unroll 8
-      for (int k = kbeg + wave; k < kend; k += 4) {
-        const float4 v = *reinterpret_cast<const float4 *>(j.x + (size_t)k * j.ld + r4);
-        m.x = fmaxf(m.x, fabsf(v.x)); m.y = fmaxf(m.y, fabsf(v.y)); m.z = fmaxf(m.z, fabsf(v.z)); m.w = fmaxf(m.w, fabsf(v.w));
-      }
-    }
-    red[tid] = m;
-    __syncthreads();
-    if (wave == 0 && r4 < j.rows) {
-#pragma unroll
-      for (int w = 1; w < 4; ++w) {
-        const float4 o = red[tid + 64 * w];
-        m.x = fmaxf(m.x, o.x); m.y = fmaxf(m.y, o.y); m.z = fmaxf(m.z, o.z); m.w = fmaxf(m.w, o.w);
-      }
-      atomicMin(j.scale + r4 + 0, row_scale_bits(__float_as_uint(m.x)));
-      atomicMin(j.scale + r4 + 1, row_scale_bits(__float_as_uint(m.y)));
-      atomicMin(j.scale + r4 + 2, row_scale_bits(__float_as_uint(m.z)));
-      atomicMin(j.scale + r4 + 3, row_scale_bits(__float_as_uint(m.w)));
-    }
-  }
-}
-
-template <bool AK, bool BKM, int NPROD, int EPI>
-int launch(const GemmParams &p, int splits, hipStream_t st) {
-  const int work = ((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN) * splits;
-  auto kern = gemm_bf16x3_mfma_kernel<AK, BKM, NPROD, EPI>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)LDS_BYTES));
-    attr_set = true;
-  }
-  const int slots = persistent_grid();  // one workgroup per CU
-  const int grid = work < slots ? work : slots;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), LDS_BYTES, st, p);
-  return pt_check_launch();
-}
-
-template <int NPROD, int EPI>
-int launch_layout(const GemmParams &p, bool ak, bool bk, int splits, hipStream_t st) {
-  if (!ak && !bk) return launch<false, false, NPROD, EPI>(p, splits, st);
-  if (!ak && bk) return launch<false, true, NPROD, EPI>(p, splits, st);
-  if (ak && !bk) return launch<true, false, NPROD, EPI>(p, splits, st);
-  return launch<true, true, NPROD, EPI>(p, splits, st);
-}
-
-}  // namespace
-
-int launch_row_scales(const GemmParams &p, bool a_kmajor, bool b_kmajor, uint32_t *scale_a, uint32_t *scale_b, hipStream_t st) {
-  auto job = [](const float *x, int ld, int rows, int K, bool kmajor, uint32_t *scale) {
-    ScaleJob j = {x, ld, rows, K, kmajor ? 1 : 0, scale, 0};
-    j.blocks = kmajor ? ((rows + 255) / 256) * ((K + RS_KCHUNK - 1) / RS_KCHUNK) : (rows + RS_ROWS - 1) / RS_ROWS;
-    return j;
-  };
-  const ScaleJob ja = job(p.A, p.lda, p.M, p.K, a_kmajor, scale_a), jb = job(p.B, p.ldb, p.N, p.K, b_kmajor, scale_b);
-  if (a_kmajor) PT_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scale_a), (int)(254u << 23), (size_t)p.M, st));
-  if (b_kmajor) PT_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scale_b), (int)(254u << 23), (size_t)p.N, st));
-  hipLaunchKernelGGL(gemm_row_scale_kernel, dim3(ja.blocks + jb.blocks), dim3(RS_THREADS), 0, st, ja, jb);
-  return pt_check_launch();
-}
 
 int launch_split(const GemmParams &p, bool a_kmajor, bool b_kmajor, int splits, int products, hipStream_t st) {
   if (products == 9) return launch_layout<9, EPI_FULL>(p, a_kmajor, b_kmajor, splits, st);
-  if (products == 3) {
-    const bool plain3 = p.slab != 0 || (!p.bias && !p.residual && !p.flags && p.dropout_p == 0.f);
-    if (plain3) return launch_layout<3, EPI_PLAIN>(p, a_kmajor, b_kmajor, splits, st);
-    if (p.dropout_p == 0.f) return launch_layout<3, EPI_NODROP>(p, a_kmajor, b_kmajor, splits, st);
-    return launch_layout<3, EPI_FULL>(p, a_kmajor, b_kmajor, splits, st);
-  }
+  if (products == 3) return launch_split_f16x2(p, a_kmajor, b_kmajor, splits, st);  // gemm_f16x2.hip
   // the smallest epilogue that does the job (instruction-cache footprint, see gemm_common.h)
   const bool plain = p.slab != 0 || (!p.bias && !p.residual && !p.flags && p.dropout_p == 0.f);
   if (plain) return launch_layout<6, EPI_PLAIN>(p, a_kmajor, b_kmajor, splits, st);

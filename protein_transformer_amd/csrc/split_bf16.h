@@ -1,5 +1,5 @@
 // Exact three-term bf16 splitting of f32 values and the LDS tile format of the split-bf16 attention kernels
-// (see gemm_split.hip for the arithmetic: x = t1 + t2 + t3 exactly, products evaluated as six bf16 MFMAs).
+// (see gemm_split_kernel.h for the arithmetic: x = t1 + t2 + t3 exactly, products evaluated as six bf16 MFMAs).
 #pragma once
 #include "common.h"
 
