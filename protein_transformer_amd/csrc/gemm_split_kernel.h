@@ -2,8 +2,12 @@
 // 6 / 9 products) and gemm_f16x2.hip (two row-scaled f16 terms, 3 products) - two translation units so that the
 // 28 instantiations compile in parallel.
 //
-// fp32 GEMM on the CDNA4 bf16 matrix pipe: each f32 operand is split exactly into three bf16 terms while it is
-// staged into LDS, and the product is evaluated as 6 (or 9) v_mfma_f32_32x32x16_bf16 products with f32 accumulation.
+// fp32 GEMM on the CDNA4 bf16 / f16 matrix pipe: each f32 operand is split while it is staged into LDS - exactly into
+// three bf16 terms (NPROD = 6 or 9 v_mfma_f32_32x32x16_bf16 products per fp32 product), or, after scaling each operand
+// row by a power of two, into two f16 terms (NPROD = 3 v_mfma_f32_32x32x16_f16 products; the error model and the
+// row-scale pass are described in include/ptamd.h and gemm_f16x2.hip) - with f32 accumulation.  The text below
+// describes the bf16 form; the f16 form differs by two planes instead of three, the scale loaded with every stage
+// and the two inverse scales applied to the accumulators in front of the epilogue.
 //
 // Same role, interface and epilogues as gemm.hip (every torch.nn.Linear of the reference encoder and the backward
 // GEMMs: Attention.py:38-41,49,69; Sublayers.py:28-34; encoder_only.py:18,39-41) - see ptamd_gemm_set_mode.
