@@ -10,7 +10,9 @@ namespace {
 //   K-contiguous operand [rows][K]: a wavefront reduces two rows (RS_ROWS = 8 per block) and stores their scales;
 //   row-contiguous operand [K][rows]: a block takes 256 rows x a chunk of RS_KCHUNK k, its threads 4 consecutive rows
 //                                   each, and the chunks meet in an atomicMin on the scale bits (a larger maximum is a
-//                                   smaller scale; the array is preset to the largest scale by the launcher).
+//                                   smaller scale; the array is preset to the largest scale by the launcher);
+//   a SMALL row-contiguous operand (a weight matrix, <= 2^21 elements): a block takes 16 rows and all of K, 64 k at a
+//                                   time (4 threads x 4 rows per k), and stores the scales - no preset, no atomics.
 struct ScaleJob {
   const float *x;
   int ld, rows, K, kmajor;
@@ -18,6 +20,7 @@ struct ScaleJob {
   int blocks;
 };
 constexpr int RS_THREADS = 256, RS_ROWS = 8, RS_KCHUNK = 128;
+constexpr int RS_KMAJOR_CHUNKS = 1, RS_KMAJOR_WHOLE = 2;  // ScaleJob::kmajor
 
 __device__ __forceinline__ float absmax4(float m, const float4 v) {
   return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
@@ -50,6 +53,31 @@ __global__ __launch_bounds__(RS_THREADS) void gemm_row_scale_kernel(const ScaleJ
         j.scale[r0] = row_scale_bits(__float_as_uint(m0));
         j.scale[r1] = row_scale_bits(__float_as_uint(m1));
       }
+    }
+  } else if (j.kmajor == RS_KMAJOR_WHOLE) {
+    __shared__ float4 red[RS_THREADS];
+    const int r4 = min(b * 16 + (tid & 3) * 4, j.rows - 4);  // (rows % 4 == 0; a clamped quad repeats its neighbour's work)
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int k = tid >> 2; k < j.K; k += RS_THREADS / 4) {
+      const float4 v = *reinterpret_cast<const float4 *>(j.x + (size_t)k * j.ld + r4);
+      m.x = fmaxf(m.x, fabsf(v.x)); m.y = fmaxf(m.y, fabsf(v.y)); m.z = fmaxf(m.z, fabsf(v.z)); m.w = fmaxf(m.w, fabsf(v.w));
+    }
+    red[tid] = m;
+    __syncthreads();
+    for (int half = RS_THREADS / 2; half >= 4; half >>= 1) {  // tid & 3 (the row quad) is preserved by every step
+      if (tid < half) {
+        const float4 o = red[tid + half];
+        m.x = fmaxf(m.x, o.x); m.y = fmaxf(m.y, o.y); m.z = fmaxf(m.z, o.z); m.w = fmaxf(m.w, o.w);
+        red[tid] = m;
+      }
+      __syncthreads();
+    }
+    if (tid < 4) {
+      j.scale[r4 + 0] = row_scale_bits(__float_as_uint(m.x));
+      j.scale[r4 + 1] = row_scale_bits(__float_as_uint(m.y));
+      j.scale[r4 + 2] = row_scale_bits(__float_as_uint(m.z));
+      j.scale[r4 + 3] = row_scale_bits(__float_as_uint(m.w));
     }
   } else {
     __shared__ float4 red[RS_THREADS];
@@ -85,13 +113,18 @@ __global__ __launch_bounds__(RS_THREADS) void gemm_row_scale_kernel(const ScaleJ
 
 int launch_row_scales(const GemmParams &p, bool a_kmajor, bool b_kmajor, uint32_t *scale_a, uint32_t *scale_b, hipStream_t st) {
   auto job = [](const float *x, int ld, int rows, int K, bool kmajor, uint32_t *scale) {
-    ScaleJob j = {x, ld, rows, K, kmajor ? 1 : 0, scale, 0};
-    j.blocks = kmajor ? ((rows + 255) / 256) * ((K + RS_KCHUNK - 1) / RS_KCHUNK) : (rows + RS_ROWS - 1) / RS_ROWS;
+    const int mode = !kmajor ? 0 : ((size_t)rows * K <= ((size_t)1 << 21) ? RS_KMAJOR_WHOLE : RS_KMAJOR_CHUNKS);
+    ScaleJob j = {x, ld, rows, K, mode, scale, 0};
+    j.blocks = mode == RS_KMAJOR_CHUNKS  ? ((rows + 255) / 256) * ((K + RS_KCHUNK - 1) / RS_KCHUNK)
+               : mode == RS_KMAJOR_WHOLE ? (rows + 15) / 16
+                                         : (rows + RS_ROWS - 1) / RS_ROWS;
     return j;
   };
   const ScaleJob ja = job(p.A, p.lda, p.M, p.K, a_kmajor, scale_a), jb = job(p.B, p.ldb, p.N, p.K, b_kmajor, scale_b);
-  if (a_kmajor) PT_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scale_a), (int)(254u << 23), (size_t)p.M, st));
-  if (b_kmajor) PT_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scale_b), (int)(254u << 23), (size_t)p.N, st));
+  if (ja.kmajor == RS_KMAJOR_CHUNKS)
+    PT_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scale_a), (int)(254u << 23), (size_t)p.M, st));
+  if (jb.kmajor == RS_KMAJOR_CHUNKS)
+    PT_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scale_b), (int)(254u << 23), (size_t)p.N, st));
   hipLaunchKernelGGL(gemm_row_scale_kernel, dim3(ja.blocks + jb.blocks), dim3(RS_THREADS), 0, st, ja, jb);
   return pt_check_launch();
 }

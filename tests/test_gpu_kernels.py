@@ -256,7 +256,7 @@ def test_gemm_f16x2_error_model(dev):
         g = torch.Generator().manual_seed(11)
         # (1) per-row magnitudes over 12 decades, a few binades inside a row
         for (M, N, Kd, a_km, b_km, split) in [(512, 256, 512, False, False, 1), (384, 512, 2048, False, True, 1),
-                                              (256, 128, 8192, True, True, 8), (260, 132, 516, True, False, 1)]:
+                                              (516, 128, 8192, True, True, 8), (260, 132, 516, True, False, 1)]:   # (k-major A of 516 x 8192: the chunked scale pass)
             a = torch.randn(M, Kd, generator=g) * torch.exp(torch.empty(M, 1).uniform_(-20, 7, generator=g))
             b = torch.randn(N, Kd, generator=g) * torch.exp(torch.empty(N, 1).uniform_(-8, 2, generator=g))
             a[:, ::7] *= 64.0
