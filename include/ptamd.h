@@ -159,7 +159,7 @@ int ptamd_gemm(const ptamd_gemm_args *args, void *stream);
  *   PTAMD_GEMM_AUTO         per call: F16X2 when A is K-contiguous (activations / per-token gradients x weights: the
  *                           pass over the operands is cheap next to the product), BF16X3 when A is k-major (the
  *                           weight-gradient reductions over all tokens, where that pass would read both big operands
- *                           once more).  Measured on the benchmark step: 15.0 ms against 15.75 (all BF16X3) and 15.3
+ *                           once more).  Measured on the benchmark step: 15.0 ms against 15.8 (all BF16X3) and 15.25
  *                           (all F16X2); gradients of a whole step against fp64: same level in every mode
  *                           (tests/test_gpu_model.py).
  * Whatever the mode, products with K < 16 or an operand of 4 GiB or more run in PTAMD_GEMM_F32. */
