@@ -63,6 +63,30 @@ def test_host_only_entry_points(built_lib):
     assert lib.ptamd_attention_fwd(None, None, 1, 8, 2, 24, 0.0, 0, 0, None, None, None) == -1
 
 
+def test_gemm_arithmetic_policy(built_lib):
+    """ptamd_gemm_set_mode / ptamd_gemm_products (host only): which arithmetic a call runs in (include/ptamd.h)."""
+    import ctypes as C
+    from protein_transformer_amd import kernels as K
+    lib = built_lib.lib()
+
+    def products(a_kmajor, Kd=512, lda=512):
+        args = built_lib.GemmArgs(M=256, N=128, K=Kd, A=None, lda=lda, a_kmajor=a_kmajor, B=None, ldb=Kd, b_kmajor=0,
+                                  C=None, ldc=128)
+        return lib.ptamd_gemm_products(C.byref(args))
+    old = lib.ptamd_gemm_get_mode()
+    try:
+        assert lib.ptamd_gemm_set_mode(99) == -1                      # PTAMD_ERR_BAD_SHAPE, mode unchanged
+        assert lib.ptamd_gemm_get_mode() == old
+        for mode, want in [(K.GEMM_F32, (1, 1)), (K.GEMM_BF16X3, (6, 6)), (K.GEMM_BF16X3_FULL, (9, 9)), (K.GEMM_F16X2, (3, 3)),
+                           (K.GEMM_AUTO, (3, 6))]:                   # (K-contiguous A, k-major A)
+            assert lib.ptamd_gemm_set_mode(mode) == 0 and lib.ptamd_gemm_get_mode() == mode
+            assert (products(0), products(1, lda=256)) == want, mode
+            assert products(0, Kd=8, lda=8) == 1                      # K < 16 always runs on the exact-f32 MFMA
+        assert lib.ptamd_gemm_products(None) == -1
+    finally:
+        lib.ptamd_gemm_set_mode(old)
+
+
 def test_product_has_no_cpu_fallback(built_lib):
     from protein_transformer_amd import losses
     from protein_transformer_amd.models.encoder_only import EncoderOnlyTransformer
