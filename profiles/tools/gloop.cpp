@@ -19,6 +19,10 @@ int main(int argc, char **argv) {
   hipMemcpy(A, hv.data(), (size_t)M * K * 4, hipMemcpyHostToDevice); hipMemcpy(B, hv.data(), (size_t)N * K * 4, hipMemcpyHostToDevice);
   ptamd_gemm_args a = {};
   a.M = M; a.N = N; a.K = K; a.A = A; a.lda = K; a.B = B; a.ldb = K; a.C = C; a.ldc = N; a.split_k = 1;
+  auto wsb = (size_t (*)(int, int, int))dlsym(h, "ptamd_gemm_workspace_bytes");   // (row scales of the f16x2 arithmetic)
+  a.workspace_bytes = wsb(M, N, 1);
+  hipMalloc(&a.workspace, a.workspace_bytes);
+  if (gemm(&a, 0)) { printf("gemm error\n"); return 1; }
   auto t0 = std::chrono::steady_clock::now();
   long n = 0;
   while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < secs) {

@@ -1,5 +1,5 @@
 for v in product; do
-  for mode in 1 0; do
+  for mode in 3 1 0; do
     ./profiles/tools/gloop protein_transformer_amd/csrc/libptamd.so $mode 4096 4096 4096 6 &
     PID=$!
     sleep 2.5
