@@ -1,0 +1,222 @@
+"""MI355X parity tests at the workloads BASELINE.json names (configs[1], [3], [4]; configs[2] is tests/test_gpu_conv.py,
+configs[0] is `__graft_entry__.smoke()` and the golden steps of tests/test_gpu_model.py).
+
+All runs use the DEFAULT arithmetic policy of the library (PTAMD_GEMM_AUTO) unless a test says otherwise, dropout 0
+(RNG streams cannot match a CPU run).  The CPU side is the fp64 evaluation of the oracle's formulas
+(`oracle.encoder` + `oracle.batched`, themselves pinned to the golden vectors captured from the reference).
+
+Tolerances: per-protein lndrmsd rel 2e-5 against fp64, drmsd rel 1e-4, whole-gradient relative L2
+error 2e-4 (an order of magnitude inside the 1e-3 gradient tolerance, so that the arithmetic mode is actually tested).
+"""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _model(dev, nl, nh, dm, dff, L, am, seed):
+    from protein_transformer_amd.models.encoder_only import EncoderOnlyTransformer
+    from protein_transformer_amd.protein.Sequence import VOCAB
+    torch.manual_seed(seed)
+    model = EncoderOnlyTransformer(nl, nh, dm, dff, L, VOCAB, am, True, dropout=0.0)
+    model.set_dropout(0.0)
+    model = model.to(dev).train()
+    with torch.no_grad():
+        dict(model.named_parameters())["output_projection.weight"].normal_(0, 0.02)   # off the zero init
+    return model
+
+
+def _fp64_step(model, nhead, seq, crd):
+    """The same step in fp64 on the CPU: returns (per-protein stats, {name: gradient})."""
+    from oracle import batched as obat
+    from oracle import encoder as oenc
+    B, L = seq.shape
+    params = {k: v.detach().cpu().double() for k, v in model.state_dict().items()}
+    leaf = {k: v.clone().requires_grad_() for k, v in params.items() if not k.endswith(".pe")}
+    pred = oenc.encoder_forward({**leaf, "encoder.positional_enc.pe": params["encoder.positional_enc.pe"]}, seq.cpu(), nhead)
+    cs = pred.view(B, L, 12, 2)
+    rad = torch.atan2(cs[..., 1], cs[..., 0])
+    stats, _, dang = obat.batch_loss_and_grads(rad, seq.cpu(), crd.cpu(), dtype=torch.float64)
+    rad.backward(dang)
+    return stats, {n: v.grad for n, v in leaf.items()}
+
+
+def _grad_error(model, ref):
+    nrm = np.sqrt(sum((g ** 2).sum().item() for g in ref.values()))
+    err = np.sqrt(sum(((p.grad.detach().cpu().double() - ref[n]) ** 2).sum().item() for n, p in model.named_parameters()))
+    return err / nrm
+
+
+def test_config2_step_vs_fp64_oracle(dev):
+    """BASELINE configs[1] at its workload: enc-only d_model 256, 4 layers, 8 heads (dk = 32), dff 2048, 16 proteins x
+    L = 256, `-l drmsd`, default arithmetic.  Losses of every protein and the full parameter gradient against fp64."""
+    from protein_transformer_amd import kernels as K_
+    from protein_transformer_amd import synthetic
+    from protein_transformer_amd.losses import batch_loss
+    from protein_transformer_amd.protein.Structure import nerf_forward
+    from protein_transformer_amd.train import get_losses
+    assert K_.get_gemm_mode() == K_.GEMM_AUTO
+    B, L = 16, 256
+    lens = [L] * 12 + [201, 97, 256, 30]
+    build = lambda ang, seq: nerf_forward(ang.to(dev), seq.to(dev))[0]  # noqa: E731
+    batch = synthetic.make_batch(lens, L_pad=L, seed=31, build_coords=build)
+    seq, ang, crd = (batch[k].to(dev) for k in ("seq", "true_ang", "true_crd"))
+    model = _model(dev, 4, 8, 256, 2048, L, synthetic.angle_means(batch["true_ang"]), seed=5)
+    args = types.SimpleNamespace(loss="drmsd", combined_drmsd_weight=0.5, backbone_loss=False, clip=None)
+    model.zero_grad()
+    pred = model(seq, ang)
+    losses = get_losses(args, pred, ang, crd, seq)
+    stats_dev, _, _ = batch_loss(pred, crd, seq, do_backward=False)
+    stats_dev = stats_dev.cpu().numpy()
+    stats, ref = _fp64_step(model, 8, seq, crd)
+    for b in range(B):
+        assert stats_dev[b, 0] == pytest.approx(stats[b][0], rel=1e-4)            # drmsd
+        assert stats_dev[b, 1] == pytest.approx(stats[b][1], rel=2e-5, abs=1e-6)  # lndrmsd
+        assert stats_dev[b, 2] == pytest.approx(stats[b][2], rel=1e-4)            # backbone drmsd
+        assert (stats_dev[b, 4], stats_dev[b, 5]) == (stats[b][4], stats[b][5])   # atom counts
+    assert float(losses["loss"]) == pytest.approx(np.mean([s[0] for s in stats]), rel=1e-4)
+    err = _grad_error(model, ref)
+    print("config 2: gradient rel-L2 error vs fp64 (AUTO arithmetic):", err)
+    assert err < 2e-4, err
+
+
+def test_config4_full_size_auto_mode(dev):
+    """BASELINE configs[3] at FULL size (d512, 6 layers, 32 x 512) in the default AUTO arithmetic - the mode of the
+    headline bench line - against the exact-f32 MFMA mode on the same inputs, plus the fp64 oracle on a slice of the same
+    batch (4 proteins: the per-protein loss and gradient contribution do not depend on the rest of the batch)."""
+    from protein_transformer_amd import kernels as K_
+    from protein_transformer_amd import synthetic
+    from protein_transformer_amd.protein.Structure import nerf_forward
+    from protein_transformer_amd.train import get_losses
+    B, L = 32, 512
+    lens = [L] * 26 + [300, 411, 77, 512, 129, 256]
+    build = lambda ang, seq: nerf_forward(ang.to(dev), seq.to(dev))[0]  # noqa: E731
+    batch = synthetic.make_batch(lens, L_pad=L, seed=13, build_coords=build)
+    seq, ang, crd = (batch[k].to(dev) for k in ("seq", "true_ang", "true_crd"))
+    model = _model(dev, 6, 8, 512, 2048, L, synthetic.angle_means(batch["true_ang"]), seed=3)
+    args = types.SimpleNamespace(loss="drmsd", combined_drmsd_weight=0.5, backbone_loss=False, clip=None)
+
+    def run(sl, mode):
+        K_.set_gemm_mode(mode)
+        model.zero_grad()
+        losses = get_losses(args, model(seq[sl], ang[sl]), ang[sl], crd[sl], seq[sl])
+        _, g = model.flat_parameters()
+        return g.clone(), float(losses["drmsd-full"]), float(losses["lndrmsd-full"])
+
+    old = K_.get_gemm_mode()
+    try:
+        g_auto, d_auto, ln_auto = run(slice(0, B), K_.GEMM_AUTO)
+        g_f32, d_f32, ln_f32 = run(slice(0, B), K_.GEMM_F32)
+        sl = slice(B - 4, B)                                     # lens 77, 512, 129, 256
+        K_.set_gemm_mode(K_.GEMM_AUTO)
+        model.zero_grad()
+        losses = get_losses(args, model(seq[sl], ang[sl]), ang[sl], crd[sl], seq[sl])
+        stats, ref = _fp64_step(model, 8, seq[sl], crd[sl])
+        err = _grad_error(model, ref)
+    finally:
+        K_.set_gemm_mode(old)
+    norm = g_auto.norm().item()
+    assert norm > 0 and torch.isfinite(g_auto).all()
+    assert (g_f32 - g_auto).norm().item() <= 2e-3 * norm
+    assert d_f32 == pytest.approx(d_auto, rel=1e-5) and ln_f32 == pytest.approx(ln_auto, rel=1e-5)
+    assert float(losses["lndrmsd-full"]) == pytest.approx(np.mean([s[1] for s in stats]), rel=2e-5)
+    assert float(losses["drmsd-full"]) == pytest.approx(np.mean([s[0] for s in stats]), rel=1e-4)
+    print("config 4 slice: gradient rel-L2 error vs fp64 (AUTO arithmetic):", err)
+    assert err < 2e-4, err
+
+
+def test_config5_ragged_long_step(dev):
+    """BASELINE configs[4]: enc-only d_model 512 on a ragged batch with lengths up to 1500 (> the reference's 500),
+    `-l lndrmsd`.  (i) gradient additivity over sub-batches, (ii) losses independent of the padding / batch context,
+    (iii) the three shortest proteins against the fp64 oracle (evaluated at their own padding)."""
+    from protein_transformer_amd import synthetic
+    from protein_transformer_amd.protein.Structure import nerf_forward
+    from protein_transformer_amd.train import get_losses
+    Lp = 1500
+    lens = [1500, 1203, 733, 412, 90, 20]
+    build = lambda ang, seq: nerf_forward(ang.to(dev), seq.to(dev))[0]  # noqa: E731
+    batch = synthetic.make_batch(lens, L_pad=Lp, seed=17, build_coords=build)
+    seq, ang, crd = (batch[k].to(dev) for k in ("seq", "true_ang", "true_crd"))
+    model = _model(dev, 6, 8, 512, 2048, Lp, synthetic.angle_means(batch["true_ang"]), seed=6)
+    args = types.SimpleNamespace(loss="lndrmsd", combined_drmsd_weight=0.5, backbone_loss=False, clip=None)
+
+    def run(s, a, c):
+        model.zero_grad()
+        losses = get_losses(args, model(s, a), a, c, s)
+        _, g = model.flat_parameters()
+        return g.clone(), losses
+
+    g_all, l_all = run(seq, ang, crd)
+    g_a, l_a = run(seq[:3], ang[:3], crd[:3])
+    g_b, l_b = run(seq[3:], ang[3:], crd[3:])
+    norm = g_all.norm().item()
+    assert norm > 0 and torch.isfinite(g_all).all()
+    assert (g_a + g_b - g_all).norm().item() <= 5e-5 * norm
+    assert float(l_all["loss"]) == float(l_all["lndrmsd-full"])
+    assert 0.5 * (float(l_a["lndrmsd-full"]) + float(l_b["lndrmsd-full"])) == pytest.approx(float(l_all["lndrmsd-full"]), rel=1e-6)
+    # the short half again at its own padding (412): same gradient, same losses
+    Ls = 412
+    g_c, l_c = run(seq[3:, :Ls].contiguous(), ang[3:, :Ls].contiguous(), crd[3:, :Ls * 14].contiguous())
+    assert (g_c - g_b).norm().item() <= 5e-5 * g_b.norm().item()
+    assert float(l_c["lndrmsd-full"]) == pytest.approx(float(l_b["lndrmsd-full"]), rel=1e-6)
+    stats, ref = _fp64_step(model, 8, seq[3:, :Ls].contiguous(), crd[3:, :Ls * 14].contiguous())
+    assert float(l_c["lndrmsd-full"]) == pytest.approx(np.mean([s[1] for s in stats]), rel=2e-5)
+    assert float(l_c["drmsd-full"]) == pytest.approx(np.mean([s[0] for s in stats]), rel=1e-4)
+    err = _grad_error(model, ref)
+    print("config 5 slice: gradient rel-L2 error vs fp64:", err)
+    assert err < 2e-4, err
+
+
+def test_config5_binned_batching_end_to_end(dev):
+    """`BinnedProteinDataset` -> `SimilarLengthBatchSampler` -> `paired_collate_fn` -> `train_step` on variable-length
+    proteins (log-normal lengths, median 200, clipped to [20, 1500]), `-l lndrmsd`, d_model 512, Adam: the chain the
+    reference's `prepare_dataloaders` builds for `--batching_order binned-random` (dataset.py:228-262)."""
+    from protein_transformer_amd import synthetic
+    from protein_transformer_amd.dataset import prepare_dataloaders
+    from protein_transformer_amd.optim import FusedAdam
+    from protein_transformer_amd.protein.Sequence import VOCAB
+    from protein_transformer_amd.protein.Structure import nerf_forward
+    from protein_transformer_amd.train import train_step
+    rng = np.random.default_rng(3)
+    lens = sorted(int(x) for x in np.clip(rng.lognormal(np.log(200), 0.8, 96), 20, 1500))
+    lens[-1] = 1500
+    build = lambda ang, seq: nerf_forward(ang.to(dev), seq.to(dev))[0]  # noqa: E731
+    batch = synthetic.make_batch(lens, L_pad=1500, seed=19, build_coords=build)
+    split = {"seq": [VOCAB.ints2str(batch["seq"][i, :n].tolist()) for i, n in enumerate(lens)],
+             "ang": [batch["true_ang"][i, :n].double().numpy() for i, n in enumerate(lens)],
+             "crd": [batch["true_crd"][i, :n * 14].double().numpy() for i, n in enumerate(lens)]}
+    data = {"train": split, "settings": {"max_len": 1500, "angle_means": synthetic.angle_means(batch["true_ang"])}}
+    args = types.SimpleNamespace(batching_order="binned-random", loss="lndrmsd", add_sos_eos=False, skip_missing_res_train=False,
+                                 bins="auto", batch_size=2, repeat_train=1, train_eval_downsample=0.1,
+                                 combined_drmsd_weight=0.5, backbone_loss=False, clip=1.0)
+    np.random.seed(5)
+    train_loader, _, valid, test = prepare_dataloaders(data, args, 1500, num_workers=0)
+    assert valid == {} and test is None
+    ds = train_loader.dataset
+    model = _model(dev, 2, 8, 512, 2048, 1500, data["settings"]["angle_means"], seed=7)
+    opt = FusedAdam(model, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=10e-3)
+    seen, n = set(), 0
+    for seq, ang, crd in train_loader:
+        B, L = seq.shape
+        real = (seq != VOCAB.pad_id).sum(1)
+        edge = min(e for e in ds.hist_bins if e >= int(real.max()))
+        assert B == max(1, int(2 * 1500 / edge))                      # residue budget / right edge of the drawn bin
+        assert ang.shape == (B, L, 24) and crd.shape == (B, L * 14, 3) and L == int(real.max())
+        losses = train_step(model, opt, args, seq.to(dev), ang.to(dev), crd.to(dev))
+        assert np.isfinite(float(losses["loss"])) and float(losses["loss"]) == float(losses["lndrmsd-full"])
+        seen.add(L)
+        n += 1
+        if n == 6:
+            break
+    assert n >= 4 and len(seen) > 1                                  # batches of different lengths went through
+    _, g = model.flat_parameters()
+    assert torch.isfinite(g).all()
