@@ -1,20 +1,28 @@
 #!/usr/bin/env python
-"""Headline benchmark: train-step residues/s of the enc-only d512 model with the dRMSD loss on MI355X.
+"""Headline benchmark: train-step residues/s of the protein-transformer hot path on MI355X.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--global-batch 32]
 
-Workload (BASELINE.json configs[3], the one its metric is quoted on): `-m enc-only -dm 512 -nl 6 -nh 8
--dih 2048 -l drmsd`, SGD lr 1e-4 wd 0.01 clip 1, dropout 0.1 ON, 32 synthetic proteins of L=512 per GPU
-(weak scaling: the global batch is 32 x N).  One step = zero_grad, forward, NeRF + dRMSD loss + backward,
-gradient all-reduce, clip, optimizer step (train.train_step = reference train.py:36-46), inputs already
-resident in HBM.  Prints ONE JSON line on rank 0 (contract in the task description) with
-  roofline     - the fp32 MFMA GEMM kernel (dominant: ~80% of the step), timed live with HIP events on
-                 its launch stream during the timed steps: algorithmic FLOP / measured kernel time
-                 against the 157.3 TF/s dense f32 matrix peak;
-  cpu_baseline - the CPU oracle (a port of the reference's --no_cuda path) on a bounded sample of the
-                 same workload, on the host cores of this box.
+Default workload = BASELINE.json configs[3], the one its metric is quoted on: `-m enc-only -dm 512 -nl 6 -nh 8
+-dih 2048 -l drmsd`, SGD lr 1e-4 wd 0.01 clip 1, dropout 0.1 ON, 32 synthetic proteins of L=512 per GPU (weak scaling:
+the global batch is 32 x N; `--global-batch B` fixes the global batch instead = strong scaling, B / N proteins per GPU).
+`--config 1|2|3|5` selects the other BASELINE configurations (parity-test cases; measured for the record, not the
+headline).  One step = zero_grad, forward, NeRF + dRMSD loss + backward, gradient all-reduce, clip, optimizer step
+(train.train_step = reference train.py:36-46).  Prints ONE JSON line on rank 0 with
+
+  value        - residues/s of the whole job with the batches resident in HBM when the timed region starts;
+  h2d_inclusive- the same loop with every step's batch uploaded from pinned host memory inside the step;
+  roofline     - ptamd_gemm (the dominant kernel family), timed live with HIP events on its launch stream during the
+                 timed steps: algorithmic fp32 FLOP / measured time against the f32-equivalent ceiling of the launch
+                 mix (dense f16 / bf16 MFMA peak / matrix products per fp32 product);
+  arithmetic_modes - ms/step of the same workload, measured in THIS run, with every GEMM / attention in bf16x3 and in
+                 the exact-f32 MFMA arithmetic (the strictly fp32-grade alternatives to the default AUTO policy);
+  cpu_baseline - the CPU oracle (a port of the reference's --no_cuda path) on a bounded sample of the same workload on
+                 the host cores of this box, run the way the reference runs: torch.set_num_threads(1) in the main
+                 process + a spawn Pool of loss workers (train.py:344,360-365; losses.py:144-147), plus the
+                 --sequential_drmsd_loss leg for a per-core figure.
 """
 import argparse
 import gc
@@ -31,7 +39,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak
-BF16_MFMA_PEAK_TFLOPS = 2500.0        # same table: dense bf16 matrix peak (the marketing figure includes 2:1 sparsity)
+BF16_MFMA_PEAK_TFLOPS = 2500.0        # same table: dense bf16 / f16 matrix peak (the marketing figure includes 2:1 sparsity)
+
+CONFIGS = {   # BASELINE.json configs[i-1]
+    1: dict(model="enc-only", d_model=64, n_layers=2, n_head=8, d_ff=128, batch=4, length=64, loss="drmsd", ragged="short"),
+    2: dict(model="enc-only", d_model=256, n_layers=4, n_head=8, d_ff=2048, batch=16, length=256, loss="drmsd"),
+    3: dict(model="conv-enc|3,7,11|2,2,2", d_model=256, n_layers=6, n_head=8, d_ff=2048, batch=32, length=512, loss="combined"),
+    4: dict(model="enc-only", d_model=512, n_layers=6, n_head=8, d_ff=2048, batch=32, length=512, loss="drmsd"),
+    5: dict(model="enc-only", d_model=512, n_layers=6, n_head=8, d_ff=2048, batch=8, length=1500, loss="lndrmsd", ragged="binned"),
+}
 
 
 def parse():
@@ -39,45 +55,130 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="proteins per GPU")
-    ap.add_argument("--length", type=int, default=512)
-    ap.add_argument("--d_model", type=int, default=512)
-    ap.add_argument("--n_layers", type=int, default=6)
-    ap.add_argument("--n_head", type=int, default=8)
-    ap.add_argument("--d_ff", type=int, default=2048)
-    ap.add_argument("--loss", default="drmsd")
+    ap.add_argument("--config", type=int, default=4, choices=sorted(CONFIGS), help="BASELINE.json configuration (1-based)")
+    ap.add_argument("--batch", type=int, default=None, help="proteins per GPU (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=None, help="proteins of the whole job (strong scaling)")
+    ap.add_argument("--length", type=int, default=None)
+    ap.add_argument("--d_model", type=int, default=None)
+    ap.add_argument("--n_layers", type=int, default=None)
+    ap.add_argument("--n_head", type=int, default=None)
+    ap.add_argument("--d_ff", type=int, default=None)
+    ap.add_argument("--loss", default=None)
     ap.add_argument("--optimizer", default="sgd")
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-proteins", type=int, default=2, help="proteins in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-proteins", type=int, default=None, help="proteins in the bounded CPU-baseline sample (pool leg)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-mode-sweep", action="store_true", help="skip the bf16x3 / f32 re-runs of the timed loop")
     ap.add_argument("--gemm-mode", default="auto", choices=["f32", "bf16x3", "bf16x3full", "f16x2", "auto"],
-                    help="arithmetic of the encoder GEMMs (include/ptamd.h: ptamd_gemm_set_mode)")
-    return ap.parse_args()
+                    help="arithmetic of the encoder GEMMs and attention (include/ptamd.h: PTAMD_GEMM_*)")
+    a = ap.parse_args()
+    cfg = dict(CONFIGS[a.config])
+    for k in ("batch", "length", "d_model", "n_layers", "n_head", "d_ff", "loss"):
+        if getattr(a, k) is None:
+            setattr(a, k, cfg[k])
+    a.model, a.ragged = cfg["model"], cfg.get("ragged")
+    return a
 
 
-def cpu_baseline(a, batch_cpu, angle_means):
-    """Time ONE step of the CPU oracle on `--cpu-proteins` proteins of the same workload (1 thread, sequential
-    loss, like the reference with --sequential_drmsd_loss; the reference pins torch.set_num_threads(1), train.py:344)."""
-    from oracle import encoder as oenc, step as ostep
-    n = a.cpu_proteins
-    torch.set_num_threads(1)
-    params = oenc.init_params(a.n_layers, a.d_model, a.d_ff, a.length, angle_means, seed=11731)
-    trainer = ostep.CpuTrainer(params, a.n_head, loss=a.loss, optimizer=a.optimizer, lr=1e-4, clip=1.0)
+# ----------------------------------------------------------------------------- CPU baseline (the checker, timed)
+def _cpu_leg(a, batch_cpu, params, n, pool):
+    from oracle import step as ostep
+    trainer = ostep.CpuTrainer(params, a.n_head, loss=a.loss, optimizer=a.optimizer, lr=1e-4, clip=1.0, pool=pool)
     seq, ang, crd = (batch_cpu[k][:n] for k in ("seq", "true_ang", "true_crd"))
-    res_per_s, dt = ostep.time_cpu_steps(trainer, (seq, ang, crd), n_steps=1)
-    return {"value": round(res_per_s, 2), "unit": "residues/s", "cores": 1, "kind": "port",
-            "sample": f"1 step of oracle.step.CpuTrainer on {n} of the {a.batch} proteins (L={a.length}, same model, "
-                      f"dropout 0, sequential loss, torch threads=1): {dt:.1f} s"}
+    return ostep.time_cpu_steps(trainer, (seq, ang, crd), n_steps=1)
+
+
+def cpu_baseline(a, batch_cpu, params):
+    """One step of the CPU oracle the way the reference's --no_cuda path runs it: single-threaded torch in the main
+    process (train.py:344) and the per-protein loss fanned out over a spawn Pool (train.py:360-365, losses.py:144-147);
+    then one step with the sequential loss (--sequential_drmsd_loss) for a per-core figure.  Bounded samples of the
+    same workload: the per-protein loss alone takes ~12 s of one core at L = 512."""
+    import multiprocessing as mp
+    torch.set_num_threads(1)
+    host_cores = os.cpu_count() or 1
+    avail, L = batch_cpu["seq"].shape
+    heavy = L * L * a.d_model >= 200 * 200 * 512
+    n_pool = a.cpu_proteins or (min(4, avail) if heavy else min(avail, 16))
+    workers = max(1, min(host_cores, n_pool))           # the reference asks for cpu_count() workers; only n_pool get work
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(workers) as pool:
+        pool.map(abs, range(workers))                    # workers up (imports done) before the clock starts
+        t_spawn = time.perf_counter() - t0
+        rate_pool, dt_pool = _cpu_leg(a, batch_cpu, params, n_pool, pool)
+    n_seq = 1 if heavy else min(avail, 4)
+    rate_seq, dt_seq = _cpu_leg(a, batch_cpu, params, n_seq, None)
+    return {"value": round(rate_pool, 2), "unit": "residues/s", "cores": workers, "kind": "port",
+            "host_cores": host_cores,
+            "sample": f"1 step of oracle.step.CpuTrainer on {n_pool} of the {avail} proteins of a batch (L={L}, same "
+                      f"model, dropout 0, torch threads = 1, loss in a spawn Pool of {workers} workers [the reference asks for "
+                      f"cpu_count() = {host_cores}; {n_pool} proteins keep {workers} busy]): {dt_pool:.1f} s (+ {t_spawn:.1f} s pool start-up)",
+            "sequential": {"value": round(rate_seq, 2), "unit": "residues/s", "cores": 1,
+                           "sample": f"1 step on {n_seq} protein(s), --sequential_drmsd_loss: {dt_seq:.1f} s"}}
+
+
+# ----------------------------------------------------------------------------- workloads
+def make_batches(a, rank, dev, n_batches):
+    """Synthetic batches on the host (pinned); returns (list of (seq, ang, crd) CPU tensors, angle_means, first batch dict)."""
+    from protein_transformer_amd import synthetic
+    from protein_transformer_amd.protein.Structure import nerf_forward
+    build = lambda ang, seq: nerf_forward(ang.to(dev), seq.to(dev))[0]            # noqa: E731
+    seed0 = synthetic.DEFAULT_SEED + 97 * rank
+    if a.ragged == "binned":
+        # BASELINE configs[4]: variable lengths (log-normal, median 200, clipped to [20, L]) drawn through the reference's
+        # binned-random batching: BinnedProteinDataset -> SimilarLengthBatchSampler (residue budget batch x L per batch)
+        from protein_transformer_amd.dataset import BinnedProteinDataset, SimilarLengthBatchSampler, make_paired_collate_fn
+        from protein_transformer_amd.protein.Sequence import VOCAB
+        rng = np.random.default_rng(seed0)
+        lens = sorted(int(x) for x in np.clip(rng.lognormal(np.log(200), 0.8, 256), 20, a.length))
+        seqs, angs, crds, first = [], [], [], None
+        for i in range(0, len(lens), 64):
+            chunk = lens[i:i + 64]
+            b = synthetic.make_batch(chunk, L_pad=max(chunk), seed=seed0 + i, build_coords=build)
+            first = first or b
+            for j, n in enumerate(chunk):
+                seqs.append(VOCAB.ints2str(b["seq"][j, :n].tolist()))
+                angs.append(b["true_ang"][j, :n].double().numpy())
+                crds.append(b["true_crd"][j, :n * 14].double().numpy())
+        ds = BinnedProteinDataset(seqs=seqs, angs=angs, crds=crds, add_sos_eos=False, skip_missing_residues=False,
+                                  max_seq_len=a.length)
+        smp = SimilarLengthBatchSampler(ds, a.batch, dynamic_batch=a.batch * a.length, optimize_batch_for_cpus=False)
+        collate = make_paired_collate_fn(a.length)
+        np.random.seed(seed0)
+        it = iter(smp)
+        batches = [collate([ds[int(i)] for i in next(it)]) for _ in range(n_batches)]
+        am = synthetic.angle_means(first["true_ang"])
+        return [tuple(t.pin_memory() for t in b) for b in batches], am, first
+    out, first = [], None
+    for i in range(min(n_batches, 2)):
+        if a.ragged == "short":                                     # configs[0]: mixed lengths in [16, L]
+            lens = list(np.random.default_rng(seed0 + i).integers(16, a.length + 1, a.batch))
+            lens[0] = a.length
+        else:
+            lens = [a.length] * a.batch
+        b = synthetic.make_batch([int(x) for x in lens], L_pad=a.length, seed=seed0 + i, build_coords=build)
+        first = first or b
+        out.append(tuple(b[k].pin_memory() for k in ("seq", "true_ang", "true_crd")))
+    return out, synthetic.angle_means(first["true_ang"]), first
+
+
+def make_model(a, angle_means, dev):
+    from protein_transformer_amd.models.convolutional_encoder import ConvEncoderOnlyTransformer
+    from protein_transformer_amd.models.encoder_only import EncoderOnlyTransformer
+    from protein_transformer_amd.protein.Sequence import VOCAB
+    if a.model.startswith("conv-enc"):
+        _, ks, rs = a.model.split("|")
+        return ConvEncoderOnlyTransformer(a.n_layers, a.n_head, a.d_model, a.d_ff, a.length, VOCAB, angle_means, True,
+                                          [int(k) for k in ks.split(",")], [float(r) for r in rs.split(",")], True, True,
+                                          dropout=a.dropout).to(dev).train()
+    return EncoderOnlyTransformer(a.n_layers, a.n_head, a.d_model, a.d_ff, a.length, VOCAB, angle_means, True,
+                                  dropout=a.dropout).to(dev).train()
 
 
 def main():
     a = parse()
     from protein_transformer_amd import dp, kernels, synthetic
-    from protein_transformer_amd.models.encoder_only import EncoderOnlyTransformer
     from protein_transformer_amd.optim import FusedAdam, FusedSGD
-    from protein_transformer_amd.protein.Sequence import VOCAB
-    from protein_transformer_amd.protein.Structure import nerf_forward
     from protein_transformer_amd.train import train_step
 
     dp.init_from_env()
@@ -86,35 +187,56 @@ def main():
         sys.exit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     dev = torch.device("cuda", dp.local_rank())
     torch.cuda.set_device(dev)
-    kernels.set_gemm_mode({"f32": kernels.GEMM_F32, "bf16x3": kernels.GEMM_BF16X3, "bf16x3full": kernels.GEMM_BF16X3_FULL,
-                           "f16x2": kernels.GEMM_F16X2, "auto": kernels.GEMM_AUTO}[a.gemm_mode])
+    modes = {"f32": kernels.GEMM_F32, "bf16x3": kernels.GEMM_BF16X3, "bf16x3full": kernels.GEMM_BF16X3_FULL,
+             "f16x2": kernels.GEMM_F16X2, "auto": kernels.GEMM_AUTO}
+    scaling = "weak"
+    if a.global_batch is not None:                                   # strong scaling: fixed global batch, B / N per GPU
+        if a.global_batch % world:
+            sys.exit(f"--global-batch {a.global_batch} is not a multiple of {world} GPUs")
+        a.batch, scaling = a.global_batch // world, "strong"
 
-    # ---- synthetic, device-resident batches (two per rank, alternated)
-    build = lambda ang, seq: nerf_forward(ang.to(dev), seq.to(dev))[0]            # noqa: E731
-    batches_cpu = [synthetic.make_batch([a.length] * a.batch, seed=synthetic.DEFAULT_SEED + 97 * rank + i,
-                                        build_coords=build) for i in range(2)]
-    angle_means = synthetic.angle_means(batches_cpu[0]["true_ang"])
-    batches = [tuple(b[k].to(dev) for k in ("seq", "true_ang", "true_crd")) for b in batches_cpu]
-    n_res = int((batches[0][0] != 20).sum())
+    n_host_batches = a.steps + a.warmup if a.ragged == "binned" else 2
+    host_batches, angle_means, first = make_batches(a, rank, dev, n_host_batches)
+    resident = [tuple(t.to(dev) for t in b) for b in host_batches]
+    res_of = [int((b[0] != 20).sum()) for b in host_batches]
 
     torch.manual_seed(synthetic.DEFAULT_SEED)
-    model = EncoderOnlyTransformer(a.n_layers, a.n_head, a.d_model, a.d_ff, a.length, VOCAB, angle_means, True,
-                                   dropout=a.dropout).to(dev).train()
+    model = make_model(a, angle_means, dev)
+    model.gemm_mode = modes[a.gemm_mode]
     model.dropout_seed += 7919 * rank
     dp.attach(model)
     opt = (FusedAdam(model, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=10e-3) if a.optimizer == "adam"
            else FusedSGD(model, lr=1e-4, weight_decay=10e-3))
     args = types.SimpleNamespace(loss=a.loss, combined_drmsd_weight=0.5, backbone_loss=False, clip=1.0)
+    nb = len(resident)
 
     def step(i):
-        return train_step(model, opt, args, *batches[i % 2])
+        return train_step(model, opt, args, *resident[i % nb], n_res=res_of[i % nb])
+
+    def step_h2d(i):                                                 # the batch comes from pinned host memory inside the step
+        b = tuple(t.to(dev, non_blocking=True) for t in host_batches[i % nb])
+        return train_step(model, opt, args, *b, n_res=res_of[i % nb])
+
+    def timed(fn, first_step):
+        dp.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            out = fn(first_step + i)
+        dp.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t.item()), out
 
     for i in range(a.warmup):
         losses = step(i)
     timing = None if a.no_kernel_timing else []
     if timing is not None:      # GEMM launches per step are counted in the warm-up; events are created up front
-        kernels.GEMM_TIMING, kernels.GEMM_EVENT_POOL = [], [torch.cuda.Event(enable_timing=True) for _ in range(400)]
-        step(0)
+        kernels.GEMM_TIMING, kernels.GEMM_EVENT_POOL = [], [torch.cuda.Event(enable_timing=True) for _ in range(1200)]
+        step(0)                                                      # the launch count per step does not depend on the batch
         per_step = len(kernels.GEMM_TIMING)
         kernels.GEMM_TIMING = None
         kernels.GEMM_BYTES.clear()
@@ -123,25 +245,24 @@ def main():
             e.record()          # materialise the underlying hipEvents outside the timed region
     gc.collect()
     gc.disable()                # a generation-2 collection over the event pool costs ~60 ms when it lands in the timed steps
-    dp.barrier()
-    torch.cuda.synchronize()
     kernels.GEMM_TIMING = timing
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        losses = step(i)
-    dp.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    gc.enable()
+    dt, losses = timed(step, a.warmup)
     kernels.GEMM_TIMING = None
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    dt = float(t.item())
+    n_res_timed = sum(res_of[(a.warmup + i) % nb] for i in range(a.steps))
+    dt_h2d, _ = timed(step_h2d, a.warmup)
+    sweep = {}
+    if not a.no_mode_sweep and a.gemm_mode == "auto":
+        for name in ("bf16x3", "f32"):
+            model.gemm_mode = modes[name]
+            step(0)
+            d, _ = timed(step, a.warmup)
+            sweep[name] = {"ms_per_step": round(1e3 * d / a.steps, 3), "residues_per_s": round(world * n_res_timed / d, 1)}
+        model.gemm_mode = modes[a.gemm_mode]
+    gc.enable()
 
     traffic = None          # HBM bytes per GEMM launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-    tpath = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
-    if os.path.exists(tpath) and (a.batch, a.length, a.d_model, a.n_layers) == (32, 512, 512, 6):
+    tpath = os.path.join(ROOT, "profiles", "r02_gemm_hbm_traffic.json")
+    if os.path.exists(tpath) and a.config == 4 and a.batch == 32 and a.gemm_mode == "auto":
         with open(tpath) as f:
             traffic = round(json.load(f)["hbm_bytes_per_launch"])
     roofline = None
@@ -160,63 +281,62 @@ def main():
         for t in timing:
             e = by_products.setdefault(t[3], [0, 0.0, 0.0])
             e[0] += 1; e[1] += t[0]; e[2] += t[1].elapsed_time(t[2])
-        names = {1: "gemm_f32_mfma_kernel (v_mfma_f32_32x32x2_f32)",
-                 3: "gemm_bf16x3_mfma_kernel<NPROD=3> (two row-scaled f16 terms, 3 x v_mfma_f32_32x32x16_f16 per fp32 product; "
-                    "time includes gemm_row_scale_kernel)",
-                 6: "gemm_bf16x3_mfma_kernel<NPROD=6> (three bf16 terms, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product)",
-                 9: "gemm_bf16x3_mfma_kernel<NPROD=9> (three bf16 terms, all 9 products)"}
-        mix = {names[k]: {"launches_per_step": v[0] // a.steps, "tflops_f32_equivalent": round(v[1] / (v[2] * 1e-3) / 1e12, 1),
+        names = {1: "exact-f32 MFMA (v_mfma_f32_32x32x2_f32)",
+                 3: "f16x2: two row-scaled f16 terms, 3 x v_mfma_f32_32x32x16_f16 per fp32 product (time includes the operand "
+                    "preparation launches of the call)",
+                 6: "bf16x3: three bf16 terms, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product",
+                 9: "bf16x3 full: three bf16 terms, all 9 products"}
+        mix = {names[k]: {"launches_per_step": round(v[0] / a.steps, 1), "tflops_f32_equivalent": round(v[1] / (v[2] * 1e-3) / 1e12, 1),
                           "peak_f32_equivalent": round((F32_MFMA_PEAK_TFLOPS if k == 1 else BF16_MFMA_PEAK_TFLOPS) / k, 1),
                           "ms_per_step": round(v[2] / a.steps, 3)} for k, v in sorted(by_products.items())}
-        kern = "ptamd_gemm: " + " + ".join(f"{v[0] // a.steps} x NPROD={k}" for k, v in sorted(by_products.items()))
+        kern = "ptamd_gemm: " + " + ".join(f"{round(v[0] / a.steps, 1)} x NPROD={k}" for k, v in sorted(by_products.items()))
         products = issued / achieved
         roofline = {"bound": "mfma", "kernel": kern,
                     "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
-                    "achieved_is": "algorithmic fp32 FLOP (2*M*N*K) per second of GEMM kernel time",
+                    "achieved_is": "algorithmic fp32 FLOP (2*M*N*K) per second of GEMM kernel time (HIP events around every ptamd_gemm call)",
                     "peak_is": "f32-equivalent ceiling of the launch mix: sum(flop) / sum(flop_i * products_i / dense MFMA peak_i)",
                     "mfma_flops_issued_tflops": round(issued, 1),
                     "mfma_instruction_peak_tflops": BF16_MFMA_PEAK_TFLOPS if products > 1 else F32_MFMA_PEAK_TFLOPS,
                     "launch_mix": mix,
-                    "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_gemm_hbm_traffic.json)",
+                    "traffic_unit": "HBM bytes per launch (PMC, profiles/r02_gemm_hbm_traffic.json)",
                     "algorithmic_bytes_per_launch": round(sum(b for b in gemm_bytes) / max(len(gemm_bytes), 1)),
-                    "launches_per_step": len(timing) // a.steps, "avg_launch_us": round(1e3 * ms / len(timing), 2),
+                    "launches_per_step": round(len(timing) / a.steps, 1), "avg_launch_us": round(1e3 * ms / len(timing), 2),
                     "gflop_per_step": round(flops / a.steps / 1e9, 1),
                     "share_of_step_time": round(ms / (dt * 1e3), 3)}
 
-    dtype = {kernels.GEMM_F32: "f32",
-             kernels.GEMM_F16X2: "f32 (GEMM operands row-scaled and split into 2 f16 terms on the f16 MFMA pipe, f32 accumulate; "
-                                 "attention operands split into 3 bf16 terms; the rest f32)",
-             kernels.GEMM_AUTO: "f32 (GEMM operands split into 2 row-scaled f16 terms [activation x weight products] or exactly "
-                                "into 3 bf16 terms [weight-gradient products, attention] on the f16 / bf16 MFMA pipe, f32 "
-                                "accumulate; the rest f32)"}.get(
-        kernels.get_gemm_mode(),
-        "f32 (GEMM operands split exactly into 3 bf16 terms on the bf16 MFMA pipe, f32 accumulate; the rest f32)")
-    # the stored line of the same bench in the exact-f32 MFMA mode (python bench.py --gemm-mode f32), for comparison
-    f32_ref = None
-    fpath = os.path.join(ROOT, "profiles", "r01_v9_bench_gemm_mode_f32.json")
-    if roofline is not None and kernels.get_gemm_mode() != kernels.GEMM_F32 and os.path.exists(fpath):
-        with open(fpath) as f:
-            r = json.load(f)
-        f32_ref = {"ms_per_step": r["ms_per_step"], "residues_per_s": r["value"], "gemm_tflops": r["roofline"]["achieved"],
-                   "gemm_frac_of_f32_mfma_peak": r["roofline"]["frac"], "source": "profiles/r01_v9_bench_gemm_mode_f32.json"}
-    if roofline is not None:
-        roofline["exact_f32_mfma_mode_reference"] = f32_ref
+    dtype = {"f32": "f32",
+             "f16x2": "f32 (GEMM operands row-scaled and split into 2 f16 terms on the f16 MFMA pipe, f32 accumulate; attention "
+                      "operands split into 3 bf16 terms; the rest f32)",
+             "auto": "f32 (GEMM operands split into 2 row-scaled f16 terms [activation x weight products] or exactly into 3 bf16 "
+                     "terms [weight-gradient products, attention] on the f16 / bf16 MFMA pipe, f32 accumulate; the rest f32)"}.get(
+        a.gemm_mode, "f32 (GEMM operands split exactly into 3 bf16 terms on the bf16 MFMA pipe, f32 accumulate; the rest f32)")
     if rank == 0:
+        shape = (f"{a.batch} proteins x L={a.length} per GPU" if not a.ragged else
+                 f"ragged batches, L <= {a.length}" + (f", binned-random batching with a budget of {a.batch * a.length} residues "
+                                                       f"per GPU and batch" if a.ragged == "binned" else f", {a.batch} proteins per GPU"))
         out = {
-            "metric": "train-step residues/sec (enc-only d512, dRMSD loss)",
-            "value": round(world * n_res * a.steps / dt, 1), "unit": "residues/s", "n_gpus": world,
+            "metric": f"train-step residues/sec ({a.model.split('|')[0]} d{a.d_model}, {a.loss} loss)",
+            "value": round(world * n_res_timed / dt, 1), "unit": "residues/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": f"enc-only d_model={a.d_model} n_layers={a.n_layers} n_head={a.n_head} "
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": f"{a.model} d_model={a.d_model} n_layers={a.n_layers} n_head={a.n_head} "
                                    f"d_ff={a.d_ff}, -l {a.loss}, {a.optimizer} lr 1e-4 wd 0.01 clip 1, dropout {a.dropout}, "
-                                   f"{a.batch} proteins x L={a.length} per GPU (BASELINE.json configs[3])",
+                                   f"{shape} (BASELINE.json configs[{a.config - 1}])",
                        "global_batch": a.batch * world, "seq_len": a.length, "parallelism": f"dp{world}",
-                       "last_loss": {k: float(losses[k]) for k in ("drmsd-full", "lndrmsd-full")}},
+                       "residues_per_step": round(world * n_res_timed / a.steps, 1),
+                       "last_loss": {k: float(losses[k]) for k in ("drmsd-full", "lndrmsd-full", "mse-full")}},
+            "h2d_inclusive": {"value": round(world * n_res_timed / dt_h2d, 1), "ms_per_step": round(1e3 * dt_h2d / a.steps, 3),
+                              "what": "same loop, every step's batch copied from pinned host memory inside the step"},
+            "arithmetic_modes": {a.gemm_mode: {"ms_per_step": round(1e3 * dt / a.steps, 3)}, **sweep},
             "roofline": roofline,
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a, batches_cpu[0], angle_means)
+            keys = ("seq", "true_ang", "true_crd")
+            pick = min(range(nb), key=lambda i: abs(host_batches[i][0].shape[1] - 200)) if a.ragged == "binned" else 0
+            cpu_batch = dict(zip(keys, (t.clone() for t in host_batches[pick])))
+            params = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}   # the same model, reference keys
+            out["cpu_baseline"] = cpu_baseline(a, cpu_batch, params)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -89,6 +89,12 @@ size_t ptamd_drmsd_workspace_bytes(int B, int L);
 int ptamd_drmsd_fwd_bwd(const float *pred_crd, const float *true_crd, const int64_t *seq, int B, int L,
                         float *stats, float *dcrd, void *workspace, size_t workspace_bytes, void *stream);
 
+/* rmsd (losses.py:281-286, ProDy calcTransformation + calcRMSD) for a whole batch: RMSD of the predicted atoms after optimal
+ * rigid superposition (Kabsch) onto the true ones, over the atoms whose truth is present (NaN = absent), residues with
+ * PTAMD_PAD_ID skipped.  rmsd [B] out (NaN for a protein without atoms).  One workgroup per protein, fp64 moments. */
+int ptamd_kabsch_rmsd(const float *pred_crd, const float *true_crd, const int64_t *seq, int B, int L, float *rmsd,
+                      void *stream);
+
 /* mse_over_angles x3 (losses.py:175-214; train.py:64-66) in one pass.
  *   pred, truth [T,24]; out[6] = {sum_full, cnt_full, sum_bb, cnt_bb, sum_sc, cnt_sc} (fp32); the workspace holds
  *   the fp64 partial sums of the first pass */
@@ -100,7 +106,7 @@ int ptamd_mse_angles_bwd(const float *pred, const float *truth, int64_t T, const
                          int accumulate, float *dpred, void *stream);
 
 /* ------------------------------------------------------------------ encoder building blocks
- * Row-major fp32 GEMM on the matrix cores (see ptamd_gemm_set_mode for the arithmetic):
+ * Row-major fp32 GEMM on the matrix cores (the `arith` field selects the arithmetic, see PTAMD_GEMM_* below):
  *     C[M,N] = epilogue( A (*) B )          with reduction length K
  *   a_kmajor = 0: A is [M,K] (K contiguous, lda);  1: A is stored [K,M] (M contiguous, lda)
  *   b_kmajor = 0: B is [N,K] (K contiguous, ldb) - the torch.nn.Linear weight layout;
@@ -128,12 +134,15 @@ typedef struct {
   void *workspace; size_t workspace_bytes;
   float *colsum;          /* optional, a_kmajor only: colsum[m] += sum_k A[k][m] (the bias gradient of a dW product) */
   float gate_scale;       /* PTAMD_EPI_GATE: 1 / (1 - p) of the dropout that followed the ReLU */
+  int arith;              /* PTAMD_GEMM_* below: the arithmetic of THIS call (the library keeps no mode of its own) */
+  int reserved_cus;       /* the persistent kernels leave this many CUs free, e.g. for an RCCL all-reduce of the layer above
+                             that runs beside the backward GEMMs under data parallelism; 0 = take every CU */
 } ptamd_gemm_args;
 size_t ptamd_gemm_workspace_bytes(int M, int N, int split_k);
 int ptamd_gemm(const ptamd_gemm_args *args, void *stream);
 
-/* Arithmetic of ptamd_gemm (process-wide; default PTAMD_GEMM_AUTO, or the PTAMD_GEMM_MODE environment variable).
- * The reference computes its Linear layers in fp32 (torch.nn.Linear on fp32 tensors); all modes take and
+/* Arithmetic of a ptamd_gemm call (`arith` field of its arguments; the library holds no process-wide mode - two
+ * models, or two streams, may use different arithmetics side by side).  The reference computes its Linear layers in fp32 (torch.nn.Linear on fp32 tensors); all modes take and
  * return fp32 and accumulate in fp32:
  *   PTAMD_GEMM_F32          v_mfma_f32_32x32x2_f32: bit-for-bit an fmaf chain over k (157 TF/s peak).
  *   PTAMD_GEMM_BF16X3       every f32 operand is split EXACTLY into three bf16 terms x = x1 + x2 + x3 (round to nearest
@@ -168,9 +177,7 @@ int ptamd_gemm(const ptamd_gemm_args *args, void *stream);
 #define PTAMD_GEMM_BF16X3_FULL 2
 #define PTAMD_GEMM_F16X2 3
 #define PTAMD_GEMM_AUTO 4
-int ptamd_gemm_set_mode(int mode);
-int ptamd_gemm_get_mode(void);
-/* matrix-pipe products per fp32 product that ptamd_gemm would use for these arguments in the current mode:
+/* matrix-pipe products per fp32 product that ptamd_gemm would use for these arguments (shapes, layouts, `arith`):
  * 1 (F32), 3 (F16X2), 6 (BF16X3), 9 (BF16X3_FULL); host only, nothing is launched */
 int ptamd_gemm_products(const ptamd_gemm_args *args);
 
@@ -193,14 +200,16 @@ size_t ptamd_embed_bwd_workspace_bytes(int D);
 int ptamd_embed_bwd(const int64_t *seq, const float *dout, int B, int L, int D, float dropout_p, uint64_t seed,
                     float *demb, void *workspace, size_t workspace_bytes, void *stream);
 
-/* Fused masked multi-head attention (Attention.py:14-22,55-69), fp32 MFMA, scores never materialised.
+/* Fused masked multi-head attention (Attention.py:14-22,55-69), scores never materialised.  `arith`: PTAMD_GEMM_F32 =
+ * the exact-f32 MFMA kernels; anything else = operands split exactly into three bf16 terms on the bf16 matrix pipe
+ * (six products, f32 accumulate) where a split kernel exists for the head size, the exact-f32 kernels otherwise.
  *   qkv [T,3D]: Q | K | V column blocks, head h at columns h*dk..; key-padding mask from seq != 20;
  *   softmax(QK^T/sqrt(dk)) with dropout p on the probabilities; out [T,D] heads merged.
  *   lse [B,H,L] saves log-sum-exp per query row for the backward. dk must be 32 or 64. */
 int ptamd_attention_fwd(const float *qkv, const int64_t *seq, int B, int L, int H, int dk, float dropout_p,
-                        uint64_t seed, uint32_t stream_id, float *out, float *lse, void *stream);
+                        uint64_t seed, uint32_t stream_id, int arith, float *out, float *lse, void *stream);
 int ptamd_attention_bwd(const float *qkv, const int64_t *seq, const float *out, const float *dout, const float *lse,
-                        int B, int L, int H, int dk, float dropout_p, uint64_t seed, uint32_t stream_id,
+                        int B, int L, int H, int dk, float dropout_p, uint64_t seed, uint32_t stream_id, int arith,
                         float *dqkv, void *workspace, size_t workspace_bytes, void *stream);
 size_t ptamd_attention_workspace_bytes(int B, int L, int H, int dk);
 

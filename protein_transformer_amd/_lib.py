@@ -28,7 +28,9 @@ class GemmArgs(C.Structure):
                 ("split_k", _i),
                 ("workspace", _p), ("workspace_bytes", _sz),
                 ("colsum", _p),
-                ("gate_scale", _f)]
+                ("gate_scale", _f),
+                ("arith", _i),
+                ("reserved_cus", _i)]
 
 
 # name -> (restype, argtypes); mirrors include/ptamd.h one to one
@@ -45,13 +47,12 @@ SIGNATURES = {
     "ptamd_nerf_bwd": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _sz, _p]),
     "ptamd_drmsd_workspace_bytes": (_sz, [_i, _i]),
     "ptamd_drmsd_fwd_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _sz, _p]),
+    "ptamd_kabsch_rmsd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "ptamd_mse_angles_workspace_bytes": (_sz, []),
     "ptamd_mse_angles_fwd": (_i, [_p, _p, _i64, _p, _p, _sz, _p]),
     "ptamd_mse_angles_bwd": (_i, [_p, _p, _i64, _p, _f, _i, _p, _p]),
     "ptamd_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
     "ptamd_gemm": (_i, [C.POINTER(GemmArgs), _p]),
-    "ptamd_gemm_set_mode": (_i, [_i]),
-    "ptamd_gemm_get_mode": (_i, []),
     "ptamd_gemm_products": (_i, [C.POINTER(GemmArgs)]),
     "ptamd_layernorm_fwd": (_i, [_p, _p, _p, _i64, _i, _p, _p, _p, _p]),
     "ptamd_layernorm_bwd_workspace_bytes": (_sz, [_i]),
@@ -59,8 +60,8 @@ SIGNATURES = {
     "ptamd_embed_fwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _u64, _p, _p]),
     "ptamd_embed_bwd_workspace_bytes": (_sz, [_i]),
     "ptamd_embed_bwd": (_i, [_p, _p, _i, _i, _i, _f, _u64, _p, _p, _sz, _p]),
-    "ptamd_attention_fwd": (_i, [_p, _p, _i, _i, _i, _i, _f, _u64, _u32, _p, _p, _p]),
-    "ptamd_attention_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _u32, _p, _p, _sz, _p]),
+    "ptamd_attention_fwd": (_i, [_p, _p, _i, _i, _i, _i, _f, _u64, _u32, _i, _p, _p, _p]),
+    "ptamd_attention_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _u32, _i, _p, _p, _sz, _p]),
     "ptamd_attention_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ptamd_colsum_workspace_bytes": (_sz, [_i]),
     "ptamd_colsum": (_i, [_p, _i64, _i, _i, _i, _p, _p, _sz, _p]),
@@ -133,8 +134,10 @@ _workspaces = {}
 
 
 def workspace(tag, nbytes, device):
-    """Per-(tag, device) scratch buffer from the PyTorch caching allocator, grown on demand."""
-    key = (tag, device)
+    """Scratch buffer from the PyTorch caching allocator, grown on demand.  One per (tag, device, STREAM): kernels
+    enqueued on one stream run in order, so a buffer is never shared by two launches that could overlap - two models
+    driven from two streams of one process get separate workspaces."""
+    key = (tag, device, torch.cuda.current_stream(device).cuda_stream)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)

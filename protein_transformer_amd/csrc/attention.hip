@@ -19,13 +19,12 @@
 //     backward kernels instead of being stored.
 #include "attn_dropout.h"
 
-// split-bf16 variants for dk = 64 (attention_split.hip), selected by the matrix arithmetic mode of ptamd_gemm_set_mode
+// split-bf16 variants for dk = 64 (attention_split.hip), selected by the `arith` argument of the entry points
 int pt_attention_fwd_split(const float *qkv, const int64_t *seq, int B, int L, int H, float p, uint64_t seed, uint32_t sid,
                            float *out, float *lse, hipStream_t st);
 int pt_attention_bwd_split(const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse,
                            float *delta, int B, int L, int H, float p, uint64_t seed, uint32_t sid, float *dqkv,
                            hipStream_t st);
-extern "C" int ptamd_gemm_get_mode(void);
 
 namespace {
 
@@ -486,12 +485,12 @@ size_t ptamd_attention_workspace_bytes(int B, int L, int H, int dk) {
 }
 
 int ptamd_attention_fwd(const float *qkv, const int64_t *seq, int B, int L, int H, int dk, float dropout_p,
-                        uint64_t seed, uint32_t stream_id, float *out, float *lse, void *stream) {
-  if (B <= 0 || L <= 0 || H <= 0) return PTAMD_ERR_BAD_SHAPE;
+                        uint64_t seed, uint32_t stream_id, int arith, float *out, float *lse, void *stream) {
+  if (B <= 0 || L <= 0 || H <= 0 || arith < PTAMD_GEMM_F32 || arith > PTAMD_GEMM_AUTO) return PTAMD_ERR_BAD_SHAPE;
   if (dropout_p < 0.f || dropout_p >= 1.f) return PTAMD_ERR_BAD_SHAPE;
   if (!pt_aligned16(qkv) || !pt_aligned16(out)) return PTAMD_ERR_ALIGN;
   hipStream_t st = (hipStream_t)stream;
-  if (dk == 64 && ptamd_gemm_get_mode() != PTAMD_GEMM_F32)
+  if (dk == 64 && arith != PTAMD_GEMM_F32)
     return pt_attention_fwd_split(qkv, seq, B, L, H, dropout_p, seed, stream_id, out, lse, st);
   switch (dk) {
     case 8: return launch_fwd<8>(qkv, seq, B, L, H, dropout_p, seed, stream_id, out, lse, st);
@@ -503,15 +502,15 @@ int ptamd_attention_fwd(const float *qkv, const int64_t *seq, int B, int L, int 
 }
 
 int ptamd_attention_bwd(const float *qkv, const int64_t *seq, const float *out, const float *dout, const float *lse,
-                        int B, int L, int H, int dk, float dropout_p, uint64_t seed, uint32_t stream_id, float *dqkv,
-                        void *workspace, size_t workspace_bytes, void *stream) {
-  if (B <= 0 || L <= 0 || H <= 0) return PTAMD_ERR_BAD_SHAPE;
+                        int B, int L, int H, int dk, float dropout_p, uint64_t seed, uint32_t stream_id, int arith,
+                        float *dqkv, void *workspace, size_t workspace_bytes, void *stream) {
+  if (B <= 0 || L <= 0 || H <= 0 || arith < PTAMD_GEMM_F32 || arith > PTAMD_GEMM_AUTO) return PTAMD_ERR_BAD_SHAPE;
   if (dropout_p < 0.f || dropout_p >= 1.f) return PTAMD_ERR_BAD_SHAPE;
   if (!workspace || workspace_bytes < ptamd_attention_workspace_bytes(B, L, H, dk)) return PTAMD_ERR_WORKSPACE;
   if (!pt_aligned16(qkv) || !pt_aligned16(out) || !pt_aligned16(dout) || !pt_aligned16(dqkv)) return PTAMD_ERR_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   float *delta = static_cast<float *>(workspace);
-  if (dk == 64 && ptamd_gemm_get_mode() != PTAMD_GEMM_F32)
+  if (dk == 64 && arith != PTAMD_GEMM_F32)
     return pt_attention_bwd_split(qkv, seq, out, dout, lse, delta, B, L, H, dropout_p, seed, stream_id, dqkv, st);
   switch (dk) {
     case 8: return launch_bwd<8>(qkv, seq, out, dout, lse, delta, B, L, H, dropout_p, seed, stream_id, dqkv, st);

@@ -4,7 +4,7 @@
 //   /root/reference/protein_transformer/models/transformer/Attention.py:14-22,55-68
 // but every f32 matrix product (QK^T, PV and the five products of the backward pass) is evaluated as six
 // v_mfma_f32_32x32x16_bf16 products of exactly split operands (see gemm_split_kernel.h / split_bf16.h): 6/16 of the matrix
-// pipe time of the f32 MFMA at the same accuracy.  Selected by ptamd_gemm_set_mode like the GEMMs.
+// pipe time of the f32 MFMA at the same accuracy.  Selected by the `arith` argument of ptamd_attention_fwd / _bwd.
 //
 // Decomposition as in attention.hip but with 8 wavefronts: one workgroup = (protein, head, 256 queries), 32 per
 // wavefront (a staged tile is converted once per 256 queries: -10 % against 4-wavefront workgroups), scores
@@ -470,11 +470,7 @@ int set_lds(Kern kern) {
 int pt_attention_fwd_split(const float *qkv, const int64_t *seq, int B, int L, int H, float p, uint64_t seed, uint32_t sid,
                            float *out, float *lse, hipStream_t st) {
   using namespace ptattn;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (int rc = set_lds(attn_fwd_split_kernel)) return rc;
-    attr_set = true;
-  }
+  if (int rc = set_lds(attn_fwd_split_kernel)) return rc;  // idempotent, host-only: no state kept between calls
   hipLaunchKernelGGL(attn_fwd_split_kernel, dim3((L + QB - 1) / QB, H, B), dim3(NTHR), ATTN_LDS, st, qkv, seq, L, H, p, seed,
                      sid, out, lse);
   return pt_check_launch();
@@ -484,12 +480,8 @@ int pt_attention_bwd_split(const float *qkv, const int64_t *seq, const float *o_
                            float *delta, int B, int L, int H, float p, uint64_t seed, uint32_t sid, float *dqkv,
                            hipStream_t st) {
   using namespace ptattn;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (int rc = set_lds(attn_bwd_dq_split_kernel)) return rc;
-    if (int rc = set_lds(attn_bwd_dkv_split_kernel)) return rc;
-    attr_set = true;
-  }
+  if (int rc = set_lds(attn_bwd_dq_split_kernel)) return rc;
+  if (int rc = set_lds(attn_bwd_dkv_split_kernel)) return rc;
   const dim3 grid((L + QB - 1) / QB, H, B);
   hipLaunchKernelGGL(attn_bwd_dq_split_kernel, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, o_fwd, d_o, lse, delta, L, H, p, seed,
                      sid, dqkv);

@@ -285,17 +285,13 @@ __global__ void gemm_splitk_reduce_kernel(const GemmParams p, const float *__res
 
 }  // namespace
 
-int persistent_grid() {
-  static int slots = 0;
-  if (!slots) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-      hipDeviceProp_t prop;
-      if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    }
-    slots = cus;
-  }
-  return slots;
+int persistent_grid(int reserved_cus) {  // CUs of the current device (a cheap attribute query: no state kept between calls)
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      cus <= 0)
+    cus = 256;
+  if (reserved_cus > 0) cus -= reserved_cus;
+  return cus > 0 ? cus : 1;
 }
 
 namespace {
@@ -306,13 +302,9 @@ int launch(const GemmParams &p, int splits, hipStream_t st) {
   const size_t lds = (size_t)2 * (SA + SB) * sizeof(float);
   const int work = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * splits;
   auto kern = gemm_f32_mfma_kernel<AK, BKM, BK>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
-    attr_set = true;
-  }
-  const int slots = persistent_grid() * 2;
+  // idempotent and host-only: set on every launch so that the library keeps no state between calls
+  PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int slots = persistent_grid(p.reserved_cus) * 2;
   const int grid = work < slots ? work : slots;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, p);
   return pt_check_launch();
@@ -324,19 +316,6 @@ int launch_f32(const GemmParams &p, bool a_kmajor, bool b_kmajor, int splits, hi
   if (!a_kmajor && b_kmajor) return launch<false, true>(p, splits, st);
   if (a_kmajor && !b_kmajor) return launch<true, false>(p, splits, st);
   return launch<true, true>(p, splits, st);
-}
-
-// precision mode of ptamd_gemm: see ptamd_gemm_set_mode in include/ptamd.h
-int g_mode = -1;
-int current_mode() {
-  if (g_mode < 0) {
-    g_mode = PTAMD_GEMM_AUTO;
-    if (const char *e = getenv("PTAMD_GEMM_MODE")) {
-      const int v = atoi(e);
-      if (v == PTAMD_GEMM_F32 || v == PTAMD_GEMM_BF16X3 || v == PTAMD_GEMM_BF16X3_FULL || v == PTAMD_GEMM_F16X2 || v == PTAMD_GEMM_AUTO) g_mode = v;
-    }
-  }
-  return g_mode;
 }
 
 }  // namespace ptgemm
@@ -358,21 +337,16 @@ size_t ptamd_gemm_workspace_bytes(int M, int N, int split_k) {
   return slab_bytes(M, N, split_k) + (size_t)(round4(M) + round4(N)) * sizeof(uint32_t);  // + row scales (f16x2 arithmetic)
 }
 
-int ptamd_gemm_set_mode(int mode) {
-  if (mode != PTAMD_GEMM_F32 && mode != PTAMD_GEMM_BF16X3 && mode != PTAMD_GEMM_BF16X3_FULL && mode != PTAMD_GEMM_F16X2 &&
-      mode != PTAMD_GEMM_AUTO)
-    return PTAMD_ERR_BAD_SHAPE;
-  ptgemm::g_mode = mode;
-  return PTAMD_OK;
-}
-int ptamd_gemm_get_mode(void) { return ptgemm::current_mode(); }
-
 namespace {
-// the arithmetic one call runs in: the process-wide mode, AUTO resolved by operand layout, and the exact-f32 kernel
-// for what the split kernels do not take (they address an operand with 32-bit byte offsets and start a K tail 16 k
-// before its end)
+bool valid_arith(int mode) {
+  return mode == PTAMD_GEMM_F32 || mode == PTAMD_GEMM_BF16X3 || mode == PTAMD_GEMM_BF16X3_FULL || mode == PTAMD_GEMM_F16X2 ||
+         mode == PTAMD_GEMM_AUTO;
+}
+// the arithmetic one call runs in: the call's own `arith` field (there is no process-wide mode), AUTO resolved by operand
+// layout, and the exact-f32 kernel for what the split kernels do not take (they address an operand with 32-bit byte
+// offsets and start a K tail 16 k before its end)
 int resolve_mode(const ptamd_gemm_args *a) {
-  int mode = current_mode();
+  int mode = a->arith;
   // AUTO: f16x2 where the pass over the operands is cheap next to the product (K-contiguous A: activations x weights),
   // bf16x3 for the long token reductions of the weight gradients (both operands are read whole by that pass)
   if (mode == PTAMD_GEMM_AUTO) mode = a->a_kmajor ? PTAMD_GEMM_BF16X3 : PTAMD_GEMM_F16X2;
@@ -384,13 +358,13 @@ int resolve_mode(const ptamd_gemm_args *a) {
 }  // namespace
 
 int ptamd_gemm_products(const ptamd_gemm_args *a) {
-  if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0) return PTAMD_ERR_BAD_SHAPE;
+  if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0 || !valid_arith(a->arith)) return PTAMD_ERR_BAD_SHAPE;
   const int mode = resolve_mode(a);
   return mode == PTAMD_GEMM_F32 ? 1 : mode == PTAMD_GEMM_F16X2 ? 3 : mode == PTAMD_GEMM_BF16X3_FULL ? 9 : 6;
 }
 
 int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
-  if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0) return PTAMD_ERR_BAD_SHAPE;
+  if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0 || !valid_arith(a->arith)) return PTAMD_ERR_BAD_SHAPE;
   if ((a->lda & 3) || (a->ldb & 3)) return PTAMD_ERR_BAD_SHAPE;
   if ((!a->a_kmajor || !a->b_kmajor) && (a->K & 3)) return PTAMD_ERR_BAD_SHAPE;  // K-contiguous rows are read 16 B at a time
   if (a->a_kmajor && (a->M & 3)) return PTAMD_ERR_BAD_SHAPE;
@@ -406,6 +380,7 @@ int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
   p.A = a->A; p.lda = a->lda; p.B = a->B; p.ldb = a->ldb; p.C = a->C; p.ldc = a->ldc;
   p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr; p.flags = a->flags;
   p.dropout_p = a->dropout_p; p.seed = a->seed; p.stream_id = a->stream_id; p.gate_scale = a->gate_scale;
+  p.reserved_cus = a->reserved_cus;
   p.k_per_split = ((kblocks + splits - 1) / splits) * BK;
   splits = (a->K + p.k_per_split - 1) / p.k_per_split;
   p.splits = splits;

@@ -38,6 +38,7 @@ struct GemmParams {
   int colsum_share;  // N tiles sharing the column-sum work of one (M tile, split): power of two <= min(tiles_n, 16)
   float gate_scale;  // PTAMD_EPI_GATE
   const uint32_t *scale_a, *scale_b;  // f16x2 arithmetic only: power-of-two scale (bits) per row of A / column of B
+  int reserved_cus;  // CUs the persistent grid leaves free (room for a concurrent collective kernel); 0 = none
 };
 
 // ---- staging: each thread carries 4 float4 per operand per stage; global -> registers -> LDS, no transposition:
@@ -220,7 +221,7 @@ struct WorkRange {
   }
 };
 
-int persistent_grid();  // CUs of the current device (gemm.hip)
+int persistent_grid(int reserved_cus);  // CUs of the current device minus the reserve, at least 1 (gemm.hip)
 // launchers of the two kernels: a_kmajor / b_kmajor select the instantiation
 int launch_f32(const GemmParams &p, bool a_kmajor, bool b_kmajor, int splits, hipStream_t st);
 int launch_split(const GemmParams &p, bool a_kmajor, bool b_kmajor, int splits, int products, hipStream_t st);

@@ -10,7 +10,7 @@
 // and the two inverse scales applied to the accumulators in front of the epilogue.
 //
 // Same role, interface and epilogues as gemm.hip (every torch.nn.Linear of the reference encoder and the backward
-// GEMMs: Attention.py:38-41,49,69; Sublayers.py:28-34; encoder_only.py:18,39-41) - see ptamd_gemm_set_mode.
+// GEMMs: Attention.py:38-41,49,69; Sublayers.py:28-34; encoder_only.py:18,39-41) - see the `arith` field of ptamd_gemm_args.
 //
 // Why: on MI355X the f32-input MFMA runs at the vector rate (157 TF/s) while the bf16 MFMA is 16x faster.  An f32
 // has 24 significand bits = 3 x the 8 of a bf16 and the same exponent range, so with round-to-nearest at each level
@@ -456,13 +456,9 @@ template <bool AK, bool BKM, int NPROD, int EPI>
 int launch(const GemmParams &p, int splits, hipStream_t st) {
   const int work = ((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN) * splits;
   auto kern = gemm_bf16x3_mfma_kernel<AK, BKM, NPROD, EPI>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)LDS_BYTES));
-    attr_set = true;
-  }
-  const int slots = persistent_grid();  // one workgroup per CU
+  PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)LDS_BYTES));  // idempotent, host-only: no state kept between calls
+  const int slots = persistent_grid(p.reserved_cus);  // one workgroup per CU
   const int grid = work < slots ? work : slots;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), LDS_BYTES, st, p);
   return pt_check_launch();

@@ -41,6 +41,8 @@ def collate_fn(insts, coords=False, sequences=False, max_seq_len=None):
 
 def make_paired_collate_fn(max_seq_len=MAX_SEQ_LEN):
     def paired(insts):
+        if len(insts) == 0:      # this rank's shard of a batch with fewer proteins than ranks (dp.shard_indices)
+            return (torch.zeros(0, 0, dtype=torch.int64), torch.zeros(0, 0, 24), torch.zeros(0, 0, 3))
         sequences, angles, coords = list(zip(*insts))
         return (collate_fn(sequences, sequences=True, max_seq_len=max_seq_len),
                 collate_fn(angles, max_seq_len=max_seq_len),
@@ -132,7 +134,10 @@ class SimilarLengthBatchSampler(torch.utils.data.Sampler):
         self.batch_size = batch_size
         self.dynamic_batch = dynamic_batch
         self.optimize_batch_for_cpus = optimize_batch_for_cpus
+        # the reference rounds dRMSD batches down to a multiple of its CPU loss workers (dataset.py:186,218-220); the
+        # loss workers of this path are the GPUs of the job, which `prepare_dataloaders` writes here (1 GPU: no rounding)
         self.cpu_count = torch.multiprocessing.cpu_count()
+        self.min_batch = 1
         self.downsample = downsample
         self.use_largest_bin = use_largest_bin
         self.repeat_train = repeat_train if repeat_train else 1
@@ -157,36 +162,69 @@ class SimilarLengthBatchSampler(torch.utils.data.Sampler):
                 size = int(self.dynamic_batch / ds.hist_bins[b])
                 if self.optimize_batch_for_cpus:
                     size -= size % self.cpu_count
-                size = max(1, size)
+                size = max(self.min_batch, size)
             else:
                 size = self.batch_size
             yield np.random.choice(ds.bin_map[b], size=size)
 
 
+class ShardedBatchSampler(torch.utils.data.Sampler):
+    """Data-parallel view of a batch sampler: yields, for every batch of the wrapped sampler, the indices that THIS rank
+    takes (serpentine deal by length, dp.shard_indices) - so each rank collates, pads (to its own longest protein) and
+    uploads only its shard.  Every rank draws the same global batches (same seed, same numpy stream: train.seed_rngs)."""
+
+    def __init__(self, batch_sampler, lengths, world=None, rank=None):
+        self.batch_sampler, self.lengths = batch_sampler, lengths
+        self.world, self.rank = world, rank
+
+    def __len__(self):
+        return len(self.batch_sampler)
+
+    def __iter__(self):
+        from . import dp
+        for batch in self.batch_sampler:
+            batch = [int(i) for i in batch]
+            keep = dp.shard_indices([self.lengths[i] for i in batch], self.world, self.rank)
+            yield [batch[k] for k in keep]
+
+
 def prepare_dataloaders(data, args, max_seq_len, num_workers=1):
-    """train (binned, dynamic batches), train-eval, 7 validation splits and test loaders."""
+    """train (binned, dynamic batches), train-eval, 7 validation splits and test loaders (dataset.py:228-290).  With more
+    than one rank every loader is sharded (ShardedBatchSampler) and dRMSD batch sizes are multiples of the rank count."""
+    from . import dp
     if args.batching_order in ["descending", "ascending"]:
         raise NotImplementedError("Descending and ascending order have not been reimplemented.")
+    world = dp.world_size()
     collate = make_paired_collate_fn(max_seq_len)
     cpu_opt = args.loss in ["combined", "drmsd", "ln-drmsd"]
     common = dict(num_workers=num_workers, collate_fn=collate, pin_memory=torch.cuda.is_available())
     train_dataset = BinnedProteinDataset(seqs=data['train']['seq'], crds=data['train']['crd'], angs=data['train']['ang'],
                                          add_sos_eos=args.add_sos_eos, skip_missing_residues=args.skip_missing_res_train,
                                          bins=args.bins, max_seq_len=max_seq_len)
+
+    def sharded(sampler, lengths):
+        return ShardedBatchSampler(sampler, lengths) if world > 1 else sampler
+
+    def binned_sampler(**kw):
+        smp = SimilarLengthBatchSampler(train_dataset, args.batch_size, optimize_batch_for_cpus=cpu_opt, **kw)
+        smp.cpu_count = world            # the "loss workers" of this path are the GPUs; every rank gets a protein
+        smp.min_batch = world if cpu_opt else 1
+        return sharded(smp, train_dataset.lens)
+
     train_loader = torch.utils.data.DataLoader(
-        train_dataset, batch_sampler=SimilarLengthBatchSampler(
-            train_dataset, args.batch_size, dynamic_batch=args.batch_size * max_seq_len,
-            optimize_batch_for_cpus=cpu_opt, repeat_train=args.repeat_train), **common)
+        train_dataset, batch_sampler=binned_sampler(dynamic_batch=args.batch_size * max_seq_len,
+                                                    repeat_train=args.repeat_train), **common)
     train_eval_loader = torch.utils.data.DataLoader(
-        train_dataset, batch_sampler=SimilarLengthBatchSampler(
-            train_dataset, args.batch_size, dynamic_batch=None, optimize_batch_for_cpus=cpu_opt,
-            downsample=args.train_eval_downsample), **common)
+        train_dataset, batch_sampler=binned_sampler(dynamic_batch=None, downsample=args.train_eval_downsample), **common)
 
     def plain(split):
-        return torch.utils.data.DataLoader(
-            ProteinDataset(seqs=data[split]['seq'], crds=data[split]['crd'], angs=data[split]['ang'],
-                           add_sos_eos=args.add_sos_eos, skip_missing_residues=args.skip_missing_res_train),
-            batch_size=args.batch_size, **common)
+        ds = ProteinDataset(seqs=data[split]['seq'], crds=data[split]['crd'], angs=data[split]['ang'],
+                            add_sos_eos=args.add_sos_eos, skip_missing_residues=args.skip_missing_res_train)
+        if world == 1:
+            return torch.utils.data.DataLoader(ds, batch_size=args.batch_size, **common)
+        batches = torch.utils.data.BatchSampler(torch.utils.data.SequentialSampler(ds), args.batch_size, drop_last=False)
+        lengths = [min(len(ds[i][0]), max_seq_len) for i in range(len(ds))]
+        return torch.utils.data.DataLoader(ds, batch_sampler=sharded(batches, lengths), **common)
 
     valid_loaders = {split: plain(f'valid-{split}') for split in VALID_SPLITS if f'valid-{split}' in data}
     test_loader = plain('test') if 'test' in data else None

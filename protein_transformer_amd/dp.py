@@ -12,13 +12,16 @@ gradient buffer per step.
     (12.6 MB each at d512) as soon as the backward pass has finished a layer, on RCCL's own stream,
     overlapped with the remaining backward kernels; `all_reduce_gradients` only waits for the tail.
   * gradient clipping needs the GLOBAL norm, so it runs after the reduction on every rank (identical).
+  * every reported loss is a statistic of the GLOBAL batch: the MSE term (`-l mse` / `combined`) is a mean over all
+    selected elements of the global batch, so its numerator and count are SUM-reduced before the gradient is formed, and
+    the dRMSD / RMSD statistics are reduced with them (losses.LossReport) - all ranks log, schedule and stop identically.
+  * ragged batches are dealt to the ranks in serpentine order of length (`shard_indices`), each rank collates, pads (to
+    its own longest protein) and uploads only its shard; a rank whose shard is empty still joins every collective.
 """
 import os
 
 import torch
 import torch.distributed as dist
-
-_pending = []
 
 
 def is_initialized():
@@ -71,7 +74,7 @@ def shard_bounds(n, world, r):
 
 
 def shard_batch(*tensors):
-    """This rank's contiguous slice (along dim 0) of every tensor of a global batch."""
+    """This rank's contiguous slice (along dim 0) of every tensor of a global batch (equal-length batches: bench, tests)."""
     w = world_size()
     if w == 1:
         return tensors
@@ -79,33 +82,70 @@ def shard_batch(*tensors):
     return tuple(t[lo:hi] for t in tensors)
 
 
+def shard_indices(lengths, world=None, r=None):
+    """Length-balanced deal of a ragged batch: positions of the proteins of `lengths` that rank
+    `r` takes.  Proteins are sorted by length (longest first, ties by position) and dealt in serpentine order
+    0..W-1, W-1..0, ... so that every rank gets the same number of proteins (+-1) and about the same sum of lengths and of
+    squared lengths (the dRMSD cost).  Deterministic, identical on every rank, a partition of range(len(lengths));
+    the positions of a rank come back in ascending order."""
+    world = world_size() if world is None else world
+    r = rank() if r is None else r
+    if world == 1:
+        return list(range(len(lengths)))
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    mine = []
+    for pos, i in enumerate(order):
+        rnd, k = divmod(pos, world)
+        owner = k if rnd % 2 == 0 else world - 1 - k
+        if owner == r:
+            mine.append(i)
+    return sorted(mine)
+
+
 def attach(model):
     """Overlap the gradient reduction with backward: reduce each slice of the flat gradient buffer as soon
-    as `_EncoderFn.backward` reports it final (model.grad_hook)."""
+    as `_EncoderFn.backward` reports it final (model.grad_hook).  The work handles live on the model."""
+    model._dp_pending = []
     if world_size() == 1:
         model.grad_hook = None
         return model
 
     def hook(offset, numel):
-        _, g = model._flat, model._flat_grad
-        _pending.append(dist.all_reduce(g[offset:offset + numel], op=dist.ReduceOp.SUM, async_op=True))
+        g = model._flat_grad
+        model._dp_pending.append(dist.all_reduce(g[offset:offset + numel], op=dist.ReduceOp.SUM, async_op=True))
 
     model.grad_hook = hook
+    reserve_cus_for_collectives()
     return model
 
 
-def all_reduce_gradients(model):
+def reserve_cus_for_collectives(n=None):
+    """The split-arithmetic GEMMs are persistent kernels that take every CU (one 512-thread workgroup with ~150 KB of LDS
+    per CU): an RCCL kernel enqueued meanwhile cannot start before one of them retires.  Under data parallelism the GEMMs
+    therefore leave `n` CUs free (PTAMD_DP_RESERVE_CUS, default 8 of 256) so that the per-layer all-reduce overlaps the
+    backward pass instead of queueing behind it."""
+    from . import kernels
+    if n is None:
+        n = int(os.environ.get("PTAMD_DP_RESERVE_CUS", "8"))
+    kernels.GEMM_RESERVED_CUS = max(0, int(n))
+
+
+def all_reduce_gradients(model, empty=False):
     """Finish the step's gradient exchange.  With `attach(model)` this only waits for the slices already
-    in flight; without it the whole flat buffer is reduced here in one call."""
+    in flight; without it the whole flat buffer is reduced here in one call.  `empty`: this rank had no proteins in
+    the step (its gradient buffer is zero and no backward ran): it issues the same reductions, in the same order."""
     if world_size() == 1:
         return
-    if model.grad_hook is None:
+    if getattr(model, "grad_hook", None) is None:
         _, g = model.flat_parameters()
         dist.all_reduce(g, op=dist.ReduceOp.SUM)
         return
-    for work in _pending:
+    if empty:
+        for off, n in model.grad_slices():
+            model.grad_hook(off, n)
+    for work in model._dp_pending:
         work.wait()
-    _pending.clear()
+    model._dp_pending.clear()
 
 
 def all_reduce_sum_(t):

@@ -17,11 +17,13 @@ EPI_RELU, EPI_TANH, EPI_ACCUM, EPI_GATE = 1, 2, 4, 8
 GEMM_TIMING = None
 GEMM_EVENT_POOL = []
 GEMM_BYTES = []          # algorithmic operand bytes (A + B + C [+ residual, + accumulate]) of every timed launch
+GEMM_RESERVED_CUS = 0    # CUs the persistent GEMMs leave free (dp.reserve_cus_for_collectives sets it under data parallelism)
 
 
 def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, bias=None, residual=None,
-         ldr=0, flags=0, dropout_p=0.0, seed=0, stream_id=0, split_k=1, colsum=None, gate_scale=0.0):
-    """C[M,N] = epilogue(A (*) B); operand layouts as documented in ptamd.h."""
+         ldr=0, flags=0, dropout_p=0.0, seed=0, stream_id=0, split_k=1, colsum=None, gate_scale=0.0, arith=None):
+    """C[M,N] = epilogue(A (*) B); operand layouts as documented in ptamd.h.  `arith`: GEMM_* constant of this call
+    (None = the host-side default, `set_gemm_mode`); the library itself keeps no mode."""
     # split-K slabs and, for the f16x2 arithmetic, the row scales of the two operands
     ws = workspace("gemm", lib().ptamd_gemm_workspace_bytes(M, N, split_k), C_out.device)
     args = GemmArgs(M=M, N=N, K=K, A=A.data_ptr(), lda=lda, a_kmajor=int(a_kmajor), B=B.data_ptr(), ldb=ldb,
@@ -31,7 +33,8 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False,
                     dropout_p=float(dropout_p), seed=int(seed) & (2 ** 64 - 1), stream_id=int(stream_id),
                     split_k=int(split_k), workspace=ws.data_ptr() if ws is not None else None,
                     workspace_bytes=ws.numel() if ws is not None else 0,
-                    colsum=colsum.data_ptr() if colsum is not None else None, gate_scale=float(gate_scale))
+                    colsum=colsum.data_ptr() if colsum is not None else None, gate_scale=float(gate_scale),
+                    arith=int(_DEFAULT_ARITH if arith is None else arith), reserved_cus=int(GEMM_RESERVED_CUS))
     if GEMM_TIMING is None:
         check(lib().ptamd_gemm(C.byref(args), stream()), "gemm")
     else:
@@ -49,13 +52,33 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False,
 GEMM_F32, GEMM_BF16X3, GEMM_BF16X3_FULL, GEMM_F16X2, GEMM_AUTO = 0, 1, 2, 3, 4   # ptamd.h: PTAMD_GEMM_*
 
 
+
+
+def _env_arith():
+    import os
+    try:
+        v = int(os.environ.get("PTAMD_GEMM_MODE", GEMM_AUTO))
+    except ValueError:
+        v = GEMM_AUTO
+    return v if v in (GEMM_F32, GEMM_BF16X3, GEMM_BF16X3_FULL, GEMM_F16X2, GEMM_AUTO) else GEMM_AUTO
+
+
+# Host-side DEFAULT arithmetic of calls / models that do not name one (PTAMD_GEMM_* of include/ptamd.h).  The library has
+# no mode of its own: every ptamd_gemm / ptamd_attention call carries its arithmetic, and a model keeps the one it was
+# given (`model.gemm_mode`), so two models with different arithmetics can run side by side in one process.
+_DEFAULT_ARITH = _env_arith()
+
+
 def set_gemm_mode(mode):
-    """Select the arithmetic of every subsequent GEMM (see ptamd_gemm_set_mode in include/ptamd.h)."""
-    check(lib().ptamd_gemm_set_mode(int(mode)), "gemm_set_mode")
+    """Set the default arithmetic for calls and models that do not carry their own (`arith=` / `model.gemm_mode`)."""
+    global _DEFAULT_ARITH
+    if int(mode) not in (GEMM_F32, GEMM_BF16X3, GEMM_BF16X3_FULL, GEMM_F16X2, GEMM_AUTO):
+        raise ValueError(f"unknown GEMM arithmetic {mode}")
+    _DEFAULT_ARITH = int(mode)
 
 
 def get_gemm_mode():
-    return lib().ptamd_gemm_get_mode()
+    return _DEFAULT_ARITH
 
 
 def pick_split_k(M, N, K, slots=512):
@@ -76,7 +99,7 @@ def linear_fwd(x, w, b, out=None, **epi):
     return gemm(x, w, out, M=T, N=N, K=K, lda=x.stride(0), ldb=w.stride(0), ldc=out.stride(0), bias=b, **epi)
 
 
-def linear_bwd_input(dy, w, out=None, flags=0, gate=None, gate_dropout_p=0.0):
+def linear_bwd_input(dy, w, out=None, flags=0, gate=None, gate_dropout_p=0.0, arith=None):
     """dx[T,K] = dy[T,N] w[N,K];  with `gate` (the saved output of a ReLU + dropout layer, [T,K]) the product is passed
     through the backward of that layer in the epilogue: dx = gate > 0 ? dx / (1 - p) : 0."""
     T, N = dy.shape
@@ -85,18 +108,19 @@ def linear_bwd_input(dy, w, out=None, flags=0, gate=None, gate_dropout_p=0.0):
         out = torch.empty(T, K, dtype=torch.float32, device=dy.device)
     if gate is not None:
         return gemm(dy, w, out, M=T, N=K, K=N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0), b_kmajor=True,
-                    flags=flags | EPI_GATE, residual=gate, ldr=gate.stride(0), gate_scale=1.0 / (1.0 - gate_dropout_p))
+                    flags=flags | EPI_GATE, residual=gate, ldr=gate.stride(0), gate_scale=1.0 / (1.0 - gate_dropout_p),
+                    arith=arith)
     return gemm(dy, w, out, M=T, N=K, K=N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0), b_kmajor=True,
-                flags=flags)
+                flags=flags, arith=arith)
 
 
-def linear_bwd_weight(dy, x, dw, dbias=None):
+def linear_bwd_weight(dy, x, dw, dbias=None, arith=None):
     """dw[N,K] += dy[T,N]^T x[T,K]  (reduction over the T tokens, split across workgroups) and, fused into the same
     pass over dy, dbias[N] += sum_t dy[t,N]."""
     T, N = dy.shape
     K = x.shape[1]
     return gemm(dy, x, dw, M=N, N=K, K=T, lda=dy.stride(0), ldb=x.stride(0), ldc=dw.stride(0), a_kmajor=True,
-                b_kmajor=True, flags=EPI_ACCUM, split_k=pick_split_k(N, K, T), colsum=dbias)
+                b_kmajor=True, flags=EPI_ACCUM, split_k=pick_split_k(N, K, T), colsum=dbias, arith=arith)
 
 
 def colsum(x, out, accumulate=True):
@@ -143,23 +167,25 @@ def embed_bwd(seq, dout, D, dropout_p, seed, demb):
                                 ws.numel(), stream()), "embed_bwd")
 
 
-def attention_fwd(qkv, seq, H, dropout_p, seed, stream_id):
+def attention_fwd(qkv, seq, H, dropout_p, seed, stream_id, arith=None):
     B, L = seq.shape
     D = qkv.shape[1] // 3
     out = torch.empty(B * L, D, dtype=torch.float32, device=qkv.device)
     lse = torch.empty(B, H, L, dtype=torch.float32, device=qkv.device)
     check(lib().ptamd_attention_fwd(ptr(qkv), ptr(seq), B, L, H, D // H, float(dropout_p), int(seed), int(stream_id),
-                                    ptr(out), ptr(lse), stream()), "attention_fwd")
+                                    int(_DEFAULT_ARITH if arith is None else arith), ptr(out), ptr(lse), stream()),
+          "attention_fwd")
     return out, lse
 
 
-def attention_bwd(qkv, seq, out, dout, lse, H, dropout_p, seed, stream_id):
+def attention_bwd(qkv, seq, out, dout, lse, H, dropout_p, seed, stream_id, arith=None):
     B, L = seq.shape
     D = qkv.shape[1] // 3
     dqkv = torch.empty_like(qkv)
     ws = workspace("attn", lib().ptamd_attention_workspace_bytes(B, L, H, D // H), qkv.device)
     check(lib().ptamd_attention_bwd(ptr(qkv), ptr(seq), ptr(out), ptr(dout), ptr(lse), B, L, H, D // H,
-                                    float(dropout_p), int(seed), int(stream_id), ptr(dqkv), ptr(ws), ws.numel(),
+                                    float(dropout_p), int(seed), int(stream_id),
+                                    int(_DEFAULT_ARITH if arith is None else arith), ptr(dqkv), ptr(ws), ws.numel(),
                                     stream()), "attention_bwd")
     return dqkv
 
@@ -207,29 +233,29 @@ def pad4(c):
     return (c + 3) // 4 * 4
 
 
-def conv1d_fwd(x, B, L, C, w, bias, k):
+def conv1d_fwd(x, B, L, C, w, bias, k, arith=None):
     """x [T, pad4(C)] token-major, w [Co, C, k] (torch Conv1d layout) -> y [T, Co]; returns (y, packed weight)."""
     T, Co, Cp = x.shape[0], w.shape[0], pad4(C)
     col = torch.empty(T, k * Cp, dtype=torch.float32, device=x.device)
     check(lib().ptamd_im2col1d(ptr(x), x.stride(0), B, L, Cp, k, ptr(col), stream()), "im2col1d")
     w2 = torch.empty(Co, k * Cp, dtype=torch.float32, device=x.device)
     check(lib().ptamd_conv_weight_pack(ptr(w), Co, C, k, ptr(w2), stream()), "conv_weight_pack")
-    y = linear_fwd(col, w2, bias)
+    y = linear_fwd(col, w2, bias, arith=arith)
     return y, w2
 
 
-def conv1d_bwd(dy, x, B, L, C, w2, k, dw, dbias, need_dx=True):
+def conv1d_bwd(dy, x, B, L, C, w2, k, dw, dbias, need_dx=True, arith=None):
     """Accumulates dw [Co, C, k] and dbias [Co]; returns dx [T, pad4(C)] (or None)."""
     T, Co, Cp = x.shape[0], dy.shape[1], pad4(C)
     col = torch.empty(T, k * Cp, dtype=torch.float32, device=x.device)          # recomputed, not stored
     check(lib().ptamd_im2col1d(ptr(x), x.stride(0), B, L, Cp, k, ptr(col), stream()), "im2col1d")
     dw2 = torch.zeros(Co, k * Cp, dtype=torch.float32, device=x.device)
-    linear_bwd_weight(dy, col, dw2)
+    linear_bwd_weight(dy, col, dw2, arith=arith)
     check(lib().ptamd_conv_weight_unpack_add(ptr(dw2), Co, C, k, ptr(dw), stream()), "conv_weight_unpack_add")
     colsum(dy, dbias)
     if not need_dx:
         return None
-    dcol = linear_bwd_input(dy, w2)
+    dcol = linear_bwd_input(dy, w2, arith=arith)
     dx = torch.empty(T, Cp, dtype=torch.float32, device=x.device)
     check(lib().ptamd_col2im1d(ptr(dcol), B, L, Cp, k, ptr(dx), dx.stride(0), stream()), "col2im1d")
     return dx

@@ -67,7 +67,11 @@ def update_metrics(metrics, losses, mode, src_seq, tracking_loss=None, batch_lev
             m[f"epoch-{k}"] += v
         else:
             m[f"epoch-{k}"] = v                       # the reference overwrites the bb/sc entries (log.py:413-416)
-    num_res = int((src_seq != VOCAB.pad_id).sum().item()) * dp.world_size()
+    # residues of the GLOBAL batch: counted on the host before the upload and reduced with the loss statistics
+    # (losses.LossReport); the device count is only the fall-back for callers that did not pass one
+    num_res = losses.get("n-residues")
+    if num_res is None:
+        num_res = int((src_seq != VOCAB.pad_id).sum().item()) * dp.world_size()
     now = time.time()
     m["speed"] = num_res / max(now - m["batch-time"], 1e-9)        # log.py:422-424
     m.setdefault("speeds", []).append(m["speed"])
@@ -110,6 +114,10 @@ def prepare_log_header(args):
 
 
 def log_batch(log_writer, metrics, start_time, mode="valid", end_of_epoch=False, t=None):
+    """One CSV row (log.py:115-130): ten values - drmsd, ln_drmsd, rmse, rmsd, combined, lr, mode, granularity, time,
+    speed; like upstream the `combined` value is written whatever the header of `prepare_log_header` lists.  One
+    deliberate difference: the granularity column says "batch" for per-batch rows (upstream writes the literal "epoch"
+    in both cases, log.py:130)."""
     t = t or time.time()
     m = metrics[mode]
     be = "epoch" if end_of_epoch else "batch"

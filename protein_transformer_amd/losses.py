@@ -123,10 +123,11 @@ def angles_to_coords(angles, seq, remove_batch_padding=False):
     return generate_coords(angles, seq)
 
 
-def batch_loss(pred_sincos, true_crds, input_seqs, do_backward=True):
+def batch_loss(pred_sincos, true_crds, input_seqs, do_backward=True, return_crd=False):
     """Device-resident core of compute_batch_drmsd: no host synchronisation.
 
-    Returns (stats [B,8] device tensor, d(sum_i lndrmsd_i)/d(pred_sincos) or None, status int32[1]).
+    Returns (stats [B,8] device tensor, d(sum_i lndrmsd_i)/d(pred_sincos) or None, status int32[1]) and, with
+    `return_crd`, the predicted coordinates [B, L*14, 3] as a fourth value.
     """
     pred_sincos = pred_sincos.detach().float().contiguous()
     B, L = input_seqs.shape
@@ -138,19 +139,115 @@ def batch_loss(pred_sincos, true_crds, input_seqs, do_backward=True):
     if do_backward:
         dang = nerf_backward(ang, input_seqs, crd, dcrd)
         grad = angles_backward(sc, dang)
-    return stats, grad, status
+    return (stats, grad, status, crd) if return_crd else (stats, grad, status)
 
 
-_HOST_STATS = {}
+# ----------------------------------------------------------------------------- statistics hand-over
+_PINNED = {}
+
+
+def _pinned(kind, n, dtype, device):
+    """Pinned host buffer per (kind, size, device, STREAM): a stream's reports are consumed in order (`LossReport.wait`
+    runs before the next one is built), two streams never share one."""
+    key = (kind, n, dtype, device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _PINNED.get(key)
+    if buf is None:
+        buf = _PINNED[key] = torch.empty(n, dtype=dtype).pin_memory()
+    return buf
+
+
+class LossReport:
+    """The loss statistics of one batch on their way to the host, without draining the stream.
+
+    The reference returns host numbers every step (losses.py:169-172, train.py:64-66).  Here the kernels leave
+    per-protein dRMSD statistics [B,8], the six MSE sums, the status word and (evaluation) per-protein RMSDs on the
+    device; this object enqueues ONE set of asynchronous copies into a pinned buffer right behind them, records an event,
+    and `wait()` - called after the backward pass has been enqueued - blocks on that event only.
+
+    Data parallel: every reported loss is a statistic of the GLOBAL batch, so the ranks first
+    SUM-reduce a small fp64 vector (sums over proteins, protein / residue counts, MSE numerators and denominators, status
+    flags): every rank then sees the same numbers and takes the same NaN / early-stopping / scheduler decisions.
+    `global_mse_sums` is the device tensor the MSE gradient must be normalised with (count of the whole global batch).
+    A rank whose shard is empty passes None for everything and still takes part in the reduction.
+    """
+
+    _NVEC = 18  # [0:4] sums of drmsd, ln, bb, bb-ln  [4] proteins  [5] sum rmsd  [6:12] mse sums  [12:16] status bits  [16] residues  [17] proteins with rmsd
+
+    def __init__(self, device, stats=None, status=None, mse_sums_local=None, rmsd=None, n_res=None):
+        from . import dp
+        self.world = dp.world_size()
+        self.n_res = n_res
+        if self.world == 1:
+            B = 0 if stats is None else stats.shape[0]
+            self._B = B
+            n = B * 8 + 6 + 1 + B
+            buf = _pinned("report32", n, torch.float32, device)
+            if stats is not None:
+                buf[:B * 8].copy_(stats.reshape(-1), non_blocking=True)
+            if mse_sums_local is not None:
+                buf[B * 8:B * 8 + 6].copy_(mse_sums_local, non_blocking=True)
+            if status is not None:       # raw int32 bits into the float slot
+                buf.view(torch.int32)[B * 8 + 6:B * 8 + 7].copy_(status, non_blocking=True)
+            if rmsd is not None:
+                buf[B * 8 + 7:].copy_(rmsd, non_blocking=True)
+            self._has = (stats is not None, mse_sums_local is not None, status is not None, rmsd is not None)
+            self._buf = buf
+            self.global_mse_sums = mse_sums_local
+        else:
+            v = torch.zeros(self._NVEC, dtype=torch.float64, device=device)
+            if stats is not None:
+                v[0:4] = stats[:, :4].double().sum(0)
+                v[4] = stats.shape[0]
+            if rmsd is not None:
+                v[5] = rmsd.double().sum()
+                v[17] = rmsd.shape[0]
+            if mse_sums_local is not None:
+                v[6:12] = mse_sums_local.double()
+            if status is not None:
+                v[12:16] = ((status.to(torch.int64) >> torch.arange(4, device=device)) & 1).double()
+            v[16] = float(n_res or 0)
+            dp.all_reduce_sum_(v)
+            self.global_mse_sums = v[6:12].float()
+            buf = _pinned("report64", self._NVEC, torch.float64, device)
+            buf.copy_(v, non_blocking=True)
+            self._buf = buf
+        self._event = torch.cuda.Event()
+        self._event.record()
+
+    def wait(self):
+        """Block until the copies have landed; returns a dict of host numbers (float64 / int)."""
+        self._event.synchronize()
+        out = {"drmsd": 0.0, "lndrmsd": 0.0, "drmsd-bb": 0.0, "lndrmsd-bb": 0.0, "rmsd": None, "n_proteins": 0,
+               "status": 0, "n_res": self.n_res, "mse": None}
+        if self.world == 1:
+            B = self._B
+            host = self._buf.numpy()
+            has_stats, has_mse, has_status, has_rmsd = self._has
+            if has_stats and B:
+                st = host[:B * 8].reshape(B, 8).astype(np.float64)
+                out.update({"drmsd": np.mean(st[:, 0]), "lndrmsd": np.mean(st[:, 1]), "drmsd-bb": np.mean(st[:, 2]),
+                            "lndrmsd-bb": np.mean(st[:, 3]), "n_proteins": B})
+            if has_mse:
+                out["mse"] = host[B * 8:B * 8 + 6].astype(np.float64)
+            if has_status:
+                out["status"] = int(host[B * 8 + 6:B * 8 + 7].view(np.int32)[0])
+            if has_rmsd and B:
+                out["rmsd"] = float(np.mean(host[B * 8 + 7:].astype(np.float64)))
+        else:
+            v = self._buf.numpy().copy()
+            n = max(v[4], 1.0)
+            out.update({"drmsd": v[0] / n, "lndrmsd": v[1] / n, "drmsd-bb": v[2] / n, "lndrmsd-bb": v[3] / n,
+                        "n_proteins": int(v[4]), "mse": v[6:12],
+                        "status": sum((1 << k) for k in range(4) if v[12 + k] > 0), "n_res": int(v[16])})
+            if v[17] > 0:
+                out["rmsd"] = v[5] / v[17]
+        return out
 
 
 def _stats_to_host(stats, status):
-    """Asynchronous copy of the per-protein statistics [B,8] and the status word into a (cached) pinned buffer;
-    returns (buffer of B*8 + 1 floats, event recorded behind the copy)."""
+    """Back-compatible helper: (pinned buffer of B*8 + 1 floats, event recorded behind the copy)."""
     n = stats.numel()
-    buf = _HOST_STATS.get(n)
-    if buf is None:
-        buf = _HOST_STATS[n] = torch.empty(n + 1, dtype=torch.float32).pin_memory()
+    buf = _pinned("stats", n + 1, torch.float32, stats.device)
     buf[:n].copy_(stats.reshape(-1), non_blocking=True)
     buf[n:].copy_(status.float(), non_blocking=True)   # a handful of flag bits: exact in fp32
     done = torch.cuda.Event()
@@ -165,25 +262,29 @@ def compute_batch_drmsd(pred_angs, true_crds, input_seqs, device=None, return_rm
     pred_angs [B,L,24] (cos,sin) predictions attached to the model's graph, true_crds [B,L*14,3]
     (NaN = missing atom), input_seqs [B,L].  With do_backward the SUM over proteins of
     d(lndrmsd_i)/d(pred_angs) is back-propagated through pred_angs (losses.py:166-167).
-    Returns np.mean over proteins of (drmsd, lndrmsd, bb drmsd, bb lndrmsd[, rmsd]).
+    Returns np.mean over proteins of (drmsd, lndrmsd, bb drmsd, bb lndrmsd[, rmsd]); under data parallelism the means
+    are those of the global batch (every rank calls this with its shard).
     """
     if backbone_only:
         raise NotImplementedError("--backbone_loss is broken in the reference too (SURVEY.md A-4)")
     dev = pred_angs.device
-    stats, grad, status = batch_loss(pred_angs, true_crds.to(dev), input_seqs.to(dev), do_backward)
-    # The reference returns host numbers every step.  The copy is enqueued right behind the loss kernels and the host
-    # waits for THAT copy only after the whole backward pass has been enqueued: waiting on the stream instead would
-    # drain the queue at the end of every step and leave the GPU idle while the next launches are being issued.
-    host_buf, copied = _stats_to_host(stats, status)
+    true_crds, input_seqs = true_crds.to(dev), input_seqs.to(dev)
+    stats, grad, status, crd = batch_loss(pred_angs, true_crds, input_seqs, do_backward, return_crd=True)
+    rmsd = None
+    if return_rmsd:
+        from .eval_metrics import kabsch_rmsd_batch
+        rmsd = kabsch_rmsd_batch(crd, true_crds, input_seqs)
+    # The copy to the host is enqueued right behind the loss kernels and the host waits for THAT copy only after the
+    # whole backward pass has been enqueued: waiting on the stream instead would drain the queue at the end of every
+    # step and leave the GPU idle while the next launches are being issued.
+    report = LossReport(dev, stats=stats, status=status, rmsd=rmsd)
     if do_backward:
         pred_angs.backward(gradient=grad.view_as(pred_angs), retain_graph=retain_graph)
-    copied.synchronize()
-    host = host_buf[:-1].view(-1, 8).numpy().astype(np.float64)
-    raise_for_status(int(host_buf[-1].item()), theta_is_error=False)
-    out = (np.mean(host[:, 0]), np.mean(host[:, 1]), np.mean(host[:, 2]), np.mean(host[:, 3]))
+    host = report.wait()
+    raise_for_status(host["status"], theta_is_error=False)
+    out = (host["drmsd"], host["lndrmsd"], host["drmsd-bb"], host["lndrmsd-bb"])
     if return_rmsd:
-        from .eval_metrics import batch_rmsd
-        out = out + (batch_rmsd(pred_angs, true_crds.to(dev), input_seqs.to(dev)),)
+        out = out + (host["rmsd"],)
     return out
 
 
@@ -202,23 +303,16 @@ def drmsd_work(pred_ang, true_crd, input_seq, return_rmsd=False, do_backward=Tru
     s = stats[0].cpu().numpy().astype(np.float64)
     out = (grad, float(s[0]), float(s[1]), float(s[2]), float(s[3]))
     if return_rmsd:
-        from .eval_metrics import rmsd_of_slots
-        out = out + (rmsd_of_slots(crd[0], crd_t[0]),)
+        from .eval_metrics import kabsch_rmsd_batch
+        out = out + (float(kabsch_rmsd_batch(crd, crd_t, seq)[0]),)
     return out
 
 
 # ----------------------------------------------------------------------------- angle MSE
-_mse_cache = (None, None, None, None)
-
-
 def mse_sums(pred, true):
-    """One pass over [B,L,24]: device tensor [6] = (sum, count) for full / backbone / side-chain columns.
-    get_losses asks for the three variants back to back (train.py:64-66); the pass runs once per (pred, true)."""
-    global _mse_cache
+    """One pass over [B,L,24]: device tensor [6] = (sum, count) for full / backbone / side-chain columns, i.e. the three
+    variants get_losses asks for back to back (train.py:64-66).  No host synchronisation."""
     _lib.require_gpu(pred, true)
-    key = (pred.data_ptr(), pred._version, true.data_ptr(), true._version)
-    if _mse_cache[0] == key and _mse_cache[1] is pred and _mse_cache[2] is true:
-        return _mse_cache[3]
     T = pred.shape[0] * pred.shape[1]
     out = torch.empty(6, dtype=torch.float32, device=pred.device)
     ws = _lib.workspace("mse_angles", _lib.lib().ptamd_mse_angles_workspace_bytes(), pred.device)
@@ -226,8 +320,21 @@ def mse_sums(pred, true):
                                          _lib.ptr(true.float().contiguous()), T, _lib.ptr(out), _lib.ptr(ws), ws.numel(),
                                          _lib.stream())
     _lib.check(rc, "mse_angles_fwd")
-    _mse_cache = (key, pred, true, out)
     return out
+
+
+def mse_grad(pred, true, sums, coef=1.0, accumulate_into=None):
+    """d(coef * mse_full)/d(pred) = coef * 2 (pred - true) / count on the selected elements, where count = sums[1] is
+    read ON THE DEVICE (under data parallelism it is the count of the global batch, so the SUM of the ranks' parameter
+    gradients is the gradient of the global mean).  `accumulate_into`: add to that [B,L,24] tensor instead of a new one."""
+    T = pred.shape[0] * pred.shape[1]
+    acc = accumulate_into is not None
+    dpred = accumulate_into if acc else torch.empty(pred.shape, dtype=torch.float32, device=pred.device)
+    assert dpred.is_contiguous()
+    rc = _lib.lib().ptamd_mse_angles_bwd(_lib.ptr(pred.detach().float().contiguous()), _lib.ptr(true.float().contiguous()),
+                                         T, _lib.ptr(sums), float(coef), int(acc), _lib.ptr(dpred), _lib.stream())
+    _lib.check(rc, "mse_angles_bwd")
+    return dpred
 
 
 class _MseFn(torch.autograd.Function):
@@ -243,13 +350,8 @@ class _MseFn(torch.autograd.Function):
         pred, true, sums = ctx.saved_tensors
         if ctx.which != 0:
             raise NotImplementedError("only the full-angle MSE is ever differentiated (train.py:86,97)")
-        T = pred.shape[0] * pred.shape[1]
-        dpred = torch.empty_like(pred, dtype=torch.float32)
-        rc = _lib.lib().ptamd_mse_angles_bwd(_lib.ptr(pred.detach().float().contiguous()),
-                                             _lib.ptr(true.float().contiguous()), T, _lib.ptr(sums), float(g), 0,
-                                             _lib.ptr(dpred), _lib.stream())
-        _lib.check(rc, "mse_angles_bwd")
-        return dpred.view_as(pred), None, None
+        # API-parity path (a host read of the incoming scalar); the training step uses mse_grad directly
+        return mse_grad(pred, true, sums, coef=float(g)).view_as(pred), None, None
 
 
 def mse_over_angles(pred, true, bb_only=False, sc_only=False):

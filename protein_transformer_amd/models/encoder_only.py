@@ -147,6 +147,7 @@ class _TransformerBase(nn.Module):
         self.dropout_seed = 0x5DEECE66D
         self._step_counter = 0
         self.grad_hook = None                        # called with (offset, numel) as soon as a gradient slice is final
+        self.gemm_mode = None                        # kernels.GEMM_* arithmetic of THIS model; None = kernels.get_gemm_mode()
         self._init_parameters()
 
     # ------------------------------------------------------------------ parameters
@@ -232,6 +233,24 @@ class _TransformerBase(nn.Module):
         else:
             super().zero_grad(set_to_none=set_to_none)
 
+    def grad_slices(self):
+        """(offset, numel) of the flat-gradient slices in the order `_EncoderFn.backward` reports them final (the
+        order of the overlapped data-parallel reduction; a rank with an empty shard walks the same list, dp.py)."""
+        def span(first, last):
+            o0, _ = self._layout[first]
+            o1, s1 = self._layout[last]
+            return o0, o1 + int(np.prod(s1)) - o0
+        out = [span("output_projection.weight", "output_projection.bias")]
+        for i in reversed(range(self.nlayers)):
+            b = f"encoder.enc_layers.{i}."
+            out.append(span(b + "self_attn.wq.weight", b + "sublayer_connections.1.norm.bias"))
+        n_conv = len(self.conv_shapes or [])
+        if n_conv:
+            out.append(span("encoder.conv_layers.0.weight", f"encoder.conv_layers.{n_conv - 1}.bias"))
+        if self.use_embedding:
+            out.append(span("encoder.input_embedding.emb.weight", "encoder.input_embedding.emb.weight"))
+        return out
+
     def _slice(self, buf, name):
         off, shape = self._layout[name]
         return buf[off:off + int(np.prod(shape))].view(shape)
@@ -278,6 +297,7 @@ class _EncoderFn(torch.autograd.Function):
         p = m.dropout if train else 0.0
         pa = m.attn_dropout if train else 0.0
         W = lambda name: m._slice(flat, name)                                      # noqa: E731
+        ar = K.get_gemm_mode() if m.gemm_mode is None else int(m.gemm_mode)        # every launch below carries it
         pe = m.encoder.positional_enc.pe[0]
         # ---- front end: embedding (+ doubled positional add) or one-hot, then the optional Conv1d stack
         if m.use_embedding:
@@ -288,7 +308,8 @@ class _EncoderFn(torch.autograd.Function):
             x = K.onehot(seq, cin)
         conv_saved = []
         for j, (ci, co, k) in enumerate(m.conv_shapes or []):
-            y, w2 = K.conv1d_fwd(x, B, L, ci, W(f"encoder.conv_layers.{j}.weight"), W(f"encoder.conv_layers.{j}.bias"), k)
+            y, w2 = K.conv1d_fwd(x, B, L, ci, W(f"encoder.conv_layers.{j}.weight"), W(f"encoder.conv_layers.{j}.bias"), k,
+                                   arith=ar)
             conv_saved.append((x, w2))
             x, cin = y, co
         if not m.use_embedding:
@@ -300,20 +321,21 @@ class _EncoderFn(torch.autograd.Function):
             wqkv, bqkv = m._qkv(flat, i)
             h1, mean1, rstd1 = K.layernorm_fwd(x, W(b + "sublayer_connections.0.norm.weight"),
                                                W(b + "sublayer_connections.0.norm.bias"))
-            qkv = K.linear_fwd(h1, wqkv, bqkv)
-            att, lse = K.attention_fwd(qkv, seq, H, pa, seed, sid + _SITE_ATTN)
+            qkv = K.linear_fwd(h1, wqkv, bqkv, arith=ar)
+            att, lse = K.attention_fwd(qkv, seq, H, pa, seed, sid + _SITE_ATTN, arith=ar)
             x2 = K.linear_fwd(att, W(b + "self_attn.wo.weight"), W(b + "self_attn.wo.bias"), residual=x, ldr=D,
-                              dropout_p=p, seed=seed, stream_id=sid + _SITE_ATTN_OUT)
+                              dropout_p=p, seed=seed, stream_id=sid + _SITE_ATTN_OUT, arith=ar)
             h2, mean2, rstd2 = K.layernorm_fwd(x2, W(b + "sublayer_connections.1.norm.weight"),
                                                W(b + "sublayer_connections.1.norm.bias"))
             f1 = K.linear_fwd(h2, W(b + "pwff.layer1.weight"), W(b + "pwff.layer1.bias"), flags=K.EPI_RELU,
-                              dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_HID)
+                              dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_HID, arith=ar)
             x3 = K.linear_fwd(f1, W(b + "pwff.layer2.weight"), W(b + "pwff.layer2.bias"), residual=x2, ldr=D,
-                              dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_OUT)
+                              dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_OUT, arith=ar)
             saved.append((x, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, f1))
             x = x3
-        pred = K.linear_fwd(x, W("output_projection.weight"), W("output_projection.bias"), flags=K.EPI_TANH)
-        ctx.model, ctx.seed, ctx.seq, ctx.flat = m, seed, seq, flat
+        pred = K.linear_fwd(x, W("output_projection.weight"), W("output_projection.bias"), flags=K.EPI_TANH,
+                            arith=ar)
+        ctx.model, ctx.seed, ctx.seq, ctx.flat, ctx.arith = m, seed, seq, flat, ar
         ctx.p, ctx.pa = p, pa
         ctx.saved, ctx.conv_saved = saved, conv_saved
         ctx.x_last, ctx.pred = x, pred
@@ -322,7 +344,7 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dpred):
         m, seed, seq, flat = ctx.model, ctx.seed, ctx.seq, ctx.flat
-        p, pa = ctx.p, ctx.pa
+        p, pa, ar = ctx.p, ctx.pa, ctx.arith
         B, L = seq.shape
         D, H = m.dlayer, m.nhead
         gflat = m._flat_grad
@@ -337,8 +359,9 @@ class _EncoderFn(torch.autograd.Function):
 
         dpred = dpred.contiguous().view(-1, NUM_PREDICTED_ANGLES * 2)
         dpre = K.tanh_bwd(dpred, ctx.pred)
-        K.linear_bwd_weight(dpre, ctx.x_last, G("output_projection.weight"), G("output_projection.bias"))
-        dx = K.linear_bwd_input(dpre, W("output_projection.weight"))
+        K.linear_bwd_weight(dpre, ctx.x_last, G("output_projection.weight"), G("output_projection.bias"),
+                            arith=ar)
+        dx = K.linear_bwd_input(dpre, W("output_projection.weight"), arith=ar)
         done("output_projection.weight", "output_projection.bias")
         for i in reversed(range(m.nlayers)):
             b = f"encoder.enc_layers.{i}."
@@ -346,23 +369,23 @@ class _EncoderFn(torch.autograd.Function):
             x, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, f1 = ctx.saved[i]
             # x3 = x2 + drop(f1 W2^T + b2)
             dy2 = K.dropout_bwd(dx, p, seed, sid + _SITE_FFN_OUT) if p > 0 else dx
-            K.linear_bwd_weight(dy2, f1, G(b + "pwff.layer2.weight"), G(b + "pwff.layer2.bias"))
+            K.linear_bwd_weight(dy2, f1, G(b + "pwff.layer2.weight"), G(b + "pwff.layer2.bias"), arith=ar)
             # backward of layer2 and, in its epilogue, of the ReLU + dropout in front of it (gate = saved f1)
-            dz1 = K.linear_bwd_input(dy2, W(b + "pwff.layer2.weight"), gate=f1, gate_dropout_p=p)
-            K.linear_bwd_weight(dz1, h2, G(b + "pwff.layer1.weight"), G(b + "pwff.layer1.bias"))
-            dh2 = K.linear_bwd_input(dz1, W(b + "pwff.layer1.weight"))
+            dz1 = K.linear_bwd_input(dy2, W(b + "pwff.layer2.weight"), gate=f1, gate_dropout_p=p, arith=ar)
+            K.linear_bwd_weight(dz1, h2, G(b + "pwff.layer1.weight"), G(b + "pwff.layer1.bias"), arith=ar)
+            dh2 = K.linear_bwd_input(dz1, W(b + "pwff.layer1.weight"), arith=ar)
             dx2 = K.layernorm_bwd(dh2, x2, W(b + "sublayer_connections.1.norm.weight"), mean2, rstd2,
                                   G(b + "sublayer_connections.1.norm.weight"), G(b + "sublayer_connections.1.norm.bias"),
                                   dres=dx)
             # x2 = x + drop(att Wo^T + bo)
             dyo = K.dropout_bwd(dx2, p, seed, sid + _SITE_ATTN_OUT) if p > 0 else dx2
-            K.linear_bwd_weight(dyo, att, G(b + "self_attn.wo.weight"), G(b + "self_attn.wo.bias"))
-            datt = K.linear_bwd_input(dyo, W(b + "self_attn.wo.weight"))
-            dqkv = K.attention_bwd(qkv, seq, att, datt, lse, H, pa, seed, sid + _SITE_ATTN)
+            K.linear_bwd_weight(dyo, att, G(b + "self_attn.wo.weight"), G(b + "self_attn.wo.bias"), arith=ar)
+            datt = K.linear_bwd_input(dyo, W(b + "self_attn.wo.weight"), arith=ar)
+            dqkv = K.attention_bwd(qkv, seq, att, datt, lse, H, pa, seed, sid + _SITE_ATTN, arith=ar)
             gw, gb = m._qkv(gflat, i)
             wqkv, _ = m._qkv(flat, i)
-            K.linear_bwd_weight(dqkv, h1, gw, gb)
-            dh1 = K.linear_bwd_input(dqkv, wqkv)
+            K.linear_bwd_weight(dqkv, h1, gw, gb, arith=ar)
+            dh1 = K.linear_bwd_input(dqkv, wqkv, arith=ar)
             dx = K.layernorm_bwd(dh1, x, W(b + "sublayer_connections.0.norm.weight"), mean1, rstd1,
                                  G(b + "sublayer_connections.0.norm.weight"), G(b + "sublayer_connections.0.norm.bias"),
                                  dres=dx2)
@@ -377,7 +400,7 @@ class _EncoderFn(torch.autograd.Function):
             xin, w2 = ctx.conv_saved[j]
             need_dx = m.use_embedding or j > 0                     # the one-hot input is data, not a parameter
             dx = K.conv1d_bwd(dx, xin, B, L, ci, w2, k, G(f"encoder.conv_layers.{j}.weight"),
-                              G(f"encoder.conv_layers.{j}.bias"), need_dx=need_dx)
+                              G(f"encoder.conv_layers.{j}.bias"), need_dx=need_dx, arith=ar)
             ctx.conv_saved[j] = None
         if convs:
             done("encoder.conv_layers.0.weight", f"encoder.conv_layers.{len(convs) - 1}.bias")

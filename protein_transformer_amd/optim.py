@@ -65,8 +65,10 @@ class FusedAdam(_FlatOptimizer):
     @torch.no_grad()
     def step(self, closure=None):
         w, g = self.model.flat_parameters()
-        if self._m is None or self._m.device != w.device:
+        if self._m is None:
             self._m, self._v = torch.zeros_like(w), torch.zeros_like(w)
+        elif self._m.device != w.device:      # moments loaded from a checkpoint (CPU) or a model moved since: migrate
+            self._m, self._v = self._m.to(w.device), self._v.to(w.device)
         grp = self.param_groups[0]
         self._t += 1
         sq, mx = self._clip_args()
@@ -83,7 +85,12 @@ class FusedAdam(_FlatOptimizer):
         fs = sd.pop("flat_state", None)
         super().load_state_dict(sd)
         if fs is not None:
-            self._t, self._m, self._v = fs["step"], fs["exp_avg"], fs["exp_avg_sq"]
+            self._t, self._m, self._v = int(fs["step"]), fs["exp_avg"], fs["exp_avg_sq"]
+            if self._m is not None:           # keep the moments: move them next to the flat parameter buffer
+                params = list(self.model.parameters())
+                dev = params[0].device if params else self._m.device
+                self._m = self._m.detach().to(dev, torch.float32).contiguous().clone()
+                self._v = self._v.detach().to(dev, torch.float32).contiguous().clone()
 
 
 class ScheduledOptim():

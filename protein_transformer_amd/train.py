@@ -28,8 +28,7 @@ from .dataset import MAX_SEQ_LEN, prepare_dataloaders
 from .log import (EarlyStoppingCondition, do_eval_batch_logging, do_eval_epoch_logging, do_train_batch_logging,
                   init_metrics, log_batch, prepare_log_header, reset_metrics_for_epoch, update_loss_trackers,
                   update_metrics_end_of_epoch)
-from .losses import (_stats_to_host, batch_loss, combine_drmsd_mse, compute_batch_drmsd, mse_over_angles,
-                     mse_sums)
+from .losses import LossReport, batch_loss, combine_drmsd_mse, mse_grad, mse_sums
 from .models.convolutional_encoder import ConvEncoderOnlyTransformer
 from .models.encoder_only import EncoderOnlyTransformer
 from .optim import FusedAdam, FusedSGD, ScheduledOptim
@@ -41,15 +40,17 @@ START_TIME = time.time()
 
 
 def train_epoch(model, training_data, validation_datasets, optimizer, device, args, log_writer, metrics, pool=None):
-    """ One complete training epoch (train.py:28-54). """
+    """ One complete training epoch (train.py:28-54).  Under data parallelism the loader already yields this rank's
+    shard of every batch (dataset.ShardedBatchSampler): only that shard is collated and uploaded. """
     model.train()
     metrics = reset_metrics_for_epoch(metrics, "train")
     for step, batch in enumerate(training_data):
+        n_res = int((batch[0] != VOCAB.pad_id).sum())        # on the host, before the upload: no device sync
         src_seq, tgt_ang, tgt_crds = map(lambda x: x.to(device, non_blocking=True), batch)
-        src_seq, tgt_ang, tgt_crds = dp.shard_batch(src_seq, tgt_ang, tgt_crds)
-        losses = train_step(model, optimizer, args, src_seq, tgt_ang, tgt_crds, pool=pool)
+        losses = train_step(model, optimizer, args, src_seq, tgt_ang, tgt_crds, pool=pool, n_res=n_res)
         metrics = do_train_batch_logging(metrics, losses, src_seq, optimizer, args, log_writer, START_TIME, step)
-        if getattr(args, "structure_dir", None) and dp.is_main() and step % max(1, args.log_structure_step) == 0:
+        if (getattr(args, "structure_dir", None) and dp.is_main() and src_seq.shape[0]
+                and step % max(1, args.log_structure_step) == 0):
             dump_structure(model, args, src_seq, tgt_crds, step)
     metrics = update_metrics_end_of_epoch(metrics, "train")
     return metrics
@@ -72,13 +73,16 @@ def dump_structure(model, args, src_seq, tgt_crds, step, struct_name="train"):
     return log_structure(args, crd, tgt_crds[0, :n * 14], src_seq[0, :n], step, struct_name)
 
 
-def train_step(model, optimizer, args, src_seq, tgt_ang, tgt_crds, pool=None):
+def train_step(model, optimizer, args, src_seq, tgt_ang, tgt_crds, pool=None, n_res=None):
     """The body of the reference's training loop (train.py:36-46) for one device-resident batch:
-    zero_grad, forward, losses + backward, (gradient all-reduce), clip, optimizer step."""
+    zero_grad, forward, losses + backward, (gradient all-reduce), clip, optimizer step.
+    A rank whose shard of the batch is empty (fewer proteins than ranks) skips forward / backward and joins the
+    collectives with zeros."""
     optimizer.zero_grad()
-    pred = model(src_seq, tgt_ang)
-    losses = get_losses(args, pred, tgt_ang, tgt_crds, src_seq, pool=pool)
-    dp.all_reduce_gradients(model)
+    empty = src_seq.shape[0] == 0
+    pred = None if empty else model(src_seq, tgt_ang)
+    losses = get_losses(args, pred, tgt_ang, tgt_crds, src_seq, pool=pool, n_res=n_res)
+    dp.all_reduce_gradients(model, empty=empty)
     if args.clip:
         optimizer.clip_grad_norm_(args.clip)
     optimizer.step()
@@ -86,39 +90,55 @@ def train_step(model, optimizer, args, src_seq, tgt_ang, tgt_crds, pool=None):
 
 
 def get_losses(args, pred, tgt_ang, tgt_crds, src_seq, pool=None, log=True, do_backwards=True, return_rmsd=False,
-               eval_mode=False):
-    """Losses/metrics of a batch (train.py:57-111); `loss` depends on `args.loss`.
+               eval_mode=False, n_res=None):
+    """Losses/metrics of a batch (train.py:57-111); `loss` depends on `args.loss`.  Returns the reference's dictionary
+    of 10 entries as HOST numbers (np.float64 / 0-d CPU tensors), obtained with one asynchronous copy that is waited
+    for only after the backward pass has been enqueued (losses.LossReport) - no other device synchronisation.
 
     Gradient bookkeeping is the reference's: the dRMSD term back-propagates the SUM
     over proteins of the length-normalised loss whatever the reported loss is; `combined` adds
     (1-w)/0.01 * d(mse); `mse` back-propagates the MSE only.  Where the reference runs two backward
     passes through the model for `combined` (retain_graph), the two gradients are added first and
     the model is traversed once.
+
+    Data parallel: `pred`, the targets and `src_seq` are this rank's shard; every returned value is a statistic of
+    the GLOBAL batch and the MSE gradient is normalised by the global count of selected elements, so that the SUM of
+    the ranks' parameter gradients is the single-process gradient.  `pred` may be None for an
+    empty shard.
     """
-    m_loss_full = mse_over_angles(pred, tgt_ang)
-    m_loss_bb = mse_over_angles(pred, tgt_ang, bb_only=True)
-    m_loss_sc = mse_over_angles(pred, tgt_ang, sc_only=True)
-    rmsd_loss = None
-    if args.loss in ["lndrmsd", "drmsd", "combined"] or eval_mode:
-        if args.loss == "combined" and do_backwards:
-            stats, grad, status = batch_loss(pred, tgt_crds, src_seq, do_backward=True)
-            host_buf, copied = _stats_to_host(stats, status)   # see compute_batch_drmsd: no stream-wide wait
-            (g_mse,) = torch.autograd.grad(m_loss_full, pred, retain_graph=False)
-            w = args.combined_drmsd_weight
-            pred.backward(gradient=grad.view_as(pred) + ((1 - w) / 0.01) * g_mse)
-            copied.synchronize()
-            host = host_buf[:-1].view(-1, 8).numpy().astype(np.float64)
-            raise_for_status(int(host_buf[-1].item()), theta_is_error=False)
-            d_loss, ln_d_loss, d_bb_loss, d_bb_ln_loss = (np.mean(host[:, k]) for k in range(4))
-        else:
-            ls = compute_batch_drmsd(pred, tgt_crds, src_seq, do_backward=do_backwards, retain_graph=False,
-                                     pool=pool, backbone_only=getattr(args, "backbone_loss", False),
-                                     return_rmsd=return_rmsd)
+    dev = src_seq.device
+    empty = src_seq.shape[0] == 0
+    need_drmsd = args.loss in ["lndrmsd", "drmsd", "combined"] or eval_mode
+    if getattr(args, "backbone_loss", False) and need_drmsd:
+        raise NotImplementedError("--backbone_loss is broken in the reference too (SURVEY.md A-4)")
+    sums = stats = grad = status = rmsd = None
+    if not empty:
+        sums = mse_sums(pred, tgt_ang)                         # the three MSEs of train.py:64-66 in one pass
+        if need_drmsd:
+            stats, grad, status, crd = batch_loss(pred, tgt_crds, src_seq, do_backward=do_backwards, return_crd=True)
             if return_rmsd:
-                d_loss, ln_d_loss, d_bb_loss, d_bb_ln_loss, rmsd_loss = ls
-            else:
-                d_loss, ln_d_loss, d_bb_loss, d_bb_ln_loss = ls
-        c_loss = combine_drmsd_mse(ln_d_loss, m_loss_full.detach(), w=args.combined_drmsd_weight, log=log)
+                from .eval_metrics import kabsch_rmsd_batch
+                rmsd = kabsch_rmsd_batch(crd, tgt_crds, src_seq)
+    report = LossReport(dev, stats=stats, status=status, mse_sums_local=sums, rmsd=rmsd, n_res=n_res)
+    if do_backwards and not empty:
+        w = args.combined_drmsd_weight
+        if args.loss == "mse":
+            g = mse_grad(pred, tgt_ang, report.global_mse_sums, coef=1.0)
+        elif args.loss == "combined":
+            g = mse_grad(pred, tgt_ang, report.global_mse_sums, coef=(1 - w) / 0.01, accumulate_into=grad.view_as(pred))
+        else:
+            g = grad
+        pred.backward(gradient=g.view_as(pred))
+    host = report.wait()
+    if need_drmsd:
+        raise_for_status(host["status"], theta_is_error=False)
+    m = host["mse"] if host["mse"] is not None else np.full(6, np.nan)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        m_loss_full, m_loss_bb, m_loss_sc = (torch.tensor(m[2 * k] / m[2 * k + 1], dtype=torch.float32) for k in range(3))
+    rmsd_loss = host["rmsd"] if return_rmsd else None
+    if need_drmsd:
+        d_loss, ln_d_loss, d_bb_loss, d_bb_ln_loss = (np.float64(host[k]) for k in ("drmsd", "lndrmsd", "drmsd-bb", "lndrmsd-bb"))
+        c_loss = combine_drmsd_mse(ln_d_loss, m_loss_full, w=args.combined_drmsd_weight, log=log)
         if args.loss == "lndrmsd":
             loss = ln_d_loss
         elif args.loss == "drmsd":
@@ -127,26 +147,28 @@ def get_losses(args, pred, tgt_ang, tgt_crds, src_seq, pool=None, log=True, do_b
             loss = c_loss
         else:
             loss = m_loss_full
-    elif args.loss == "mse":
+    else:
         d_loss, ln_d_loss, d_bb_loss, d_bb_ln_loss, c_loss = (torch.tensor(0),) * 5
         loss = m_loss_full
-        if do_backwards:
-            m_loss_full.backward()
-    return {"loss": loss, "drmsd-full": d_loss, "lndrmsd-full": ln_d_loss, "drmsd-bb": d_bb_loss,
-            "lndrmsd-bb": d_bb_ln_loss, "combined-full": c_loss, "mse-full": m_loss_full, "mse-bb": m_loss_bb,
-            "mse-sc": m_loss_sc, "rmsd-full": rmsd_loss}
+    out = {"loss": loss, "drmsd-full": d_loss, "lndrmsd-full": ln_d_loss, "drmsd-bb": d_bb_loss,
+           "lndrmsd-bb": d_bb_ln_loss, "combined-full": c_loss, "mse-full": m_loss_full, "mse-bb": m_loss_bb,
+           "mse-sc": m_loss_sc, "rmsd-full": rmsd_loss}
+    if host["n_res"] is not None:
+        out["n-residues"] = host["n_res"]                      # residues of the GLOBAL batch (speed meter, log.py)
+    return out
 
 
 def eval_epoch(model, validation_data, device, args, metrics, mode="valid", pool=None):
-    """ One complete evaluation epoch (train.py:114-135). """
+    """ One complete evaluation epoch (train.py:114-135); sharded over the ranks like training. """
     model.eval()
     metrics = reset_metrics_for_epoch(metrics, mode)
     with torch.no_grad():
         for batch in validation_data:
-            src_seq, tgt_ang, tgt_crds = map(lambda x: x.to(device), batch)
-            pred = model(src_seq, tgt_ang)
+            n_res = int((batch[0] != VOCAB.pad_id).sum())
+            src_seq, tgt_ang, tgt_crds = map(lambda x: x.to(device, non_blocking=True), batch)
+            pred = model(src_seq, tgt_ang) if src_seq.shape[0] else None
             losses = get_losses(args, pred, tgt_ang, tgt_crds, src_seq, pool=pool, do_backwards=False,
-                                eval_mode=True, return_rmsd=True)
+                                eval_mode=True, return_rmsd=True, n_res=n_res)
             metrics = do_eval_batch_logging(metrics, losses, src_seq, args, mode)
     do_eval_epoch_logging(metrics, mode)
     return metrics
@@ -171,6 +193,8 @@ def train(model, metrics, training_data, train_eval_loader, validation_datasets,
                                      pool=drmsd_worker_pool)
                 if dp.is_main():
                     log_batch(log_writer, metrics, START_TIME, mode=f"valid-{split}", end_of_epoch=True)
+        # every rank holds the same (globally reduced) metrics, so the scheduler, the early-stopping test and the
+        # checkpoint policy below take the same branch on every rank
         if scheduler:
             scheduler.step(metrics[args.es_mode][f"epoch-{args.es_metric}-full"])
         try:
@@ -178,8 +202,7 @@ def train(model, metrics, training_data, train_eval_loader, validation_datasets,
         except EarlyStoppingCondition:
             break
         if dp.is_main():
-            checkpoint_model(args, optimizer, model, scheduler, epoch_i, metrics["loss_to_compare"],
-                             metrics["losses_to_compare"], metrics)
+            checkpoint_model(args, optimizer, model, metrics, epoch_i, scheduler)
     if not args.train_only and test_data is not None:
         metrics = eval_epoch(model, test_data, device, args, metrics, mode="test", pool=drmsd_worker_pool)
         if dp.is_main():
@@ -187,37 +210,52 @@ def train(model, metrics, training_data, train_eval_loader, validation_datasets,
     return metrics
 
 
-def checkpoint_model(args, optimizer, model, scheduler, epoch_i, loss_this_epoch, losses, metrics=None):
-    """Best / periodic checkpoints with the reference's dictionary layout (train.py:189-230)."""
-    state = {'model_state_dict': model.state_dict(), 'settings': args, 'epoch': epoch_i,
-             'optimizer_state_dict': optimizer.state_dict(),
-             'scheduler_state_dict': scheduler.state_dict() if scheduler else None,
-             'loss': loss_this_epoch, 'metrics': metrics, 'elapsed_time': time.time() - START_TIME}
-    better = loss_this_epoch <= min(losses) if len(losses) else True
-    if better:
-        torch.save(state, args.chkpt_path + "_best.chkpt")            # file name quirk of train.py:207
-    interval = getattr(args, "checkpoint_time_interval", 0) * 3600
-    last = metrics.get("last_chkpt_time", START_TIME) if metrics else START_TIME
-    if interval and time.time() - last >= interval:
-        torch.save(state, args.chkpt_path + "_latest.chkpt")
-        metrics["last_chkpt_time"] = time.time()
+def checkpoint_model(args, optimizer, model, metrics, epoch_i, scheduler):
+    """Records model state according to the reference's checkpointing policy (train.py:189-230): `<chkpt_path>_best.chkpt`
+    when this epoch's loss beats every earlier one, else `_latest.chkpt` when --checkpoint_time_interval hours have
+    passed since the last checkpoint, else nothing.  Same dictionary layout.  Returns True iff the model was saved."""
+    cur_loss, loss_history = metrics["loss_to_compare"], metrics["losses_to_compare"]
+    if args.checkpoint_time_interval == 0:
+        do_time_chkpt = False
+    else:
+        do_time_chkpt = (time.time() - metrics["last_chkpt_time"]) / 3600 > args.checkpoint_time_interval
+    if len(loss_history) == 1 or cur_loss < min(loss_history[:-1]):
+        modifier = "best"
+    elif do_time_chkpt:
+        modifier = "latest"
+    else:
+        return False
+    chkpt_file_name = args.chkpt_path + f"_{modifier}.chkpt"
+    checkpoint = {'model_state_dict': model.state_dict(), 'settings': args, 'epoch': epoch_i,
+                  'optimizer_state_dict': optimizer.state_dict(),
+                  'scheduler_state_dict': scheduler.state_dict() if scheduler else None,
+                  'loss': cur_loss, 'metrics': metrics, 'elapsed_time': time.time() - START_TIME}
+    torch.save(checkpoint, chkpt_file_name)
+    metrics["last_chkpt_time"] = time.time()
+    print('\r    - [Info] The checkpoint file has been updated.')
+    return True
 
 
 def load_model(model, optimizer, scheduler, args):
-    """Resume from `<chkpt_path>_best.chkpt` unless --restart (train.py:233-271)."""
+    """Resume from `<chkpt_path>_best.chkpt` (or --load_chkpt) unless --restart (train.py:233-271).  START_TIME is moved
+    back by the checkpoint's elapsed time so that the `time` column of the log stays cumulative."""
     global START_EPOCH, START_TIME
     path = args.load_chkpt if getattr(args, "load_chkpt", None) else args.chkpt_path + "_best.chkpt"
     if args.restart or not os.path.exists(path):
-        return model, optimizer, scheduler, False, None
+        return model, optimizer, scheduler, False, init_metrics(args)
+    if dp.is_main():
+        print(f"[Info] Attempting to load model from {path}.")
     checkpoint = torch.load(path, map_location="cpu", weights_only=False)
     model.load_state_dict(checkpoint['model_state_dict'])
     if not args.restart_opt:
         optimizer.load_state_dict(checkpoint['optimizer_state_dict'])
-        if scheduler and checkpoint.get('scheduler_state_dict'):
-            scheduler.load_state_dict(checkpoint['scheduler_state_dict'])
+    if scheduler and checkpoint.get('scheduler_state_dict'):
+        scheduler.load_state_dict(checkpoint['scheduler_state_dict'])
     START_EPOCH = checkpoint['epoch'] + 1
-    START_TIME -= checkpoint.get('elapsed_time', 0)
-    print(f"[Info] Resuming from {path} at epoch {START_EPOCH}, loss = {checkpoint['loss']:.4f}.")
+    START_TIME -= checkpoint['elapsed_time']
+    if dp.is_main():
+        print(f"[Info] Resuming model training from end of Epoch {checkpoint['epoch']}. Previous validation loss"
+              f" = {checkpoint['loss']:.4f}.")
     return model, optimizer, scheduler, True, checkpoint['metrics']
 
 
@@ -409,14 +447,14 @@ def main():
     os.makedirs(args.chkpt_dir, exist_ok=True)
     args.log_file = os.path.join(args.log_dir, args.name + '.train')
     args.chkpt_path = os.path.join(args.chkpt_dir, args.name)
+    START_TIME = time.time()                      # load_model moves it back by the checkpoint's elapsed time
     model, optimizer, scheduler, resumed, metrics = load_model(model, optimizer, scheduler, args)
+    dp.attach(model)                              # per-layer gradient all-reduce overlapped with backward (no-op for 1 rank)
     log_f = open(args.log_file, 'a' if resumed else 'w', buffering=1) if dp.is_main() else open(os.devnull, "w")
     log_writer = csv.writer(log_f)
     if not resumed:
         log_writer.writerow(prepare_log_header(args).split(","))
-        metrics = init_metrics(args)
     training_data, training_eval_loader, validation_datasets, test_data = prepare_dataloaders(data, args, args.max_seq_len)
-    START_TIME = time.time()
     train(model, metrics, training_data, training_eval_loader, validation_datasets, test_data, optimizer, device, args,
           log_writer, scheduler, drmsd_worker_pool)
     log_f.close()

@@ -60,31 +60,55 @@ def test_host_only_entry_points(built_lib):
     assert lib.ptamd_nerf_fwd(None, None, 0, 5, None, None, None) == -1          # PTAMD_ERR_BAD_SHAPE
     assert lib.ptamd_nerf_fwd(None, None, 2, 5000, None, None, None) == -2       # PTAMD_ERR_TOO_LONG
     assert lib.ptamd_drmsd_fwd_bwd(None, None, None, 2, 8, None, None, None, 0, None) == -3   # PTAMD_ERR_WORKSPACE
-    assert lib.ptamd_attention_fwd(None, None, 1, 8, 2, 24, 0.0, 0, 0, None, None, None) == -1
+    assert lib.ptamd_attention_fwd(None, None, 1, 8, 2, 24, 0.0, 0, 0, 4, None, None, None) == -1      # head size 24
+    assert lib.ptamd_attention_fwd(None, None, 1, 8, 2, 32, 0.0, 0, 0, 7, None, None, None) == -1      # unknown arithmetic
+    assert lib.ptamd_kabsch_rmsd(None, None, None, 0, 8, None, None) == -1
 
 
 def test_gemm_arithmetic_policy(built_lib):
-    """ptamd_gemm_set_mode / ptamd_gemm_products (host only): which arithmetic a call runs in (include/ptamd.h)."""
+    """`arith` of ptamd_gemm_args / ptamd_gemm_products (host only): which arithmetic a call runs in (include/ptamd.h).
+    The library has no process-wide mode: there is nothing to set, the answer depends on the arguments alone."""
     import ctypes as C
     from protein_transformer_amd import kernels as K
     lib = built_lib.lib()
+    assert not hasattr(lib, "ptamd_gemm_set_mode") and not hasattr(lib, "ptamd_gemm_get_mode")
 
-    def products(a_kmajor, Kd=512, lda=512):
+    def products(arith, a_kmajor, Kd=512, lda=512):
         args = built_lib.GemmArgs(M=256, N=128, K=Kd, A=None, lda=lda, a_kmajor=a_kmajor, B=None, ldb=Kd, b_kmajor=0,
-                                  C=None, ldc=128)
+                                  C=None, ldc=128, arith=arith)
         return lib.ptamd_gemm_products(C.byref(args))
-    old = lib.ptamd_gemm_get_mode()
+    for mode, want in [(K.GEMM_F32, (1, 1)), (K.GEMM_BF16X3, (6, 6)), (K.GEMM_BF16X3_FULL, (9, 9)), (K.GEMM_F16X2, (3, 3)),
+                       (K.GEMM_AUTO, (3, 6))]:                   # (K-contiguous A, k-major A)
+        assert (products(mode, 0), products(mode, 1, lda=256)) == want, mode
+        assert products(mode, 0, Kd=8, lda=8) == 1               # K < 16 always runs on the exact-f32 MFMA
+    assert products(99, 0) == -1 and products(-1, 0) == -1       # PTAMD_ERR_BAD_SHAPE: unknown arithmetic
+    assert lib.ptamd_gemm_products(None) == -1
+    # the host-side default (kernels.set_gemm_mode) is plain Python state that calls without `arith=` pick up
+    old = K.get_gemm_mode()
     try:
-        assert lib.ptamd_gemm_set_mode(99) == -1                      # PTAMD_ERR_BAD_SHAPE, mode unchanged
-        assert lib.ptamd_gemm_get_mode() == old
-        for mode, want in [(K.GEMM_F32, (1, 1)), (K.GEMM_BF16X3, (6, 6)), (K.GEMM_BF16X3_FULL, (9, 9)), (K.GEMM_F16X2, (3, 3)),
-                           (K.GEMM_AUTO, (3, 6))]:                   # (K-contiguous A, k-major A)
-            assert lib.ptamd_gemm_set_mode(mode) == 0 and lib.ptamd_gemm_get_mode() == mode
-            assert (products(0), products(1, lda=256)) == want, mode
-            assert products(0, Kd=8, lda=8) == 1                      # K < 16 always runs on the exact-f32 MFMA
-        assert lib.ptamd_gemm_products(None) == -1
+        K.set_gemm_mode(K.GEMM_BF16X3)
+        assert K.get_gemm_mode() == K.GEMM_BF16X3
+        with pytest.raises(ValueError):
+            K.set_gemm_mode(99)
+        assert K.get_gemm_mode() == K.GEMM_BF16X3
     finally:
-        lib.ptamd_gemm_set_mode(old)
+        K.set_gemm_mode(old)
+
+
+def test_library_keeps_no_mutable_state():
+    """'re-entrant, no hidden global state'.  No function-static or namespace-scope mutable
+    variable in csrc/ besides the thread-local last-HIP-error word."""
+    import glob
+    import re
+    bad = []
+    for path in glob.glob(os.path.join(PKG, "csrc", "*.h*")) + glob.glob(os.path.join(PKG, "csrc", "*.cpp")):
+        for n, line in enumerate(open(path), 1):
+            code = line.split("//")[0]
+            if re.match(r"\s+static\s+(?!const|constexpr|inline|__device__|__global__|__forceinline__)", code):
+                bad.append(f"{os.path.basename(path)}:{n}: {line.strip()}")
+            if re.match(r"^(int|bool|float|double|unsigned|size_t)\s+g_\w+", code):
+                bad.append(f"{os.path.basename(path)}:{n}: {line.strip()}")
+    assert not bad, bad
 
 
 def test_product_has_no_cpu_fallback(built_lib):

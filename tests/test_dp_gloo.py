@@ -50,9 +50,11 @@ def _worker(rank, world, port, out_dir):
     # overlapped path: reduce two slices as "backward" finishes them, then wait
     dp.attach(model)
     n = model._flat_grad.numel()
+    model.grad_slices = lambda: [(0, n // 2), (n // 2, n - n // 2)]
     model.grad_hook(0, n // 2)
     model.grad_hook(n // 2, n - n // 2)
     dp.all_reduce_gradients(model)
+    assert model._dp_pending == []
     if rank == 0:
         full = flat_grad(batch["seq"], batch["true_crd"])
         np.save(os.path.join(out_dir, "dp.npy"), model._flat_grad.numpy())
@@ -64,6 +66,45 @@ def _worker(rank, world, port, out_dir):
     assert torch.allclose(model2._flat_grad, model._flat_grad, rtol=1e-6, atol=1e-9)
     t = dp.all_reduce_sum_(torch.tensor([float(rank + 1)]))
     assert float(t) == 3.0
+    # a rank with an EMPTY shard (fewer proteins than ranks) has run no backward: it walks the model's slice list with a
+    # zero buffer and must end with rank 0's gradient
+    g_one = flat_grad(batch["seq"][:1], batch["true_crd"][:1])
+    model3 = types.SimpleNamespace(_flat=None, _flat_grad=g_one.clone() if rank == 0 else torch.zeros_like(g_one), grad_hook=None)
+    model3.flat_parameters = lambda: (model3._flat, model3._flat_grad)
+    model3.grad_slices = lambda: [(0, 100), (100, n - 100)]
+    dp.attach(model3)
+    if rank == 0:
+        for off, cnt in model3.grad_slices():
+            model3.grad_hook(off, cnt)
+    dp.all_reduce_gradients(model3, empty=rank != 0)
+    assert torch.equal(model3._flat_grad, g_one)
+    # sharded loaders: the ranks' batches partition the global batches; dRMSD batch sizes are multiples of the rank count
+    from protein_transformer_amd.dataset import prepare_dataloaders
+    from protein_transformer_amd.protein.Sequence import VOCAB
+    rng = np.random.default_rng(0)
+    lens2 = sorted(int(x) for x in rng.integers(5, 60, 40))
+    seqs = ["".join(VOCAB.int2char(int(i)) for i in rng.integers(0, 20, m)) for m in lens2]
+    split = {"seq": seqs, "ang": [np.full((m, 24), float(m)) for m in lens2], "crd": [np.zeros((m * 14, 3)) for m in lens2]}
+    data = {"train": split, "valid-10": split, "test": split}
+    a = types.SimpleNamespace(batching_order="binned-random", loss="drmsd", add_sos_eos=False, skip_missing_res_train=False,
+                              bins=4, batch_size=3, repeat_train=1, train_eval_downsample=0.5)
+    tag = lambda t: [int(x) for x in t[:, 0, 0]] if t.shape[0] else []      # noqa: E731
+    np.random.seed(11)
+    tr, tre, val, te = prepare_dataloaders(data, a, 60, num_workers=0)
+    got = []
+    for i, (s_, a_, c_) in enumerate(tr):
+        got.append(tag(a_))                                 # the angle tensor carries the protein's length as a tag
+        assert s_.shape[0] == a_.shape[0] == c_.shape[0] and (s_.shape[0] == 0 or s_.shape[1] == max(got[-1]))
+    ev = [tag(a_) for _, a_, _ in te]
+    out = [None, None]
+    torch.distributed.all_gather_object(out, (got, ev))
+    for b0, b1 in zip(out[0][0], out[1][0]):
+        assert (len(b0) + len(b1)) % 2 == 0 and abs(len(b0) - len(b1)) == 0          # multiples of the rank count, dealt evenly
+        both = sorted(b0 + b1, reverse=True)
+        assert abs(sum(b0) - sum(b1)) <= max(both)                                   # length-balanced
+    assert len(out[0][0]) == len(out[1][0]) > 0
+    flat_eval = sorted(x for r in (0, 1) for b in out[r][1] for x in b)
+    assert flat_eval == sorted(lens2)                                               # evaluation covers every protein once
     dp.barrier()
     dp.shutdown()
 
@@ -73,6 +114,39 @@ def test_shard_bounds():
     assert [shard_bounds(32, 8, r) for r in range(8)] == [(4 * r, 4 * r + 4) for r in range(8)]
     assert [shard_bounds(5, 2, r) for r in range(2)] == [(0, 3), (3, 5)]
     assert [shard_bounds(3, 4, r) for r in range(4)] == [(0, 1), (1, 2), (2, 3), (3, 3)]
+
+
+def test_shard_indices_serpentine():
+    from protein_transformer_amd.dp import shard_indices
+    lens = [50, 10, 40, 30, 20, 60, 5]
+    parts = [shard_indices(lens, 3, r) for r in range(3)]
+    assert sorted(i for p in parts for i in p) == list(range(7))                    # a partition
+    assert [len(p) for p in parts] == [3, 2, 2]
+    # sorted by length: 60 50 40 | 30 20 10 | 5 -> ranks 0 1 2 | 2 1 0 | 0
+    assert [sorted(lens[i] for i in p) for p in parts] == [[5, 10, 60], [20, 50], [30, 40]]
+    assert shard_indices(lens, 1, 0) == list(range(7))
+    assert [shard_indices([7], 2, r) for r in range(2)] == [[0], []]                # fewer proteins than ranks
+    assert shard_indices([], 4, 2) == []
+    # equal lengths: ties broken by position, deterministic
+    assert [shard_indices([9] * 8, 4, r) for r in range(4)] == [[0, 7], [1, 6], [2, 5], [3, 4]]
+
+
+def test_sampler_batches_are_multiples_of_the_workers():
+    """the reference rounds dRMSD batches down to a multiple of cpu_count() (dataset.py:218-220); on a
+    many-core GPU host that collapsed every batch to one protein.  The workers of this path are the GPUs."""
+    from protein_transformer_amd import dataset as D
+    seqs = ["A" * n for n in (5, 10, 10, 21, 30, 30, 31, 64)]
+    angs = [np.ones((len(s), 24)) for s in seqs]
+    crds = [np.ones((len(s) * 14, 3)) for s in seqs]
+    ds = D.BinnedProteinDataset(seqs=seqs, angs=angs, crds=crds, add_sos_eos=False, skip_missing_residues=False, bins=3)
+    smp = D.SimilarLengthBatchSampler(ds, 4, dynamic_batch=256, optimize_batch_for_cpus=True)
+    smp.cpu_count, smp.min_batch = 8, 8                                             # an 8-GPU job
+    np.random.seed(0)
+    sizes = {len(b) for b in smp}
+    assert sizes and all(sz % 8 == 0 and sz >= 8 for sz in sizes)
+    smp.cpu_count, smp.min_batch = 1, 1                                             # one GPU: the plain residue budget
+    np.random.seed(0)
+    assert {len(b) for b in smp} <= {int(256 / e) for e in ds.hist_bins}
 
 
 def test_dp_sum_allreduce_equals_full_batch(tmp_path):
