@@ -181,6 +181,38 @@ int ptamd_gemm(const ptamd_gemm_args *args, void *stream);
  * 1 (F32), 3 (F16X2), 6 (BF16X3), 9 (BF16X3_FULL); host only, nothing is launched */
 int ptamd_gemm_products(const ptamd_gemm_args *args);
 
+/* ------------------------------------------------------------------ pre-split ("half-pair", hp) operands
+ * An fp32 matrix [rows, K] stored as TWO f16 planes + one power-of-two scale per row, x * scale = hi + lo to 22 bits (the
+ * PTAMD_GEMM_F16X2 arithmetic with the splitting done once by the WRITER of the operand instead of by every GEMM that
+ * reads it).  4 bytes per element; 32 x 16 blocks that are byte-for-byte the LDS image of an MFMA operand, so that the
+ * GEMM fills its stages by LDS-DMA without touching the vector ALU (layout: csrc/hp_format.h).  rows / K are zero padded
+ * to multiples of 32.
+ *   ptamd_hp_bytes        size of the planes buffer;  ptamd_hp_padded_rows  length of the scale array
+ *   ptamd_hp_split        x [rows, K] (ld; transposed != 0: x is stored [K, rows] and the operand is its transpose)
+ *                         -> planes, scale.  Row maximum pass + write pass.
+ *   ptamd_gemm_hp         C[M,N] = epilogue(A B^T), A = hp [M,K], B = hp [N,K]; same epilogue, flags, dropout masks and
+ *                         split-K convention as ptamd_gemm.  Replaces the same torch.nn.Linear forward / dX products
+ *                         (Attention.py:49,69; Sublayers.py:34; encoder_only.py:39). */
+size_t ptamd_hp_bytes(int rows, int K);
+int ptamd_hp_padded_rows(int rows);
+int ptamd_hp_split(const float *x, int ld, int rows, int K, int transposed, void *planes, float *scale, void *stream);
+typedef struct {
+  int M, N, K;
+  const void *A; const float *A_scale;
+  const void *B; const float *B_scale;
+  float *C; int ldc;
+  const float *bias;
+  const float *residual; int ldr;
+  int flags;
+  float dropout_p; uint64_t seed; uint32_t stream_id;
+  int split_k;
+  void *workspace; size_t workspace_bytes;
+  float gate_scale;
+  int reserved_cus;
+} ptamd_gemm_hp_args;
+size_t ptamd_gemm_hp_workspace_bytes(int M, int N, int split_k);
+int ptamd_gemm_hp(const ptamd_gemm_hp_args *args, void *stream);
+
 /* torch.nn.LayerNorm(D, eps=1e-5) (Sublayers.py:13,17): y = (x-mean)*rstd*gamma+beta; saves mean,rstd [T] */
 int ptamd_layernorm_fwd(const float *x, const float *gamma, const float *beta, int64_t T, int D, float *y,
                         float *mean, float *rstd, void *stream);

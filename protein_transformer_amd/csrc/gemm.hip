@@ -318,6 +318,22 @@ int launch_f32(const GemmParams &p, bool a_kmajor, bool b_kmajor, int splits, hi
   return launch<true, true>(p, splits, st);
 }
 
+// fixed-order sum of the split-K slabs (+ the epilogue; + the column-sum slabs of a fused bias gradient) into p.C
+int launch_splitk_reduce(const GemmParams &p, const float *slabs, int splits, const float *cs_slabs, float *colsum,
+                         hipStream_t st) {
+  const bool plain = !p.bias && !p.residual && !(p.flags & (PTAMD_EPI_RELU | PTAMD_EPI_TANH)) && p.dropout_p == 0.f;
+  if (plain && !(p.N & 3) && !(p.ldc & 3) && pt_aligned16(p.C) && pt_aligned16(slabs)) {
+    const size_t work = (size_t)p.M * (p.N >> 2), cs_work = colsum ? (size_t)p.M * 16 : 0;
+    const size_t threads = work > cs_work ? work : cs_work;
+    hipLaunchKernelGGL(gemm_splitk_reduce_plain_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p, slabs,
+                       splits, cs_slabs, colsum);
+  } else {
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((p.N + 255) / 256, (p.M + 3) / 4), dim3(256), 0, st, p, slabs,
+                       splits, cs_slabs, colsum);
+  }
+  return pt_check_launch();
+}
+
 }  // namespace ptgemm
 
 using namespace ptgemm;
@@ -422,17 +438,7 @@ int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
   const float *slabs = p.C;
   p.C = user_c;
   const float *cs_slabs = a->colsum ? slabs + (size_t)splits * p.slab : nullptr;
-  const bool plain = !a->bias && !a->residual && !(a->flags & (PTAMD_EPI_RELU | PTAMD_EPI_TANH)) && a->dropout_p == 0.f;
-  if (plain && !(a->N & 3) && !(a->ldc & 3) && pt_aligned16(user_c) && pt_aligned16(slabs)) {
-    const size_t work = (size_t)a->M * (a->N >> 2), cs_work = a->colsum ? (size_t)a->M * 16 : 0;
-    const size_t threads = work > cs_work ? work : cs_work;
-    hipLaunchKernelGGL(gemm_splitk_reduce_plain_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p, slabs,
-                       splits, cs_slabs, a->colsum);
-  } else {
-    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((a->N + 255) / 256, (a->M + 3) / 4), dim3(256), 0, st, p, slabs,
-                       splits, cs_slabs, a->colsum);
-  }
-  return pt_check_launch();
+  return launch_splitk_reduce(p, slabs, splits, cs_slabs, a->colsum, st);
 }
 
 }  // extern "C"

@@ -226,6 +226,8 @@ int persistent_grid(int reserved_cus);  // CUs of the current device minus the r
 int launch_f32(const GemmParams &p, bool a_kmajor, bool b_kmajor, int splits, hipStream_t st);
 int launch_split(const GemmParams &p, bool a_kmajor, bool b_kmajor, int splits, int products, hipStream_t st);
 int launch_split_f16x2(const GemmParams &p, bool a_kmajor, bool b_kmajor, int splits, hipStream_t st);
+// fixed-order reduction of split-K slabs into p.C with the epilogue of p (gemm.hip)
+int launch_splitk_reduce(const GemmParams &p, const float *slabs, int splits, const float *cs_slabs, float *colsum, hipStream_t st);
 // f16x2 arithmetic: fills scale_a[M] / scale_b[N] (device, uint32 bits of powers of two) from the operands of p
 int launch_row_scales(const GemmParams &p, bool a_kmajor, bool b_kmajor, uint32_t *scale_a, uint32_t *scale_b, hipStream_t st);
 

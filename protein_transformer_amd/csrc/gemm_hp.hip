@@ -1,0 +1,374 @@
+// ptamd_gemm_hp: fp32-grade GEMM on the f16 matrix pipe from PRE-SPLIT operands (hp_format.h), and the kernels that write
+// that format from fp32 tensors.
+//
+// Same role, epilogues and dropout masks as ptamd_gemm (every torch.nn.Linear of the reference encoder and its backward
+// dX products: Attention.py:38-41,49,69; Sublayers.py:28-34; encoder_only.py:18,39-41) in the PTAMD_GEMM_F16X2
+// arithmetic (include/ptamd.h):  C = A B^T  with both operands K-contiguous, evaluated as the three products
+// hi hi' + hi lo' + lo hi' of v_mfma_f32_32x32x16_f16 with f32 accumulation, the two row scales taken out of the
+// accumulators (exactly: powers of two) in front of the epilogue.
+//
+// What is different from gemm_split_kernel.h (which splits fp32 operands while it stages them): nothing is converted
+// here.  Operands arrive as two f16 planes in 32 x 16 blocks that are byte-for-byte the LDS image of an MFMA operand,
+// so a stage is filled by `global_load_lds_dwordx4` (LDS-DMA: no VGPRs, no VALU, no ds_write - the conversion chain, the
+// LDS store traffic and half of the wavefronts of the old kernel existed only for that) and all eight wavefronts of the
+// workgroup issue MFMAs.
+//
+// Structure: one persistent workgroup per CU (512 threads = 8 wavefronts, two per SIMD), 256 x 128 output tile, wavefront
+// (wm, wn) owns 64 x 64 = 2 x 2 MFMA tiles (64 accumulator VGPRs).  A stage is 32 k: 32 KiB of A + 16 KiB of B, 48
+// wave-level 1-KiB DMA pieces, six per wavefront; two stage buffers; the pieces of stage q + 1 are issued right after the
+// barrier that opens stage q and land while the 24 MFMAs per wavefront of stage q run (one `s_waitcnt vmcnt(0)` +
+// `s_barrier` per stage).  Per 16 k a wavefront reads 8 fragments (ds_read_b128, conflict-free by the chunk swizzle) for
+// 12 MFMAs.  Work items (tile x K split) are walked in contiguous XCD-aware ranges like the other kernels; the stage
+// stream runs across items, so the first stage of the next tile is in flight under the epilogue of this one.
+// Epilogue: the shared tile_epilogue_vec (bias -> ReLU -> dropout -> residual / gate -> tanh -> accumulate, float4 rows
+// through a per-wavefront LDS transpose).
+#include <stdlib.h>
+
+#include "gemm_common.h"
+#include "hp_format.h"
+#include "split_bf16.h"
+
+namespace pthp {
+namespace {
+
+using ptgemm::GemmParams;
+using ptgemm::f32x16;
+using ptsplit::f16x8;
+
+constexpr int HBM = 256, HBN = 128, HBK = 32, HTHREADS = 512;
+constexpr int A_STAGE = (HBM / 32) * 4096, B_STAGE = (HBN / 32) * 4096, STAGE_BYTES = A_STAGE + B_STAGE;  // 48 KiB
+constexpr int SCRATCH_BYTES = 8 * 2048 * 4;                                                            // 64 KiB
+constexpr size_t HP_LDS = (size_t)2 * STAGE_BYTES + SCRATCH_BYTES;
+static_assert(HP_LDS <= 160 * 1024, "LDS budget of a CU");
+
+struct HpParams {
+  GemmParams g;            // shapes, C, epilogue operands, split-K bookkeeping (A / B / lda / ldb unused)
+  const char *a_planes, *b_planes;
+  const float *a_scale, *b_scale;
+  int kb16;                // 16-column blocks per block row (= Kp / 16)
+  int a_rb_last, b_rb_last;  // last valid block row of each operand (tile rows beyond are clamped, never stored)
+};
+
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+__device__ __forceinline__ void dma16(const char *g, char *l) {  // 64 lanes x 16 B -> 1 KiB of LDS at l (wave-uniform) + 16 lane
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+
+struct Item {
+  int bm0, bn0, z, kbeg, kend;
+};
+struct Cursor {
+  int w, k0;
+  Item it;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(HTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_hp_kernel(const HpParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *const scratch = reinterpret_cast<float *>(smem + 2 * STAGE_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const ptgemm::WorkRange work(p.g, HBM, HBN);
+  if (work.begin >= work.end) return;
+  const int Kp = p.kb16 * 16;
+  auto item_at = [&](int logical) __attribute__((always_inline)) {
+    Item it;
+    work.decode(logical, it.bm0, it.bn0, it.z);
+    it.kbeg = it.z * p.g.k_per_split;
+    it.kend = min(Kp, it.kbeg + p.g.k_per_split);
+    return it;
+  };
+  // next stage of the stream; false past the last one
+  auto advance = [&](Cursor &c) __attribute__((always_inline)) {
+    if (c.k0 + HBK < c.it.kend) {
+      c.k0 += HBK;
+      return true;
+    }
+    if (c.w + 1 < work.end) {
+      c.it = item_at(++c.w);
+      c.k0 = c.it.kbeg;
+      return true;
+    }
+    return false;
+  };
+  // the six DMA pieces of this wavefront for stage (item, k0) into stage buffer `buf`
+  const int lane16 = lane * 16;
+  auto issue = [&](const Cursor &c, int buf) __attribute__((always_inline)) {
+    char *sbase = smem + buf * STAGE_BYTES;
+    const int kb = c.k0 >> 4;
+    const int arb = min((c.it.bm0 >> 5) + wave, p.a_rb_last);
+    const char *ga = p.a_planes + block_offset(arb, kb, 0, p.kb16) + lane16;   // 4 KiB: (kb, hi) (kb, lo) (kb+1, hi) (kb+1, lo)
+    char *la = sbase + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma16(ga + i * 1024, la + i * 1024);
+    const int brb = min((c.it.bn0 >> 5) + (wave >> 1), p.b_rb_last);
+    const char *gb = p.b_planes + block_offset(brb, kb + (wave & 1), 0, p.kb16) + lane16;  // 2 KiB: hi, lo of one k block
+    char *lb = sbase + A_STAGE + (wave >> 1) * 4096 + (wave & 1) * 2048;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma16(gb + i * 1024, lb + i * 1024);
+  };
+
+  f32x16 acc[2][2];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  zero_acc();
+  const uint32_t thr = dropout_threshold(p.g.dropout_p);
+  const float keep_scale = 1.f / (1.f - p.g.dropout_p);
+  const bool partial = p.g.slab != 0;
+  const int frag_off = chunk_index(lane & 31, lane >> 5) * 16;  // this lane's 16-byte chunk inside every block
+
+  Cursor ld = {work.begin, 0, item_at(work.begin)};
+  ld.k0 = ld.it.kbeg;
+  Cursor cc = ld;
+  issue(ld, 0);
+  bool more_loads = advance(ld);
+  int buf = 0;
+  for (;;) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's pieces of the stage have landed ...
+    __syncthreads();                                   // ... and everybody's; everybody is done with the other buffer
+    if (more_loads) {
+      issue(ld, buf ^ 1);
+      more_loads = advance(ld);
+    }
+    const char *sa = smem + buf * STAGE_BYTES + (2 * wm) * 4096 + frag_off;
+    const char *sb = smem + buf * STAGE_BYTES + A_STAGE + (2 * wn) * 4096 + frag_off;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f16x8 fa[2][2], fb[2][2];  // [tile][plane]
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          fa[i][t] = *reinterpret_cast<const f16x8 *>(sa + i * 4096 + (kb * 2 + t) * 1024);
+          fb[i][t] = *reinterpret_cast<const f16x8 *>(sb + i * 4096 + (kb * 2 + t) * 1024);
+        }
+      // smallest products first
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+    }
+    if (cc.k0 + HBK >= cc.it.kend) {  // that was the item's last stage (uniform)
+      float *C = p.g.C + (partial ? (size_t)cc.it.z * p.g.slab : 0);
+      const int ldc = partial ? p.g.N : p.g.ldc;
+      const int row0 = cc.it.bm0 + wm * 64, col0 = cc.it.bn0 + wn * 64;
+      {  // back from the scaled operands: acc / (scale_a[row] scale_b[col]), exact (powers of two)
+        const int l31 = lane & 31, lh = lane >> 5;
+        float ib[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ib[j] = inverse_of_scale(p.b_scale[min(col0 + j * 32 + l31, p.g.N - 1)]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float ia = inverse_of_scale(p.a_scale[min(row0 + i * 32 + 8 * g + 4 * lh + e, p.g.M - 1)]);
+#pragma unroll
+              for (int j = 0; j < 2; ++j) acc[i][j][g * 4 + e] = acc[i][j][g * 4 + e] * ia * ib[j];
+            }
+      }
+      if (p.g.vec_epilogue)
+        ptgemm::tile_epilogue_vec<2, true, EPI>(p.g, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 2048);
+      else
+        ptgemm::tile_epilogue_vec<2, false, EPI>(p.g, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 2048);
+      zero_acc();
+    }
+    if (!advance(cc)) break;
+    buf ^= 1;
+  }
+}
+
+template <int EPI>
+int launch_hp(const HpParams &p, int splits, hipStream_t st) {
+  const int work = ((p.g.M + HBM - 1) / HBM) * ((p.g.N + HBN - 1) / HBN) * splits;
+  auto kern = gemm_hp_kernel<EPI>;
+  PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HP_LDS));
+  const int slots = ptgemm::persistent_grid(p.g.reserved_cus);
+  hipLaunchKernelGGL(kern, dim3(work < slots ? work : slots), dim3(HTHREADS), HP_LDS, st, p);
+  return pt_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------- writers of the format
+// scale[r] from the row maximum of a K-contiguous fp32 matrix: one wavefront per row
+__global__ __launch_bounds__(256) void hp_rowscale_kernel(const float *__restrict__ x, int ld, int rows, int K, int rows_p,
+                                                          float *__restrict__ scale) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= rows_p) return;
+  if (r >= rows) {
+    if (lane == 0) scale[r] = 1.f;
+    return;
+  }
+  const float *p = x + (size_t)r * ld;
+  float m = 0.f;
+  for (int k = lane * 4; k < K; k += 256) {
+    const float4 v = *reinterpret_cast<const float4 *>(p + k);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  m = wave_max(m);
+  if (lane == 0) scale[r] = __uint_as_float(scale_bits_of(__float_as_uint(m)));
+}
+// transposed source ([K][rows], the operand's rows are the source's columns): column maxima by atomicMax on the bits
+__global__ __launch_bounds__(256) void hp_colmax_kernel(const float *__restrict__ x, int ld, int rows, int K,
+                                                        uint32_t *__restrict__ amax) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  const int k0 = blockIdx.y * 64, k1 = min(K, k0 + 64);
+  float m = 0.f;
+  for (int k = k0; k < k1; ++k) m = fmaxf(m, fabsf(x[(size_t)k * ld + r]));
+  atomicMax(amax + r, __float_as_uint(m));
+}
+__global__ __launch_bounds__(256) void hp_amax_to_scale_kernel(uint32_t *__restrict__ amax_scale, int rows, int rows_p) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r < rows_p) amax_scale[r] = r < rows ? scale_bits_of(amax_scale[r]) : 0x3f800000u;
+}
+// one thread per 16-byte chunk of the padded matrix: 8 consecutive k of one row -> hi and lo
+template <bool TRANSPOSED, bool SCALE_IS_AMAX>
+__global__ __launch_bounds__(256) void hp_write_kernel(const float *__restrict__ x, int ld, int rows, int K, int kb16v,
+                                                       const float *__restrict__ scale, char *__restrict__ planes,
+                                                       int64_t nchunks) {
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= nchunks) return;
+  const int c = (int)(id & 63);
+  const int64_t blk = id >> 6;
+  const int kb = (int)(blk % kb16v), rb = (int)(blk / kb16v);
+  int r, h;
+  chunk_coords(c, r, h);
+  const int row = rb * 32 + r, k0 = kb * 16 + h * 8;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  float s = 1.f;
+  if (row < rows) {
+    s = SCALE_IS_AMAX ? __uint_as_float(scale_bits_of(__float_as_uint(scale[row]))) : scale[row];
+    if (!TRANSPOSED) {
+      if (k0 + 8 <= K) {
+        const float4 a = *reinterpret_cast<const float4 *>(x + (size_t)row * ld + k0);
+        const float4 b = *reinterpret_cast<const float4 *>(x + (size_t)row * ld + k0 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (k0 + e < K) v[e] = x[(size_t)row * ld + k0 + e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (k0 + e < K) v[e] = x[(size_t)(k0 + e) * ld + row];
+    }
+  }
+  uint4 hi, lo;
+  ptsplit::split_pair_f16(v[0], v[1], s, s, hi.x, lo.x);
+  ptsplit::split_pair_f16(v[2], v[3], s, s, hi.y, lo.y);
+  ptsplit::split_pair_f16(v[4], v[5], s, s, hi.z, lo.z);
+  ptsplit::split_pair_f16(v[6], v[7], s, s, hi.w, lo.w);
+  char *dst = planes + block_offset(rb, kb, 0, kb16v) + c * 16;
+  *reinterpret_cast<uint4 *>(dst) = hi;
+  *reinterpret_cast<uint4 *>(dst + BLK_BYTES) = lo;
+}
+
+size_t slab_bytes(int M, int N, int split_k) {
+  if (split_k <= 1) return 0;
+  return ((size_t)split_k * M * N * sizeof(float) + 15) & ~(size_t)15;
+}
+
+}  // namespace
+}  // namespace pthp
+
+using namespace pthp;
+
+extern "C" {
+
+size_t ptamd_hp_bytes(int rows, int K) { return (rows <= 0 || K <= 0) ? 0 : plane_bytes(rows, K); }
+int ptamd_hp_padded_rows(int rows) { return rows <= 0 ? 0 : round_up(rows, 32); }
+
+int ptamd_hp_split(const float *x, int ld, int rows, int K, int transposed, void *planes, float *scale, void *stream) {
+  if (rows <= 0 || K <= 0 || !x || !planes || !scale) return PTAMD_ERR_BAD_SHAPE;
+  if (!transposed && ((ld & 3) || (K & 3) || !pt_aligned16(x))) return PTAMD_ERR_ALIGN;
+  if (!pt_aligned16(planes)) return PTAMD_ERR_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  const int rows_p = round_up(rows, 32), kbv = kb16(K);
+  const int64_t nchunks = (int64_t)(rows_p / 32) * kbv * 64;
+  const unsigned wblocks = (unsigned)((nchunks + 255) / 256);
+  if (!transposed) {
+    hipLaunchKernelGGL(hp_rowscale_kernel, dim3((rows_p + 3) / 4), dim3(256), 0, st, x, ld, rows, K, rows_p, scale);
+    hipLaunchKernelGGL((hp_write_kernel<false, false>), dim3(wblocks), dim3(256), 0, st, x, ld, rows, K, kbv, scale,
+                       static_cast<char *>(planes), nchunks);
+  } else {
+    PT_HIP_TRY(hipMemsetAsync(scale, 0, (size_t)rows_p * sizeof(float), st));
+    hipLaunchKernelGGL(hp_colmax_kernel, dim3((rows + 255) / 256, (K + 63) / 64), dim3(256), 0, st, x, ld, rows, K,
+                       reinterpret_cast<uint32_t *>(scale));
+    hipLaunchKernelGGL((hp_write_kernel<true, true>), dim3(wblocks), dim3(256), 0, st, x, ld, rows, K, kbv, scale,
+                       static_cast<char *>(planes), nchunks);
+    hipLaunchKernelGGL(hp_amax_to_scale_kernel, dim3((rows_p + 255) / 256), dim3(256), 0, st, reinterpret_cast<uint32_t *>(scale),
+                       rows, rows_p);
+  }
+  return pt_check_launch();
+}
+
+size_t ptamd_gemm_hp_workspace_bytes(int M, int N, int split_k) { return (M <= 0 || N <= 0) ? 0 : slab_bytes(M, N, split_k); }
+
+int ptamd_gemm_hp(const ptamd_gemm_hp_args *a, void *stream) {
+  if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0) return PTAMD_ERR_BAD_SHAPE;
+  if (!a->A || !a->B || !a->A_scale || !a->B_scale || !a->C) return PTAMD_ERR_BAD_SHAPE;
+  if (!pt_aligned16(a->A) || !pt_aligned16(a->B)) return PTAMD_ERR_ALIGN;
+  if (a->dropout_p < 0.f || a->dropout_p >= 1.f) return PTAMD_ERR_BAD_SHAPE;
+  if ((a->flags & PTAMD_EPI_GATE) && !a->residual) return PTAMD_ERR_BAD_SHAPE;
+  HpParams p;
+  GemmParams &g = p.g;
+  g.M = a->M; g.N = a->N; g.K = a->K;
+  g.A = nullptr; g.lda = 0; g.B = nullptr; g.ldb = 0; g.C = a->C; g.ldc = a->ldc;
+  g.bias = a->bias; g.residual = a->residual; g.ldr = a->ldr; g.flags = a->flags;
+  g.dropout_p = a->dropout_p; g.seed = a->seed; g.stream_id = a->stream_id; g.gate_scale = a->gate_scale;
+  g.reserved_cus = a->reserved_cus;
+  g.colsum = nullptr; g.colsum_share = 1; g.scale_a = g.scale_b = nullptr;
+  const int Kp = round_up(a->K, 32), stages = Kp / HBK;
+  int splits = a->split_k > 1 ? a->split_k : 1;
+  if (splits > stages) splits = stages;
+  g.k_per_split = ((stages + splits - 1) / splits) * HBK;
+  splits = (Kp + g.k_per_split - 1) / g.k_per_split;
+  g.splits = splits;
+  g.vec_epilogue = !(a->N & 3) && !(a->ldc & 3) && pt_aligned16(a->C) &&
+                   (!a->residual || (!(a->ldr & 3) && pt_aligned16(a->residual))) && (splits == 1 || pt_aligned16(a->workspace));
+  g.slab = 0;
+  float *user_c = a->C;
+  if (splits > 1) {
+    if (!a->workspace || a->workspace_bytes < slab_bytes(a->M, a->N, splits)) return PTAMD_ERR_WORKSPACE;
+    g.slab = (size_t)a->M * a->N;
+    g.C = static_cast<float *>(a->workspace);
+  }
+  p.a_planes = static_cast<const char *>(a->A);
+  p.b_planes = static_cast<const char *>(a->B);
+  p.a_scale = a->A_scale;
+  p.b_scale = a->B_scale;
+  p.kb16 = Kp / 16;
+  p.a_rb_last = (round_up(a->M, 32) / 32) - 1;
+  p.b_rb_last = (round_up(a->N, 32) / 32) - 1;
+  hipStream_t st = (hipStream_t)stream;
+  const bool plain = !a->bias && !a->residual && !(a->flags & (PTAMD_EPI_RELU | PTAMD_EPI_TANH | PTAMD_EPI_ACCUM)) && a->dropout_p == 0.f;
+  int rc;
+  if (plain || splits > 1) rc = launch_hp<ptgemm::EPI_PLAIN>(p, splits, st);
+  else if (a->dropout_p == 0.f) rc = launch_hp<ptgemm::EPI_NODROP>(p, splits, st);
+  else rc = launch_hp<ptgemm::EPI_FULL>(p, splits, st);
+  if (rc || splits == 1) return rc;
+  const float *slabs = g.C;
+  g.C = user_c;
+  return ptgemm::launch_splitk_reduce(g, slabs, splits, nullptr, nullptr, st);
+}
+
+}  // extern "C"
