@@ -33,6 +33,21 @@ class GemmArgs(C.Structure):
                 ("reserved_cus", _i)]
 
 
+class GemmHpArgs(C.Structure):
+    _fields_ = [("M", _i), ("N", _i), ("K", _i),
+                ("A", _p), ("A_scale", _p),
+                ("B", _p), ("B_scale", _p),
+                ("C", _p), ("ldc", _i),
+                ("bias", _p),
+                ("residual", _p), ("ldr", _i),
+                ("flags", _i),
+                ("dropout_p", _f), ("seed", _u64), ("stream_id", _u32),
+                ("split_k", _i),
+                ("workspace", _p), ("workspace_bytes", _sz),
+                ("gate_scale", _f),
+                ("reserved_cus", _i)]
+
+
 # name -> (restype, argtypes); mirrors include/ptamd.h one to one
 SIGNATURES = {
     "ptamd_version": (C.c_char_p, []),
@@ -54,6 +69,11 @@ SIGNATURES = {
     "ptamd_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
     "ptamd_gemm": (_i, [C.POINTER(GemmArgs), _p]),
     "ptamd_gemm_products": (_i, [C.POINTER(GemmArgs)]),
+    "ptamd_hp_bytes": (_sz, [_i, _i]),
+    "ptamd_hp_padded_rows": (_i, [_i]),
+    "ptamd_hp_split": (_i, [_p, _i, _i, _i, _i, _p, _p, _p]),
+    "ptamd_gemm_hp_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ptamd_gemm_hp": (_i, [C.POINTER(GemmHpArgs), _p]),
     "ptamd_layernorm_fwd": (_i, [_p, _p, _p, _i64, _i, _p, _p, _p, _p]),
     "ptamd_layernorm_bwd_workspace_bytes": (_sz, [_i]),
     "ptamd_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _p, _p, _p, _p, _sz, _p]),

@@ -35,11 +35,7 @@ using ptgemm::GemmParams;
 using ptgemm::f32x16;
 using ptsplit::f16x8;
 
-constexpr int HBM = 256, HBN = 128, HBK = 32, HTHREADS = 512;
-constexpr int A_STAGE = (HBM / 32) * 4096, B_STAGE = (HBN / 32) * 4096, STAGE_BYTES = A_STAGE + B_STAGE;  // 48 KiB
-constexpr int SCRATCH_BYTES = 8 * 2048 * 4;                                                            // 64 KiB
-constexpr size_t HP_LDS = (size_t)2 * STAGE_BYTES + SCRATCH_BYTES;
-static_assert(HP_LDS <= 160 * 1024, "LDS budget of a CU");
+constexpr int HBN = 128;  // tile columns: two wavefront columns of 64
 
 struct HpParams {
   GemmParams g;            // shapes, C, epilogue operands, split-K bookkeeping (A / B / lda / ldb unused)
@@ -63,13 +59,33 @@ struct Cursor {
   Item it;
 };
 
-template <int EPI>
-__global__ __launch_bounds__(HTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_hp_kernel(const HpParams p) {
+// Geometry of a variant: WM wavefront rows x 2 wavefront columns; a wavefront owns (32 TI) x 64 of the (32 TI WM) x 128
+// tile; a stage is 16 KB16 k.  ILV: the DMA pieces of the next stage are issued between the MFMA groups of this one
+// instead of in a burst behind the barrier (an LDS-DMA issue occupies the wavefront's instruction stream for ~100 cycles).
+template <int WM_, int TI_, int KB_, bool ILV_>
+struct HpGeom {
+  static constexpr int WM = WM_, TI = TI_, KB = KB_;
+  static constexpr bool ILV = ILV_;
+  static constexpr int NW = 2 * WM, THREADS = 64 * NW, TILE_M = 32 * TI * WM, BK = 16 * KB;
+  static constexpr int A_BLOCKS = TILE_M / 32, B_BLOCKS = HBN / 32;
+  static constexpr int RB_BYTES = KB * 2048;                       // one block row of a stage: KB x (hi, lo) x 1 KiB
+  static constexpr int A_STAGE = A_BLOCKS * RB_BYTES, STAGE_BYTES = (A_BLOCKS + B_BLOCKS) * RB_BYTES;
+  static constexpr int PIECES = STAGE_BYTES / 1024, PER_WAVE = PIECES / NW;
+  static constexpr int SCRATCH_BYTES = NW * 2048 * 4;
+  static constexpr size_t LDS = (size_t)2 * STAGE_BYTES + SCRATCH_BYTES;
+  static constexpr int WG_PER_CU = LDS <= 80 * 1024 ? 2 : 1;
+  static_assert(PIECES % NW == 0, "pieces must divide evenly over the wavefronts");
+  static_assert(LDS <= 160 * 1024, "LDS budget of a CU");
+};
+
+template <typename G, int EPI>
+__global__ __launch_bounds__(G::THREADS, G::WG_PER_CU * G::NW / 4) void gemm_hp_kernel(const HpParams p) {
+  constexpr int TI = G::TI, KB = G::KB, BK = G::BK;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float *const scratch = reinterpret_cast<float *>(smem + 2 * STAGE_BYTES);
+  float *const scratch = reinterpret_cast<float *>(smem + 2 * G::STAGE_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const ptgemm::WorkRange work(p.g, HBM, HBN);
+  const ptgemm::WorkRange work(p.g, G::TILE_M, HBN);
   if (work.begin >= work.end) return;
   const int Kp = p.kb16 * 16;
   auto item_at = [&](int logical) __attribute__((always_inline)) {
@@ -81,8 +97,8 @@ __global__ __launch_bounds__(HTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
   };
   // next stage of the stream; false past the last one
   auto advance = [&](Cursor &c) __attribute__((always_inline)) {
-    if (c.k0 + HBK < c.it.kend) {
-      c.k0 += HBK;
+    if (c.k0 + BK < c.it.kend) {
+      c.k0 += BK;
       return true;
     }
     if (c.w + 1 < work.end) {
@@ -92,27 +108,22 @@ __global__ __launch_bounds__(HTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
     }
     return false;
   };
-  // the six DMA pieces of this wavefront for stage (item, k0) into stage buffer `buf`
+  // DMA piece i (0 .. PER_WAVE-1) of this wavefront for stage (item, k0) into stage buffer `buf`.  Piece q = wave +
+  // NW i of the stage covers 1 KiB: stage offset q KiB = [block row][k block][plane], the same order as in memory.
   const int lane16 = lane * 16;
-  auto issue = [&](const Cursor &c, int buf) __attribute__((always_inline)) {
-    char *sbase = smem + buf * STAGE_BYTES;
-    const int kb = c.k0 >> 4;
-    const int arb = min((c.it.bm0 >> 5) + wave, p.a_rb_last);
-    const char *ga = p.a_planes + block_offset(arb, kb, 0, p.kb16) + lane16;   // 4 KiB: (kb, hi) (kb, lo) (kb+1, hi) (kb+1, lo)
-    char *la = sbase + wave * 4096;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dma16(ga + i * 1024, la + i * 1024);
-    const int brb = min((c.it.bn0 >> 5) + (wave >> 1), p.b_rb_last);
-    const char *gb = p.b_planes + block_offset(brb, kb + (wave & 1), 0, p.kb16) + lane16;  // 2 KiB: hi, lo of one k block
-    char *lb = sbase + A_STAGE + (wave >> 1) * 4096 + (wave & 1) * 2048;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) dma16(gb + i * 1024, lb + i * 1024);
+  auto issue_piece = [&](const Cursor &c, int buf, int i) __attribute__((always_inline)) {
+    const int q = wave + G::NW * i;
+    const int rbq = q / (2 * KB), rest = q - rbq * (2 * KB);          // block row of the stage, (k block, plane) inside it
+    const bool is_b = rbq >= G::A_BLOCKS;
+    const int rb = is_b ? min((c.it.bn0 >> 5) + rbq - G::A_BLOCKS, p.b_rb_last) : min((c.it.bm0 >> 5) + rbq, p.a_rb_last);
+    const char *g = (is_b ? p.b_planes : p.a_planes) + block_offset(rb, c.k0 >> 4, 0, p.kb16) + rest * 1024 + lane16;
+    dma16(g, smem + buf * G::STAGE_BYTES + q * 1024);
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TI][2];
   auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -127,53 +138,72 @@ __global__ __launch_bounds__(HTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
   Cursor ld = {work.begin, 0, item_at(work.begin)};
   ld.k0 = ld.it.kbeg;
   Cursor cc = ld;
-  issue(ld, 0);
+#pragma unroll
+  for (int i = 0; i < G::PER_WAVE; ++i) issue_piece(ld, 0, i);
   bool more_loads = advance(ld);
   int buf = 0;
   for (;;) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's pieces of the stage have landed ...
     __syncthreads();                                   // ... and everybody's; everybody is done with the other buffer
-    if (more_loads) {
-      issue(ld, buf ^ 1);
-      more_loads = advance(ld);
+    if (!G::ILV && more_loads) {
+#pragma unroll
+      for (int i = 0; i < G::PER_WAVE; ++i) issue_piece(ld, buf ^ 1, i);
     }
-    const char *sa = smem + buf * STAGE_BYTES + (2 * wm) * 4096 + frag_off;
-    const char *sb = smem + buf * STAGE_BYTES + A_STAGE + (2 * wn) * 4096 + frag_off;
+    const char *sa = smem + buf * G::STAGE_BYTES + (TI * wm) * G::RB_BYTES + frag_off;
+    const char *sb = smem + buf * G::STAGE_BYTES + G::A_STAGE + (2 * wn) * G::RB_BYTES + frag_off;
+    int piece = 0;
+    auto dma_slot = [&](int n) __attribute__((always_inline)) {  // ILV: n pieces of the next stage here
+      if (G::ILV) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (more_loads) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      f16x8 fa[2][2], fb[2][2];  // [tile][plane]
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          fa[i][t] = *reinterpret_cast<const f16x8 *>(sa + i * 4096 + (kb * 2 + t) * 1024);
-          fb[i][t] = *reinterpret_cast<const f16x8 *>(sb + i * 4096 + (kb * 2 + t) * 1024);
+          for (int u = 0; u < n; ++u)
+            if (piece + u < G::PER_WAVE) issue_piece(ld, buf ^ 1, piece + u);
         }
+        piece += n;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    constexpr int SLOTS = 3 * KB, PER_SLOT = (G::PER_WAVE + SLOTS - 1) / SLOTS;
+    f16x8 fa[TI][2], fb[2][2];  // [tile][plane]
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i) fa[i][t] = *reinterpret_cast<const f16x8 *>(sa + i * G::RB_BYTES + (kb * 2 + t) * 1024);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j][t] = *reinterpret_cast<const f16x8 *>(sb + j * G::RB_BYTES + (kb * 2 + t) * 1024);
+      }
       // smallest products first
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+      dma_slot(PER_SLOT);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+      dma_slot(PER_SLOT);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+      dma_slot(PER_SLOT);
     }
-    if (cc.k0 + HBK >= cc.it.kend) {  // that was the item's last stage (uniform)
+    if (more_loads) more_loads = advance(ld);
+    if (cc.k0 + BK >= cc.it.kend) {  // that was the item's last stage (uniform)
       float *C = p.g.C + (partial ? (size_t)cc.it.z * p.g.slab : 0);
       const int ldc = partial ? p.g.N : p.g.ldc;
-      const int row0 = cc.it.bm0 + wm * 64, col0 = cc.it.bn0 + wn * 64;
+      const int row0 = cc.it.bm0 + wm * 32 * TI, col0 = cc.it.bn0 + wn * 64;
       {  // back from the scaled operands: acc / (scale_a[row] scale_b[col]), exact (powers of two)
         const int l31 = lane & 31, lh = lane >> 5;
         float ib[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) ib[j] = inverse_of_scale(p.b_scale[min(col0 + j * 32 + l31, p.g.N - 1)]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
           for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -184,9 +214,9 @@ __global__ __launch_bounds__(HTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
             }
       }
       if (p.g.vec_epilogue)
-        ptgemm::tile_epilogue_vec<2, true, EPI>(p.g, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 2048);
+        ptgemm::tile_epilogue_vec<TI, true, EPI>(p.g, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 2048);
       else
-        ptgemm::tile_epilogue_vec<2, false, EPI>(p.g, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 2048);
+        ptgemm::tile_epilogue_vec<TI, false, EPI>(p.g, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 2048);
       zero_acc();
     }
     if (!advance(cc)) break;
@@ -194,14 +224,25 @@ __global__ __launch_bounds__(HTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
   }
 }
 
+template <typename G, int EPI>
+int launch_hp_g(const HpParams &p, int splits, hipStream_t st) {
+  const int work = ((p.g.M + G::TILE_M - 1) / G::TILE_M) * ((p.g.N + HBN - 1) / HBN) * splits;
+  auto kern = gemm_hp_kernel<G, EPI>;
+  PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
+  const int slots = ptgemm::persistent_grid(p.g.reserved_cus) * G::WG_PER_CU;
+  hipLaunchKernelGGL(kern, dim3(work < slots ? work : slots), dim3(G::THREADS), G::LDS, st, p);
+  return pt_check_launch();
+}
+
+// The geometry in use: 8 wavefronts x (64 x 64) = 256 x 128 tile, 32 k per stage, one workgroup per CU, DMA pieces between
+// the MFMA groups.  Measured alternatives (profiles/r02_hp_gemm_ablations.txt): the DMA burst behind the barrier
+// (HpGeom<4, 2, 2, false>) is 5-8 % slower; two workgroups of 4 wavefronts x (128 x 64) per CU (HpGeom<2, 4, 1, true>) 20-40 %
+// slower and at the 256-VGPR limit; 128 x 128 tiles (HpGeom<2, 2, 2, true>) 30-50 % slower.
+typedef HpGeom<4, 2, 2, true> Geom;
+
 template <int EPI>
 int launch_hp(const HpParams &p, int splits, hipStream_t st) {
-  const int work = ((p.g.M + HBM - 1) / HBM) * ((p.g.N + HBN - 1) / HBN) * splits;
-  auto kern = gemm_hp_kernel<EPI>;
-  PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HP_LDS));
-  const int slots = ptgemm::persistent_grid(p.g.reserved_cus);
-  hipLaunchKernelGGL(kern, dim3(work < slots ? work : slots), dim3(HTHREADS), HP_LDS, st, p);
-  return pt_check_launch();
+  return launch_hp_g<Geom, EPI>(p, splits, st);
 }
 
 // ---------------------------------------------------------------------------------------------- writers of the format
@@ -337,6 +378,7 @@ int ptamd_gemm_hp(const ptamd_gemm_hp_args *a, void *stream) {
   g.dropout_p = a->dropout_p; g.seed = a->seed; g.stream_id = a->stream_id; g.gate_scale = a->gate_scale;
   g.reserved_cus = a->reserved_cus;
   g.colsum = nullptr; g.colsum_share = 1; g.scale_a = g.scale_b = nullptr;
+  constexpr int HBK = 32;
   const int Kp = round_up(a->K, 32), stages = Kp / HBK;
   int splits = a->split_k > 1 ? a->split_k : 1;
   if (splits > stages) splits = stages;

@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import GemmArgs, check, lib, ptr, stream, workspace
+from ._lib import GemmArgs, GemmHpArgs, check, lib, ptr, stream, workspace
 
 EPI_RELU, EPI_TANH, EPI_ACCUM, EPI_GATE = 1, 2, 4, 8
 
@@ -79,6 +79,54 @@ def set_gemm_mode(mode):
 
 def get_gemm_mode():
     return _DEFAULT_ARITH
+
+
+class HpOperand:
+    """An fp32 matrix [rows, K] in the pre-split "half-pair" format of include/ptamd.h (two f16 planes in MFMA-operand
+    blocks + one power-of-two scale per row): what ptamd_gemm_hp reads by LDS-DMA."""
+    __slots__ = ("planes", "scale", "rows", "K")
+
+    def __init__(self, rows, K, device):
+        self.rows, self.K = int(rows), int(K)
+        self.planes = torch.empty(lib().ptamd_hp_bytes(self.rows, self.K), dtype=torch.uint8, device=device)
+        self.scale = torch.empty(lib().ptamd_hp_padded_rows(self.rows), dtype=torch.float32, device=device)
+
+
+def hp_split(x, transposed=False, out=None):
+    """fp32 [rows, K] (or, transposed, [K, rows]) -> HpOperand."""
+    assert x.dim() == 2 and x.stride(1) == 1
+    rows, K = (x.shape[1], x.shape[0]) if transposed else (x.shape[0], x.shape[1])
+    if out is None:
+        out = HpOperand(rows, K, x.device)
+    check(lib().ptamd_hp_split(ptr(x), x.stride(0), rows, K, int(transposed), ptr(out.planes), ptr(out.scale), stream()),
+          "hp_split")
+    return out
+
+
+def gemm_hp(a, b, C_out, *, bias=None, residual=None, ldr=0, flags=0, dropout_p=0.0, seed=0, stream_id=0, split_k=1,
+            gate_scale=0.0):
+    """C[M,N] = epilogue(A B^T) from pre-split operands a = hp [M,K], b = hp [N,K]."""
+    assert a.K == b.K
+    M, N = a.rows, b.rows
+    ws = workspace("gemm_hp", lib().ptamd_gemm_hp_workspace_bytes(M, N, split_k), C_out.device) if split_k > 1 else None
+    args = GemmHpArgs(M=M, N=N, K=a.K, A=a.planes.data_ptr(), A_scale=a.scale.data_ptr(), B=b.planes.data_ptr(),
+                      B_scale=b.scale.data_ptr(), C=C_out.data_ptr(), ldc=C_out.stride(0),
+                      bias=bias.data_ptr() if bias is not None else None,
+                      residual=residual.data_ptr() if residual is not None else None, ldr=ldr, flags=flags,
+                      dropout_p=float(dropout_p), seed=int(seed) & (2 ** 64 - 1), stream_id=int(stream_id),
+                      split_k=int(split_k), workspace=ws.data_ptr() if ws is not None else None,
+                      workspace_bytes=ws.numel() if ws is not None else 0, gate_scale=float(gate_scale),
+                      reserved_cus=int(GEMM_RESERVED_CUS))
+    if GEMM_TIMING is None:
+        check(lib().ptamd_gemm_hp(C.byref(args), stream()), "gemm_hp")
+    else:
+        e0, e1 = GEMM_EVENT_POOL.pop(), GEMM_EVENT_POOL.pop()
+        e0.record()
+        check(lib().ptamd_gemm_hp(C.byref(args), stream()), "gemm_hp")
+        e1.record()
+        GEMM_TIMING.append((2.0 * M * N * a.K, e0, e1, 3))
+        GEMM_BYTES.append(4 * (M * a.K + N * a.K + M * N * (1 + (residual is not None) + bool(flags & EPI_ACCUM))))
+    return C_out
 
 
 def pick_split_k(M, N, K, slots=512):
