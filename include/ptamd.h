@@ -137,6 +137,13 @@ typedef struct {
   int arith;              /* PTAMD_GEMM_* below: the arithmetic of THIS call (the library keeps no mode of its own) */
   int reserved_cus;       /* the persistent kernels leave this many CUs free, e.g. for an RCCL all-reduce of the layer above
                              that runs beside the backward GEMMs under data parallelism; 0 = take every CU */
+  /* F16X2 arithmetic only, optional: the row scales of the operands (uint32 bits of a power of two s with
+   * max |x_row| * s < 2^15, see PTAMD_GEMM_F16X2) when the caller already has them - written by the kernel that
+   * produced the operand (ptamd_layernorm_fwd, ptamd_layernorm_bwd_dropout) or derived from a bound of the row maxima
+   * (ptamd_encoder_bounds).  NULL: ptamd_gemm finds them with a pass over the operand (needs the workspace).
+   * a_scale_stride: 1 = a_scale[m] per row of A; 0 = a_scale[0] for every row (K-contiguous A only). */
+  const uint32_t *a_scale; int a_scale_stride;
+  const uint32_t *b_scale;
 } ptamd_gemm_args;
 size_t ptamd_gemm_workspace_bytes(int M, int N, int split_k);
 int ptamd_gemm(const ptamd_gemm_args *args, void *stream);
@@ -213,15 +220,53 @@ typedef struct {
 size_t ptamd_gemm_hp_workspace_bytes(int M, int N, int split_k);
 int ptamd_gemm_hp(const ptamd_gemm_hp_args *args, void *stream);
 
-/* torch.nn.LayerNorm(D, eps=1e-5) (Sublayers.py:13,17): y = (x-mean)*rstd*gamma+beta; saves mean,rstd [T] */
+/* ------------------------------------------------------------------ f16x2 bookkeeping without passes over activations
+ * (csrc/scales.hip).  Scales are uint32 bit patterns of powers of two, as ptamd_gemm_args.a_scale / b_scale take them.
+ * ptamd_weight_scales: for each job (a weight matrix or a sub-matrix / vector of the flat parameter buffer,
+ *   w [rows, cols], row stride ld): row_scale[rows] (B operand of x W^T), col_scale[cols] (B operand of dy W),
+ *   stats[4] = {largest row L2 norm, largest column L2 norm, largest |w|, 0}; any output may be NULL.  Two launches for
+ *   the whole list (at most 40 jobs per call).
+ * ptamd_bound_scales: out = ((max|gamma| sqrt_d + |beta|_2) if a LayerNorm feeds the product else 1) * w_stats[w_stat_index]
+ *   [+ max|bias|], times post_scale - an upper bound of |x W^T + b|_inf for every row x = LN(.) (Cauchy-Schwarz), or of
+ *   |dy W|_inf / |dy|_2 when no LayerNorm is given; out_scale receives the f16x2 scale of a row with that maximum (to be
+ *   used with a_scale_stride = 0), out_value the bound itself (the `bound_factor` of ptamd_layernorm_bwd_dropout).
+ *   ln_*_stats / w_stats / bias_stats point at stats[4] records written by ptamd_weight_scales earlier on the stream. */
+typedef struct {
+  const float *w; int rows, cols, ld;
+  uint32_t *row_scale; uint32_t *col_scale; float *stats;
+} ptamd_wscale_job;
+int ptamd_weight_scales(const ptamd_wscale_job *jobs_host, int njobs, void *stream);
+typedef struct {
+  const float *ln_gamma_stats; const float *ln_beta_stats;
+  const float *w_stats; int w_stat_index;
+  const float *bias_stats;
+  float sqrt_d, post_scale;
+  uint32_t *out_scale; float *out_value;
+} ptamd_bound_job;
+int ptamd_bound_scales(const ptamd_bound_job *jobs_host, int njobs, void *stream);
+
+/* torch.nn.LayerNorm(D, eps=1e-5) (Sublayers.py:13,17): y = (x-mean)*rstd*gamma+beta; saves mean,rstd [T];
+ * row_scale [T] (may be NULL): the f16x2 scale of every row of y, for the GEMM that reads y as its A operand */
 int ptamd_layernorm_fwd(const float *x, const float *gamma, const float *beta, int64_t T, int D, float *y,
-                        float *mean, float *rstd, void *stream);
+                        float *mean, float *rstd, uint32_t *row_scale, void *stream);
 /* dx [T,D] = LN'(dy) + dres (dres: gradient of the residual branch, may be NULL; dx may alias dres);
  * dgamma, dbeta [D] accumulated (+=) through fixed-order partials in workspace */
 size_t ptamd_layernorm_bwd_workspace_bytes(int D);
 int ptamd_layernorm_bwd(const float *dy, const float *x, const float *gamma, const float *mean, const float *rstd,
                         const float *dres, int64_t T, int D, float *dx, float *dgamma, float *dbeta, void *workspace,
                         size_t workspace_bytes, void *stream);
+
+/* ptamd_layernorm_bwd fused with the dropout backward that follows it in the encoder (SublayerConnection: x + drop(f(LN(x))),
+ * Sublayers.py:17): dx as above, and `dropped` [T,D] = dx * mask / (1 - p) with the mask the GEMM epilogue drew for
+ * (seed, stream_id) - what ptamd_dropout_bwd would make of dx (dropout_p = 0: dropped is not written, it equals dx).
+ * Also, for the GEMMs that read `dropped` as their A operand: row_scale [T] = its f16x2 row scales, and bound_scale [T] =
+ * the scale of a row bounded by |dropped[t]|_2 * *bound_factor (device scalar, e.g. from ptamd_bound_scales): the scale of
+ * row t of dropped W.  row_scale / bound_scale may be NULL.  D <= 1024. */
+int ptamd_layernorm_bwd_dropout(const float *dy, const float *x, const float *gamma, const float *mean, const float *rstd,
+                                const float *dres, int64_t T, int D, float dropout_p, uint64_t seed, uint32_t stream_id,
+                                float *dx, float *dropped, uint32_t *row_scale, const float *bound_factor,
+                                uint32_t *bound_scale, float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,
+                                void *stream);
 
 /* Embeddings * sqrt(D) and the doubled positional add of Encoder.py:30 + Sublayers.py:59-62,72:
  *   x0 = emb[seq]*sqrt(D); out = drop2(x0 + drop1(x0 + pe[pos]))      (eval: 2*x0 + pe) */

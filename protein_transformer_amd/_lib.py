@@ -30,7 +30,18 @@ class GemmArgs(C.Structure):
                 ("colsum", _p),
                 ("gate_scale", _f),
                 ("arith", _i),
-                ("reserved_cus", _i)]
+                ("reserved_cus", _i),
+                ("a_scale", _p), ("a_scale_stride", _i),
+                ("b_scale", _p)]
+
+
+class WScaleJob(C.Structure):
+    _fields_ = [("w", _p), ("rows", _i), ("cols", _i), ("ld", _i), ("row_scale", _p), ("col_scale", _p), ("stats", _p)]
+
+
+class BoundJob(C.Structure):
+    _fields_ = [("ln_gamma_stats", _p), ("ln_beta_stats", _p), ("w_stats", _p), ("w_stat_index", _i), ("bias_stats", _p),
+                ("sqrt_d", _f), ("post_scale", _f), ("out_scale", _p), ("out_value", _p)]
 
 
 class GemmHpArgs(C.Structure):
@@ -74,7 +85,10 @@ SIGNATURES = {
     "ptamd_hp_split": (_i, [_p, _i, _i, _i, _i, _p, _p, _p]),
     "ptamd_gemm_hp_workspace_bytes": (_sz, [_i, _i, _i]),
     "ptamd_gemm_hp": (_i, [C.POINTER(GemmHpArgs), _p]),
-    "ptamd_layernorm_fwd": (_i, [_p, _p, _p, _i64, _i, _p, _p, _p, _p]),
+    "ptamd_weight_scales": (_i, [C.POINTER(WScaleJob), _i, _p]),
+    "ptamd_bound_scales": (_i, [C.POINTER(BoundJob), _i, _p]),
+    "ptamd_layernorm_fwd": (_i, [_p, _p, _p, _i64, _i, _p, _p, _p, _p, _p]),
+    "ptamd_layernorm_bwd_dropout": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _u64, _u32, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "ptamd_layernorm_bwd_workspace_bytes": (_sz, [_i]),
     "ptamd_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _p, _p, _p, _p, _sz, _p]),
     "ptamd_embed_fwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _u64, _p, _p]),

@@ -85,6 +85,11 @@ __device__ __forceinline__ uint32_t drop_field_value(const uint4 &r, int f) {
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint32_t stream_id, int64_t row, int col, int cols, uint32_t thr16) {
   return drop_field_value(pt_rand4(seed, drop_call_index(row, col, cols), stream_id), drop_field(row)) >= thr16;
 }
+// f16x2 arithmetic (include/ptamd.h, PTAMD_GEMM_F16X2): scale (bits of a power of two) of an operand row whose largest
+// |x| - or an upper bound of it - has the bits `amax`: amax * scale in [2^14, 2^15); rows of zeros get the largest
+// finite power.  A larger maximum gives a SMALLER scale.
+__device__ __forceinline__ uint32_t pt_row_scale_bits(uint32_t amax) { return min(268u - (amax >> 23), 254u) << 23; }
+
 // keep-threshold on the 32-bit word: keep iff word >= p * 2^32
 __device__ __forceinline__ uint32_t dropout_threshold(float p) {
   double t = (double)p * 4294967296.0;

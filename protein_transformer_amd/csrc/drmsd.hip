@@ -21,6 +21,7 @@
 namespace {
 
 constexpr int CB = 256;  // threads per block of the compaction / finalize kernels
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int PB = 128;  // rows (= threads) per block of the pair sweep: ~34 blocks per protein keep 256 CUs balanced
 
 struct Counts {
@@ -97,7 +98,11 @@ __global__ __launch_bounds__(PB) void drmsd_pairs_kernel(const float4 *__restric
                                                          const float4 *__restrict__ true4,
                                                          const Counts *__restrict__ counts, int L, int row_blocks,
                                                          float4 *__restrict__ gcomp, double *__restrict__ partials) {
-  __shared__ float4 s_p[PB], s_t[PB];
+  // column tile in LDS, predicted and true coordinate side by side: (px, tx, py, ty) and (pz, tz), so that the two
+  // distance computations of a pair run as ONE stream of packed f32 instructions (v_pk_add / v_pk_fma_f32: two lanes'
+  // worth of arithmetic per issue slot - the pair loop is VALU-bound, not memory-bound)
+  __shared__ float4 s_xy[PB];
+  __shared__ float2 s_z[PB];
   __shared__ double s_red[2 * (PB / 64)];
   const int b = blockIdx.y, tid = threadIdx.x;
   const Counts cn = counts[b];
@@ -115,34 +120,36 @@ __global__ __launch_bounds__(PB) void drmsd_pairs_kernel(const float4 *__restric
   const bool live = i < n;
   const float4 pi = live ? pred4[i] : make_float4(0, 0, 0, 0);
   const float4 ti = live ? true4[i] : make_float4(0, 0, 0, 0);
+  const f32x2 ix = {pi.x, ti.x}, iy = {pi.y, ti.y}, iz = {pi.z, ti.z};
   float accA = 0.f, accB = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
 
   auto pair = [&](int j, float &acc) {
-    const float4 pj = s_p[j], tj = s_t[j];  // same address in every lane: LDS broadcast
-    float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-    float d2 = fmaxf(dx * dx + dy * dy + dz * dz, 1e-30f);  // clamp_min(1e-30) of losses.py:252
-    float inv = __builtin_amdgcn_rsqf(d2);
-    float d = d2 * inv;
-    asm("" : "+v"(d));  // keep the rounded product: no FMA contraction into e, so pred == true gives e == 0 exactly
-    float ex = ti.x - tj.x, ey = ti.y - tj.y, ez = ti.z - tj.z;
-    float t2 = fmaxf(ex * ex + ey * ey + ez * ez, 1e-30f);
-    float tau = t2 * __builtin_amdgcn_rsqf(t2);
-    asm("" : "+v"(tau));
-    float e = d - tau;
-    acc += e * e;
+    const float4 a = s_xy[j];  // same address in every lane: LDS broadcast
+    const float2 c = s_z[j];
+    const f32x2 dx = ix - (f32x2){a.x, a.y}, dy = iy - (f32x2){a.z, a.w}, dz = iz - (f32x2){c.x, c.y};  // (pred, true)
+    f32x2 q = dx * dx;
+    q = __builtin_elementwise_fma(dy, dy, q);
+    q = __builtin_elementwise_fma(dz, dz, q);
+    const float d2 = fmaxf(q[0], 1e-30f), t2 = fmaxf(q[1], 1e-30f);  // clamp_min(1e-30) of losses.py:252
+    const float inv = __builtin_amdgcn_rsqf(d2), invt = __builtin_amdgcn_rsqf(t2);
+    f32x2 dt = (f32x2){d2, t2} * (f32x2){inv, invt};  // (d, tau)
+    asm("" : "+v"(dt));  // keep the rounded products: no FMA contraction into e, so pred == true gives e == 0 exactly
+    const float e = dt[0] - dt[1];
+    acc = fmaf(e, e, acc);
     if (WITH_GRAD) {
-      float cf = e * inv;
-      gx += cf * dx;
-      gy += cf * dy;
-      gz += cf * dz;
+      const float cf = e * inv;
+      gx = fmaf(cf, dx[0], gx);
+      gy = fmaf(cf, dy[0], gy);
+      gz = fmaf(cf, dz[0], gz);
     }
   };
 
   for (int c0 = 0; c0 < n; c0 += PB) {
     __syncthreads();
     if (c0 + tid < n) {
-      s_p[tid] = pred4[c0 + tid];
-      s_t[tid] = true4[c0 + tid];
+      const float4 pj = pred4[c0 + tid], tj = true4[c0 + tid];
+      s_xy[tid] = make_float4(pj.x, tj.x, pj.y, tj.y);
+      s_z[tid] = make_float2(pj.z, tj.z);
     }
     __syncthreads();
     const int cnt = min(PB, n - c0);

@@ -99,7 +99,7 @@ template <int NV>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                             const float *__restrict__ beta, int64_t T, int D,
                                                             float *__restrict__ y, float *__restrict__ mean_out,
-                                                            float *__restrict__ rstd_out) {
+                                                            float *__restrict__ rstd_out, uint32_t *__restrict__ row_scale) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= T) return;
@@ -124,19 +124,23 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restr
   }
   const float rstd = 1.f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
   float *yr = y + row * D;
+  float amax = 0.f;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int c = (j * 64 + lane) * 4;
     if (c < D) {
       const float4 g = *reinterpret_cast<const float4 *>(gamma + c), b = *reinterpret_cast<const float4 *>(beta + c);
-      *reinterpret_cast<float4 *>(yr + c) =
-          make_float4((v[j].x - mean) * rstd * g.x + b.x, (v[j].y - mean) * rstd * g.y + b.y,
-                      (v[j].z - mean) * rstd * g.z + b.z, (v[j].w - mean) * rstd * g.w + b.w);
+      const float4 o = make_float4((v[j].x - mean) * rstd * g.x + b.x, (v[j].y - mean) * rstd * g.y + b.y,
+                                   (v[j].z - mean) * rstd * g.z + b.z, (v[j].w - mean) * rstd * g.w + b.w);
+      *reinterpret_cast<float4 *>(yr + c) = o;
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
   }
+  if (row_scale) amax = wave_max(amax);  // the f16x2 row scale of y as a GEMM operand (include/ptamd.h), for free here
   if (lane == 0) {
     mean_out[row] = mean;
     rstd_out[row] = rstd;
+    if (row_scale) row_scale[row] = pt_row_scale_bits(__float_as_uint(amax));
   }
 }
 
@@ -190,6 +194,126 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
     }
   }
   // the four wavefronts of the block add up their (dgamma, dbeta) in a fixed order: one partial row per block
+  __shared__ float4 s_dg[3][NV * 64], s_db[3][NV * 64];
+  const int wave = threadIdx.x >> 6;
+  if (wave > 0) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      s_dg[wave - 1][j * 64 + lane] = dg[j];
+      s_db[wave - 1][j * 64 + lane] = db[j];
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = (j * 64 + lane) * 4;
+      if (c < D) {
+        float4 a = dg[j], b = db[j];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          const float4 pa = s_dg[w][j * 64 + lane], pb = s_db[w][j * 64 + lane];
+          a.x += pa.x; a.y += pa.y; a.z += pa.z; a.w += pa.w;
+          b.x += pb.x; b.y += pb.y; b.z += pb.z; b.w += pb.w;
+        }
+        *reinterpret_cast<float4 *>(part + ((size_t)blockIdx.x * 2) * D + c) = a;
+        *reinterpret_cast<float4 *>(part + ((size_t)blockIdx.x * 2 + 1) * D + c) = b;
+      }
+    }
+  }
+}
+// LayerNorm backward FUSED with the dropout backward that always follows it in the encoder (the output dx is the gradient
+// of the residual stream; the next sublayer's GEMMs take dropout'(dx)), and with the f16x2 bookkeeping of that operand:
+//   dx       = LN'(dy) + dres                                            (as layernorm_bwd_kernel)
+//   dropped  = dx * mask / (1 - p), mask of the GEMM epilogue that drew it (common.h: drop_call_index / drop_field)
+//   row_scale[t]   = f16x2 scale of row t of `dropped` (exact row maximum)
+//   bound_scale[t] = f16x2 scale for a row bounded by |dropped[t]|_2 * *bound_factor - the rows of the product
+//                    dropped W that the next GEMM writes (Cauchy-Schwarz with the largest column norm of W)
+// One generator call serves the 8 rows {r0, r0+1, r0+2, r0+3, r0+8, .., r0+11} of a column, so a wavefront takes such a
+// GROUP of rows, draws its words once (4 NV calls per lane) and walks the 8 rows with them.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_dropout_kernel(
+    const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ mean,
+    const float *__restrict__ rstd, const float *__restrict__ dres, int64_t T, int D, float *__restrict__ dx,
+    float *__restrict__ part, float p, uint64_t seed, uint32_t stream_id, float *__restrict__ dropped,
+    uint32_t *__restrict__ row_scale, const float *__restrict__ bound_factor, uint32_t *__restrict__ bound_scale) {
+  const int lane = threadIdx.x & 63, wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  float4 g[NV], dg[NV], db[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    g[j] = c < D ? *reinterpret_cast<const float4 *>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    dg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    db[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const uint32_t t16 = dropout_threshold(p) >> 16;
+  const float ks = 1.f / (1.f - p), bf = bound_factor ? *bound_factor : 0.f;
+  const int64_t ngroups = ((T + 31) / 32) * 4;
+  for (int64_t cr = wid; cr < ngroups; cr += LN_BWD_BLOCKS * 4) {  // cr = call row (4 I + 2 h + gp)
+    const int64_t r0 = ((cr >> 2) << 5) + 16 * (cr & 1) + 4 * ((cr >> 1) & 1);
+    uint4 rnd[NV][4];
+    if (p > 0.f) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = (j * 64 + lane) * 4 + k;
+          rnd[j][k] = pt_rand4(seed, (uint64_t)cr * (uint64_t)D + (uint64_t)(c < D ? c : 0), stream_id);
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      const int64_t row = r0 + 8 * (f >> 2) + (f & 3);
+      if (row >= T) continue;  // wavefront-uniform
+      const float mu = mean[row], rs = rstd[row];
+      float4 xh[NV], gy[NV];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int c = (j * 64 + lane) * 4;
+        if (c < D) {
+          const float4 xv = *reinterpret_cast<const float4 *>(x + row * D + c);
+          const float4 d = *reinterpret_cast<const float4 *>(dy + row * D + c);
+          xh[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+          gy[j] = make_float4(d.x * g[j].x, d.y * g[j].y, d.z * g[j].z, d.w * g[j].w);
+          s1 += (gy[j].x + gy[j].y) + (gy[j].z + gy[j].w);
+          s2 += (gy[j].x * xh[j].x + gy[j].y * xh[j].y) + (gy[j].z * xh[j].z + gy[j].w * xh[j].w);
+          dg[j].x += d.x * xh[j].x; dg[j].y += d.y * xh[j].y; dg[j].z += d.z * xh[j].z; dg[j].w += d.w * xh[j].w;
+          db[j].x += d.x; db[j].y += d.y; db[j].z += d.z; db[j].w += d.w;
+        }
+      }
+      const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+      float amax = 0.f, sq = 0.f;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int c = (j * 64 + lane) * 4;
+        if (c < D) {
+          float4 o = make_float4(rs * (gy[j].x - m1 - xh[j].x * m2), rs * (gy[j].y - m1 - xh[j].y * m2),
+                                 rs * (gy[j].z - m1 - xh[j].z * m2), rs * (gy[j].w - m1 - xh[j].w * m2));
+          if (dres) {
+            const float4 r = *reinterpret_cast<const float4 *>(dres + row * D + c);
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+          }
+          *reinterpret_cast<float4 *>(dx + row * D + c) = o;
+          if (p > 0.f) {
+            o.x = drop_field_value(rnd[j][0], f) >= t16 ? o.x * ks : 0.f;
+            o.y = drop_field_value(rnd[j][1], f) >= t16 ? o.y * ks : 0.f;
+            o.z = drop_field_value(rnd[j][2], f) >= t16 ? o.z * ks : 0.f;
+            o.w = drop_field_value(rnd[j][3], f) >= t16 ? o.w * ks : 0.f;
+            *reinterpret_cast<float4 *>(dropped + row * D + c) = o;
+          }
+          amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+          sq += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+        }
+      }
+      amax = wave_max(amax);
+      sq = wave_sum(sq);
+      if (lane == 0) {
+        if (row_scale) row_scale[row] = pt_row_scale_bits(__float_as_uint(amax));
+        if (bound_scale) bound_scale[row] = pt_row_scale_bits(__float_as_uint(sqrtf(sq) * bf));
+      }
+    }
+  }
   __shared__ float4 s_dg[3][NV * 64], s_db[3][NV * 64];
   const int wave = threadIdx.x >> 6;
   if (wave > 0) {
@@ -332,14 +456,14 @@ int ptamd_embed_bwd(const int64_t *seq, const float *dout, int B, int L, int D, 
 }
 
 int ptamd_layernorm_fwd(const float *x, const float *gamma, const float *beta, int64_t T, int D, float *y, float *mean,
-                        float *rstd, void *stream) {
+                        float *rstd, uint32_t *row_scale, void *stream) {
   if (T <= 0 || D <= 0 || (D & 3) || D > 2048) return PTAMD_ERR_BAD_SHAPE;
   const dim3 grid((unsigned)((T + 3) / 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (D <= 256) hipLaunchKernelGGL(layernorm_fwd_kernel<1>, grid, block, 0, st, x, gamma, beta, T, D, y, mean, rstd);
-  else if (D <= 512) hipLaunchKernelGGL(layernorm_fwd_kernel<2>, grid, block, 0, st, x, gamma, beta, T, D, y, mean, rstd);
-  else if (D <= 1024) hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, block, 0, st, x, gamma, beta, T, D, y, mean, rstd);
-  else hipLaunchKernelGGL(layernorm_fwd_kernel<8>, grid, block, 0, st, x, gamma, beta, T, D, y, mean, rstd);
+  if (D <= 256) hipLaunchKernelGGL(layernorm_fwd_kernel<1>, grid, block, 0, st, x, gamma, beta, T, D, y, mean, rstd, row_scale);
+  else if (D <= 512) hipLaunchKernelGGL(layernorm_fwd_kernel<2>, grid, block, 0, st, x, gamma, beta, T, D, y, mean, rstd, row_scale);
+  else if (D <= 1024) hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, block, 0, st, x, gamma, beta, T, D, y, mean, rstd, row_scale);
+  else hipLaunchKernelGGL(layernorm_fwd_kernel<8>, grid, block, 0, st, x, gamma, beta, T, D, y, mean, rstd, row_scale);
   return pt_check_launch();
 }
 
@@ -359,6 +483,31 @@ int ptamd_layernorm_bwd(const float *dy, const float *x, const float *gamma, con
   else if (D <= 512) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, block, 0, st, dy, x, gamma, mean, rstd, dres, T, D, dx, part);
   else if (D <= 1024) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, st, dy, x, gamma, mean, rstd, dres, T, D, dx, part);
   else hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, block, 0, st, dy, x, gamma, mean, rstd, dres, T, D, dx, part);
+  int rc = pt_check_launch();
+  if (rc) return rc;
+  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((D + 63) / 64), dim3(1024), 0, st, part, D, dgamma, dbeta);
+  return pt_check_launch();
+}
+
+int ptamd_layernorm_bwd_dropout(const float *dy, const float *x, const float *gamma, const float *mean, const float *rstd,
+                                const float *dres, int64_t T, int D, float dropout_p, uint64_t seed, uint32_t stream_id,
+                                float *dx, float *dropped, uint32_t *row_scale, const float *bound_factor,
+                                uint32_t *bound_scale, float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,
+                                void *stream) {
+  if (T <= 0 || D <= 0 || (D & 3) || D > 1024) return PTAMD_ERR_BAD_SHAPE;  // 4 D / 256 generator words per lane stay in registers
+  if (dropout_p < 0.f || dropout_p >= 1.f || (dropout_p > 0.f && !dropped)) return PTAMD_ERR_BAD_SHAPE;
+  if (bound_scale && !bound_factor) return PTAMD_ERR_BAD_SHAPE;
+  if (!workspace || workspace_bytes < ptamd_layernorm_bwd_workspace_bytes(D)) return PTAMD_ERR_WORKSPACE;
+  float *part = static_cast<float *>(workspace);
+  const dim3 grid(LN_BWD_BLOCKS), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define PT_LN_FUSED(NV)                                                                                                   \
+  hipLaunchKernelGGL(layernorm_bwd_dropout_kernel<NV>, grid, block, 0, st, dy, x, gamma, mean, rstd, dres, T, D, dx, part, \
+                     dropout_p, seed, stream_id, dropped, row_scale, bound_factor, bound_scale)
+  if (D <= 256) PT_LN_FUSED(1);
+  else if (D <= 512) PT_LN_FUSED(2);
+  else PT_LN_FUSED(4);
+#undef PT_LN_FUSED
   int rc = pt_check_launch();
   if (rc) return rc;
   hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((D + 63) / 64), dim3(1024), 0, st, part, D, dgamma, dbeta);

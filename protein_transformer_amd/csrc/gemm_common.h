@@ -38,6 +38,7 @@ struct GemmParams {
   int colsum_share;  // N tiles sharing the column-sum work of one (M tile, split): power of two <= min(tiles_n, 16)
   float gate_scale;  // PTAMD_EPI_GATE
   const uint32_t *scale_a, *scale_b;  // f16x2 arithmetic only: power-of-two scale (bits) per row of A / column of B
+  int scale_a_stride;                 // 1: one scale per row of A; 0: scale_a[0] for every row (a caller-provided bound)
   int reserved_cus;  // CUs the persistent grid leaves free (room for a concurrent collective kernel); 0 = none
 };
 
@@ -229,6 +230,7 @@ int launch_split_f16x2(const GemmParams &p, bool a_kmajor, bool b_kmajor, int sp
 // fixed-order reduction of split-K slabs into p.C with the epilogue of p (gemm.hip)
 int launch_splitk_reduce(const GemmParams &p, const float *slabs, int splits, const float *cs_slabs, float *colsum, hipStream_t st);
 // f16x2 arithmetic: fills scale_a[M] / scale_b[N] (device, uint32 bits of powers of two) from the operands of p
+// (a NULL scale pointer skips that operand: its scales were provided by the caller)
 int launch_row_scales(const GemmParams &p, bool a_kmajor, bool b_kmajor, uint32_t *scale_a, uint32_t *scale_b, hipStream_t st);
 
 }  // namespace ptgemm

@@ -120,10 +120,13 @@ int launch_row_scales(const GemmParams &p, bool a_kmajor, bool b_kmajor, uint32_
                                          : (rows + RS_ROWS - 1) / RS_ROWS;
     return j;
   };
-  const ScaleJob ja = job(p.A, p.lda, p.M, p.K, a_kmajor, scale_a), jb = job(p.B, p.ldb, p.N, p.K, b_kmajor, scale_b);
-  if (ja.kmajor == RS_KMAJOR_CHUNKS)
+  ScaleJob ja = job(p.A, p.lda, p.M, p.K, a_kmajor, scale_a), jb = job(p.B, p.ldb, p.N, p.K, b_kmajor, scale_b);
+  if (!scale_a) ja.blocks = 0;  // provided by the caller
+  if (!scale_b) jb.blocks = 0;
+  if (ja.blocks + jb.blocks == 0) return PTAMD_OK;
+  if (ja.blocks && ja.kmajor == RS_KMAJOR_CHUNKS)
     PT_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scale_a), (int)(254u << 23), (size_t)p.M, st));
-  if (jb.kmajor == RS_KMAJOR_CHUNKS)
+  if (jb.blocks && jb.kmajor == RS_KMAJOR_CHUNKS)
     PT_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scale_b), (int)(254u << 23), (size_t)p.N, st));
   hipLaunchKernelGGL(gemm_row_scale_kernel, dim3(ja.blocks + jb.blocks), dim3(RS_THREADS), 0, st, ja, jb);
   return pt_check_launch();

@@ -124,11 +124,11 @@ __device__ __forceinline__ void store_split(unsigned short *__restrict__ s, int 
 // the producers load it with the stage (unconditionally, like the operand itself), multiply and split into TWO f16
 // planes, and the consumers undo the two scales on the accumulators before the epilogue.
 template <bool KMAJOR, int ROWS>
-__device__ __forceinline__ void scale_offsets(int rows, int r0, int pt, uint32_t (&soff)[4]) {
+__device__ __forceinline__ void scale_offsets(int rows, int r0, int pt, uint32_t (&soff)[4], int stride = 1) {
   constexpr int LPK = ROWS / 4;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    if (!KMAJOR) soff[i] = (uint32_t)min(r0 + pt / 4 + 64 * (i < ROWS / 64 ? i : 0), rows - 1) * 4u;  // the row of v[i]
+    if (!KMAJOR) soff[i] = (uint32_t)min(r0 + pt / 4 + 64 * (i < ROWS / 64 ? i : 0), rows - 1) * 4u * (uint32_t)stride;  // the row of v[i]
     else soff[i] = (uint32_t)min(r0 + 4 * (pt % LPK), rows - 4) * 4u;                                  // the 4 rows of every v[i]
   }
 }
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
     float rsa[NSETS][4], rsb[NSETS][4];                // f16x2 only: the row scales that go with them
     uint32_t soa[4], sob[4];
     if (F16) {
-      scale_offsets<A_KMAJOR, TBM>(p.M, ld.it.bm0, pt, soa);
+      scale_offsets<A_KMAJOR, TBM>(p.M, ld.it.bm0, pt, soa, A_KMAJOR ? 1 : p.scale_a_stride);
       scale_offsets<B_KMAJOR, TBN>(p.N, ld.it.bn0, pt, sob);
     }
     int rskip[NSETS];
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
         item_offsets<A_KMAJOR, TBM>(p.lda, p.M, ld.it.bm0, pt, voa);
         item_offsets<B_KMAJOR, TBN>(p.ldb, p.N, ld.it.bn0, pt, vob);
         if (F16) {
-          scale_offsets<A_KMAJOR, TBM>(p.M, ld.it.bm0, pt, soa);
+          scale_offsets<A_KMAJOR, TBM>(p.M, ld.it.bm0, pt, soa, A_KMAJOR ? 1 : p.scale_a_stride);
           scale_offsets<B_KMAJOR, TBN>(p.N, ld.it.bn0, pt, sob);
         }
       }
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
             for (int g = 0; g < 4; ++g)
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                const float ia = inverse_scale(p.scale_a[min(row0 + i * 32 + 8 * g + 4 * lh + e, p.M - 1)]);
+                const float ia = inverse_scale(p.scale_a[min(row0 + i * 32 + 8 * g + 4 * lh + e, p.M - 1) * p.scale_a_stride]);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j][g * 4 + e] = acc[i][j][g * 4 + e] * ia * ib[j];
               }

@@ -1,0 +1,150 @@
+// Per-step bookkeeping of the f16x2 GEMM arithmetic (include/ptamd.h, PTAMD_GEMM_F16X2) that does NOT need a pass over
+// the activations: the row / column scales of the weight matrices, and upper bounds of the row maxima of activations
+// that follow from the weights alone.
+//
+// ptamd_gemm in f16x2 arithmetic wants, per operand row, a power of two that takes the row's largest |x| just below
+// 2^15.  Left to itself it finds them with a pass over both operands in front of every product (gemm_row_scale_kernel:
+// 0.72 ms of the 15 ms benchmark step).  Instead:
+//   * weights change once per step: ONE launch here computes, for every weight matrix of the model, the scale of every
+//     row (the B operand of the forward products x W^T) and of every column (the B operand of the backward products
+//     dy W), plus the largest row / column L2 norm and the largest |w| of the matrix;
+//   * activations written by row-wise kernels get their exact scale from that kernel (LayerNorm forward; LayerNorm
+//     backward + dropout);
+//   * activations written tile-wise (attention output, ReLU(x W1^T + b1), dy W2) get a BOUND instead of the maximum:
+//       |LN(x)|_2 <= max|gamma| sqrt(D) + |beta|_2                      (the normalised row has |z|_2 <= sqrt(D))
+//       |x W^T + b|_inf <= |x|_2 max_n |W[n]|_2 + max|b|                (Cauchy-Schwarz)
+//       |softmax-average of V rows| <= max |V|;  ReLU and the dropout mask only shrink;  / (1 - p) for the dropout scale
+//     A bound that is 2^k above the true maximum costs k of the 18 binades in which an element keeps its full 22 bits
+//     (measured 2-5 on the benchmark model, tests/test_gpu_scales.py), nothing else: the scale stays a power of two, the
+//     products stay exact.  ptamd_bound_scales turns the statistics of the weight launch into those scales on the device.
+// No host synchronisation anywhere; both entry points take their (small) job lists by value in the kernel arguments.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_JOBS = 40;
+struct WJobs {
+  ptamd_wscale_job job[MAX_JOBS];
+  int first_block[MAX_JOBS + 1];  // blocks [first_block[j], first_block[j+1]) work on job j: row blocks, then column blocks
+  int row_blocks[MAX_JOBS];
+  int n;
+};
+
+__global__ void wscale_init_kernel(const WJobs js) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < js.n && js.job[j].stats) {
+    float *s = js.job[j].stats;
+    s[0] = s[1] = s[2] = s[3] = 0.f;
+  }
+}
+
+// rows: 8 per block (a wavefront per row, two rows each); columns: 16 per block over all rows (16 x 16 threads, LDS tree)
+__global__ __launch_bounds__(256) void wscale_kernel(const WJobs js) {
+  int j = 0;
+  while (j + 1 < js.n && (int)blockIdx.x >= js.first_block[j + 1]) ++j;
+  const ptamd_wscale_job jb = js.job[j];
+  const int b = (int)blockIdx.x - js.first_block[j];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t *stat_bits = reinterpret_cast<uint32_t *>(jb.stats);
+  if (b < js.row_blocks[j]) {
+    for (int rr = 0; rr < 2; ++rr) {
+      const int r = b * 8 + wave * 2 + rr;
+      if (r >= jb.rows) break;  // wavefront-uniform
+      const float *p = jb.w + (size_t)r * jb.ld;
+      float m = 0.f, sq = 0.f;
+      for (int c = lane; c < jb.cols; c += 64) {
+        const float v = p[c];
+        m = fmaxf(m, fabsf(v));
+        sq = fmaf(v, v, sq);
+      }
+      m = wave_max(m);
+      sq = wave_sum(sq);  // (fixed order: deterministic)
+      if (lane == 0) {
+        if (jb.row_scale) jb.row_scale[r] = pt_row_scale_bits(__float_as_uint(m));
+        if (stat_bits) {  // non-negative floats order like their bit patterns
+          atomicMax(stat_bits + 0, __float_as_uint(sqrtf(sq)));
+          atomicMax(stat_bits + 2, __float_as_uint(m));
+        }
+      }
+    }
+  } else {
+    __shared__ float s_m[16][17], s_q[16][17];
+    const int cb = b - js.row_blocks[j];
+    const int cx = tid & 15, ry = tid >> 4, c = cb * 16 + cx;
+    float m = 0.f, sq = 0.f;
+    if (c < jb.cols)
+#pragma unroll 8
+      for (int r = ry; r < jb.rows; r += 16) {
+        const float v = jb.w[(size_t)r * jb.ld + c];
+        m = fmaxf(m, fabsf(v));
+        sq = fmaf(v, v, sq);
+      }
+    s_m[ry][cx] = m;
+    s_q[ry][cx] = sq;
+    __syncthreads();
+    if (ry == 0 && c < jb.cols) {
+#pragma unroll
+      for (int k = 1; k < 16; ++k) {
+        m = fmaxf(m, s_m[k][cx]);
+        sq += s_q[k][cx];
+      }
+      if (jb.col_scale) jb.col_scale[c] = pt_row_scale_bits(__float_as_uint(m));
+      if (stat_bits) atomicMax(stat_bits + 1, __float_as_uint(sqrtf(sq)));
+    }
+  }
+}
+
+struct BJobs {
+  ptamd_bound_job job[MAX_JOBS];
+  int n;
+};
+__global__ void bound_kernel(const BJobs js) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= js.n) return;
+  const ptamd_bound_job b = js.job[j];
+  float x = 1.f;  // bound of the L2 norm of the input row
+  if (b.ln_gamma_stats) x = b.ln_gamma_stats[2] * b.sqrt_d + (b.ln_beta_stats ? b.ln_beta_stats[0] : 0.f);
+  float v = x * b.w_stats[b.w_stat_index];
+  if (b.bias_stats) v += b.bias_stats[2];
+  v *= b.post_scale;
+  if (b.out_scale) *b.out_scale = pt_row_scale_bits(__float_as_uint(v));
+  if (b.out_value) *b.out_value = v;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptamd_weight_scales(const ptamd_wscale_job *jobs, int njobs, void *stream) {
+  if (!jobs || njobs <= 0 || njobs > MAX_JOBS) return PTAMD_ERR_BAD_SHAPE;
+  WJobs js;
+  js.n = njobs;
+  int blocks = 0;
+  for (int j = 0; j < njobs; ++j) {
+    const ptamd_wscale_job &q = jobs[j];
+    if (!q.w || q.rows <= 0 || q.cols <= 0 || q.ld < q.cols) return PTAMD_ERR_BAD_SHAPE;
+    js.job[j] = q;
+    js.first_block[j] = blocks;
+    js.row_blocks[j] = (q.row_scale || q.stats) ? (q.rows + 7) / 8 : 0;
+    blocks += js.row_blocks[j] + ((q.col_scale || q.stats) ? (q.cols + 15) / 16 : 0);
+  }
+  js.first_block[njobs] = blocks;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(wscale_init_kernel, dim3(1), dim3(64), 0, st, js);
+  if (blocks > 0) hipLaunchKernelGGL(wscale_kernel, dim3(blocks), dim3(256), 0, st, js);
+  return pt_check_launch();
+}
+
+int ptamd_bound_scales(const ptamd_bound_job *jobs, int njobs, void *stream) {
+  if (!jobs || njobs <= 0 || njobs > MAX_JOBS) return PTAMD_ERR_BAD_SHAPE;
+  BJobs js;
+  js.n = njobs;
+  for (int j = 0; j < njobs; ++j) {
+    if (!jobs[j].w_stats || jobs[j].w_stat_index < 0 || jobs[j].w_stat_index > 2) return PTAMD_ERR_BAD_SHAPE;
+    js.job[j] = jobs[j];
+  }
+  hipLaunchKernelGGL(bound_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, js);
+  return pt_check_launch();
+}
+
+}  // extern "C"

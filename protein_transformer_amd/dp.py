@@ -121,12 +121,14 @@ def attach(model):
 
 def reserve_cus_for_collectives(n=None):
     """The split-arithmetic GEMMs are persistent kernels that take every CU (one 512-thread workgroup with ~150 KB of LDS
-    per CU): an RCCL kernel enqueued meanwhile cannot start before one of them retires.  Under data parallelism the GEMMs
-    therefore leave `n` CUs free (PTAMD_DP_RESERVE_CUS, default 8 of 256) so that the per-layer all-reduce overlaps the
-    backward pass instead of queueing behind it."""
+    per CU): an RCCL kernel enqueued meanwhile shares the chip only with the non-GEMM kernels of the backward pass
+    (attention, LayerNorm, loss) and the gaps between launches.  `n` > 0 (or PTAMD_DP_RESERVE_CUS) makes every GEMM leave
+    n CUs free for it.  The default is 0: the benchmark's tile counts are multiples of 256 (T = 16384 tokens), so a grid
+    of 256 - n workgroups needs a second round for the left-over tiles - a K = 512, N = 512 product would take twice as
+    long; reserve only together with shapes that do not quantise on the full chip."""
     from . import kernels
     if n is None:
-        n = int(os.environ.get("PTAMD_DP_RESERVE_CUS", "8"))
+        n = int(os.environ.get("PTAMD_DP_RESERVE_CUS", "0"))
     kernels.GEMM_RESERVED_CUS = max(0, int(n))
 
 

@@ -21,7 +21,8 @@ GEMM_RESERVED_CUS = 0    # CUs the persistent GEMMs leave free (dp.reserve_cus_f
 
 
 def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, bias=None, residual=None,
-         ldr=0, flags=0, dropout_p=0.0, seed=0, stream_id=0, split_k=1, colsum=None, gate_scale=0.0, arith=None):
+         ldr=0, flags=0, dropout_p=0.0, seed=0, stream_id=0, split_k=1, colsum=None, gate_scale=0.0, arith=None,
+         a_scale=None, a_scale_stride=1, b_scale=None):
     """C[M,N] = epilogue(A (*) B); operand layouts as documented in ptamd.h.  `arith`: GEMM_* constant of this call
     (None = the host-side default, `set_gemm_mode`); the library itself keeps no mode."""
     # split-K slabs and, for the f16x2 arithmetic, the row scales of the two operands
@@ -34,7 +35,9 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False,
                     split_k=int(split_k), workspace=ws.data_ptr() if ws is not None else None,
                     workspace_bytes=ws.numel() if ws is not None else 0,
                     colsum=colsum.data_ptr() if colsum is not None else None, gate_scale=float(gate_scale),
-                    arith=int(_DEFAULT_ARITH if arith is None else arith), reserved_cus=int(GEMM_RESERVED_CUS))
+                    arith=int(_DEFAULT_ARITH if arith is None else arith), reserved_cus=int(GEMM_RESERVED_CUS),
+                    a_scale=a_scale.data_ptr() if a_scale is not None else None, a_scale_stride=int(a_scale_stride),
+                    b_scale=b_scale.data_ptr() if b_scale is not None else None)
     if GEMM_TIMING is None:
         check(lib().ptamd_gemm(C.byref(args), stream()), "gemm")
     else:
@@ -147,7 +150,7 @@ def linear_fwd(x, w, b, out=None, **epi):
     return gemm(x, w, out, M=T, N=N, K=K, lda=x.stride(0), ldb=w.stride(0), ldc=out.stride(0), bias=b, **epi)
 
 
-def linear_bwd_input(dy, w, out=None, flags=0, gate=None, gate_dropout_p=0.0, arith=None):
+def linear_bwd_input(dy, w, out=None, flags=0, gate=None, gate_dropout_p=0.0, arith=None, **scales):
     """dx[T,K] = dy[T,N] w[N,K];  with `gate` (the saved output of a ReLU + dropout layer, [T,K]) the product is passed
     through the backward of that layer in the epilogue: dx = gate > 0 ? dx / (1 - p) : 0."""
     T, N = dy.shape
@@ -157,9 +160,9 @@ def linear_bwd_input(dy, w, out=None, flags=0, gate=None, gate_dropout_p=0.0, ar
     if gate is not None:
         return gemm(dy, w, out, M=T, N=K, K=N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0), b_kmajor=True,
                     flags=flags | EPI_GATE, residual=gate, ldr=gate.stride(0), gate_scale=1.0 / (1.0 - gate_dropout_p),
-                    arith=arith)
+                    arith=arith, **scales)
     return gemm(dy, w, out, M=T, N=K, K=N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0), b_kmajor=True,
-                flags=flags, arith=arith)
+                flags=flags, arith=arith, **scales)
 
 
 def linear_bwd_weight(dy, x, dw, dbias=None, arith=None):
@@ -179,14 +182,62 @@ def colsum(x, out, accumulate=True):
     return out
 
 
-def layernorm_fwd(x, gamma, beta):
+def layernorm_fwd(x, gamma, beta, row_scale=None):
+    """y, mean, rstd; `row_scale` (uint32-as-int32 [T], optional) receives the f16x2 scale of every row of y."""
     T, D = x.shape
     y = torch.empty_like(x)
     mean = torch.empty(T, dtype=torch.float32, device=x.device)
     rstd = torch.empty(T, dtype=torch.float32, device=x.device)
-    check(lib().ptamd_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), T, D, ptr(y), ptr(mean), ptr(rstd), stream()),
-          "layernorm_fwd")
+    check(lib().ptamd_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), T, D, ptr(y), ptr(mean), ptr(rstd), ptr(row_scale),
+                                    stream()), "layernorm_fwd")
     return y, mean, rstd
+
+
+def layernorm_bwd_dropout(dy, x, gamma, mean, rstd, dgamma, dbeta, dres, dropout_p, seed, stream_id, row_scale=None,
+                          bound_factor=None, bound_scale=None):
+    """LayerNorm backward fused with the dropout backward of its output (ptamd_layernorm_bwd_dropout): returns
+    (dx, dropped); dropped is dx itself when dropout_p == 0.  Fills row_scale / bound_scale [T] when given."""
+    T, D = x.shape
+    dx = torch.empty_like(x)
+    dropped = torch.empty_like(x) if dropout_p > 0 else None
+    ws = workspace("ln", lib().ptamd_layernorm_bwd_workspace_bytes(D), x.device)
+    check(lib().ptamd_layernorm_bwd_dropout(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), T, D, float(dropout_p),
+                                            int(seed), int(stream_id), ptr(dx), ptr(dropped), ptr(row_scale),
+                                            ptr(bound_factor), ptr(bound_scale), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(),
+                                            stream()), "layernorm_bwd_dropout")
+    return dx, (dropped if dropped is not None else dx)
+
+
+def weight_scales(jobs):
+    """jobs: list of dict(w=tensor view [rows, cols] (row stride ld), row_scale=, col_scale=, stats=) -> ptamd_weight_scales."""
+    from ._lib import WScaleJob
+    for i in range(0, len(jobs), 40):
+        chunk = jobs[i:i + 40]
+        arr = (WScaleJob * len(chunk))()
+        for k, j in enumerate(chunk):
+            w = j["w"]
+            rows, cols = (w.shape[0], w.shape[1]) if w.dim() == 2 else (1, w.shape[0])
+            arr[k] = WScaleJob(w=w.data_ptr(), rows=rows, cols=cols, ld=w.stride(0) if w.dim() == 2 else cols,
+                               row_scale=j["row_scale"].data_ptr() if j.get("row_scale") is not None else None,
+                               col_scale=j["col_scale"].data_ptr() if j.get("col_scale") is not None else None,
+                               stats=j["stats"].data_ptr() if j.get("stats") is not None else None)
+        check(lib().ptamd_weight_scales(arr, len(chunk), stream()), "weight_scales")
+
+
+def bound_scales(jobs):
+    """jobs: list of dict(ln_gamma=, ln_beta=, w=, w_index=, bias=, sqrt_d=, post_scale=, out_scale=, out_value=) of stats
+    records / outputs (tensors) -> ptamd_bound_scales."""
+    from ._lib import BoundJob
+    P = lambda t: t.data_ptr() if t is not None else None                     # noqa: E731
+    for i in range(0, len(jobs), 40):
+        chunk = jobs[i:i + 40]
+        arr = (BoundJob * len(chunk))()
+        for k, j in enumerate(chunk):
+            arr[k] = BoundJob(ln_gamma_stats=P(j.get("ln_gamma")), ln_beta_stats=P(j.get("ln_beta")), w_stats=P(j["w"]),
+                              w_stat_index=int(j["w_index"]), bias_stats=P(j.get("bias")), sqrt_d=float(j.get("sqrt_d", 0.0)),
+                              post_scale=float(j.get("post_scale", 1.0)), out_scale=P(j.get("out_scale")),
+                              out_value=P(j.get("out_value")))
+        check(lib().ptamd_bound_scales(arr, len(chunk), stream()), "bound_scales")
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None):

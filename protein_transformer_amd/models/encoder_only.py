@@ -251,6 +251,64 @@ class _TransformerBase(nn.Module):
             out.append(span("encoder.input_embedding.emb.weight", "encoder.input_embedding.emb.weight"))
         return out
 
+    # ------------------------------------------------------------------ f16x2 bookkeeping (csrc/scales.hip)
+    def _step_scales(self, flat, arith, p, pa):
+        """Row / column scales of every encoder weight matrix and the weight-derived bounds of the attention output, the
+        FFN hidden layer and its gradient - computed on the device in three small launches per forward pass, so that no
+        GEMM of the step has to run a pass over its operands for them.  Returns a list of per-layer dicts (or None when the
+        arithmetic of this pass has no use for them)."""
+        D, F = self.dlayer, self.dff
+        if arith not in (K.GEMM_AUTO, K.GEMM_F16X2) or D > 1024 or self.nlayers == 0:
+            return None
+        key = (flat.data_ptr(), float(p), float(pa))
+        caches = self.__dict__.setdefault("_scale_caches", {})
+        if len(caches) > 4:
+            caches.clear()
+        cache = caches.get(key)
+        if cache is None:
+            dev = flat.device
+            n_i = self.nlayers * (8 * D + 2 * F + 2)                  # int32: scales (+ 2 bound scales per layer)
+            ints = torch.zeros(n_i, dtype=torch.int32, device=dev)
+            stats = torch.zeros(self.nlayers, 9, 4, dtype=torch.float32, device=dev)
+            factor = torch.zeros(self.nlayers, dtype=torch.float32, device=dev)
+            layers, wjobs, bjobs, o = [], [], [], 0
+
+            def take(n):
+                nonlocal o
+                v = ints[o:o + n]
+                o += n
+                return v
+            W = lambda name: self._slice(flat, name)                                     # noqa: E731
+            for i in range(self.nlayers):
+                b = f"encoder.enc_layers.{i}."
+                wqkv, bqkv = self._qkv(flat, i)
+                L = dict(rs_qkv=take(3 * D), cs_qkv=take(D), rs_o=take(D), cs_o=take(D), rs_1=take(F), cs_1=take(D),
+                         rs_2=take(D), cs_2=take(F), att_scale=take(1), f1_scale=take(1), dz1_factor=factor[i:i + 1])
+                st = stats[i]
+                wjobs += [dict(w=wqkv, row_scale=L["rs_qkv"], col_scale=L["cs_qkv"]),
+                          dict(w=wqkv[2 * D:], stats=st[0]),                                     # W_v: row norms
+                          dict(w=W(b + "self_attn.wo.weight"), row_scale=L["rs_o"], col_scale=L["cs_o"]),
+                          dict(w=W(b + "pwff.layer1.weight"), row_scale=L["rs_1"], col_scale=L["cs_1"], stats=st[1]),
+                          dict(w=W(b + "pwff.layer2.weight"), row_scale=L["rs_2"], col_scale=L["cs_2"], stats=st[2]),
+                          dict(w=W(b + "sublayer_connections.0.norm.weight"), stats=st[3]),
+                          dict(w=W(b + "sublayer_connections.0.norm.bias"), stats=st[4]),
+                          dict(w=W(b + "sublayer_connections.1.norm.weight"), stats=st[5]),
+                          dict(w=W(b + "sublayer_connections.1.norm.bias"), stats=st[6]),
+                          dict(w=bqkv[2 * D:], stats=st[7]),                                     # b_v
+                          dict(w=W(b + "pwff.layer1.bias"), stats=st[8])]
+                sq = math.sqrt(D)
+                bjobs += [dict(ln_gamma=st[3], ln_beta=st[4], w=st[0], w_index=0, bias=st[7], sqrt_d=sq,
+                               post_scale=1.0 / (1.0 - pa), out_scale=L["att_scale"]),
+                          dict(ln_gamma=st[5], ln_beta=st[6], w=st[1], w_index=0, bias=st[8], sqrt_d=sq,
+                               post_scale=1.0 / (1.0 - p), out_scale=L["f1_scale"]),
+                          dict(w=st[2], w_index=1, post_scale=1.0 / (1.0 - p), out_value=L["dz1_factor"])]
+                layers.append(L)
+            assert o == n_i
+            cache = caches[key] = dict(layers=layers, wjobs=wjobs, bjobs=bjobs, keep=(ints, stats, factor))
+        K.weight_scales(cache["wjobs"])
+        K.bound_scales(cache["bjobs"])
+        return cache["layers"]
+
     def _slice(self, buf, name):
         off, shape = self._layout[name]
         return buf[off:off + int(np.prod(shape))].view(shape)
@@ -315,29 +373,39 @@ class _EncoderFn(torch.autograd.Function):
         if not m.use_embedding:
             x = K.posenc_add_fwd(x, pe, B, L, p, seed)             # enc_output += positional_enc(enc_output)
         saved = []
+        # f16x2 row scales without passes over the operands: weights and weight-derived bounds once per forward, LayerNorm
+        # outputs from the LayerNorm kernel itself (None: the arithmetic of this pass does not use them)
+        scales = m._step_scales(flat, ar, p, pa)
+        Tn = B * L
         for i in range(m.nlayers):
             b = f"encoder.enc_layers.{i}."
             sid = i * 8
+            sc = scales[i] if scales is not None else None
             wqkv, bqkv = m._qkv(flat, i)
+            s_h1 = torch.empty(Tn, dtype=torch.int32, device=x.device) if sc else None
             h1, mean1, rstd1 = K.layernorm_fwd(x, W(b + "sublayer_connections.0.norm.weight"),
-                                               W(b + "sublayer_connections.0.norm.bias"))
-            qkv = K.linear_fwd(h1, wqkv, bqkv, arith=ar)
+                                               W(b + "sublayer_connections.0.norm.bias"), row_scale=s_h1)
+            qkv = K.linear_fwd(h1, wqkv, bqkv, arith=ar, a_scale=s_h1, b_scale=sc and sc["rs_qkv"])
             att, lse = K.attention_fwd(qkv, seq, H, pa, seed, sid + _SITE_ATTN, arith=ar)
             x2 = K.linear_fwd(att, W(b + "self_attn.wo.weight"), W(b + "self_attn.wo.bias"), residual=x, ldr=D,
-                              dropout_p=p, seed=seed, stream_id=sid + _SITE_ATTN_OUT, arith=ar)
+                              dropout_p=p, seed=seed, stream_id=sid + _SITE_ATTN_OUT, arith=ar,
+                              a_scale=sc and sc["att_scale"], a_scale_stride=0, b_scale=sc and sc["rs_o"])
+            s_h2 = torch.empty(Tn, dtype=torch.int32, device=x.device) if sc else None
             h2, mean2, rstd2 = K.layernorm_fwd(x2, W(b + "sublayer_connections.1.norm.weight"),
-                                               W(b + "sublayer_connections.1.norm.bias"))
+                                               W(b + "sublayer_connections.1.norm.bias"), row_scale=s_h2)
             f1 = K.linear_fwd(h2, W(b + "pwff.layer1.weight"), W(b + "pwff.layer1.bias"), flags=K.EPI_RELU,
-                              dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_HID, arith=ar)
+                              dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_HID, arith=ar,
+                              a_scale=s_h2, b_scale=sc and sc["rs_1"])
             x3 = K.linear_fwd(f1, W(b + "pwff.layer2.weight"), W(b + "pwff.layer2.bias"), residual=x2, ldr=D,
-                              dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_OUT, arith=ar)
+                              dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_OUT, arith=ar,
+                              a_scale=sc and sc["f1_scale"], a_scale_stride=0, b_scale=sc and sc["rs_2"])
             saved.append((x, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, f1))
             x = x3
         pred = K.linear_fwd(x, W("output_projection.weight"), W("output_projection.bias"), flags=K.EPI_TANH,
                             arith=ar)
         ctx.model, ctx.seed, ctx.seq, ctx.flat, ctx.arith = m, seed, seq, flat, ar
         ctx.p, ctx.pa = p, pa
-        ctx.saved, ctx.conv_saved = saved, conv_saved
+        ctx.saved, ctx.conv_saved, ctx.scales = saved, conv_saved, scales
         ctx.x_last, ctx.pred = x, pred
         return pred
 
@@ -363,32 +431,52 @@ class _EncoderFn(torch.autograd.Function):
                             arith=ar)
         dx = K.linear_bwd_input(dpre, W("output_projection.weight"), arith=ar)
         done("output_projection.weight", "output_projection.bias")
+        scales = ctx.scales
+        fuse = D <= 1024                                   # LayerNorm backward + the dropout backward behind it in one kernel
+        i32 = lambda: torch.empty(B * L, dtype=torch.int32, device=dx.device)                 # noqa: E731
+        dy2 = s_dy2 = bs_dz1 = None                        # dropout'(dx) of the FFN output site, made by the layer above
         for i in reversed(range(m.nlayers)):
             b = f"encoder.enc_layers.{i}."
             sid = i * 8
+            sc = scales[i] if scales is not None else None
             x, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, f1 = ctx.saved[i]
             # x3 = x2 + drop(f1 W2^T + b2)
-            dy2 = K.dropout_bwd(dx, p, seed, sid + _SITE_FFN_OUT) if p > 0 else dx
+            if dy2 is None:
+                dy2 = K.dropout_bwd(dx, p, seed, sid + _SITE_FFN_OUT) if p > 0 else dx
             K.linear_bwd_weight(dy2, f1, G(b + "pwff.layer2.weight"), G(b + "pwff.layer2.bias"), arith=ar)
             # backward of layer2 and, in its epilogue, of the ReLU + dropout in front of it (gate = saved f1)
-            dz1 = K.linear_bwd_input(dy2, W(b + "pwff.layer2.weight"), gate=f1, gate_dropout_p=p, arith=ar)
+            dz1 = K.linear_bwd_input(dy2, W(b + "pwff.layer2.weight"), gate=f1, gate_dropout_p=p, arith=ar,
+                                     a_scale=s_dy2 if sc else None, b_scale=sc and sc["cs_2"])
             K.linear_bwd_weight(dz1, h2, G(b + "pwff.layer1.weight"), G(b + "pwff.layer1.bias"), arith=ar)
-            dh2 = K.linear_bwd_input(dz1, W(b + "pwff.layer1.weight"), arith=ar)
-            dx2 = K.layernorm_bwd(dh2, x2, W(b + "sublayer_connections.1.norm.weight"), mean2, rstd2,
-                                  G(b + "sublayer_connections.1.norm.weight"), G(b + "sublayer_connections.1.norm.bias"),
-                                  dres=dx)
+            dh2 = K.linear_bwd_input(dz1, W(b + "pwff.layer1.weight"), arith=ar,
+                                     a_scale=bs_dz1 if sc else None, b_scale=sc and sc["cs_1"])
             # x2 = x + drop(att Wo^T + bo)
-            dyo = K.dropout_bwd(dx2, p, seed, sid + _SITE_ATTN_OUT) if p > 0 else dx2
+            g2w, g2b = G(b + "sublayer_connections.1.norm.weight"), G(b + "sublayer_connections.1.norm.bias")
+            if fuse:
+                s_dyo = i32() if sc else None
+                dx2, dyo = K.layernorm_bwd_dropout(dh2, x2, W(b + "sublayer_connections.1.norm.weight"), mean2, rstd2, g2w, g2b,
+                                                   dx, p, seed, sid + _SITE_ATTN_OUT, row_scale=s_dyo)
+            else:
+                s_dyo = None
+                dx2 = K.layernorm_bwd(dh2, x2, W(b + "sublayer_connections.1.norm.weight"), mean2, rstd2, g2w, g2b, dres=dx)
+                dyo = K.dropout_bwd(dx2, p, seed, sid + _SITE_ATTN_OUT) if p > 0 else dx2
             K.linear_bwd_weight(dyo, att, G(b + "self_attn.wo.weight"), G(b + "self_attn.wo.bias"), arith=ar)
-            datt = K.linear_bwd_input(dyo, W(b + "self_attn.wo.weight"), arith=ar)
+            datt = K.linear_bwd_input(dyo, W(b + "self_attn.wo.weight"), arith=ar, a_scale=s_dyo, b_scale=sc and sc["cs_o"])
             dqkv = K.attention_bwd(qkv, seq, att, datt, lse, H, pa, seed, sid + _SITE_ATTN, arith=ar)
             gw, gb = m._qkv(gflat, i)
             wqkv, _ = m._qkv(flat, i)
             K.linear_bwd_weight(dqkv, h1, gw, gb, arith=ar)
-            dh1 = K.linear_bwd_input(dqkv, wqkv, arith=ar)
-            dx = K.layernorm_bwd(dh1, x, W(b + "sublayer_connections.0.norm.weight"), mean1, rstd1,
-                                 G(b + "sublayer_connections.0.norm.weight"), G(b + "sublayer_connections.0.norm.bias"),
-                                 dres=dx2)
+            dh1 = K.linear_bwd_input(dqkv, wqkv, arith=ar, b_scale=sc and sc["cs_qkv"])
+            g1w, g1b = G(b + "sublayer_connections.0.norm.weight"), G(b + "sublayer_connections.0.norm.bias")
+            if fuse and i > 0:      # the gradient enters layer i - 1 through ITS FFN-output dropout: made here, with its scales
+                s_dy2, bs_dz1 = (i32(), i32()) if scales is not None else (None, None)
+                dx, dy2 = K.layernorm_bwd_dropout(dh1, x, W(b + "sublayer_connections.0.norm.weight"), mean1, rstd1, g1w, g1b,
+                                                  dx2, p, seed, (i - 1) * 8 + _SITE_FFN_OUT, row_scale=s_dy2,
+                                                  bound_factor=scales[i - 1]["dz1_factor"] if scales is not None else None,
+                                                  bound_scale=bs_dz1)
+            else:
+                dx = K.layernorm_bwd(dh1, x, W(b + "sublayer_connections.0.norm.weight"), mean1, rstd1, g1w, g1b, dres=dx2)
+                dy2 = s_dy2 = bs_dz1 = None
             done(b + "self_attn.wq.weight", b + "sublayer_connections.1.norm.bias")
             ctx.saved[i] = None
         # ---- front end

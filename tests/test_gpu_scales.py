@@ -1,0 +1,172 @@
+"""MI355X tests of the f16x2 bookkeeping that replaces the per-product pass over the operands (csrc/scales.hip, the
+row-scale output of ptamd_layernorm_fwd, ptamd_layernorm_bwd_dropout, ptamd_gemm_args.a_scale / b_scale):
+
+  * weight scales / statistics against numpy;
+  * the weight-derived BOUNDS really bound the attention output, the FFN hidden layer and its gradient on a model with
+    trained-looking (non-trivial) LayerNorm parameters, and are within a few binades of the true maxima;
+  * LayerNorm backward fused with the dropout backward == the two separate kernels, bit for bit, and its row scales are the
+    exact ones;
+  * a product with caller-provided exact scales == the product that finds them itself, bit for bit; with a bound instead
+    of the maximum it stays inside the f16x2 error model.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def scale_of(amax):
+    """numpy restatement of pt_row_scale_bits: the power of two that takes amax into [2^14, 2^15)."""
+    amax = np.asarray(amax, np.float32)
+    e = (amax.view(np.uint32) >> 23).astype(np.int64)
+    return np.ldexp(1.0, np.minimum(268 - e, 254) - 127)
+
+
+def as_float(bits):
+    return bits.cpu().numpy().view(np.float32).astype(np.float64)
+
+
+def test_weight_scales_vs_numpy(dev):
+    from protein_transformer_amd import kernels as K
+    g = torch.Generator().manual_seed(1)
+    flat = (torch.randn(2048 * 512 + 4096, generator=g) * torch.exp(torch.randn(2048 * 512 + 4096, generator=g))).to(dev)
+    w1 = flat[:2048 * 512].view(2048, 512)
+    sub = w1[700:1200]                                   # a sub-matrix (rows 700..1199), like W_v inside W_qkv
+    vec = flat[2048 * 512:2048 * 512 + 1000]
+    rs, cs = torch.zeros(2048, dtype=torch.int32, device=dev), torch.zeros(512, dtype=torch.int32, device=dev)
+    st = torch.full((3, 4), -1.0, device=dev)
+    K.weight_scales([dict(w=w1, row_scale=rs, col_scale=cs, stats=st[0]), dict(w=sub, stats=st[1]), dict(w=vec, stats=st[2])])
+    w = w1.cpu().numpy()
+    assert np.array_equal(as_float(rs), scale_of(np.abs(w).max(1)))
+    assert np.array_equal(as_float(cs), scale_of(np.abs(w).max(0)))
+    s = st.cpu().numpy().astype(np.float64)
+    w64 = w.astype(np.float64)
+    assert s[0, 0] == pytest.approx(np.sqrt((w64 ** 2).sum(1)).max(), rel=1e-5)
+    assert s[0, 1] == pytest.approx(np.sqrt((w64 ** 2).sum(0)).max(), rel=1e-5)
+    assert s[0, 2] == np.abs(w).max() and s[0, 3] == 0
+    assert s[1, 0] == pytest.approx(np.sqrt((w64[700:1200] ** 2).sum(1)).max(), rel=1e-5)
+    v = vec.cpu().numpy().astype(np.float64)
+    assert s[2, 0] == pytest.approx(np.sqrt((v ** 2).sum()), rel=1e-5) and s[2, 2] == np.abs(v).max()
+    top = np.abs(w).max(1) * as_float(rs)
+    assert np.all((top >= 2.0 ** 14) & (top < 2.0 ** 15))
+
+
+def test_layernorm_fwd_row_scale(dev):
+    from protein_transformer_amd import kernels as K
+    x = torch.randn(1000, 512, device=dev) * 3 + 1
+    gam, bet = torch.rand(512, device=dev) + 0.5, torch.randn(512, device=dev) * 0.1
+    s = torch.zeros(1000, dtype=torch.int32, device=dev)
+    y, _, _ = K.layernorm_fwd(x, gam, bet, row_scale=s)
+    y0, _, _ = K.layernorm_fwd(x, gam, bet)
+    assert torch.equal(y, y0)
+    assert np.array_equal(as_float(s), scale_of(y.abs().max(1).values.cpu().numpy()))
+
+
+@pytest.mark.parametrize("T,D,p", [(16384, 512, 0.1), (1000, 256, 0.3), (77, 64, 0.1), (640, 1024, 0.0), (333, 512, 0.0)])
+def test_layernorm_bwd_dropout_equals_separate_kernels(dev, T, D, p):
+    from protein_transformer_amd import kernels as K
+    g = torch.Generator().manual_seed(T + D)
+    x, dy, dres = (torch.randn(T, D, generator=g).to(dev) for _ in range(3))
+    dy = dy * torch.exp(torch.randn(T, 1, generator=g) * 2).to(dev)                      # per-token gradient magnitudes
+    gam = (torch.rand(D, generator=g) + 0.5).to(dev)
+    _, mean, rstd = K.layernorm_fwd(x, gam, torch.zeros(D, device=dev))
+    dg0, db0 = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    dx0 = K.layernorm_bwd(dy, x, gam, mean, rstd, dg0, db0, dres=dres)
+    dr0 = K.dropout_bwd(dx0, p, 1234, 13) if p > 0 else dx0
+    dg1, db1 = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    rs, bs = torch.zeros(T, dtype=torch.int32, device=dev), torch.zeros(T, dtype=torch.int32, device=dev)
+    factor = torch.tensor([3.5], device=dev)
+    dx1, dr1 = K.layernorm_bwd_dropout(dy, x, gam, mean, rstd, dg1, db1, dres, p, 1234, 13, row_scale=rs, bound_factor=factor,
+                                       bound_scale=bs)
+    assert torch.equal(dx1, dx0) and torch.equal(dr1, dr0)
+    # (rows are dealt to the wavefronts in another order: the partial sums differ in their rounding)
+    assert float((dg1 - dg0).abs().max()) <= 2e-5 * float(dg0.abs().max()) and float((db1 - db0).abs().max()) <= 2e-5 * float(db0.abs().max())
+    assert np.array_equal(as_float(rs), scale_of(dr0.abs().max(1).values.cpu().numpy()))
+    nrm = np.sqrt((dr0.cpu().double().numpy() ** 2).sum(1)) * 3.5
+    got = as_float(bs)
+    want = scale_of(nrm.astype(np.float32))
+    assert np.all((got == want) | (got == want * 2) | (got * 2 == want))                 # fp32 rounding of the norm at a binade edge
+    assert np.all(nrm * got < 2.0 ** 15 * (1 + 1e-6))
+
+
+def test_gemm_with_caller_scales(dev):
+    from protein_transformer_amd import kernels as K
+    g = torch.Generator().manual_seed(5)
+    M, N, Kd = 1024, 384, 512
+    a = (torch.randn(M, Kd, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).to(dev)
+    w = (torch.randn(N, Kd, generator=g) * 0.05).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+
+    def run(**kw):
+        c = torch.empty(M, N, device=dev)
+        K.gemm(a, w, c, M=M, N=N, K=Kd, lda=Kd, ldb=Kd, ldc=N, bias=bias, arith=K.GEMM_F16X2, **kw)
+        return c
+    ref = run()
+    sa = torch.zeros(M, dtype=torch.int32, device=dev)
+    K.weight_scales([dict(w=a, row_scale=sa)])
+    rs = torch.zeros(N, dtype=torch.int32, device=dev)
+    K.weight_scales([dict(w=w, row_scale=rs)])
+    assert torch.equal(run(a_scale=sa, b_scale=rs), ref)                                 # exact scales: the same arithmetic
+    assert torch.equal(run(a_scale=sa), ref) and torch.equal(run(b_scale=rs), ref)       # one operand provided, one found
+    # dX layout: B k-major, scale per output column
+    dy = (torch.randn(M, N, generator=g)).to(dev)
+    cs = torch.zeros(Kd, dtype=torch.int32, device=dev)
+    K.weight_scales([dict(w=w, col_scale=cs)])
+    dx0 = K.linear_bwd_input(dy, w, arith=K.GEMM_F16X2)
+    assert torch.equal(K.linear_bwd_input(dy, w, arith=K.GEMM_F16X2, b_scale=cs), dx0)
+    # a bound 2^5 above the largest row maximum, one scale for all rows: inside the norm-wise error model
+    bound = torch.tensor([float(a.abs().max()) * 32], device=dev)
+    ub = torch.zeros(1, dtype=torch.int32, device=dev)
+    K.weight_scales([dict(w=bound, row_scale=ub)])
+    got = run(a_scale=ub, a_scale_stride=0, b_scale=rs)
+    exact = a.double() @ w.double().t() + bias.double()
+    allowed = 2.0 ** -20 * (a.double().abs() @ w.double().abs().t()) + 2.0 ** -36 * Kd * float(bound) * w.abs().max(1).values.double()[None, :] + 1e-6 * exact.abs()
+    assert bool(((got.double() - exact).abs() <= allowed).all())
+
+
+def test_weight_derived_bounds_hold_and_are_tight(dev):
+    """The scales the model computes from its weights alone (attention output, FFN hidden layer, FFN hidden gradient):
+    never below what the tensors need (no f16 overflow), and within 2^7 of the exact row scale."""
+    from protein_transformer_amd import kernels as K
+    from protein_transformer_amd.models.encoder_only import EncoderOnlyTransformer
+    from protein_transformer_amd.protein.Sequence import VOCAB
+    torch.manual_seed(2)
+    m = EncoderOnlyTransformer(2, 8, 512, 2048, 128, VOCAB, np.zeros(24) + 0.3, True, dropout=0.1).to(dev).train()
+    with torch.no_grad():                                  # LayerNorm parameters away from (1, 0), biases away from 0
+        for n, q in m.named_parameters():
+            if "norm.weight" in n:
+                q.uniform_(0.5, 2.0)
+            elif "norm.bias" in n:
+                q.normal_(0, 0.3)
+            elif n.endswith("bias"):
+                q.normal_(0, 0.5)
+    flat, _ = m.flat_parameters()
+    p, pa = 0.1, 0.1
+    layers = m._step_scales(flat, K.GEMM_AUTO, p, pa)
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    x = torch.randn(4 * 128, 512, device=dev) * 5
+    for i, L in enumerate(layers):
+        b = f"encoder.enc_layers.{i}."
+        ln = lambda t, j: torch.nn.functional.layer_norm(t, (512,), sd[b + f"sublayer_connections.{j}.norm.weight"],      # noqa: E731
+                                                         sd[b + f"sublayer_connections.{j}.norm.bias"], 1e-5)
+        h1 = ln(x, 0)
+        v = h1 @ sd[b + "self_attn.wv.weight"].t() + sd[b + "self_attn.wv.bias"]
+        att_max = float(v.abs().max()) / (1 - pa)          # every row of the attention output is below this
+        s_att = float(as_float(L["att_scale"])[0])
+        assert att_max * s_att < 2.0 ** 15 and att_max * s_att > 2.0 ** 7, (i, att_max * s_att)
+        h2 = ln(x * 0.3 + 1, 1)
+        f1 = torch.relu(h2 @ sd[b + "pwff.layer1.weight"].t() + sd[b + "pwff.layer1.bias"]) / (1 - p)
+        s_f1 = float(as_float(L["f1_scale"])[0])
+        assert float(f1.max()) * s_f1 < 2.0 ** 15 and float(f1.max()) * s_f1 > 2.0 ** 8
+        dy = torch.randn(512, 512, device=dev) * torch.exp(torch.randn(512, 1, device=dev) * 3)
+        dz = (dy @ sd[b + "pwff.layer2.weight"]) / (1 - p)
+        fac = float(L["dz1_factor"][0])
+        ratio = (dy.norm(dim=1) * fac) / dz.abs().max(1).values
+        assert float(ratio.min()) >= 1.0 and float(ratio.max()) < 2.0 ** 7
