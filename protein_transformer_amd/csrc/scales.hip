@@ -38,7 +38,9 @@ __global__ void wscale_init_kernel(const WJobs js) {
   }
 }
 
-// rows: 8 per block (a wavefront per row, two rows each); columns: 16 per block over all rows (16 x 16 threads, LDS tree)
+// rows: 8 per block (a wavefront per row, two rows each, 16-byte loads where the row allows them);
+// columns: 64 per block over all rows (16 x 16 threads, a float4 of columns per thread, 8 rows in flight, LDS tree)
+constexpr int COLS_PER_BLOCK = 64;
 __global__ __launch_bounds__(256) void wscale_kernel(const WJobs js) {
   int j = 0;
   while (j + 1 < js.n && (int)blockIdx.x >= js.first_block[j + 1]) ++j;
@@ -46,16 +48,25 @@ __global__ __launch_bounds__(256) void wscale_kernel(const WJobs js) {
   const int b = (int)blockIdx.x - js.first_block[j];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   uint32_t *stat_bits = reinterpret_cast<uint32_t *>(jb.stats);
+  const bool vec = !(jb.cols & 3) && !(jb.ld & 3) && !(reinterpret_cast<uintptr_t>(jb.w) & 15);
   if (b < js.row_blocks[j]) {
     for (int rr = 0; rr < 2; ++rr) {
       const int r = b * 8 + wave * 2 + rr;
       if (r >= jb.rows) break;  // wavefront-uniform
       const float *p = jb.w + (size_t)r * jb.ld;
       float m = 0.f, sq = 0.f;
-      for (int c = lane; c < jb.cols; c += 64) {
-        const float v = p[c];
-        m = fmaxf(m, fabsf(v));
-        sq = fmaf(v, v, sq);
+      if (vec) {
+        for (int c = lane * 4; c < jb.cols; c += 256) {
+          const float4 v = *reinterpret_cast<const float4 *>(p + c);
+          m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+          sq = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, sq))));
+        }
+      } else {
+        for (int c = lane; c < jb.cols; c += 64) {
+          const float v = p[c];
+          m = fmaxf(m, fabsf(v));
+          sq = fmaf(v, v, sq);
+        }
       }
       m = wave_max(m);
       sq = wave_sum(sq);  // (fixed order: deterministic)
@@ -68,28 +79,44 @@ __global__ __launch_bounds__(256) void wscale_kernel(const WJobs js) {
       }
     }
   } else {
-    __shared__ float s_m[16][17], s_q[16][17];
+    __shared__ float4 s_m[16][17], s_q[16][17];
     const int cb = b - js.row_blocks[j];
-    const int cx = tid & 15, ry = tid >> 4, c = cb * 16 + cx;
-    float m = 0.f, sq = 0.f;
-    if (c < jb.cols)
+    const int cx = tid & 15, ry = tid >> 4, c = cb * COLS_PER_BLOCK + cx * 4;
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f), sq = m;
+    auto take = [&](const float4 v) __attribute__((always_inline)) {
+      m.x = fmaxf(m.x, fabsf(v.x)); m.y = fmaxf(m.y, fabsf(v.y)); m.z = fmaxf(m.z, fabsf(v.z)); m.w = fmaxf(m.w, fabsf(v.w));
+      sq.x = fmaf(v.x, v.x, sq.x); sq.y = fmaf(v.y, v.y, sq.y); sq.z = fmaf(v.z, v.z, sq.z); sq.w = fmaf(v.w, v.w, sq.w);
+    };
+    if (c < jb.cols) {
+      if (vec) {
 #pragma unroll 8
-      for (int r = ry; r < jb.rows; r += 16) {
-        const float v = jb.w[(size_t)r * jb.ld + c];
-        m = fmaxf(m, fabsf(v));
-        sq = fmaf(v, v, sq);
+        for (int r = ry; r < jb.rows; r += 16) take(*reinterpret_cast<const float4 *>(jb.w + (size_t)r * jb.ld + c));
+      } else {
+        for (int r = ry; r < jb.rows; r += 16) {
+          const float *q = jb.w + (size_t)r * jb.ld + c;
+          take(make_float4(q[0], c + 1 < jb.cols ? q[1] : 0.f, c + 2 < jb.cols ? q[2] : 0.f, c + 3 < jb.cols ? q[3] : 0.f));
+        }
       }
+    }
     s_m[ry][cx] = m;
     s_q[ry][cx] = sq;
     __syncthreads();
     if (ry == 0 && c < jb.cols) {
 #pragma unroll
       for (int k = 1; k < 16; ++k) {
-        m = fmaxf(m, s_m[k][cx]);
-        sq += s_q[k][cx];
+        const float4 a = s_m[k][cx], q = s_q[k][cx];
+        m.x = fmaxf(m.x, a.x); m.y = fmaxf(m.y, a.y); m.z = fmaxf(m.z, a.z); m.w = fmaxf(m.w, a.w);
+        sq.x += q.x; sq.y += q.y; sq.z += q.z; sq.w += q.w;
       }
-      if (jb.col_scale) jb.col_scale[c] = pt_row_scale_bits(__float_as_uint(m));
-      if (stat_bits) atomicMax(stat_bits + 1, __float_as_uint(sqrtf(sq)));
+      const float mm[4] = {m.x, m.y, m.z, m.w}, qq[4] = {sq.x, sq.y, sq.z, sq.w};
+      float nmax = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c + e < jb.cols) {
+          if (jb.col_scale) jb.col_scale[c + e] = pt_row_scale_bits(__float_as_uint(mm[e]));
+          nmax = fmaxf(nmax, sqrtf(qq[e]));
+        }
+      if (stat_bits) atomicMax(stat_bits + 1, __float_as_uint(nmax));
     }
   }
 }
@@ -126,7 +153,7 @@ int ptamd_weight_scales(const ptamd_wscale_job *jobs, int njobs, void *stream) {
     js.job[j] = q;
     js.first_block[j] = blocks;
     js.row_blocks[j] = (q.row_scale || q.stats) ? (q.rows + 7) / 8 : 0;
-    blocks += js.row_blocks[j] + ((q.col_scale || q.stats) ? (q.cols + 15) / 16 : 0);
+    blocks += js.row_blocks[j] + ((q.col_scale || q.stats) ? (q.cols + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK : 0);
   }
   js.first_block[njobs] = blocks;
   hipStream_t st = (hipStream_t)stream;

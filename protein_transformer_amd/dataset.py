@@ -168,6 +168,46 @@ class SimilarLengthBatchSampler(torch.utils.data.Sampler):
             yield np.random.choice(ds.bin_map[b], size=size)
 
 
+class DevicePrefetcher:
+    """Host -> device hand-over of the batches of a loader, one batch ahead: while the step of batch i runs on the
+    compute stream, batch i + 1 is collated by the loader's worker, counted (non-pad residues, on the host) and copied
+    from pinned memory on a side stream; the compute stream only waits for the copy's event.  Yields
+    (seq, ang, crd, n_residues) with the tensors on `device`.  Works for any iterable of (seq, ang, crd) CPU tensors."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, torch.device(device)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        dev = self.device
+        side = torch.cuda.Stream(dev)
+        it = iter(self.loader)
+
+        def fetch():
+            try:
+                batch = next(it)
+            except StopIteration:
+                return None
+            n_res = int((batch[0] != VOCAB.pad_id).sum())
+            with torch.cuda.stream(side):
+                on_dev = tuple(t.to(dev, non_blocking=True) for t in batch)
+                done = torch.cuda.Event()
+                done.record(side)
+            return on_dev, n_res, done
+
+        nxt = fetch()
+        while nxt is not None:
+            (seq, ang, crd), n_res, done = nxt
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_event(done)
+            for t in (seq, ang, crd):
+                t.record_stream(cur)                 # allocated on the side stream, consumed on the compute stream
+            nxt = fetch()                            # the next copy is in flight while the caller works on this batch
+            yield seq, ang, crd, n_res
+
+
 class ShardedBatchSampler(torch.utils.data.Sampler):
     """Data-parallel view of a batch sampler: yields, for every batch of the wrapped sampler, the indices that THIS rank
     takes (serpentine deal by length, dp.shard_indices) - so each rank collates, pads (to its own longest protein) and

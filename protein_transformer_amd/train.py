@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import dp
-from .dataset import MAX_SEQ_LEN, prepare_dataloaders
+from .dataset import MAX_SEQ_LEN, DevicePrefetcher, prepare_dataloaders
 from .log import (EarlyStoppingCondition, do_eval_batch_logging, do_eval_epoch_logging, do_train_batch_logging,
                   init_metrics, log_batch, prepare_log_header, reset_metrics_for_epoch, update_loss_trackers,
                   update_metrics_end_of_epoch)
@@ -44,9 +44,9 @@ def train_epoch(model, training_data, validation_datasets, optimizer, device, ar
     shard of every batch (dataset.ShardedBatchSampler): only that shard is collated and uploaded. """
     model.train()
     metrics = reset_metrics_for_epoch(metrics, "train")
-    for step, batch in enumerate(training_data):
-        n_res = int((batch[0] != VOCAB.pad_id).sum())        # on the host, before the upload: no device sync
-        src_seq, tgt_ang, tgt_crds = map(lambda x: x.to(device, non_blocking=True), batch)
+    # batches arrive one ahead: the next upload runs on a side stream under this step (dataset.DevicePrefetcher); the
+    # residue count is taken on the host before the upload - no device synchronisation in the loop
+    for step, (src_seq, tgt_ang, tgt_crds, n_res) in enumerate(DevicePrefetcher(training_data, device)):
         losses = train_step(model, optimizer, args, src_seq, tgt_ang, tgt_crds, pool=pool, n_res=n_res)
         metrics = do_train_batch_logging(metrics, losses, src_seq, optimizer, args, log_writer, START_TIME, step)
         if (getattr(args, "structure_dir", None) and dp.is_main() and src_seq.shape[0]
@@ -163,9 +163,7 @@ def eval_epoch(model, validation_data, device, args, metrics, mode="valid", pool
     model.eval()
     metrics = reset_metrics_for_epoch(metrics, mode)
     with torch.no_grad():
-        for batch in validation_data:
-            n_res = int((batch[0] != VOCAB.pad_id).sum())
-            src_seq, tgt_ang, tgt_crds = map(lambda x: x.to(device, non_blocking=True), batch)
+        for src_seq, tgt_ang, tgt_crds, n_res in DevicePrefetcher(validation_data, device):
             pred = model(src_seq, tgt_ang) if src_seq.shape[0] else None
             losses = get_losses(args, pred, tgt_ang, tgt_crds, src_seq, pool=pool, do_backwards=False,
                                 eval_mode=True, return_rmsd=True, n_res=n_res)

@@ -323,3 +323,20 @@ def test_two_models_two_streams_two_arithmetics(dev):
         assert got[mode] == ref[mode][1], mode
         assert torch.equal(models[mode][0].flat_parameters()[0], ref[mode][0]), mode
     assert K_.get_gemm_mode() == K_.GEMM_AUTO                                  # nobody touched the host default
+
+
+def test_device_prefetcher(dev):
+    """dataset.DevicePrefetcher: same batches, same order, on the device, with the host-side residue count; the next
+    batch's copy is issued on a side stream before the current one is handed out."""
+    from protein_transformer_amd.dataset import DevicePrefetcher
+    g = torch.Generator().manual_seed(0)
+    batches = []
+    for n in (5, 3, 7, 1):
+        seq = torch.randint(0, 21, (n, 12), generator=g)
+        batches.append((seq.pin_memory(), torch.randn(n, 12, 24, generator=g).pin_memory(), torch.randn(n, 168, 3, generator=g).pin_memory()))
+    got = list(DevicePrefetcher(batches, dev))
+    assert len(got) == 4 and len(DevicePrefetcher(batches, dev)) == 4
+    for (seq, ang, crd), (s, a, c, n_res) in zip(batches, got):
+        assert s.is_cuda and torch.equal(s.cpu(), seq) and torch.equal(a.cpu(), ang) and torch.equal(c.cpu(), crd)
+        assert n_res == int((seq != 20).sum())
+    assert list(DevicePrefetcher([], dev)) == []
