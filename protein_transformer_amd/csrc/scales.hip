@@ -38,9 +38,9 @@ __global__ void wscale_init_kernel(const WJobs js) {
   }
 }
 
-// rows: 8 per block (a wavefront per row, two rows each, 16-byte loads where the row allows them);
+// rows: 32 per block (a wavefront per row, eight rows each, 16-byte loads where the row allows them);
 // columns: 64 per block over all rows (16 x 16 threads, a float4 of columns per thread, 8 rows in flight, LDS tree)
-constexpr int COLS_PER_BLOCK = 64;
+constexpr int COLS_PER_BLOCK = 64, ROWS_PER_BLOCK = 32;
 __global__ __launch_bounds__(256) void wscale_kernel(const WJobs js) {
   int j = 0;
   while (j + 1 < js.n && (int)blockIdx.x >= js.first_block[j + 1]) ++j;
@@ -50,8 +50,12 @@ __global__ __launch_bounds__(256) void wscale_kernel(const WJobs js) {
   uint32_t *stat_bits = reinterpret_cast<uint32_t *>(jb.stats);
   const bool vec = !(jb.cols & 3) && !(jb.ld & 3) && !(reinterpret_cast<uintptr_t>(jb.w) & 15);
   if (b < js.row_blocks[j]) {
-    for (int rr = 0; rr < 2; ++rr) {
-      const int r = b * 8 + wave * 2 + rr;
+    // 32 rows per block, 8 per wavefront; ONE pair of atomics per block (atomics on one address serialise in the L2: a pair
+    // per row made this the slowest part of the kernel)
+    __shared__ float s_nrm[4], s_amx[4];
+    float bn = 0.f, bm = 0.f;
+    for (int rr = 0; rr < ROWS_PER_BLOCK / 4; ++rr) {
+      const int r = b * ROWS_PER_BLOCK + wave * (ROWS_PER_BLOCK / 4) + rr;
       if (r >= jb.rows) break;  // wavefront-uniform
       const float *p = jb.w + (size_t)r * jb.ld;
       float m = 0.f, sq = 0.f;
@@ -70,12 +74,19 @@ __global__ __launch_bounds__(256) void wscale_kernel(const WJobs js) {
       }
       m = wave_max(m);
       sq = wave_sum(sq);  // (fixed order: deterministic)
+      if (lane == 0 && jb.row_scale) jb.row_scale[r] = pt_row_scale_bits(__float_as_uint(m));
+      bn = fmaxf(bn, sqrtf(sq));
+      bm = fmaxf(bm, m);
+    }
+    if (stat_bits) {
       if (lane == 0) {
-        if (jb.row_scale) jb.row_scale[r] = pt_row_scale_bits(__float_as_uint(m));
-        if (stat_bits) {  // non-negative floats order like their bit patterns
-          atomicMax(stat_bits + 0, __float_as_uint(sqrtf(sq)));
-          atomicMax(stat_bits + 2, __float_as_uint(m));
-        }
+        s_nrm[wave] = bn;
+        s_amx[wave] = bm;
+      }
+      __syncthreads();
+      if (tid == 0) {  // non-negative floats order like their bit patterns
+        atomicMax(stat_bits + 0, __float_as_uint(fmaxf(fmaxf(s_nrm[0], s_nrm[1]), fmaxf(s_nrm[2], s_nrm[3]))));
+        atomicMax(stat_bits + 2, __float_as_uint(fmaxf(fmaxf(s_amx[0], s_amx[1]), fmaxf(s_amx[2], s_amx[3]))));
       }
     }
   } else {
@@ -152,7 +163,7 @@ int ptamd_weight_scales(const ptamd_wscale_job *jobs, int njobs, void *stream) {
     if (!q.w || q.rows <= 0 || q.cols <= 0 || q.ld < q.cols) return PTAMD_ERR_BAD_SHAPE;
     js.job[j] = q;
     js.first_block[j] = blocks;
-    js.row_blocks[j] = (q.row_scale || q.stats) ? (q.rows + 7) / 8 : 0;
+    js.row_blocks[j] = (q.row_scale || q.stats) ? (q.rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK : 0;
     blocks += js.row_blocks[j] + ((q.col_scale || q.stats) ? (q.cols + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK : 0);
   }
   js.first_block[njobs] = blocks;

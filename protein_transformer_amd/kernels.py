@@ -141,13 +141,24 @@ def pick_split_k(M, N, K, slots=512):
     return max(1, min(K // 256, slots // tiles))
 
 
+def pick_split_k_rows(M, N, K, slots=256):
+    """K splits for an activation x weight product whose 256 x 128 output tiles do not fill the chip (few tokens: small
+    batches, the per-GPU share of a strongly scaled batch) and whose reduction is long enough to be worth cutting: the
+    slabs are summed in a fixed order by the reduce kernel, which also applies the epilogue (same dropout masks)."""
+    tiles = ((M + 255) // 256) * ((N + 127) // 128)
+    if tiles * 2 > slots or K < 1024:
+        return 1
+    return max(1, min(K // 512, slots // tiles))
+
+
 def linear_fwd(x, w, b, out=None, **epi):
     """y[T,N] = x[T,K] w[N,K]^T + b with a fused epilogue."""
     T, K = x.shape
     N = w.shape[0]
     if out is None:
         out = torch.empty(T, N, dtype=torch.float32, device=x.device)
-    return gemm(x, w, out, M=T, N=N, K=K, lda=x.stride(0), ldb=w.stride(0), ldc=out.stride(0), bias=b, **epi)
+    return gemm(x, w, out, M=T, N=N, K=K, lda=x.stride(0), ldb=w.stride(0), ldc=out.stride(0), bias=b,
+                split_k=pick_split_k_rows(T, N, K), **epi)
 
 
 def linear_bwd_input(dy, w, out=None, flags=0, gate=None, gate_dropout_p=0.0, arith=None, **scales):
@@ -157,11 +168,12 @@ def linear_bwd_input(dy, w, out=None, flags=0, gate=None, gate_dropout_p=0.0, ar
     K = w.shape[1]
     if out is None:
         out = torch.empty(T, K, dtype=torch.float32, device=dy.device)
+    sk = pick_split_k_rows(T, K, N)
     if gate is not None:
-        return gemm(dy, w, out, M=T, N=K, K=N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0), b_kmajor=True,
+        return gemm(dy, w, out, M=T, N=K, K=N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0), b_kmajor=True, split_k=sk,
                     flags=flags | EPI_GATE, residual=gate, ldr=gate.stride(0), gate_scale=1.0 / (1.0 - gate_dropout_p),
                     arith=arith, **scales)
-    return gemm(dy, w, out, M=T, N=K, K=N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0), b_kmajor=True,
+    return gemm(dy, w, out, M=T, N=K, K=N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0), b_kmajor=True, split_k=sk,
                 flags=flags, arith=arith, **scales)
 
 
