@@ -322,8 +322,9 @@ def main():
     dtype = {"f32": "f32",
              "f16x2": "f32 (GEMM operands row-scaled and split into 2 f16 terms on the f16 MFMA pipe, f32 accumulate; attention "
                       "operands split into 3 bf16 terms; the rest f32)",
-             "auto": "f32 (GEMM operands split into 2 row-scaled f16 terms [activation x weight products] or exactly into 3 bf16 "
-                     "terms [weight-gradient products, attention] on the f16 / bf16 MFMA pipe, f32 accumulate; the rest f32)"}.get(
+             "auto": "f32 (GEMM operands split into 2 row-scaled f16 terms [activation x weight products; weight-gradient products "
+                     "whose operands come with a uniform scale] or exactly into 3 bf16 terms [the other weight-gradient products, "
+                     "attention] on the f16 / bf16 MFMA pipe, f32 accumulate; the rest f32)"}.get(
         a.gemm_mode, "f32 (GEMM operands split exactly into 3 bf16 terms on the bf16 MFMA pipe, f32 accumulate; the rest f32)")
     if rank == 0:
         shape = (f"{a.batch} proteins x L={a.length} per GPU" if not a.ragged else

@@ -141,9 +141,12 @@ typedef struct {
    * max |x_row| * s < 2^15, see PTAMD_GEMM_F16X2) when the caller already has them - written by the kernel that
    * produced the operand (ptamd_layernorm_fwd, ptamd_layernorm_bwd_dropout) or derived from a bound of the row maxima
    * (ptamd_encoder_bounds).  NULL: ptamd_gemm finds them with a pass over the operand (needs the workspace).
-   * a_scale_stride: 1 = a_scale[m] per row of A; 0 = a_scale[0] for every row (K-contiguous A only). */
+   * a_scale_stride / b_scale_stride: 1 = one scale per operand row (A: per m, B: per n); 0 = ONE scale for every row of
+   * the operand - the array then holds FOUR copies of it (row-contiguous operands load the scales of four rows at once).
+   * With uniform scales on both sides the weight-gradient products (k-major A and B) can run in F16X2 without any pass:
+   * the error is then relative to the largest row of the operand (norm-wise over the whole product). */
   const uint32_t *a_scale; int a_scale_stride;
-  const uint32_t *b_scale;
+  const uint32_t *b_scale; int b_scale_stride;
 } ptamd_gemm_args;
 size_t ptamd_gemm_workspace_bytes(int M, int N, int split_k);
 int ptamd_gemm(const ptamd_gemm_args *args, void *stream);
@@ -228,12 +231,14 @@ int ptamd_gemm_hp(const ptamd_gemm_hp_args *args, void *stream);
  *   the whole list (at most 40 jobs per call).
  * ptamd_bound_scales: out = ((max|gamma| sqrt_d + |beta|_2) if a LayerNorm feeds the product else 1) * w_stats[w_stat_index]
  *   [+ max|bias|], times post_scale - an upper bound of |x W^T + b|_inf for every row x = LN(.) (Cauchy-Schwarz), or of
- *   |dy W|_inf / |dy|_2 when no LayerNorm is given; out_scale receives the f16x2 scale of a row with that maximum (to be
- *   used with a_scale_stride = 0), out_value the bound itself (the `bound_factor` of ptamd_layernorm_bwd_dropout).
+ *   |dy W|_inf / |dy|_2 when no LayerNorm is given; out_scale[0..3] receive the f16x2 scale of a row with that maximum (four
+ *   copies, to be used with a_scale_stride / b_scale_stride = 0), out_value the bound itself (the `bound_factor` of
+ *   ptamd_layernorm_bwd_dropout).
  *   ln_*_stats / w_stats / bias_stats point at stats[4] records written by ptamd_weight_scales earlier on the stream. */
 typedef struct {
   const float *w; int rows, cols, ld;
   uint32_t *row_scale; uint32_t *col_scale; float *stats;
+  int rows_only;          /* != 0: no column pass (stats[1] stays 0): for a big activation whose row scales / largest |x| are wanted */
 } ptamd_wscale_job;
 int ptamd_weight_scales(const ptamd_wscale_job *jobs_host, int njobs, void *stream);
 typedef struct {
@@ -261,12 +266,14 @@ int ptamd_layernorm_bwd(const float *dy, const float *x, const float *gamma, con
  * (seed, stream_id) - what ptamd_dropout_bwd would make of dx (dropout_p = 0: dropped is not written, it equals dx).
  * Also, for the GEMMs that read `dropped` as their A operand: row_scale [T] = its f16x2 row scales, and bound_scale [T] =
  * the scale of a row bounded by |dropped[t]|_2 * *bound_factor (device scalar, e.g. from ptamd_bound_scales): the scale of
- * row t of dropped W.  row_scale / bound_scale may be NULL.  D <= 1024. */
+ * row t of dropped W.  row_scale_min[0..3] / bound_scale_min[0..3] (may be NULL): the smallest of those scales over all
+ * rows, i.e. the scale of the largest row - atomicMin into four copies that the caller preset to 0x7F000000; the uniform
+ * scale of `dropped` / `dropped W` as an operand of a weight-gradient product.  Any of the outputs may be NULL.  D <= 1024. */
 int ptamd_layernorm_bwd_dropout(const float *dy, const float *x, const float *gamma, const float *mean, const float *rstd,
                                 const float *dres, int64_t T, int D, float dropout_p, uint64_t seed, uint32_t stream_id,
                                 float *dx, float *dropped, uint32_t *row_scale, const float *bound_factor,
-                                uint32_t *bound_scale, float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,
-                                void *stream);
+                                uint32_t *bound_scale, uint32_t *row_scale_min, uint32_t *bound_scale_min, float *dgamma,
+                                float *dbeta, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Embeddings * sqrt(D) and the doubled positional add of Encoder.py:30 + Sublayers.py:59-62,72:
  *   x0 = emb[seq]*sqrt(D); out = drop2(x0 + drop1(x0 + pe[pos]))      (eval: 2*x0 + pe) */

@@ -32,11 +32,12 @@ class GemmArgs(C.Structure):
                 ("arith", _i),
                 ("reserved_cus", _i),
                 ("a_scale", _p), ("a_scale_stride", _i),
-                ("b_scale", _p)]
+                ("b_scale", _p), ("b_scale_stride", _i)]
 
 
 class WScaleJob(C.Structure):
-    _fields_ = [("w", _p), ("rows", _i), ("cols", _i), ("ld", _i), ("row_scale", _p), ("col_scale", _p), ("stats", _p)]
+    _fields_ = [("w", _p), ("rows", _i), ("cols", _i), ("ld", _i), ("row_scale", _p), ("col_scale", _p), ("stats", _p),
+                ("rows_only", _i)]
 
 
 class BoundJob(C.Structure):
@@ -88,7 +89,7 @@ SIGNATURES = {
     "ptamd_weight_scales": (_i, [C.POINTER(WScaleJob), _i, _p]),
     "ptamd_bound_scales": (_i, [C.POINTER(BoundJob), _i, _p]),
     "ptamd_layernorm_fwd": (_i, [_p, _p, _p, _i64, _i, _p, _p, _p, _p, _p]),
-    "ptamd_layernorm_bwd_dropout": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _u64, _u32, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "ptamd_layernorm_bwd_dropout": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _u64, _u32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "ptamd_layernorm_bwd_workspace_bytes": (_sz, [_i]),
     "ptamd_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _p, _p, _p, _p, _sz, _p]),
     "ptamd_embed_fwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _u64, _p, _p]),

@@ -236,8 +236,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dropout_kernel(
     const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ mean,
     const float *__restrict__ rstd, const float *__restrict__ dres, int64_t T, int D, float *__restrict__ dx,
     float *__restrict__ part, float p, uint64_t seed, uint32_t stream_id, float *__restrict__ dropped,
-    uint32_t *__restrict__ row_scale, const float *__restrict__ bound_factor, uint32_t *__restrict__ bound_scale) {
+    uint32_t *__restrict__ row_scale, const float *__restrict__ bound_factor, uint32_t *__restrict__ bound_scale,
+    uint32_t *__restrict__ row_scale_min, uint32_t *__restrict__ bound_scale_min) {
   const int lane = threadIdx.x & 63, wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  uint32_t rmin = 0x7F000000u, bmin = 0x7F000000u;  // smallest scale = largest row seen by this wavefront
   float4 g[NV], dg[NV], db[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
@@ -308,14 +310,31 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dropout_kernel(
       }
       amax = wave_max(amax);
       sq = wave_sum(sq);
+      const uint32_t rs_bits = pt_row_scale_bits(__float_as_uint(amax)), bs_bits = pt_row_scale_bits(__float_as_uint(sqrtf(sq) * bf));
+      rmin = min(rmin, rs_bits);
+      bmin = min(bmin, bs_bits);
       if (lane == 0) {
-        if (row_scale) row_scale[row] = pt_row_scale_bits(__float_as_uint(amax));
-        if (bound_scale) bound_scale[row] = pt_row_scale_bits(__float_as_uint(sqrtf(sq) * bf));
+        if (row_scale) row_scale[row] = rs_bits;
+        if (bound_scale) bound_scale[row] = bs_bits;
       }
     }
   }
   __shared__ float4 s_dg[3][NV * 64], s_db[3][NV * 64];
+  __shared__ uint32_t s_min[2][4];
   const int wave = threadIdx.x >> 6;
+  if (row_scale_min || bound_scale_min) {  // one atomic per block and copy (atomics on one address serialise in the L2)
+    if (lane == 0) {
+      s_min[0][wave] = rmin;
+      s_min[1][wave] = bmin;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      const uint32_t a = min(min(s_min[0][0], s_min[0][1]), min(s_min[0][2], s_min[0][3]));
+      const uint32_t c = min(min(s_min[1][0], s_min[1][1]), min(s_min[1][2], s_min[1][3]));
+      if (row_scale_min) atomicMin(row_scale_min + threadIdx.x, a);
+      if (bound_scale_min && bound_factor) atomicMin(bound_scale_min + threadIdx.x, c);
+    }
+  }
   if (wave > 0) {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -492,18 +511,18 @@ int ptamd_layernorm_bwd(const float *dy, const float *x, const float *gamma, con
 int ptamd_layernorm_bwd_dropout(const float *dy, const float *x, const float *gamma, const float *mean, const float *rstd,
                                 const float *dres, int64_t T, int D, float dropout_p, uint64_t seed, uint32_t stream_id,
                                 float *dx, float *dropped, uint32_t *row_scale, const float *bound_factor,
-                                uint32_t *bound_scale, float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,
-                                void *stream) {
+                                uint32_t *bound_scale, uint32_t *row_scale_min, uint32_t *bound_scale_min, float *dgamma,
+                                float *dbeta, void *workspace, size_t workspace_bytes, void *stream) {
   if (T <= 0 || D <= 0 || (D & 3) || D > 1024) return PTAMD_ERR_BAD_SHAPE;  // 4 D / 256 generator words per lane stay in registers
   if (dropout_p < 0.f || dropout_p >= 1.f || (dropout_p > 0.f && !dropped)) return PTAMD_ERR_BAD_SHAPE;
-  if (bound_scale && !bound_factor) return PTAMD_ERR_BAD_SHAPE;
+  if ((bound_scale || bound_scale_min) && !bound_factor) return PTAMD_ERR_BAD_SHAPE;
   if (!workspace || workspace_bytes < ptamd_layernorm_bwd_workspace_bytes(D)) return PTAMD_ERR_WORKSPACE;
   float *part = static_cast<float *>(workspace);
   const dim3 grid(LN_BWD_BLOCKS), block(256);
   hipStream_t st = (hipStream_t)stream;
 #define PT_LN_FUSED(NV)                                                                                                   \
   hipLaunchKernelGGL(layernorm_bwd_dropout_kernel<NV>, grid, block, 0, st, dy, x, gamma, mean, rstd, dres, T, D, dx, part, \
-                     dropout_p, seed, stream_id, dropped, row_scale, bound_factor, bound_scale)
+                     dropout_p, seed, stream_id, dropped, row_scale, bound_factor, bound_scale, row_scale_min, bound_scale_min)
   if (D <= 256) PT_LN_FUSED(1);
   else if (D <= 512) PT_LN_FUSED(2);
   else PT_LN_FUSED(4);

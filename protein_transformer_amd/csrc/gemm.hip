@@ -422,12 +422,12 @@ int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   const int mode = resolve_mode(a);
   p.scale_a = p.scale_b = nullptr;
-  p.scale_a_stride = 1;
+  p.scale_a_stride = p.scale_b_stride = 1;
   if (mode == PTAMD_GEMM_F16X2) {
     // row scales: the caller's (a_scale / b_scale: written by the kernels that produced the operands, or bounds of the row
     // maxima) or, for an operand that comes without, a pass over it here; those live behind the split-K slabs
-    if (a->a_scale && ((a->a_scale_stride != 0 && a->a_scale_stride != 1) || (a->a_scale_stride == 0 && a->a_kmajor)))
-      return PTAMD_ERR_BAD_SHAPE;
+    if (a->a_scale && a->a_scale_stride != 0 && a->a_scale_stride != 1) return PTAMD_ERR_BAD_SHAPE;
+    if (a->b_scale && a->b_scale_stride != 0 && a->b_scale_stride != 1) return PTAMD_ERR_BAD_SHAPE;
     uint32_t *sa = nullptr, *sb = nullptr;
     if (!a->a_scale || !a->b_scale) {
       if (!a->workspace || !pt_aligned16(a->workspace) || a->workspace_bytes < ptamd_gemm_workspace_bytes(a->M, a->N, splits))
@@ -440,6 +440,7 @@ int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
     p.scale_a = a->a_scale ? a->a_scale : sa;
     p.scale_b = a->b_scale ? a->b_scale : sb;
     p.scale_a_stride = a->a_scale ? a->a_scale_stride : 1;
+    p.scale_b_stride = a->b_scale ? a->b_scale_stride : 1;
   }
   const int products = mode == PTAMD_GEMM_BF16X3_FULL ? 9 : mode == PTAMD_GEMM_F16X2 ? 3 : 6;
   const int rc = mode == PTAMD_GEMM_F32 ? launch_f32(p, a->a_kmajor != 0, a->b_kmajor != 0, splits, st)

@@ -38,7 +38,8 @@ struct GemmParams {
   int colsum_share;  // N tiles sharing the column-sum work of one (M tile, split): power of two <= min(tiles_n, 16)
   float gate_scale;  // PTAMD_EPI_GATE
   const uint32_t *scale_a, *scale_b;  // f16x2 arithmetic only: power-of-two scale (bits) per row of A / column of B
-  int scale_a_stride;                 // 1: one scale per row of A; 0: scale_a[0] for every row (a caller-provided bound)
+  int scale_a_stride, scale_b_stride; // 1: one scale per operand row; 0: ONE scale for every row (a caller-provided bound; the
+                                      // array then holds four copies, because row-contiguous operands load four rows' scales at once)
   int reserved_cus;  // CUs the persistent grid leaves free (room for a concurrent collective kernel); 0 = none
 };
 

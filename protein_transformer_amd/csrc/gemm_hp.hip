@@ -377,7 +377,7 @@ int ptamd_gemm_hp(const ptamd_gemm_hp_args *a, void *stream) {
   g.bias = a->bias; g.residual = a->residual; g.ldr = a->ldr; g.flags = a->flags;
   g.dropout_p = a->dropout_p; g.seed = a->seed; g.stream_id = a->stream_id; g.gate_scale = a->gate_scale;
   g.reserved_cus = a->reserved_cus;
-  g.colsum = nullptr; g.colsum_share = 1; g.scale_a = g.scale_b = nullptr;
+  g.colsum = nullptr; g.colsum_share = 1; g.scale_a = g.scale_b = nullptr; g.scale_a_stride = g.scale_b_stride = 1;
   constexpr int HBK = 32;
   const int Kp = round_up(a->K, 32), stages = Kp / HBK;
   int splits = a->split_k > 1 ? a->split_k : 1;

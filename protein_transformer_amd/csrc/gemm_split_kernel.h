@@ -129,7 +129,7 @@ __device__ __forceinline__ void scale_offsets(int rows, int r0, int pt, uint32_t
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if (!KMAJOR) soff[i] = (uint32_t)min(r0 + pt / 4 + 64 * (i < ROWS / 64 ? i : 0), rows - 1) * 4u * (uint32_t)stride;  // the row of v[i]
-    else soff[i] = (uint32_t)min(r0 + 4 * (pt % LPK), rows - 4) * 4u;                                  // the 4 rows of every v[i]
+    else soff[i] = (uint32_t)min(r0 + 4 * (pt % LPK), rows - 4) * 4u * (uint32_t)stride;              // the 4 rows of every v[i]
   }
 }
 template <bool KMAJOR, int ROWS>
@@ -265,8 +265,8 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
     float rsa[NSETS][4], rsb[NSETS][4];                // f16x2 only: the row scales that go with them
     uint32_t soa[4], sob[4];
     if (F16) {
-      scale_offsets<A_KMAJOR, TBM>(p.M, ld.it.bm0, pt, soa, A_KMAJOR ? 1 : p.scale_a_stride);
-      scale_offsets<B_KMAJOR, TBN>(p.N, ld.it.bn0, pt, sob);
+      scale_offsets<A_KMAJOR, TBM>(p.M, ld.it.bm0, pt, soa, p.scale_a_stride);
+      scale_offsets<B_KMAJOR, TBN>(p.N, ld.it.bn0, pt, sob, p.scale_b_stride);
     }
     int rskip[NSETS];
     auto fetch = [&](float4 (&a)[4], float4 (&b)[2], int &kskip, float (&sa_)[4], float (&sb_)[4]) __attribute__((always_inline)) {
@@ -285,8 +285,8 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
         item_offsets<A_KMAJOR, TBM>(p.lda, p.M, ld.it.bm0, pt, voa);
         item_offsets<B_KMAJOR, TBN>(p.ldb, p.N, ld.it.bn0, pt, vob);
         if (F16) {
-          scale_offsets<A_KMAJOR, TBM>(p.M, ld.it.bm0, pt, soa, A_KMAJOR ? 1 : p.scale_a_stride);
-          scale_offsets<B_KMAJOR, TBN>(p.N, ld.it.bn0, pt, sob);
+          scale_offsets<A_KMAJOR, TBM>(p.M, ld.it.bm0, pt, soa, p.scale_a_stride);
+          scale_offsets<B_KMAJOR, TBN>(p.N, ld.it.bn0, pt, sob, p.scale_b_stride);
         }
       }
     };
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
           const int l31 = lane & 31, lh = lane >> 5;
           float ib[2];
 #pragma unroll
-          for (int j = 0; j < 2; ++j) ib[j] = inverse_scale(p.scale_b[min(col0 + j * 32 + l31, p.N - 1)]);
+          for (int j = 0; j < 2; ++j) ib[j] = inverse_scale(p.scale_b[min(col0 + j * 32 + l31, p.N - 1) * p.scale_b_stride]);
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll

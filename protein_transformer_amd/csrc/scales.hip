@@ -145,7 +145,7 @@ __global__ void bound_kernel(const BJobs js) {
   float v = x * b.w_stats[b.w_stat_index];
   if (b.bias_stats) v += b.bias_stats[2];
   v *= b.post_scale;
-  if (b.out_scale) *b.out_scale = pt_row_scale_bits(__float_as_uint(v));
+  if (b.out_scale) b.out_scale[0] = b.out_scale[1] = b.out_scale[2] = b.out_scale[3] = pt_row_scale_bits(__float_as_uint(v));
   if (b.out_value) *b.out_value = v;
 }
 
@@ -164,7 +164,7 @@ int ptamd_weight_scales(const ptamd_wscale_job *jobs, int njobs, void *stream) {
     js.job[j] = q;
     js.first_block[j] = blocks;
     js.row_blocks[j] = (q.row_scale || q.stats) ? (q.rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK : 0;
-    blocks += js.row_blocks[j] + ((q.col_scale || q.stats) ? (q.cols + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK : 0);
+    blocks += js.row_blocks[j] + (((q.col_scale || q.stats) && !q.rows_only) ? (q.cols + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK : 0);
   }
   js.first_block[njobs] = blocks;
   hipStream_t st = (hipStream_t)stream;

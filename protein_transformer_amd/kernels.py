@@ -22,7 +22,7 @@ GEMM_RESERVED_CUS = 0    # CUs the persistent GEMMs leave free (dp.reserve_cus_f
 
 def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, bias=None, residual=None,
          ldr=0, flags=0, dropout_p=0.0, seed=0, stream_id=0, split_k=1, colsum=None, gate_scale=0.0, arith=None,
-         a_scale=None, a_scale_stride=1, b_scale=None):
+         a_scale=None, a_scale_stride=1, b_scale=None, b_scale_stride=1):
     """C[M,N] = epilogue(A (*) B); operand layouts as documented in ptamd.h.  `arith`: GEMM_* constant of this call
     (None = the host-side default, `set_gemm_mode`); the library itself keeps no mode."""
     # split-K slabs and, for the f16x2 arithmetic, the row scales of the two operands
@@ -37,7 +37,7 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False,
                     colsum=colsum.data_ptr() if colsum is not None else None, gate_scale=float(gate_scale),
                     arith=int(_DEFAULT_ARITH if arith is None else arith), reserved_cus=int(GEMM_RESERVED_CUS),
                     a_scale=a_scale.data_ptr() if a_scale is not None else None, a_scale_stride=int(a_scale_stride),
-                    b_scale=b_scale.data_ptr() if b_scale is not None else None)
+                    b_scale=b_scale.data_ptr() if b_scale is not None else None, b_scale_stride=int(b_scale_stride))
     if GEMM_TIMING is None:
         check(lib().ptamd_gemm(C.byref(args), stream()), "gemm")
     else:
@@ -141,12 +141,15 @@ def pick_split_k(M, N, K, slots=512):
     return max(1, min(K // 256, slots // tiles))
 
 
+SPLIT_K_ROWS = True      # knob of pick_split_k_rows (tests compare both settings)
+
+
 def pick_split_k_rows(M, N, K, slots=256):
     """K splits for an activation x weight product whose 256 x 128 output tiles do not fill the chip (few tokens: small
     batches, the per-GPU share of a strongly scaled batch) and whose reduction is long enough to be worth cutting: the
     slabs are summed in a fixed order by the reduce kernel, which also applies the epilogue (same dropout masks)."""
     tiles = ((M + 255) // 256) * ((N + 127) // 128)
-    if tiles * 2 > slots or K < 1024:
+    if not SPLIT_K_ROWS or tiles * 2 > slots or K < 1024:
         return 1
     return max(1, min(K // 512, slots // tiles))
 
@@ -177,11 +180,17 @@ def linear_bwd_input(dy, w, out=None, flags=0, gate=None, gate_dropout_p=0.0, ar
                 flags=flags, arith=arith, **scales)
 
 
-def linear_bwd_weight(dy, x, dw, dbias=None, arith=None):
+def linear_bwd_weight(dy, x, dw, dbias=None, arith=None, dy_scale=None, x_scale=None):
     """dw[N,K] += dy[T,N]^T x[T,K]  (reduction over the T tokens, split across workgroups) and, fused into the same
     pass over dy, dbias[N] += sum_t dy[t,N]."""
     T, N = dy.shape
     K = x.shape[1]
+    if dy_scale is not None and x_scale is not None:   # (the caller passes them only in the AUTO / F16X2 arithmetics)
+        # both operands come with ONE scale each (four copies; the scale of their largest row): the product runs in f16x2
+        # arithmetic - half the matrix-pipe work of bf16x3 - without a pass over the two big operands
+        return gemm(dy, x, dw, M=N, N=K, K=T, lda=dy.stride(0), ldb=x.stride(0), ldc=dw.stride(0), a_kmajor=True,
+                    b_kmajor=True, flags=EPI_ACCUM, split_k=pick_split_k(N, K, T), colsum=dbias, arith=GEMM_F16X2,
+                    a_scale=dy_scale, a_scale_stride=0, b_scale=x_scale, b_scale_stride=0)
     return gemm(dy, x, dw, M=N, N=K, K=T, lda=dy.stride(0), ldb=x.stride(0), ldc=dw.stride(0), a_kmajor=True,
                 b_kmajor=True, flags=EPI_ACCUM, split_k=pick_split_k(N, K, T), colsum=dbias, arith=arith)
 
@@ -206,7 +215,7 @@ def layernorm_fwd(x, gamma, beta, row_scale=None):
 
 
 def layernorm_bwd_dropout(dy, x, gamma, mean, rstd, dgamma, dbeta, dres, dropout_p, seed, stream_id, row_scale=None,
-                          bound_factor=None, bound_scale=None):
+                          bound_factor=None, bound_scale=None, row_scale_min=None, bound_scale_min=None):
     """LayerNorm backward fused with the dropout backward of its output (ptamd_layernorm_bwd_dropout): returns
     (dx, dropped); dropped is dx itself when dropout_p == 0.  Fills row_scale / bound_scale [T] when given."""
     T, D = x.shape
@@ -215,8 +224,8 @@ def layernorm_bwd_dropout(dy, x, gamma, mean, rstd, dgamma, dbeta, dres, dropout
     ws = workspace("ln", lib().ptamd_layernorm_bwd_workspace_bytes(D), x.device)
     check(lib().ptamd_layernorm_bwd_dropout(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), T, D, float(dropout_p),
                                             int(seed), int(stream_id), ptr(dx), ptr(dropped), ptr(row_scale),
-                                            ptr(bound_factor), ptr(bound_scale), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(),
-                                            stream()), "layernorm_bwd_dropout")
+                                            ptr(bound_factor), ptr(bound_scale), ptr(row_scale_min), ptr(bound_scale_min),
+                                            ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(), stream()), "layernorm_bwd_dropout")
     return dx, (dropped if dropped is not None else dx)
 
 
@@ -232,7 +241,8 @@ def weight_scales(jobs):
             arr[k] = WScaleJob(w=w.data_ptr(), rows=rows, cols=cols, ld=w.stride(0) if w.dim() == 2 else cols,
                                row_scale=j["row_scale"].data_ptr() if j.get("row_scale") is not None else None,
                                col_scale=j["col_scale"].data_ptr() if j.get("col_scale") is not None else None,
-                               stats=j["stats"].data_ptr() if j.get("stats") is not None else None)
+                               stats=j["stats"].data_ptr() if j.get("stats") is not None else None,
+                               rows_only=int(bool(j.get("rows_only", False))))
         check(lib().ptamd_weight_scales(arr, len(chunk), stream()), "weight_scales")
 
 

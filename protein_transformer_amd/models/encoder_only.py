@@ -267,11 +267,13 @@ class _TransformerBase(nn.Module):
         cache = caches.get(key)
         if cache is None:
             dev = flat.device
-            n_i = self.nlayers * (8 * D + 2 * F + 2)                  # int32: scales (+ 2 bound scales per layer)
+            n_i = self.nlayers * (8 * D + 2 * F + 5 * 4)              # int32: weight scales + 5 uniform scales (4 copies each) per layer
             ints = torch.zeros(n_i, dtype=torch.int32, device=dev)
             stats = torch.zeros(self.nlayers, 9, 4, dtype=torch.float32, device=dev)
             factor = torch.zeros(self.nlayers, dtype=torch.float32, device=dev)
+            ones = torch.tensor([1.0, 1.0, 1.0, 0.0], dtype=torch.float32, device=dev)     # a stats record for "no weight"
             layers, wjobs, bjobs, o = [], [], [], 0
+            minbuf = torch.zeros(self.nlayers, 12, dtype=torch.int32, device=dev)   # atomicMin targets, preset before every backward pass
 
             def take(n):
                 nonlocal o
@@ -283,7 +285,9 @@ class _TransformerBase(nn.Module):
                 b = f"encoder.enc_layers.{i}."
                 wqkv, bqkv = self._qkv(flat, i)
                 L = dict(rs_qkv=take(3 * D), cs_qkv=take(D), rs_o=take(D), cs_o=take(D), rs_1=take(F), cs_1=take(D),
-                         rs_2=take(D), cs_2=take(F), att_scale=take(1), f1_scale=take(1), dz1_factor=factor[i:i + 1])
+                         rs_2=take(D), cs_2=take(F), att_scale=take(4), f1_scale=take(4), h1_scale=take(4), h2_scale=take(4),
+                         dqkv_scale=take(4), dz1_factor=factor[i:i + 1])
+                L.update(dy2_min=minbuf[i, 0:4], dz1_min=minbuf[i, 4:8], dyo_min=minbuf[i, 8:12])
                 st = stats[i]
                 wjobs += [dict(w=wqkv, row_scale=L["rs_qkv"], col_scale=L["cs_qkv"]),
                           dict(w=wqkv[2 * D:], stats=st[0]),                                     # W_v: row norms
@@ -301,10 +305,17 @@ class _TransformerBase(nn.Module):
                                post_scale=1.0 / (1.0 - pa), out_scale=L["att_scale"]),
                           dict(ln_gamma=st[5], ln_beta=st[6], w=st[1], w_index=0, bias=st[8], sqrt_d=sq,
                                post_scale=1.0 / (1.0 - p), out_scale=L["f1_scale"]),
-                          dict(w=st[2], w_index=1, post_scale=1.0 / (1.0 - p), out_value=L["dz1_factor"])]
+                          dict(w=st[2], w_index=1, post_scale=1.0 / (1.0 - p), out_value=L["dz1_factor"]),
+                          # |LN(x)|_inf <= |LN(x)|_2 <= max|gamma| sqrt(D) + |beta|_2: ONE scale for h1 / h2 as operands of dW
+                          dict(ln_gamma=st[3], ln_beta=st[4], w=ones, w_index=0, sqrt_d=sq, out_scale=L["h1_scale"]),
+                          dict(ln_gamma=st[5], ln_beta=st[6], w=ones, w_index=0, sqrt_d=sq, out_scale=L["h2_scale"])]
                 layers.append(L)
             assert o == n_i
-            cache = caches[key] = dict(layers=layers, wjobs=wjobs, bjobs=bjobs, keep=(ints, stats, factor))
+            dq_stats = torch.zeros(self.nlayers, 4, dtype=torch.float32, device=dev)
+            for i, L in enumerate(layers):
+                L["dqkv_stats"] = dq_stats[i]
+                L["minbuf"] = minbuf
+            cache = caches[key] = dict(layers=layers, wjobs=wjobs, bjobs=bjobs, keep=(ints, stats, factor, ones, dq_stats, minbuf))
         K.weight_scales(cache["wjobs"])
         K.bound_scales(cache["bjobs"])
         return cache["layers"]
@@ -435,6 +446,9 @@ class _EncoderFn(torch.autograd.Function):
         fuse = D <= 1024                                   # LayerNorm backward + the dropout backward behind it in one kernel
         i32 = lambda: torch.empty(B * L, dtype=torch.int32, device=dx.device)                 # noqa: E731
         dy2 = s_dy2 = bs_dz1 = None                        # dropout'(dx) of the FFN output site, made by the layer above
+        have_min = False                                   # ... together with the uniform scales of dy2 / dz1 for the dW products
+        if scales is not None:
+            scales[0]["minbuf"].fill_(0x7F000000)          # atomicMin targets of this backward pass (largest scale)
         for i in reversed(range(m.nlayers)):
             b = f"encoder.enc_layers.{i}."
             sid = i * 8
@@ -443,11 +457,14 @@ class _EncoderFn(torch.autograd.Function):
             # x3 = x2 + drop(f1 W2^T + b2)
             if dy2 is None:
                 dy2 = K.dropout_bwd(dx, p, seed, sid + _SITE_FFN_OUT) if p > 0 else dx
-            K.linear_bwd_weight(dy2, f1, G(b + "pwff.layer2.weight"), G(b + "pwff.layer2.bias"), arith=ar)
+            uni = sc is not None and have_min              # uniform scales of both operands: the dW product runs in f16x2
+            K.linear_bwd_weight(dy2, f1, G(b + "pwff.layer2.weight"), G(b + "pwff.layer2.bias"), arith=ar,
+                                dy_scale=sc["dy2_min"] if uni else None, x_scale=sc["f1_scale"] if uni else None)
             # backward of layer2 and, in its epilogue, of the ReLU + dropout in front of it (gate = saved f1)
             dz1 = K.linear_bwd_input(dy2, W(b + "pwff.layer2.weight"), gate=f1, gate_dropout_p=p, arith=ar,
                                      a_scale=s_dy2 if sc else None, b_scale=sc and sc["cs_2"])
-            K.linear_bwd_weight(dz1, h2, G(b + "pwff.layer1.weight"), G(b + "pwff.layer1.bias"), arith=ar)
+            K.linear_bwd_weight(dz1, h2, G(b + "pwff.layer1.weight"), G(b + "pwff.layer1.bias"), arith=ar,
+                                dy_scale=sc["dz1_min"] if uni else None, x_scale=sc["h2_scale"] if uni else None)
             dh2 = K.linear_bwd_input(dz1, W(b + "pwff.layer1.weight"), arith=ar,
                                      a_scale=bs_dz1 if sc else None, b_scale=sc and sc["cs_1"])
             # x2 = x + drop(att Wo^T + bo)
@@ -455,28 +472,42 @@ class _EncoderFn(torch.autograd.Function):
             if fuse:
                 s_dyo = i32() if sc else None
                 dx2, dyo = K.layernorm_bwd_dropout(dh2, x2, W(b + "sublayer_connections.1.norm.weight"), mean2, rstd2, g2w, g2b,
-                                                   dx, p, seed, sid + _SITE_ATTN_OUT, row_scale=s_dyo)
+                                                   dx, p, seed, sid + _SITE_ATTN_OUT, row_scale=s_dyo,
+                                                   row_scale_min=sc["dyo_min"] if sc else None)
             else:
                 s_dyo = None
                 dx2 = K.layernorm_bwd(dh2, x2, W(b + "sublayer_connections.1.norm.weight"), mean2, rstd2, g2w, g2b, dres=dx)
                 dyo = K.dropout_bwd(dx2, p, seed, sid + _SITE_ATTN_OUT) if p > 0 else dx2
-            K.linear_bwd_weight(dyo, att, G(b + "self_attn.wo.weight"), G(b + "self_attn.wo.bias"), arith=ar)
+            uni_o = sc is not None and fuse
+            K.linear_bwd_weight(dyo, att, G(b + "self_attn.wo.weight"), G(b + "self_attn.wo.bias"), arith=ar,
+                                dy_scale=sc["dyo_min"] if uni_o else None, x_scale=sc["att_scale"] if uni_o else None)
             datt = K.linear_bwd_input(dyo, W(b + "self_attn.wo.weight"), arith=ar, a_scale=s_dyo, b_scale=sc and sc["cs_o"])
             dqkv = K.attention_bwd(qkv, seq, att, datt, lse, H, pa, seed, sid + _SITE_ATTN, arith=ar)
             gw, gb = m._qkv(gflat, i)
             wqkv, _ = m._qkv(flat, i)
-            K.linear_bwd_weight(dqkv, h1, gw, gb, arith=ar)
-            dh1 = K.linear_bwd_input(dqkv, wqkv, arith=ar, b_scale=sc and sc["cs_qkv"])
+            if sc is not None:   # one pass over dqkv gives its row scales (A of the dX product) and its largest |value| (-> the
+                s_dqkv = i32()   # uniform scale of dqkv as operand of the dW product): the pass ptamd_gemm would run anyway
+                K.weight_scales([dict(w=dqkv, row_scale=s_dqkv, stats=sc["dqkv_stats"], rows_only=True)])
+                K.bound_scales([dict(w=sc["dqkv_stats"], w_index=2, out_scale=sc["dqkv_scale"])])
+                K.linear_bwd_weight(dqkv, h1, gw, gb, arith=ar, dy_scale=sc["dqkv_scale"], x_scale=sc["h1_scale"])
+                dh1 = K.linear_bwd_input(dqkv, wqkv, arith=ar, a_scale=s_dqkv, b_scale=sc["cs_qkv"])
+            else:
+                K.linear_bwd_weight(dqkv, h1, gw, gb, arith=ar)
+                dh1 = K.linear_bwd_input(dqkv, wqkv, arith=ar)
             g1w, g1b = G(b + "sublayer_connections.0.norm.weight"), G(b + "sublayer_connections.0.norm.bias")
             if fuse and i > 0:      # the gradient enters layer i - 1 through ITS FFN-output dropout: made here, with its scales
                 s_dy2, bs_dz1 = (i32(), i32()) if scales is not None else (None, None)
+                below = scales[i - 1] if scales is not None else None
                 dx, dy2 = K.layernorm_bwd_dropout(dh1, x, W(b + "sublayer_connections.0.norm.weight"), mean1, rstd1, g1w, g1b,
                                                   dx2, p, seed, (i - 1) * 8 + _SITE_FFN_OUT, row_scale=s_dy2,
-                                                  bound_factor=scales[i - 1]["dz1_factor"] if scales is not None else None,
-                                                  bound_scale=bs_dz1)
+                                                  bound_factor=below["dz1_factor"] if below else None, bound_scale=bs_dz1,
+                                                  row_scale_min=below["dy2_min"] if below else None,
+                                                  bound_scale_min=below["dz1_min"] if below else None)
+                have_min = below is not None
             else:
                 dx = K.layernorm_bwd(dh1, x, W(b + "sublayer_connections.0.norm.weight"), mean1, rstd1, g1w, g1b, dres=dx2)
                 dy2 = s_dy2 = bs_dz1 = None
+                have_min = False
             done(b + "self_attn.wq.weight", b + "sublayer_connections.1.norm.bias")
             ctx.saved[i] = None
         # ---- front end

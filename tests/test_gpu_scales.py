@@ -170,3 +170,31 @@ def test_weight_derived_bounds_hold_and_are_tight(dev):
         fac = float(L["dz1_factor"][0])
         ratio = (dy.norm(dim=1) * fac) / dz.abs().max(1).values
         assert float(ratio.min()) >= 1.0 and float(ratio.max()) < 2.0 ** 7
+
+
+def test_weight_gradient_product_with_uniform_scales(dev):
+    """dW = dy^T x in f16x2 arithmetic with ONE scale per operand (the scale of its largest row - four copies, stride 0):
+    per-token gradients spanning four decades, activations with a bound 2^4 above their maximum.  Norm-wise fp32-grade:
+    the error against fp64 is measured in units of the exact product's own largest entries, next to the bf16x3 result."""
+    from protein_transformer_amd import kernels as K
+    g = torch.Generator().manual_seed(11)
+    T, N, Kd = 16384, 512, 2048
+    dy = (torch.randn(T, N, generator=g) * torch.exp(torch.randn(T, 1, generator=g) * 2.3)).to(dev)   # 1e-4 .. 1e4 per token
+    x = torch.relu(torch.randn(T, Kd, generator=g)).to(dev)
+    uni = torch.zeros(2, 4, dtype=torch.int32, device=dev)
+    st = torch.zeros(2, 4, device=dev)
+    K.weight_scales([dict(w=dy, stats=st[0], rows_only=True), dict(w=x, stats=st[1], rows_only=True)])
+    K.bound_scales([dict(w=st[0], w_index=2, out_scale=uni[0]), dict(w=st[1], w_index=2, post_scale=16.0, out_scale=uni[1])])
+    assert float(as_float(uni[0])[0]) * float(dy.abs().max()) < 2.0 ** 15 and len(set(uni[0].tolist())) == 1
+    dw_u, dw_b = torch.zeros(N, Kd, device=dev), torch.zeros(N, Kd, device=dev)
+    db_u, db_b = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+    K.linear_bwd_weight(dy, x, dw_u, db_u, dy_scale=uni[0], x_scale=uni[1])
+    K.linear_bwd_weight(dy, x, dw_b, db_b, arith=K.GEMM_BF16X3)
+    ref = dy.double().t() @ x.double()
+    unit = float(ref.abs().max())
+    e_u, e_b = float((dw_u.double() - ref).abs().max()) / unit, float((dw_b.double() - ref).abs().max()) / unit
+    print("dW error / max|dW|: f16x2 with uniform scales", e_u, " bf16x3", e_b)
+    assert e_b < 1e-6 and e_u < 2e-6
+    rel = float((dw_u.double() - ref).norm() / ref.norm())
+    assert rel < 1e-6
+    assert torch.allclose(db_u, db_b, rtol=1e-5, atol=1e-3 * float(db_b.abs().max()))      # the fused bias gradient is fp32 either way
