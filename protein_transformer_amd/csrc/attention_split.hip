@@ -1,4 +1,4 @@
-// Fused masked multi-head self-attention on the bf16 matrix pipe with exact three-term operand splitting (dk = 64).
+// Fused masked multi-head self-attention on the bf16 matrix pipe with exact three-term operand splitting (dk = 64 and 32).
 //
 // Same operator, interface, masking, dropout hash and outputs as attention.hip
 //   /root/reference/protein_transformer/models/transformer/Attention.py:14-22,55-68
@@ -18,7 +18,6 @@
 namespace ptattn {
 using namespace ptsplit;
 
-constexpr int DK = 64;
 constexpr int NTHR = 512;        // 8 wavefronts: a staged tile is converted once for 256 queries (keys) instead of 128
 constexpr int QB = NTHR / 2;     // queries (or keys) per workgroup: 32 per wavefront
 constexpr int TR = 32;  // rows (keys or queries) of an LDS tile
@@ -29,31 +28,38 @@ __device__ __forceinline__ int crow(int r, int lh) { return (r & 3) + 8 * (r >> 
 
 // 32 rows x 64 floats of a [*, ld] matrix, global -> registers -> split planes in LDS (512 threads, 1 float4 each).
 // The loads are unconditional (row clamped); rows beyond nrows are zeroed when they are stored.
+// DK = 32: a tile row is half as wide (8 float4), the first 256 threads carry the 32 rows; the LDS image keeps the
+// 64-wide row format of split_bf16.h with its upper half unused (same swizzle, same conflict-free reads).
+template <int DK>
 struct Stage32 {
+  static constexpr int CPR = DK / 4;  // float4 per tile row
   float4 v[512 / NTHR];
   __device__ __forceinline__ void load(const float *__restrict__ base, int ld, int row0, int nrows, int tid) {
 #pragma unroll
     for (int i = 0; i < 512 / NTHR; ++i) {
-      const int f = tid + NTHR * i, row = min(row0 + f / 16, nrows - 1);
-      v[i] = *reinterpret_cast<const float4 *>(base + (size_t)row * ld + (f % 16) * 4);
+      const int f = tid + NTHR * i, row = min(row0 + min(f / CPR, TR - 1), nrows - 1);
+      v[i] = *reinterpret_cast<const float4 *>(base + (size_t)row * ld + (f % CPR) * 4);
     }
   }
   __device__ __forceinline__ void store(unsigned short *__restrict__ s, int row0, int nrows, int tid) const {
 #pragma unroll
     for (int i = 0; i < 512 / NTHR; ++i) {
-      const int f = tid + NTHR * i, row = f / 16;
-      const bool ok = row0 + row < nrows;
-      const float4 x = make_float4(ok ? v[i].x : 0.f, ok ? v[i].y : 0.f, ok ? v[i].z : 0.f, ok ? v[i].w : 0.f);
-      Tile::store4(s, row, (f % 16) * 4, x);
+      const int f = tid + NTHR * i, row = f / CPR;
+      if (row < TR) {  // (wavefront-uniform: 64 lanes cover whole rows)
+        const bool ok = row0 + row < nrows;
+        const float4 x = make_float4(ok ? v[i].x : 0.f, ok ? v[i].y : 0.f, ok ? v[i].z : 0.f, ok ? v[i].w : 0.f);
+        Tile::store4(s, row, (f % CPR) * 4, x);
+      }
     }
   }
 };
 
-// B operands (3 planes x 4 k steps) of one row of a [*, ld] matrix: lane (l31, lh) holds d = 16 s + 8 lh + 0..7
+// B operands (3 planes x DK / 16 k steps) of one row of a [*, ld] matrix: lane (l31, lh) holds d = 16 s + 8 lh + 0..7
+template <int KS>
 __device__ __forceinline__ void load_row_split(const float *__restrict__ base, int ld, int row, bool ok, int lh,
-                                               bf16x8 (&f)[4][3]) {
+                                               bf16x8 (&f)[KS][3]) {
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
+  for (int s = 0; s < KS; ++s) {
     const float *p = base + (size_t)row * ld + 16 * s + 8 * lh;
     const float4 a = ok ? *reinterpret_cast<const float4 *>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 b = ok ? *reinterpret_cast<const float4 *>(p + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -69,6 +75,7 @@ __device__ __forceinline__ void load_row_split(const float *__restrict__ base, i
 constexpr int BUF = 2 * Tile::ELEMS;  // bf16 elements of one {K, V} buffer
 constexpr size_t ATTN_LDS = (size_t)2 * BUF * sizeof(unsigned short);
 
+template <int DK>
 __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_split_kernel(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
                                                                 int L, int H, float p_drop, uint64_t seed, uint32_t stream_id,
                                                                 float *__restrict__ out, float *__restrict__ lse) {
@@ -81,21 +88,22 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const int64_t *sq = seq + (size_t)b * L;
   const int q = q0 + l31;
   const bool q_ok = q < L;
-  const float scale = 0.125f;  // 1 / sqrt(64)
+  constexpr int KS = DK / 16, NT = DK / 32;  // k steps of Q K^T, 32-wide column tiles of the head dimension
+  const float scale = DK == 64 ? 0.125f : 0.17677669529663687f;  // 1 / sqrt(dk)
   const AttnDrop dk_ = make_attn_drop(seed, stream_id, (uint32_t)(b * H + h), p_drop);
   const uint32_t q_part = attn_q_part(dk_, (uint32_t)q);
 
-  bf16x8 qf[4][3];
+  bf16x8 qf[KS][3];
   load_row_split(base, D3, min(q, L - 1), q_ok, lh, qf);
 
-  f32x16 o[2];
+  f32x16 o[NT];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  Stage32 stK, stV;
+  Stage32<DK> stK, stV;
   const int ntiles = (L + TR - 1) / TR;
   auto publish_mask = [&](int k0, int buf) __attribute__((always_inline)) {
     if (wave == 0) {
@@ -109,22 +117,27 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
   stK.store(smem, 0, L, tid);
   stV.store(smem + Tile::ELEMS, 0, L, tid);
   publish_mask(0, 0);
+  // The loads run TWO tiles ahead of the arithmetic: tile kt + 2 is requested at the top of iteration kt into the second
+  // register set while tile kt + 1 (requested an iteration ago, long since arrived) is converted and stored - the wait in
+  // front of the conversion no longer exposes the global latency once per tile.  Loads are unconditional (rows clamped):
+  // a load behind a branch would make the compiler drain the whole queue at the next use.
+  Stage32<DK> nxK, nxV;
+  stK.load(base + D, D3, TR, L, tid);
+  stV.load(base + 2 * D, D3, TR, L, tid);
   __syncthreads();
 
   for (int kt = 0; kt < ntiles; ++kt) {
     const int k0 = kt * TR, cur = kt & 1;
     const bool more = kt + 1 < ntiles;
     const unsigned short *sK = smem + cur * BUF, *sV = sK + Tile::ELEMS;
-    if (more) {
-      stK.load(base + D, D3, k0 + TR, L, tid);
-      stV.load(base + 2 * D, D3, k0 + TR, L, tid);
-    }
+    nxK.load(base + D, D3, k0 + 2 * TR, L, tid);
+    nxV.load(base + 2 * D, D3, k0 + 2 * TR, L, tid);
     const unsigned int mask = sMask[cur];
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {  // S^T[key][q] = K Q^T
+    for (int st = 0; st < KS; ++st) {  // S^T[key][q] = K Q^T
       bf16x8 kf[3];
       Tile::frag_rows(sK, 0, st, lane, kf);
       s = mfma6(kf, qf[st], s);
@@ -160,7 +173,7 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
     m_run = m_new;
     if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {  // wave-uniform: after the first tiles the running maximum rarely moves
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {  // scalar multiplies, kept apart: packed f32 VALU stalls the matrix pipe
           float v = o[t][r] * alpha;
@@ -180,12 +193,14 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
       bf16x8 pf[3];
       split8(x, pf);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < NT; ++t) {
         bf16x8 vf[3];
         Tile::frag_cols(sV, 16 * m, 32 * t, lane, vf);
         o[t] = mfma6(vf, pf, o[t]);
       }
     }
+    stK = nxK;
+    stV = nxV;
     __syncthreads();  // the other buffer is complete; nobody reads this one any more
   }
 
@@ -194,7 +209,7 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
   if (q_ok) {
     float *op = out + (size_t)(b * L + q) * D + h * DK;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = t * 32 + 8 * g + 4 * lh;
@@ -208,6 +223,7 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
 // =================================================================================================== backward
 // dQ: same decomposition as the forward kernel.  Also computes delta[q] = sum_d dO[q,d] O[q,d] and publishes it for the
 // dK/dV kernel, which runs after this one on the same stream.
+template <int DK>
 __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq_split_kernel(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
                                                                    const float *__restrict__ o_fwd, const float *__restrict__ d_o,
                                                                    const float *__restrict__ lse, float *__restrict__ delta,
@@ -222,11 +238,12 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const int64_t *sq = seq + (size_t)b * L;
   const int q = q0 + l31, qc = min(q, L - 1);
   const bool q_ok = q < L;
-  const float scale = 0.125f;
+  constexpr int KS = DK / 16, NT = DK / 32;
+  const float scale = DK == 64 ? 0.125f : 0.17677669529663687f;
   const AttnDrop dk_ = make_attn_drop(seed, stream_id, (uint32_t)(b * H + h), p_drop);
   const uint32_t q_part = attn_q_part(dk_, (uint32_t)q);
 
-  bf16x8 qf[4][3], gf[4][3];
+  bf16x8 qf[KS][3], gf[KS][3];
   load_row_split(base, D3, qc, q_ok, lh, qf);
   load_row_split(d_o + (size_t)b * L * D + h * DK, D, qc, q_ok, lh, gf);
   const float my_lse = q_ok ? lse[((size_t)b * H + h) * L + q] : 0.f;
@@ -234,7 +251,7 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
   {  // each lane half holds half of the d of its query's row
     const float *gp = d_o + ((size_t)b * L + qc) * D + h * DK, *op = o_fwd + ((size_t)b * L + qc) * D + h * DK;
 #pragma unroll
-    for (int st = 0; st < 4; ++st)
+    for (int st = 0; st < KS; ++st)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const float4 g4 = *reinterpret_cast<const float4 *>(gp + 16 * st + 8 * lh + 4 * j);
@@ -246,13 +263,13 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (q_ok && lh == 0) delta[((size_t)b * H + h) * L + q] = my_delta;
   }
 
-  f32x16 dq[2];
+  f32x16 dq[NT];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[t][r] = 0.f;
 
-  Stage32 stK, stV;
+  Stage32<DK> stK, stV;
   const int ntiles = (L + TR - 1) / TR;
   auto publish_mask = [&](int k0, int buf) __attribute__((always_inline)) {
     if (wave == 0) {
@@ -266,22 +283,23 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
   stK.store(smem, 0, L, tid);
   stV.store(smem + Tile::ELEMS, 0, L, tid);
   publish_mask(0, 0);
+  Stage32<DK> nxK, nxV;  // loads two tiles ahead, unconditional (see the forward kernel)
+  stK.load(base + D, D3, TR, L, tid);
+  stV.load(base + 2 * D, D3, TR, L, tid);
   __syncthreads();
 
   for (int kt = 0; kt < ntiles; ++kt) {
     const int k0 = kt * TR, cur = kt & 1;
     const bool more = kt + 1 < ntiles;
     const unsigned short *sK = smem + cur * BUF, *sV = sK + Tile::ELEMS;
-    if (more) {
-      stK.load(base + D, D3, k0 + TR, L, tid);
-      stV.load(base + 2 * D, D3, k0 + TR, L, tid);
-    }
+    nxK.load(base + D, D3, k0 + 2 * TR, L, tid);
+    nxV.load(base + 2 * D, D3, k0 + 2 * TR, L, tid);
     const unsigned int mask = sMask[cur];
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
+    for (int st = 0; st < KS; ++st) {
       bf16x8 kf[3], vf[3];
       Tile::frag_rows(sK, 0, st, lane, kf);
       Tile::frag_rows(sV, 0, st, lane, vf);
@@ -312,18 +330,20 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
       bf16x8 df[3];
       split8(x, df);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < NT; ++t) {
         bf16x8 kt_[3];
         Tile::frag_cols(sK, 16 * m, 32 * t, lane, kt_);
         dq[t] = mfma6(kt_, df, dq[t]);
       }
     }
+    stK = nxK;
+    stV = nxV;
     __syncthreads();
   }
   if (q_ok) {
     float *op = dqkv + (size_t)(b * L + q) * D3 + h * DK;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = t * 32 + 8 * g + 4 * lh;
@@ -335,6 +355,7 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
 // dK, dV: one workgroup = 128 keys of one (protein, head); lane column = key.  The split K and V rows of a lane's key
 // stay in registers as B operands; Q and dO tiles of 32 queries stream through LDS and serve both as row fragments
 // (S = Q K^T, dP = dO V^T) and as transposed fragments (dK^T += Q^T dS, dV^T += dO^T Pd).
+template <int DK>
 __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv_split_kernel(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
                                                                     const float *__restrict__ d_o, const float *__restrict__ lse,
                                                                     const float *__restrict__ delta, int L, int H, float p_drop,
@@ -350,20 +371,21 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const int key = key0 + l31;
   const bool k_ok = key < L;
   const bool k_valid = k_ok && seq[(size_t)b * L + key] != PTAMD_PAD_ID;
-  const float scale = 0.125f;
+  constexpr int KS = DK / 16, NT = DK / 32;
+  const float scale = DK == 64 ? 0.125f : 0.17677669529663687f;
   const AttnDrop dk_ = make_attn_drop(seed, stream_id, (uint32_t)(b * H + h), p_drop);
 
-  bf16x8 kf[4][3], vf[4][3];
+  bf16x8 kf[KS][3], vf[KS][3];
   load_row_split(base + D, D3, min(key, L - 1), k_ok, lh, kf);
   load_row_split(base + 2 * D, D3, min(key, L - 1), k_ok, lh, vf);
 
-  f32x16 dk[2], dv[2];
+  f32x16 dk[NT], dv[NT];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dk[t][r] = dv[t][r] = 0.f;
 
-  Stage32 stQ, stG;
+  Stage32<DK> stQ, stG;
   const int ntiles = (L + TR - 1) / TR;
   float r_lse = 0.f, r_del = 0.f;
   stQ.load(base, D3, 0, L, tid);
@@ -374,15 +396,18 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
     sLse[0][tid] = tid < L ? lse_b[tid] : 0.f;
     sDel[0][tid] = tid < L ? del_b[tid] : 0.f;
   }
+  Stage32<DK> nxQ, nxG;  // loads two tiles ahead, unconditional (see the forward kernel)
+  stQ.load(base, D3, TR, L, tid);
+  stG.load(gbase, D, TR, L, tid);
   __syncthreads();
 
   for (int qt = 0; qt < ntiles; ++qt) {
     const int qq0 = qt * TR, cur = qt & 1;
     const bool more = qt + 1 < ntiles;
     const unsigned short *sQ = smem + cur * BUF, *sG = sQ + Tile::ELEMS;
+    nxQ.load(base, D3, qq0 + 2 * TR, L, tid);
+    nxG.load(gbase, D, qq0 + 2 * TR, L, tid);
     if (more) {
-      stQ.load(base, D3, qq0 + TR, L, tid);
-      stG.load(gbase, D, qq0 + TR, L, tid);
       if (tid < TR) {
         const int qn = qq0 + TR + tid;
         r_lse = qn < L ? lse_b[qn] : 0.f;
@@ -393,7 +418,7 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
+    for (int st = 0; st < KS; ++st) {
       bf16x8 qa[3], ga[3];
       Tile::frag_rows(sQ, 0, st, lane, qa);
       Tile::frag_rows(sG, 0, st, lane, ga);
@@ -435,7 +460,7 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
       split8(xs, dsf);
       split8(xp, pdf);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < NT; ++t) {
         bf16x8 qt_[3], gt_[3];
         Tile::frag_cols(sQ, 16 * m, 32 * t, lane, qt_);
         dk[t] = mfma6(qt_, dsf, dk[t]);   // dK^T[d][key] += Q^T dS
@@ -443,12 +468,14 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
         dv[t] = mfma6(gt_, pdf, dv[t]);   // dV^T[d][key] += dO^T Pd
       }
     }
+    stQ = nxQ;
+    stG = nxG;
     __syncthreads();
   }
   if (k_ok) {
     float *okp = dqkv + (size_t)(b * L + key) * D3 + D + h * DK, *ovp = okp + D;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = t * 32 + 8 * g + 4 * lh;
@@ -467,26 +494,41 @@ int set_lds(Kern kern) {
 
 }  // namespace ptattn
 
-int pt_attention_fwd_split(const float *qkv, const int64_t *seq, int B, int L, int H, float p, uint64_t seed, uint32_t sid,
-                           float *out, float *lse, hipStream_t st) {
+int pt_attention_fwd_split(const float *qkv, const int64_t *seq, int B, int L, int H, int dk, float p, uint64_t seed,
+                           uint32_t sid, float *out, float *lse, hipStream_t st) {
   using namespace ptattn;
-  if (int rc = set_lds(attn_fwd_split_kernel)) return rc;  // idempotent, host-only: no state kept between calls
-  hipLaunchKernelGGL(attn_fwd_split_kernel, dim3((L + QB - 1) / QB, H, B), dim3(NTHR), ATTN_LDS, st, qkv, seq, L, H, p, seed,
-                     sid, out, lse);
+  const dim3 grid((L + QB - 1) / QB, H, B);
+  if (dk == 64) {
+    if (int rc = set_lds(attn_fwd_split_kernel<64>)) return rc;  // idempotent, host-only: no state kept between calls
+    hipLaunchKernelGGL(attn_fwd_split_kernel<64>, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, L, H, p, seed, sid, out, lse);
+  } else {
+    if (int rc = set_lds(attn_fwd_split_kernel<32>)) return rc;
+    hipLaunchKernelGGL(attn_fwd_split_kernel<32>, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, L, H, p, seed, sid, out, lse);
+  }
   return pt_check_launch();
 }
 
 int pt_attention_bwd_split(const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse,
-                           float *delta, int B, int L, int H, float p, uint64_t seed, uint32_t sid, float *dqkv,
+                           float *delta, int B, int L, int H, int dk, float p, uint64_t seed, uint32_t sid, float *dqkv,
                            hipStream_t st) {
   using namespace ptattn;
-  if (int rc = set_lds(attn_bwd_dq_split_kernel)) return rc;
-  if (int rc = set_lds(attn_bwd_dkv_split_kernel)) return rc;
   const dim3 grid((L + QB - 1) / QB, H, B);
-  hipLaunchKernelGGL(attn_bwd_dq_split_kernel, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, o_fwd, d_o, lse, delta, L, H, p, seed,
-                     sid, dqkv);
-  if (int rc = pt_check_launch()) return rc;
-  hipLaunchKernelGGL(attn_bwd_dkv_split_kernel, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, d_o, lse, delta, L, H, p, seed, sid,
-                     dqkv);
+  if (dk == 64) {
+    if (int rc = set_lds(attn_bwd_dq_split_kernel<64>)) return rc;
+    if (int rc = set_lds(attn_bwd_dkv_split_kernel<64>)) return rc;
+    hipLaunchKernelGGL(attn_bwd_dq_split_kernel<64>, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, o_fwd, d_o, lse, delta, L, H, p,
+                       seed, sid, dqkv);
+    if (int rc = pt_check_launch()) return rc;
+    hipLaunchKernelGGL(attn_bwd_dkv_split_kernel<64>, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, d_o, lse, delta, L, H, p, seed,
+                       sid, dqkv);
+  } else {
+    if (int rc = set_lds(attn_bwd_dq_split_kernel<32>)) return rc;
+    if (int rc = set_lds(attn_bwd_dkv_split_kernel<32>)) return rc;
+    hipLaunchKernelGGL(attn_bwd_dq_split_kernel<32>, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, o_fwd, d_o, lse, delta, L, H, p,
+                       seed, sid, dqkv);
+    if (int rc = pt_check_launch()) return rc;
+    hipLaunchKernelGGL(attn_bwd_dkv_split_kernel<32>, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, d_o, lse, delta, L, H, p, seed,
+                       sid, dqkv);
+  }
   return pt_check_launch();
 }

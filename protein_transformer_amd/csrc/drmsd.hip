@@ -22,7 +22,13 @@ namespace {
 
 constexpr int CB = 256;  // threads per block of the compaction / finalize kernels
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-constexpr int PB = 128;  // rows (= threads) per block of the pair sweep: ~34 blocks per protein keep 256 CUs balanced
+#ifndef PT_DRMSD_PB
+#define PT_DRMSD_PB 128
+#endif
+#ifndef PT_DRMSD_UNROLL
+#define PT_DRMSD_UNROLL 4
+#endif
+constexpr int PB = PT_DRMSD_PB;  // rows (= threads) per block of the pair sweep: ~34 blocks per protein keep 256 CUs balanced
 
 struct Counts {
   int n, n_bb, len, pad;
@@ -157,18 +163,15 @@ __global__ __launch_bounds__(PB) void drmsd_pairs_kernel(const float4 *__restric
     // four pairs per iteration, written out by hand (the optimizer declines to unroll this loop by itself): the loop
     // bookkeeping is shared and the next pairs' LDS reads are in flight under the current pair's arithmetic
     int j = 0;
-    for (; j + 3 < ja; j += 4) {
-      pair(j, accA);
-      pair(j + 1, accA);
-      pair(j + 2, accA);
-      pair(j + 3, accA);
+    constexpr int U = PT_DRMSD_UNROLL;
+    for (; j + U - 1 < ja; j += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) pair(j + u, accA);
     }
     for (; j < ja; ++j) pair(j, accA);
-    for (; j + 3 < cnt; j += 4) {
-      pair(j, accB);
-      pair(j + 1, accB);
-      pair(j + 2, accB);
-      pair(j + 3, accB);
+    for (; j + U - 1 < cnt; j += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) pair(j + u, accB);
     }
     for (; j < cnt; ++j) pair(j, accB);
   }

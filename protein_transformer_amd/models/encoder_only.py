@@ -367,6 +367,8 @@ class _EncoderFn(torch.autograd.Function):
         pa = m.attn_dropout if train else 0.0
         W = lambda name: m._slice(flat, name)                                      # noqa: E731
         ar = K.get_gemm_mode() if m.gemm_mode is None else int(m.gemm_mode)        # every launch below carries it
+        if ar == K.GEMM_AUTO and B * L * D < AUTO_F16X2_MIN_WORK:
+            ar = K.GEMM_BF16X3         # launch-bound step: the scale bookkeeping of f16x2 costs more than its products save
         pe = m.encoder.positional_enc.pe[0]
         # ---- front end: embedding (+ doubled positional add) or one-hot, then the optional Conv1d stack
         if m.use_embedding:
@@ -527,6 +529,11 @@ class _EncoderFn(torch.autograd.Function):
             K.embed_bwd(seq, dx, m.dmodel, p, seed, G("encoder.input_embedding.emb.weight"))
             done("encoder.input_embedding.emb.weight", "encoder.input_embedding.emb.weight")
         return None, None, None, None
+
+
+# tokens x d_model below which AUTO runs the whole step in bf16x3 (measured: 2.9 against 3.2 ms/step at 4096 x 256,
+# 10.2 against 9.8 at 16384 x 256 - profiles/r02_v2_bench_cfg2.json, cfg3)
+AUTO_F16X2_MIN_WORK = 1 << 21
 
 
 class EncoderOnlyTransformer(_TransformerBase):

@@ -358,7 +358,7 @@ def ref_attention(qkv, key_ok, H, mask_keep=None, p=0.0):
 @pytest.mark.parametrize("B,L,H,dk,lens", [(2, 100, 4, 8, [100, 37]), (2, 64, 2, 16, [64, 5]), (3, 200, 8, 32, [200, 129, 64]),
                                            (2, 512, 8, 64, [512, 300]), (1, 130, 2, 64, [130])])
 def test_attention_forward_backward(dev, gemm_mode, B, L, H, dk, lens):
-    # gemm_mode selects the matrix arithmetic: exact f32 MFMA, or (dk = 64) the split-bf16 kernels of attention_split.hip
+    # gemm_mode selects the matrix arithmetic: exact f32 MFMA, or (dk = 64, 32) the split-bf16 kernels of attention_split.hip
     from protein_transformer_amd import kernels as K_
     D = H * dk
     seq = torch.full((B, L), 20, dtype=torch.int64)
@@ -378,12 +378,12 @@ def test_attention_forward_backward(dev, gemm_mode, B, L, H, dk, lens):
 
 
 def test_attention_randomised(dev, gemm_mode):
-    """25 random (batch, heads, length, padding) cases with dk = 64 - the head size of the split-bf16 kernels -
+    """30 random (batch, heads, length, padding) cases with dk = 64 or 32 - the head sizes of the split-bf16 kernels -
     forward and backward against dense fp64 attention."""
     from protein_transformer_amd import kernels as K_
     rng = np.random.default_rng(5 + gemm_mode)
-    for _ in range(25):
-        B, H, dk, L = int(rng.integers(1, 4)), int(rng.choice([1, 2, 4])), 64, int(rng.integers(2, 600))
+    for it in range(30):
+        B, H, dk, L = int(rng.integers(1, 4)), int(rng.choice([1, 2, 4])), (64, 32)[it % 2], int(rng.integers(2, 600))
         D = H * dk
         seq = torch.full((B, L), 20, dtype=torch.int64)
         for b in range(B):
@@ -402,14 +402,15 @@ def test_attention_randomised(dev, gemm_mode):
         assert_close(dqkv, ref, 1e-4, 2e-6 * max(1.0, ref.abs().max().item()), "attention bwd " + what)
 
 
-def test_attention_dropout_consistency(dev, gemm_mode):
+@pytest.mark.parametrize("dk", [64, 32])
+def test_attention_dropout_consistency(dev, gemm_mode, dk):
     """Recover the dropout mask from a forward pass with V = I, then check all three gradients against
     dense torch math that uses that mask: forward, dQ and dK/dV kernels must draw identical masks."""
     from protein_transformer_amd import kernels as K_
-    B, L, H, dk, p, seed, sid = 2, 64, 2, 64, 0.25, 4242, 5
+    B, L, H, p, seed, sid = 2, dk, 2, 0.25, 4242, 5
     D = H * dk
     seq = torch.randint(0, 20, (B, L), generator=torch.Generator().manual_seed(3))
-    seq[1, 50:] = 20
+    seq[1, L - 14:] = 20
     qkv = rnd((B, L, 3 * D), 22, 1.2)
     eye = qkv.clone()
     eye[:, :, 2 * D:] = torch.eye(L)[None].repeat(B, 1, H)          # V_h = I for every head (dk == L)
