@@ -25,6 +25,12 @@ int pt_attention_fwd_split(const float *qkv, const int64_t *seq, int B, int L, i
 int pt_attention_bwd_split(const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse,
                            float *delta, int B, int L, int H, int dk, float p, uint64_t seed, uint32_t sid, float *dqkv,
                            hipStream_t st);
+// two-term f16 variants (attention_f16x2.hip): arith = PTAMD_GEMM_AUTO / PTAMD_GEMM_F16X2
+int pt_attention_fwd_f16x2(const float *qkv, const int64_t *seq, int B, int L, int H, int dk, float p, uint64_t seed,
+                           uint32_t sid, float *out, float *lse, hipStream_t st);
+int pt_attention_bwd_f16x2(const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse,
+                           float *delta, int B, int L, int H, int dk, float p, uint64_t seed, uint32_t sid, float *dqkv,
+                           hipStream_t st);
 
 namespace {
 
@@ -490,6 +496,8 @@ int ptamd_attention_fwd(const float *qkv, const int64_t *seq, int B, int L, int 
   if (dropout_p < 0.f || dropout_p >= 1.f) return PTAMD_ERR_BAD_SHAPE;
   if (!pt_aligned16(qkv) || !pt_aligned16(out)) return PTAMD_ERR_ALIGN;
   hipStream_t st = (hipStream_t)stream;
+  if ((dk == 64 || dk == 32) && (arith == PTAMD_GEMM_AUTO || arith == PTAMD_GEMM_F16X2))
+    return pt_attention_fwd_f16x2(qkv, seq, B, L, H, dk, dropout_p, seed, stream_id, out, lse, st);
   if ((dk == 64 || dk == 32) && arith != PTAMD_GEMM_F32)
     return pt_attention_fwd_split(qkv, seq, B, L, H, dk, dropout_p, seed, stream_id, out, lse, st);
   switch (dk) {
@@ -510,6 +518,8 @@ int ptamd_attention_bwd(const float *qkv, const int64_t *seq, const float *out, 
   if (!pt_aligned16(qkv) || !pt_aligned16(out) || !pt_aligned16(dout) || !pt_aligned16(dqkv)) return PTAMD_ERR_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   float *delta = static_cast<float *>(workspace);
+  if ((dk == 64 || dk == 32) && (arith == PTAMD_GEMM_AUTO || arith == PTAMD_GEMM_F16X2))
+    return pt_attention_bwd_f16x2(qkv, seq, out, dout, lse, delta, B, L, H, dk, dropout_p, seed, stream_id, dqkv, st);
   if ((dk == 64 || dk == 32) && arith != PTAMD_GEMM_F32)
     return pt_attention_bwd_split(qkv, seq, out, dout, lse, delta, B, L, H, dk, dropout_p, seed, stream_id, dqkv, st);
   switch (dk) {

@@ -1,0 +1,737 @@
+// Fused masked multi-head self-attention on the f16 matrix pipe with two-term operand splitting (dk = 64 and 32).
+//
+// Same operator, interface, masking, dropout hash and outputs as attention.hip / attention_split.hip
+//   /root/reference/protein_transformer/models/transformer/Attention.py:14-22,55-68
+// but every f32 matrix product (QK^T, PV and the five products of the backward pass) is evaluated as THREE
+// v_mfma_f32_32x32x16_f16 products of operands that were scaled by a power of two and split into two f16 terms
+// (x s = h1 + h2 + e, |e| <= 2^-22 |x s|: the f16x2 arithmetic of gemm_f16x2.hip) - half the matrix-pipe time and
+// about a third of the splitting work of the three-term bf16 kernels, with an error bound that is relative to the
+// largest element of a scaling group instead of to every element.  Selected by arith = PTAMD_GEMM_AUTO / _F16X2.
+//
+// Scaling groups - no pass over the operands, no extra launch, no scale arrays in the interface:
+//   * the operand whose rows live in lanes (Q and dO in the forward / dQ kernels, K and V in the dK/dV kernel) is scaled
+//     by the power of two of ITS row maximum (a lane holds half a row, one exchange between the lane halves);
+//   * a tile that streams through LDS is scaled per group of FOUR rows by the wavefront that stages them (64 lanes hold
+//     exactly four rows of 64 floats), which publishes the inverse scale beside the tile.  In the 32 x 32 accumulator
+//     layout a register quadruple (r >> 2) of a lane half is one such group, so
+//       - where the tile rows are rows of the product (S^T = K Q^T, dP^T = V dO^T) the inverse scales are four
+//         per-lane constants folded into the factors the soft-max needs anyway;
+//       - where the tile rows are the CONTRACTED index (O^T += V^T P^T, dQ^T += K^T dS^T, dK^T += Q^T dS, dV^T += dO^T P)
+//         the inverse group scale is folded into the register operand (P or dS) before it is split, together with a
+//         common power of two that is adapted on line like the running maximum of the soft-max: when a later tile
+//         needs a smaller one the accumulators are rescaled (rare: the factor has 4 bits of headroom).
+// Decomposition, LDS format, dropout hash and prefetching are those of attention_split.hip (8 wavefronts = 256 queries
+// or keys per workgroup, 32-row tiles, scores transposed so that a soft-max row is lane-local), with two planes per
+// tile instead of three (48 KB of LDS instead of 72).
+#include "attn_dropout.h"
+#include "split_bf16.h"
+
+namespace ptattn16 {
+using namespace ptsplit;
+
+constexpr int NTHR = 512;        // 8 wavefronts
+constexpr int QB = NTHR / 2;     // queries (or keys) per workgroup: 32 per wavefront
+constexpr int TR = 32;           // rows (keys or queries) of an LDS tile
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float TWO14 = 16384.f, INV_TWO14 = 1.f / 16384.f;
+
+__device__ __forceinline__ int crow(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+__device__ __forceinline__ uint32_t abs_bits(float x) { return __float_as_uint(x) & 0x7fffffffu; }
+// 1 / x for x = 0 (-> 2^127, finite) or a power of two in [2^-126, 2^127]
+__device__ __forceinline__ float inv_pow2(float x) { return __uint_as_float((254u << 23) - __float_as_uint(x)); }
+__device__ __forceinline__ uint32_t umax4(const float4 &v) {
+  return max(max(abs_bits(v.x), abs_bits(v.y)), max(abs_bits(v.z), abs_bits(v.w)));
+}
+
+// maximum over groups of 32 or 64 adjacent lanes (in every lane of the group): four DPP steps inside the rows of 16,
+// then one or two lane exchanges
+template <int LANES>
+__device__ __forceinline__ uint32_t group_umax(uint32_t v) {
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));  // row_mirror
+  v = max(v, (uint32_t)__shfl_xor((int)v, 16, 64));
+  if (LANES == 64) v = max(v, (uint32_t)__shfl_xor((int)v, 32, 64));
+  return v;
+}
+
+__device__ __forceinline__ f32x16 mfma3(const f16x8 (&a)[2], const f16x8 (&b)[2], f32x16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], c, 0, 0, 0);
+  return c;
+}
+// eight f32 -> the two f16x8 MFMA operands of (x[0..3] s0, x[4..7] s1)
+__device__ __forceinline__ void split8g(const float (&x)[8], float s0, float s1, f16x8 (&f)[2]) {
+  uint32_t t[2][4];
+  split_pair_f16(x[0], x[1], s0, s0, t[0][0], t[1][0]);
+  split_pair_f16(x[2], x[3], s0, s0, t[0][1], t[1][1]);
+  split_pair_f16(x[4], x[5], s1, s1, t[0][2], t[1][2]);
+  split_pair_f16(x[6], x[7], s1, s1, t[0][3], t[1][3]);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const u32x4 u = {t[k][0], t[k][1], t[k][2], t[k][3]};
+    f[k] = __builtin_bit_cast(f16x8, u);
+  }
+}
+
+// ---- LDS image of a [32][64] f32 tile as two f16 planes: row format and swizzle of split_bf16.h (Tile64)
+constexpr int T_LD = 96;
+struct Tile2 {
+  static constexpr int PLANE = TR * T_LD;
+  static constexpr int ELEMS = 2 * PLANE;
+  static __device__ __forceinline__ int offset(int row, int d) {
+    return row * T_LD + ((((d >> 3) ^ (row >> 2)) & 3) | ((d >> 3) & 4)) * 8 + (d & 7);
+  }
+  static __device__ __forceinline__ void store4(unsigned short *__restrict__ s, int row, int d, const float4 &v, float sc) {
+    uint2 t1, t2;
+    split_pair_f16(v.x, v.y, sc, sc, t1.x, t2.x);
+    split_pair_f16(v.z, v.w, sc, sc, t1.y, t2.y);
+    const int off = offset(row, d);
+    *reinterpret_cast<uint2 *>(s + off) = t1;
+    *reinterpret_cast<uint2 *>(s + PLANE + off) = t2;
+  }
+  // lane l holds tile row (l & 31), d = 16 step + 8 (l >> 5) + 0..7
+  static __device__ __forceinline__ void frag_rows(const unsigned short *__restrict__ s, int step, int lane, f16x8 (&f)[2]) {
+    const unsigned short *q = s + offset(lane & 31, 16 * step + 8 * (lane >> 5));
+#pragma unroll
+    for (int t = 0; t < 2; ++t) f[t] = *reinterpret_cast<const f16x8 *>(q + t * PLANE);
+  }
+  // lane l holds column d0 + (l & 31) of the tile rows kb + 4 (l >> 5) + {0..3} and kb + 8 + 4 (l >> 5) + {0..3}: the k
+  // order in which a 32 x 32 accumulator holds its rows (split_bf16.h)
+  static __device__ __forceinline__ void frag_cols(const unsigned short *__restrict__ s, int kb, int d0, int lane,
+                                                   f16x8 (&f)[2]) {
+    const int q16 = lane & 15;
+    const int row = kb + 4 * (lane >> 5) + (q16 >> 2);
+    const unsigned short *q0 = s + offset(row, d0 + (lane & 16) + 4 * (q16 & 3));
+    const unsigned short *q1 = s + offset(row + 8, d0 + (lane & 16) + 4 * (q16 & 3));
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(q0 + t * PLANE));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(q1 + t * PLANE));
+      const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      f[t] = __builtin_bit_cast(f16x8, both);
+    }
+  }
+};
+
+// 32 rows x DK floats of a [*, ld] matrix: global -> registers (one float4 per thread) -> scaled f16 planes in LDS.
+// A group of four rows is held by 4 DK / 4 adjacent lanes (one wavefront for DK = 64, half of one for DK = 32); its
+// inverse scale goes to inv[(g & 1) * 4 + (g >> 1)], g = row >> 2, so that a lane half reads ITS four groups
+// (g = 2 j + lh) as one float4.  Loads are unconditional (row clamped); rows beyond nrows are zeroed when stored.
+template <int DK>
+struct Stage {
+  static constexpr int CPR = DK / 4;  // float4 per tile row
+  float4 v;
+  __device__ __forceinline__ void load(const float *__restrict__ base, int ld, int row0, int nrows, int tid) {
+    const int row = min(row0 + min(tid / CPR, TR - 1), nrows - 1);
+    v = *reinterpret_cast<const float4 *>(base + (size_t)row * ld + (tid % CPR) * 4);
+  }
+  __device__ __forceinline__ void store(unsigned short *__restrict__ s, float *__restrict__ inv, int row0, int nrows,
+                                        int tid) const {
+    const int row = tid / CPR;
+    const bool ok = row < TR && row0 + row < nrows;
+    const float4 x = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    const uint32_t amax = group_umax<4 * CPR>(umax4(x));
+    const uint32_t sbits = pt_row_scale_bits(amax);
+    if (row < TR) {  // (wavefront-uniform)
+      Tile2::store4(s, row, (tid % CPR) * 4, x, __uint_as_float(sbits));
+      if ((tid % (4 * CPR)) == 0) {
+        const int g = row >> 2;
+        inv[(g & 1) * 4 + (g >> 1)] = __uint_as_float((254u << 23) - sbits);
+      }
+    }
+  }
+};
+
+// one row of a [*, ld] matrix as the lane's B operand: lane (l31, lh) holds d = 16 s + 8 lh + 0..7; the row is scaled by
+// the power of two of its own maximum (returned: the INVERSE scale)
+template <int KS>
+__device__ __forceinline__ float load_row_scaled(const float *__restrict__ base, int ld, int row, bool ok, int lh,
+                                                 f16x8 (&f)[KS][2]) {
+  float x[KS][8];
+  uint32_t amax = 0;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const float *p = base + (size_t)row * ld + 16 * s + 8 * lh;
+    const float4 a = ok ? *reinterpret_cast<const float4 *>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 b = ok ? *reinterpret_cast<const float4 *>(p + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    x[s][0] = a.x; x[s][1] = a.y; x[s][2] = a.z; x[s][3] = a.w;
+    x[s][4] = b.x; x[s][5] = b.y; x[s][6] = b.z; x[s][7] = b.w;
+    amax = max(amax, max(umax4(a), umax4(b)));
+  }
+  amax = max(amax, (uint32_t)__shfl_xor((int)amax, 32, 64));
+  const uint32_t sbits = pt_row_scale_bits(amax);
+  const float sc = __uint_as_float(sbits);
+#pragma unroll
+  for (int s = 0; s < KS; ++s) split8g(x[s], sc, sc, f[s]);
+  return __uint_as_float((254u << 23) - sbits);
+}
+
+// On-line common power of two of a register operand (dS) whose largest magnitude of this tile is m (equal in both lane
+// halves): returns the factor the accumulators have to be multiplied by (1 when the scale stands) and updates `bscale`
+// so that m bscale < 2^14 - the products of the tile then fit f16 with a bit to spare.
+__device__ __forceinline__ float online_scale(float m, float &bscale) {
+  float ratio = 1.f;
+  if (m * bscale >= TWO14) {  // also taken when the product overflows
+    const uint32_t e = __float_as_uint(m) >> 23;                // >= 21 here, <= 254 for finite m
+    const float nb = __uint_as_float((264u - min(e, 254u)) << 23);  // m nb in [2^10, 2^11)
+    ratio = nb * inv_pow2(bscale);
+    bscale = nb;
+  }
+  return ratio;
+}
+constexpr float BSCALE0 = 1.329227995784916e36f;  // 2^120
+
+constexpr int BUF = 2 * Tile2::ELEMS;  // f16 elements of one {A, B} tile buffer
+constexpr size_t ATTN_LDS = (size_t)2 * BUF * sizeof(unsigned short);
+
+// =================================================================================================== forward
+template <int DK>
+__global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_f16x2_kernel(
+    const float *__restrict__ qkv, const int64_t *__restrict__ seq, int L, int H, float p_drop, uint64_t seed,
+    uint32_t stream_id, float *__restrict__ out, float *__restrict__ lse) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  __shared__ unsigned int sMask[2];
+  __shared__ __attribute__((aligned(16))) float sInvK[2][8], sInvV[2][8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB + wave * 32;
+  const int D = H * DK, D3 = 3 * D;
+  const float *base = qkv + (size_t)b * L * D3 + h * DK;  // Q block of this head; K at +D, V at +2D
+  const int64_t *sq = seq + (size_t)b * L;
+  const int q = q0 + l31;
+  const bool q_ok = q < L;
+  constexpr int KS = DK / 16, NT = DK / 32;
+  const float scale = DK == 64 ? 0.125f : 0.17677669529663687f;  // 1 / sqrt(dk)
+  const AttnDrop dk_ = make_attn_drop(seed, stream_id, (uint32_t)(b * H + h), p_drop);
+  const uint32_t q_part = attn_q_part(dk_, (uint32_t)q);
+
+  f16x8 qf[KS][2];
+  const float iq = load_row_scaled<KS>(base, D3, min(q, L - 1), q_ok, lh, qf);
+  const float cq = scale * LOG2E * iq;  // scores leave the accumulators in log2 units: exp(x) = exp2(x log2 e)
+
+  f32x16 o[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;  // running maximum in log2 units
+  float v_run = 0.f;                     // largest inverse V group scale so far (a power of two; wavefront-uniform)
+
+  Stage<DK> stK, stV;
+  const int ntiles = (L + TR - 1) / TR;
+  auto publish_mask = [&](int k0, int buf) __attribute__((always_inline)) {
+    if (wave == 0) {
+      const int key = k0 + l31;
+      const unsigned long long mk = __ballot(lh == 0 && key < L && sq[key < L ? key : 0] != PTAMD_PAD_ID);
+      if (lane == 0) sMask[buf] = (unsigned int)mk;
+    }
+  };
+  stK.load(base + D, D3, 0, L, tid);
+  stV.load(base + 2 * D, D3, 0, L, tid);
+  stK.store(smem, sInvK[0], 0, L, tid);
+  stV.store(smem + Tile2::ELEMS, sInvV[0], 0, L, tid);
+  publish_mask(0, 0);
+  Stage<DK> nxK, nxV;  // loads run two tiles ahead of the arithmetic (attention_split.hip)
+  stK.load(base + D, D3, TR, L, tid);
+  stV.load(base + 2 * D, D3, TR, L, tid);
+  __syncthreads();
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int k0 = kt * TR, cur = kt & 1;
+    const bool more = kt + 1 < ntiles;
+    const unsigned short *sK = smem + cur * BUF, *sV = sK + Tile2::ELEMS;
+    nxK.load(base + D, D3, k0 + 2 * TR, L, tid);
+    nxV.load(base + 2 * D, D3, k0 + 2 * TR, L, tid);
+    const unsigned int mask = sMask[cur];
+    const float4 ik4 = *reinterpret_cast<const float4 *>(&sInvK[cur][4 * lh]);  // the four key groups of this lane half
+    const float4 iva = *reinterpret_cast<const float4 *>(&sInvV[cur][0]), ivb = *reinterpret_cast<const float4 *>(&sInvV[cur][4]);
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < KS; ++st) {  // S^T[key][q] = K Q^T (scaled operands)
+      f16x8 kf[2];
+      Tile2::frag_rows(sK, st, lane, kf);
+      s = mfma3(kf, qf[st], s);
+    }
+    if (more) {  // scale + split + store the next tile into the other buffer while the soft-max runs
+      unsigned short *nK = smem + (cur ^ 1) * BUF;
+      stK.store(nK, sInvK[cur ^ 1], k0 + TR, L, tid);
+      stV.store(nK + Tile2::ELEMS, sInvV[cur ^ 1], k0 + TR, L, tid);
+      publish_mask(k0 + TR, cur ^ 1);
+    }
+    const float cu[4] = {cq * ik4.x, cq * ik4.y, cq * ik4.z, cq * ik4.w};
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool valid = (mask >> crow(r, lh)) & 1u;
+      const float t = s[r] * cu[r >> 2];  // (the product first: a masked group of zero rows has cu = 0)
+      s[r] = valid ? t : -INFINITY;
+      mt = fmaxf(mt, s[r]);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = __builtin_amdgcn_exp2f(s[r] - m_safe);
+      ps += s[r];
+    }
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+    // common scale of the V groups: O accumulates  sum P (iv_g / v_run) 2^14 * (V sv_g)  =  (2^14 / v_run) sum P V
+    const float vt = fmaxf(fmaxf(fmaxf(iva.x, iva.y), fmaxf(iva.z, iva.w)), fmaxf(fmaxf(ivb.x, ivb.y), fmaxf(ivb.z, ivb.w)));
+    float resc = alpha;
+    if (vt > v_run) {
+      resc *= v_run * inv_pow2(vt);
+      v_run = vt;
+    }
+    if (__builtin_amdgcn_ballot_w64(resc != 1.f)) {  // wave-uniform: after the first tiles neither maximum moves often
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {  // scalar multiplies, kept apart: packed f32 VALU stalls the matrix pipe
+          float v = o[t][r] * resc;
+          asm volatile("" : "+v"(v));
+          o[t][r] = v;
+        }
+    }
+    const float vn = inv_pow2(v_run);
+    const float4 ivh = lh ? ivb : iva;
+    const float fv[4] = {ivh.x * TWO14 * vn, ivh.y * TWO14 * vn, ivh.z * TWO14 * vn, ivh.w * TWO14 * vn};  // <= 2^14
+    if (p_drop > 0.f) {
+      const uint32_t keep = attn_keep_bits_keys_in_rows(dk_, q_part, k0, lh);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = (keep >> r) & 1u ? s[r] : 0.f;  // the 1 / (1 - p) is applied to O at the end
+    }
+    // O^T[d][q] += V^T[d][key] P^T[key][q]: the accumulator rows of s are already in the k order of frag_cols
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const float x[8] = {s[8 * m], s[8 * m + 1], s[8 * m + 2], s[8 * m + 3], s[8 * m + 4], s[8 * m + 5], s[8 * m + 6], s[8 * m + 7]};
+      f16x8 pf[2];
+      split8g(x, fv[2 * m], fv[2 * m + 1], pf);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        f16x8 vf[2];
+        Tile2::frag_cols(sV, 16 * m, 32 * t, lane, vf);
+        o[t] = mfma3(vf, pf, o[t]);
+      }
+    }
+    stK = nxK;
+    stV = nxV;
+    __syncthreads();  // the other buffer is complete; nobody reads this one any more
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  // soft-max normalisation, dropout scale and the common V scale in one factor
+  const float inv = (p_drop > 0.f ? dk_.ks : 1.f) * v_run * INV_TWO14 / l_tot;
+  if (q_ok) {
+    float *op = out + (size_t)(b * L + q) * D + h * DK;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = t * 32 + 8 * g + 4 * lh;
+        *reinterpret_cast<float4 *>(op + d) =
+            make_float4(o[t][4 * g] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
+      }
+    if (lh == 0) lse[((size_t)b * H + h) * L + q] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+  }
+}
+
+// =================================================================================================== backward
+// dQ: same decomposition as the forward kernel.  Also computes delta[q] = sum_d dO[q,d] O[q,d] and publishes it for the
+// dK/dV kernel, which runs after this one on the same stream.
+template <int DK>
+__global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq_f16x2_kernel(
+    const float *__restrict__ qkv, const int64_t *__restrict__ seq, const float *__restrict__ o_fwd,
+    const float *__restrict__ d_o, const float *__restrict__ lse, float *__restrict__ delta, int L, int H, float p_drop,
+    uint64_t seed, uint32_t stream_id, float *__restrict__ dqkv) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  __shared__ unsigned int sMask[2];
+  __shared__ __attribute__((aligned(16))) float sInvK[2][8], sInvV[2][8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB + wave * 32;
+  const int D = H * DK, D3 = 3 * D;
+  const float *base = qkv + (size_t)b * L * D3 + h * DK;
+  const int64_t *sq = seq + (size_t)b * L;
+  const int q = q0 + l31, qc = min(q, L - 1);
+  const bool q_ok = q < L;
+  constexpr int KS = DK / 16, NT = DK / 32;
+  const float scale = DK == 64 ? 0.125f : 0.17677669529663687f;
+  const AttnDrop dk_ = make_attn_drop(seed, stream_id, (uint32_t)(b * H + h), p_drop);
+  const uint32_t q_part = attn_q_part(dk_, (uint32_t)q);
+
+  f16x8 qf[KS][2], gf[KS][2];
+  const float iq = load_row_scaled<KS>(base, D3, qc, q_ok, lh, qf);
+  const float ig = load_row_scaled<KS>(d_o + (size_t)b * L * D + h * DK, D, qc, q_ok, lh, gf);
+  const float my_lse2 = q_ok ? lse[((size_t)b * H + h) * L + q] * LOG2E : 0.f;
+  float my_delta = 0.f;
+  {  // each lane half holds half of the d of its query's row
+    const float *gp = d_o + ((size_t)b * L + qc) * D + h * DK, *op = o_fwd + ((size_t)b * L + qc) * D + h * DK;
+#pragma unroll
+    for (int st = 0; st < KS; ++st)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float4 g4 = *reinterpret_cast<const float4 *>(gp + 16 * st + 8 * lh + 4 * j);
+        const float4 o4 = *reinterpret_cast<const float4 *>(op + 16 * st + 8 * lh + 4 * j);
+        my_delta += g4.x * o4.x + g4.y * o4.y + g4.z * o4.z + g4.w * o4.w;
+      }
+    my_delta += __shfl_xor(my_delta, 32, 64);
+    if (!q_ok) my_delta = 0.f;
+    if (q_ok && lh == 0) delta[((size_t)b * H + h) * L + q] = my_delta;
+  }
+  const float cq = scale * LOG2E * iq;
+  const float gq = ig * (p_drop > 0.f ? dk_.ks : 1.f);
+
+  f32x16 dq[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[t][r] = 0.f;
+  float bscale = BSCALE0;  // common power of two of the dS operand (per query = per accumulator column)
+
+  Stage<DK> stK, stV;
+  const int ntiles = (L + TR - 1) / TR;
+  auto publish_mask = [&](int k0, int buf) __attribute__((always_inline)) {
+    if (wave == 0) {
+      const int key = k0 + l31;
+      const unsigned long long mk = __ballot(lh == 0 && key < L && sq[key < L ? key : 0] != PTAMD_PAD_ID);
+      if (lane == 0) sMask[buf] = (unsigned int)mk;
+    }
+  };
+  stK.load(base + D, D3, 0, L, tid);
+  stV.load(base + 2 * D, D3, 0, L, tid);
+  stK.store(smem, sInvK[0], 0, L, tid);
+  stV.store(smem + Tile2::ELEMS, sInvV[0], 0, L, tid);
+  publish_mask(0, 0);
+  Stage<DK> nxK, nxV;
+  stK.load(base + D, D3, TR, L, tid);
+  stV.load(base + 2 * D, D3, TR, L, tid);
+  __syncthreads();
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int k0 = kt * TR, cur = kt & 1;
+    const bool more = kt + 1 < ntiles;
+    const unsigned short *sK = smem + cur * BUF, *sV = sK + Tile2::ELEMS;
+    nxK.load(base + D, D3, k0 + 2 * TR, L, tid);
+    nxV.load(base + 2 * D, D3, k0 + 2 * TR, L, tid);
+    const unsigned int mask = sMask[cur];
+    const float4 ik4 = *reinterpret_cast<const float4 *>(&sInvK[cur][4 * lh]);
+    const float4 iv4 = *reinterpret_cast<const float4 *>(&sInvV[cur][4 * lh]);
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < KS; ++st) {
+      f16x8 kf[2], vf[2];
+      Tile2::frag_rows(sK, st, lane, kf);
+      Tile2::frag_rows(sV, st, lane, vf);
+      s = mfma3(kf, qf[st], s);     // S^T[key][q]
+      dp = mfma3(vf, gf[st], dp);   // dP^T[key][q] = V dO^T
+    }
+    if (more) {
+      unsigned short *nK = smem + (cur ^ 1) * BUF;
+      stK.store(nK, sInvK[cur ^ 1], k0 + TR, L, tid);
+      stV.store(nK + Tile2::ELEMS, sInvV[cur ^ 1], k0 + TR, L, tid);
+      publish_mask(k0 + TR, cur ^ 1);
+    }
+    const float ik[4] = {ik4.x, ik4.y, ik4.z, ik4.w}, iv[4] = {iv4.x, iv4.y, iv4.z, iv4.w};
+    float cu[4], ug[4], wk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      cu[j] = cq * ik[j];      // accumulator -> log2-unit score
+      ug[j] = gq * iv[j];      // accumulator -> dP (with the dropout scale)
+      wk[j] = scale * ik[j];   // dS -> dS / (K group scale): the operand of the product with the SCALED K^T
+    }
+    const uint32_t keep = p_drop > 0.f ? attn_keep_bits_keys_in_rows(dk_, q_part, k0, lh) : 0xffffu;
+    float wmax = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kk = crow(r, lh), j = r >> 2;
+      const bool valid = (mask >> kk) & 1u;
+      // (the mask goes into the ARGUMENT, exp2(-inf) = 0: a select around the exp would become a branch per element)
+      const float p = __builtin_amdgcn_exp2f(valid ? fmaf(s[r], cu[j], -my_lse2) : -INFINITY);
+      float g = dp[r] * ug[j];
+      if (p_drop > 0.f) g = (keep >> r) & 1u ? g : 0.f;
+      s[r] = p * (g - my_delta) * wk[j];
+      wmax = fmaxf(wmax, fabsf(s[r]));
+    }
+    wmax = fmaxf(wmax, __shfl_xor(wmax, 32, 64));
+    const float ratio = online_scale(wmax, bscale);
+    if (__builtin_amdgcn_ballot_w64(ratio != 1.f)) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = dq[t][r] * ratio;
+          asm volatile("" : "+v"(v));
+          dq[t][r] = v;
+        }
+    }
+    // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const float x[8] = {s[8 * m], s[8 * m + 1], s[8 * m + 2], s[8 * m + 3], s[8 * m + 4], s[8 * m + 5], s[8 * m + 6], s[8 * m + 7]};
+      f16x8 df[2];
+      split8g(x, bscale, bscale, df);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        f16x8 kt_[2];
+        Tile2::frag_cols(sK, 16 * m, 32 * t, lane, kt_);
+        dq[t] = mfma3(kt_, df, dq[t]);
+      }
+    }
+    stK = nxK;
+    stV = nxV;
+    __syncthreads();
+  }
+  if (q_ok) {
+    const float un = inv_pow2(bscale);
+    float *op = dqkv + (size_t)(b * L + q) * D3 + h * DK;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = t * 32 + 8 * g + 4 * lh;
+        *reinterpret_cast<float4 *>(op + d) =
+            make_float4(dq[t][4 * g] * un, dq[t][4 * g + 1] * un, dq[t][4 * g + 2] * un, dq[t][4 * g + 3] * un);
+      }
+  }
+}
+
+// dK, dV: one workgroup = 256 keys of one (protein, head); lane column = key.  The scaled K and V rows of a lane's key
+// stay in registers as B operands; Q and dO tiles of 32 queries stream through LDS and serve both as row fragments
+// (S = Q K^T, dP = dO V^T) and as transposed fragments (dK^T += Q^T dS, dV^T += dO^T Pd).
+template <int DK>
+__global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv_f16x2_kernel(
+    const float *__restrict__ qkv, const int64_t *__restrict__ seq, const float *__restrict__ d_o,
+    const float *__restrict__ lse, const float *__restrict__ delta, int L, int H, float p_drop, uint64_t seed,
+    uint32_t stream_id, float *__restrict__ dqkv) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  __shared__ __attribute__((aligned(16))) float sLse[2][TR], sDel[2][TR];
+  __shared__ __attribute__((aligned(16))) float sInvQ[2][8], sInvG[2][8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * QB + wave * 32;
+  const int D = H * DK, D3 = 3 * D;
+  const float *base = qkv + (size_t)b * L * D3 + h * DK;
+  const float *gbase = d_o + (size_t)b * L * D + h * DK;
+  const float *lse_b = lse + ((size_t)b * H + h) * L, *del_b = delta + ((size_t)b * H + h) * L;
+  const int key = key0 + l31;
+  const bool k_ok = key < L;
+  const bool k_valid = k_ok && seq[(size_t)b * L + key] != PTAMD_PAD_ID;
+  constexpr int KS = DK / 16, NT = DK / 32;
+  const float scale = DK == 64 ? 0.125f : 0.17677669529663687f;
+  const AttnDrop dk_ = make_attn_drop(seed, stream_id, (uint32_t)(b * H + h), p_drop);
+  const float ks = p_drop > 0.f ? dk_.ks : 1.f;
+
+  f16x8 kf[KS][2], vf[KS][2];
+  const float ikl = load_row_scaled<KS>(base + D, D3, min(key, L - 1), k_ok, lh, kf);
+  const float ivl = load_row_scaled<KS>(base + 2 * D, D3, min(key, L - 1), k_ok, lh, vf);
+  const float ck = scale * LOG2E * ikl, gk = ivl * ks;
+
+  f32x16 dk[NT], dv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk[t][r] = dv[t][r] = 0.f;
+  float bscale = BSCALE0;  // common power of two of the dS operand (per key = per accumulator column)
+  float g_run = 0.f;       // largest inverse dO group scale so far (wavefront-uniform)
+
+  Stage<DK> stQ, stG;
+  const int ntiles = (L + TR - 1) / TR;
+  float r_lse = 0.f, r_del = 0.f;
+  stQ.load(base, D3, 0, L, tid);
+  stG.load(gbase, D, 0, L, tid);
+  stQ.store(smem, sInvQ[0], 0, L, tid);
+  stG.store(smem + Tile2::ELEMS, sInvG[0], 0, L, tid);
+  if (tid < TR) {
+    sLse[0][tid] = tid < L ? lse_b[tid] * LOG2E : 0.f;
+    sDel[0][tid] = tid < L ? del_b[tid] : 0.f;
+  }
+  Stage<DK> nxQ, nxG;
+  stQ.load(base, D3, TR, L, tid);
+  stG.load(gbase, D, TR, L, tid);
+  __syncthreads();
+
+  for (int qt = 0; qt < ntiles; ++qt) {
+    const int qq0 = qt * TR, cur = qt & 1;
+    const bool more = qt + 1 < ntiles;
+    const unsigned short *sQ = smem + cur * BUF, *sG = sQ + Tile2::ELEMS;
+    nxQ.load(base, D3, qq0 + 2 * TR, L, tid);
+    nxG.load(gbase, D, qq0 + 2 * TR, L, tid);
+    if (more) {
+      if (tid < TR) {
+        const int qn = qq0 + TR + tid;
+        r_lse = qn < L ? lse_b[qn] * LOG2E : 0.f;
+        r_del = qn < L ? del_b[qn] : 0.f;
+      }
+    }
+    const float4 iq4 = *reinterpret_cast<const float4 *>(&sInvQ[cur][4 * lh]);
+    const float4 iga = *reinterpret_cast<const float4 *>(&sInvG[cur][0]), igb = *reinterpret_cast<const float4 *>(&sInvG[cur][4]);
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < KS; ++st) {
+      f16x8 qa[2], ga[2];
+      Tile2::frag_rows(sQ, st, lane, qa);
+      Tile2::frag_rows(sG, st, lane, ga);
+      s = mfma3(qa, kf[st], s);     // S[q][key]
+      dp = mfma3(ga, vf[st], dp);   // dP[q][key] = dO V^T
+    }
+    if (more) {
+      unsigned short *nQ = smem + (cur ^ 1) * BUF;
+      stQ.store(nQ, sInvQ[cur ^ 1], qq0 + TR, L, tid);
+      stG.store(nQ + Tile2::ELEMS, sInvG[cur ^ 1], qq0 + TR, L, tid);
+      if (tid < TR) {
+        sLse[cur ^ 1][tid] = r_lse;
+        sDel[cur ^ 1][tid] = r_del;
+      }
+    }
+    // common scale of the dO groups: dV accumulates (2^14 / g_run) sum Pd dO
+    const float gt = fmaxf(fmaxf(fmaxf(iga.x, iga.y), fmaxf(iga.z, iga.w)), fmaxf(fmaxf(igb.x, igb.y), fmaxf(igb.z, igb.w)));
+    if (gt > g_run) {  // (wavefront-uniform)
+      const float resc = g_run * inv_pow2(gt);
+      g_run = gt;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = dv[t][r] * resc;
+          asm volatile("" : "+v"(v));
+          dv[t][r] = v;
+        }
+    }
+    const float gn = inv_pow2(g_run) * TWO14;
+    const float4 igh = lh ? igb : iga;
+    const float iq[4] = {iq4.x, iq4.y, iq4.z, iq4.w}, ig[4] = {igh.x, igh.y, igh.z, igh.w};
+    float cu[4], ug[4], wq[4], fp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      cu[j] = ck * iq[j];
+      ug[j] = gk * ig[j];
+      wq[j] = scale * iq[j];
+      fp[j] = ig[j] * gn;  // <= 2^14
+    }
+    f32x16 pd;  // dropped probabilities (operand of dV), without the 1 / (1 - p): that is applied to dV at the end
+    const uint32_t keepbits = p_drop > 0.f ? attn_keep_bits_queries_in_rows(dk_, (uint32_t)key, qq0, lh) : 0xffffu;
+    float wmax = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = crow(r, lh), qg = qq0 + qi, j = r >> 2;
+      const bool ok = k_valid && qg < L;
+      const float my_l = sLse[cur][qi], my_d = sDel[cur][qi];  // (LDS broadcast reads: registers are the scarce resource here)
+      const float p = __builtin_amdgcn_exp2f(ok ? fmaf(s[r], cu[j], -my_l) : -INFINITY);
+      float g = dp[r] * ug[j], pk = p;
+      if (p_drop > 0.f) {
+        const bool keep = (keepbits >> r) & 1u;
+        g = keep ? g : 0.f;
+        pk = keep ? p : 0.f;
+      }
+      pd[r] = pk;
+      s[r] = p * (g - my_d) * wq[j];  // dS[q][key] / (Q group scale)
+      wmax = fmaxf(wmax, fabsf(s[r]));
+    }
+    wmax = fmaxf(wmax, __shfl_xor(wmax, 32, 64));
+    const float ratio = online_scale(wmax, bscale);
+    if (__builtin_amdgcn_ballot_w64(ratio != 1.f)) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = dk[t][r] * ratio;
+          asm volatile("" : "+v"(v));
+          dk[t][r] = v;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const float xs[8] = {s[8 * m], s[8 * m + 1], s[8 * m + 2], s[8 * m + 3], s[8 * m + 4], s[8 * m + 5], s[8 * m + 6], s[8 * m + 7]};
+      const float xp[8] = {pd[8 * m], pd[8 * m + 1], pd[8 * m + 2], pd[8 * m + 3], pd[8 * m + 4], pd[8 * m + 5], pd[8 * m + 6], pd[8 * m + 7]};
+      f16x8 dsf[2], pdf[2];
+      split8g(xs, bscale, bscale, dsf);
+      split8g(xp, fp[2 * m], fp[2 * m + 1], pdf);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        f16x8 qt_[2], gt_[2];
+        Tile2::frag_cols(sQ, 16 * m, 32 * t, lane, qt_);
+        dk[t] = mfma3(qt_, dsf, dk[t]);   // dK^T[d][key] += Q^T dS
+        Tile2::frag_cols(sG, 16 * m, 32 * t, lane, gt_);
+        dv[t] = mfma3(gt_, pdf, dv[t]);   // dV^T[d][key] += dO^T Pd
+      }
+    }
+    stQ = nxQ;
+    stG = nxG;
+    __syncthreads();
+  }
+  if (k_ok) {
+    const float uk = inv_pow2(bscale), uv = ks * g_run * INV_TWO14;
+    float *okp = dqkv + (size_t)(b * L + key) * D3 + D + h * DK, *ovp = okp + D;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = t * 32 + 8 * g + 4 * lh;
+        *reinterpret_cast<float4 *>(okp + d) =
+            make_float4(dk[t][4 * g] * uk, dk[t][4 * g + 1] * uk, dk[t][4 * g + 2] * uk, dk[t][4 * g + 3] * uk);
+        *reinterpret_cast<float4 *>(ovp + d) =
+            make_float4(dv[t][4 * g] * uv, dv[t][4 * g + 1] * uv, dv[t][4 * g + 2] * uv, dv[t][4 * g + 3] * uv);
+      }
+  }
+}
+
+template <typename K>
+static int set_lds(K kernel) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)ATTN_LDS);
+  if (e != hipSuccess) {
+    g_pt_last_hip_error = e;
+    return PTAMD_ERR_HIP;
+  }
+  return PTAMD_OK;
+}
+}  // namespace ptattn16
+
+int pt_attention_fwd_f16x2(const float *qkv, const int64_t *seq, int B, int L, int H, int dk, float p, uint64_t seed,
+                           uint32_t sid, float *out, float *lse, hipStream_t st) {
+  using namespace ptattn16;
+  const dim3 grid((L + QB - 1) / QB, H, B);
+  if (dk == 64) {
+    if (int rc = set_lds(attn_fwd_f16x2_kernel<64>)) return rc;  // idempotent, host-only: no state kept between calls
+    hipLaunchKernelGGL(attn_fwd_f16x2_kernel<64>, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, L, H, p, seed, sid, out, lse);
+  } else {
+    if (int rc = set_lds(attn_fwd_f16x2_kernel<32>)) return rc;
+    hipLaunchKernelGGL(attn_fwd_f16x2_kernel<32>, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, L, H, p, seed, sid, out, lse);
+  }
+  return pt_check_launch();
+}
+
+int pt_attention_bwd_f16x2(const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse,
+                           float *delta, int B, int L, int H, int dk, float p, uint64_t seed, uint32_t sid, float *dqkv,
+                           hipStream_t st) {
+  using namespace ptattn16;
+  const dim3 grid((L + QB - 1) / QB, H, B);
+  if (dk == 64) {
+    if (int rc = set_lds(attn_bwd_dq_f16x2_kernel<64>)) return rc;
+    if (int rc = set_lds(attn_bwd_dkv_f16x2_kernel<64>)) return rc;
+    hipLaunchKernelGGL(attn_bwd_dq_f16x2_kernel<64>, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, o_fwd, d_o, lse, delta, L, H, p,
+                       seed, sid, dqkv);
+    if (int rc = pt_check_launch()) return rc;
+    hipLaunchKernelGGL(attn_bwd_dkv_f16x2_kernel<64>, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, d_o, lse, delta, L, H, p, seed,
+                       sid, dqkv);
+  } else {
+    if (int rc = set_lds(attn_bwd_dq_f16x2_kernel<32>)) return rc;
+    if (int rc = set_lds(attn_bwd_dkv_f16x2_kernel<32>)) return rc;
+    hipLaunchKernelGGL(attn_bwd_dq_f16x2_kernel<32>, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, o_fwd, d_o, lse, delta, L, H, p,
+                       seed, sid, dqkv);
+    if (int rc = pt_check_launch()) return rc;
+    hipLaunchKernelGGL(attn_bwd_dkv_f16x2_kernel<32>, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, d_o, lse, delta, L, H, p, seed,
+                       sid, dqkv);
+  }
+  return pt_check_launch();
+}

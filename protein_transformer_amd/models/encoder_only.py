@@ -147,6 +147,7 @@ class _TransformerBase(nn.Module):
         self.dropout_seed = 0x5DEECE66D
         self._step_counter = 0
         self.grad_hook = None                        # called with (offset, numel) as soon as a gradient slice is final
+        self.attn_mode = None                        # arithmetic of the attention kernels alone (ablations); None = gemm_mode
         self.gemm_mode = None                        # kernels.GEMM_* arithmetic of THIS model; None = kernels.get_gemm_mode()
         self._init_parameters()
 
@@ -399,7 +400,7 @@ class _EncoderFn(torch.autograd.Function):
             h1, mean1, rstd1 = K.layernorm_fwd(x, W(b + "sublayer_connections.0.norm.weight"),
                                                W(b + "sublayer_connections.0.norm.bias"), row_scale=s_h1)
             qkv = K.linear_fwd(h1, wqkv, bqkv, arith=ar, a_scale=s_h1, b_scale=sc and sc["rs_qkv"])
-            att, lse = K.attention_fwd(qkv, seq, H, pa, seed, sid + _SITE_ATTN, arith=ar)
+            att, lse = K.attention_fwd(qkv, seq, H, pa, seed, sid + _SITE_ATTN, arith=ar if m.attn_mode is None else m.attn_mode)
             x2 = K.linear_fwd(att, W(b + "self_attn.wo.weight"), W(b + "self_attn.wo.bias"), residual=x, ldr=D,
                               dropout_p=p, seed=seed, stream_id=sid + _SITE_ATTN_OUT, arith=ar,
                               a_scale=sc and sc["att_scale"], a_scale_stride=0, b_scale=sc and sc["rs_o"])
@@ -484,7 +485,8 @@ class _EncoderFn(torch.autograd.Function):
             K.linear_bwd_weight(dyo, att, G(b + "self_attn.wo.weight"), G(b + "self_attn.wo.bias"), arith=ar,
                                 dy_scale=sc["dyo_min"] if uni_o else None, x_scale=sc["att_scale"] if uni_o else None)
             datt = K.linear_bwd_input(dyo, W(b + "self_attn.wo.weight"), arith=ar, a_scale=s_dyo, b_scale=sc and sc["cs_o"])
-            dqkv = K.attention_bwd(qkv, seq, att, datt, lse, H, pa, seed, sid + _SITE_ATTN, arith=ar)
+            dqkv = K.attention_bwd(qkv, seq, att, datt, lse, H, pa, seed, sid + _SITE_ATTN,
+                                    arith=ar if m.attn_mode is None else m.attn_mode)
             gw, gb = m._qkv(gflat, i)
             wqkv, _ = m._qkv(flat, i)
             if sc is not None:   # one pass over dqkv gives its row scales (A of the dX product) and its largest |value| (-> the

@@ -434,6 +434,64 @@ def test_attention_dropout_consistency(dev, gemm_mode, dk):
     assert_close(dqkv, ref, 1e-4, 5e-6 * max(1.0, ref.abs().max().item()), "attention bwd (dropout)")
 
 
+@pytest.mark.parametrize("B,L,H,dk", [(2, 512, 8, 64), (3, 300, 4, 32)])
+def test_attention_f16x2_wide_row_ranges(dev, B, L, H, dk):
+    """The two-term f16 kernels scale K / V / Q / dO per row (lanes) or per group of four rows (LDS tiles) and adapt the
+    common power of two of the probability / dS operands on line: rows whose magnitudes span five decades (V 1e-3..10,
+    K 1e-2..3, dO 1e-8..1e-4) must come out as accurately as with the exact three-term bf16 kernels (norm-wise, against
+    dense fp64 attention; measured 3..6e-7 in every arithmetic - profiles/tools/r02_attn_accuracy.py)."""
+    from protein_transformer_amd import kernels as K_
+    g = torch.Generator().manual_seed(11)
+    D = H * dk
+    qkv = torch.randn(B, L, 3 * D, generator=g, dtype=torch.float64)
+    dout = torch.randn(B, L, D, generator=g, dtype=torch.float64)
+    qkv[:, :, D:2 * D] *= 10 ** (torch.rand(B, L, 1, generator=g, dtype=torch.float64) * 2.5 - 2)
+    qkv[:, :, 2 * D:] *= 10 ** (torch.rand(B, L, 1, generator=g, dtype=torch.float64) * 4 - 3)
+    dout *= 10 ** (torch.rand(B, L, 1, generator=g, dtype=torch.float64) * 4 - 8)
+    qkv = qkv.float().double().requires_grad_()
+    dout = dout.float().double()
+    seq = torch.randint(0, 20, (B, L), generator=g)
+    seq[-1, L - 37:] = 20
+    out, _ = ref_attention(qkv, seq != 20, H)
+    out.backward(dout)
+    qd = qkv.detach().float().view(B * L, 3 * D).to(dev)
+    o, lse = K_.attention_fwd(qd, seq.to(dev), H, 0.0, 0, 0, arith=K_.GEMM_F16X2)
+    dq = K_.attention_bwd(qd, seq.to(dev), o, dout.float().view(B * L, D).to(dev), lse, H, 0.0, 0, 0, arith=K_.GEMM_F16X2)
+    assert torch.isfinite(o).all() and torch.isfinite(dq).all()
+
+    def rel(a, b):
+        return ((a.double().cpu() - b).norm() / b.norm()).item()
+    assert rel(o.view(B, L, D), out.detach()) < 2e-6
+    gr = qkv.grad
+    for i, name in enumerate(("dQ", "dK", "dV")):
+        assert rel(dq.view(B, L, 3 * D)[:, :, i * D:(i + 1) * D], gr[:, :, i * D:(i + 1) * D]) < 2e-6, name
+
+
+def test_attention_f16x2_degenerate_rows(dev):
+    """All-zero K / V rows (scale groups with maximum 0), a fully padded 32-key tile and huge / tiny magnitudes: finite
+    results equal to the exact-f32 kernels' to rounding."""
+    from protein_transformer_amd import kernels as K_
+    B, L, H, dk = 2, 160, 2, 64
+    D = H * dk
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(B, L, 3 * D, generator=g)
+    qkv[0, 32:72, D:] = 0.0                      # zero K and V rows: whole scale groups and a whole tile of them
+    qkv[1, :, 2 * D:] *= 3000.0                  # large V
+    qkv[1, 5:9, 2 * D:] *= 1e-12                 # one tiny group inside
+    seq = torch.randint(0, 20, (B, L), generator=g)
+    seq[1, 96:] = 20                             # keys 96..159 padded: tiles 3 and 4 fully masked
+    dout = torch.randn(B, L, D, generator=g) * 1e-20
+    qd = qkv.view(B * L, 3 * D).to(dev)
+    res = {}
+    for mode in (K_.GEMM_F32, K_.GEMM_F16X2):
+        o, lse = K_.attention_fwd(qd, seq.to(dev), H, 0.0, 0, 0, arith=mode)
+        dq = K_.attention_bwd(qd, seq.to(dev), o, dout.view(B * L, D).to(dev), lse, H, 0.0, 0, 0, arith=mode)
+        assert torch.isfinite(o).all() and torch.isfinite(dq).all() and torch.isfinite(lse).all()
+        res[mode] = (o.double().cpu(), dq.double().cpu(), lse.double().cpu())
+    for a, b in zip(res[K_.GEMM_F32], res[K_.GEMM_F16X2]):
+        assert ((a - b).norm() / b.norm()).item() < 3e-6
+
+
 # ------------------------------------------------------------------------------------------------ optimizer
 @pytest.mark.parametrize("n", [1000003, 4096])
 def test_clip_and_sgd_adam(dev, n):
