@@ -284,9 +284,14 @@ size_t ptamd_embed_bwd_workspace_bytes(int D);
 int ptamd_embed_bwd(const int64_t *seq, const float *dout, int B, int L, int D, float dropout_p, uint64_t seed,
                     float *demb, void *workspace, size_t workspace_bytes, void *stream);
 
-/* Fused masked multi-head attention (Attention.py:14-22,55-69), scores never materialised.  `arith`: PTAMD_GEMM_F32 =
- * the exact-f32 MFMA kernels; anything else = operands split exactly into three bf16 terms on the bf16 matrix pipe
- * (six products, f32 accumulate) where a split kernel exists for the head size, the exact-f32 kernels otherwise.
+/* Fused masked multi-head attention (Attention.py:14-22,55-69), scores never materialised.  `arith` (head sizes 64
+ * and 32; other head sizes always run the exact-f32 kernels):
+ *   PTAMD_GEMM_F32                 the exact-f32 MFMA kernels;
+ *   PTAMD_GEMM_BF16X3 / _FULL      operands split exactly into three bf16 terms, six products on the bf16 matrix pipe;
+ *   PTAMD_GEMM_F16X2 / _AUTO       operands scaled by powers of two and split into two f16 terms, three products on the
+ *                                  f16 matrix pipe (the f16x2 error model of ptamd_gemm: relative to the largest element of
+ *                                  a scaling group - one Q / dO / K / V row, or four staged rows - instead of to every
+ *                                  element); the scales are found inside the kernels, nothing is added to the interface.
  *   qkv [T,3D]: Q | K | V column blocks, head h at columns h*dk..; key-padding mask from seq != 20;
  *   softmax(QK^T/sqrt(dk)) with dropout p on the probabilities; out [T,D] heads merged.
  *   lse [B,H,L] saves log-sum-exp per query row for the backward. dk must be 32 or 64. */

@@ -22,6 +22,7 @@ OBJ_DIR = os.path.join(CSRC, "build")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", f"-I{INCLUDE}"]
+FLAGS += os.environ.get("PTAMD_EXTRA_FLAGS", "").split()      # ablation builds (e.g. -DPT_NO_MIX_SPLIT), part of the object digest
 
 
 def hipcc():
