@@ -294,12 +294,16 @@ int ptamd_embed_bwd(const int64_t *seq, const float *dout, int B, int L, int D, 
  *                                  element); the scales are found inside the kernels, nothing is added to the interface.
  *   qkv [T,3D]: Q | K | V column blocks, head h at columns h*dk..; key-padding mask from seq != 20;
  *   softmax(QK^T/sqrt(dk)) with dropout p on the probabilities; out [T,D] heads merged.
- *   lse [B,H,L] saves log-sum-exp per query row for the backward. dk must be 32 or 64. */
+ *   lse [B,H,L] saves log-sum-exp per query row for the backward. dk must be 32 or 64.
+ *   ptamd_attention_bwd, row_scale [T] / row_scale_min [4] (optional, both or only the first; f16x2 arithmetic with
+ *   dk 32 / 64 only, PTAMD_ERR_BAD_SHAPE otherwise): the f16x2 row scales of dqkv (ptamd_gemm a_scale) and the smallest
+ *   of them (4 copies: a uniform scale, stride 0), accumulated with atomicMin - preset both to 0x7F000000. */
 int ptamd_attention_fwd(const float *qkv, const int64_t *seq, int B, int L, int H, int dk, float dropout_p,
                         uint64_t seed, uint32_t stream_id, int arith, float *out, float *lse, void *stream);
 int ptamd_attention_bwd(const float *qkv, const int64_t *seq, const float *out, const float *dout, const float *lse,
                         int B, int L, int H, int dk, float dropout_p, uint64_t seed, uint32_t stream_id, int arith,
-                        float *dqkv, void *workspace, size_t workspace_bytes, void *stream);
+                        float *dqkv, uint32_t *row_scale, uint32_t *row_scale_min, void *workspace,
+                        size_t workspace_bytes, void *stream);
 size_t ptamd_attention_workspace_bytes(int B, int L, int H, int dk);
 
 /* column sums: out[N] (+)= sum_t x[t,N]   (bias gradients) */

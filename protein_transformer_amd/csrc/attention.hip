@@ -30,7 +30,7 @@ int pt_attention_fwd_f16x2(const float *qkv, const int64_t *seq, int B, int L, i
                            uint32_t sid, float *out, float *lse, hipStream_t st);
 int pt_attention_bwd_f16x2(const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse,
                            float *delta, int B, int L, int H, int dk, float p, uint64_t seed, uint32_t sid, float *dqkv,
-                           hipStream_t st);
+                           uint32_t *row_scale, uint32_t *row_min, hipStream_t st);
 
 namespace {
 
@@ -511,7 +511,8 @@ int ptamd_attention_fwd(const float *qkv, const int64_t *seq, int B, int L, int 
 
 int ptamd_attention_bwd(const float *qkv, const int64_t *seq, const float *out, const float *dout, const float *lse,
                         int B, int L, int H, int dk, float dropout_p, uint64_t seed, uint32_t stream_id, int arith,
-                        float *dqkv, void *workspace, size_t workspace_bytes, void *stream) {
+                        float *dqkv, uint32_t *row_scale, uint32_t *row_scale_min, void *workspace,
+                        size_t workspace_bytes, void *stream) {
   if (B <= 0 || L <= 0 || H <= 0 || arith < PTAMD_GEMM_F32 || arith > PTAMD_GEMM_AUTO) return PTAMD_ERR_BAD_SHAPE;
   if (dropout_p < 0.f || dropout_p >= 1.f) return PTAMD_ERR_BAD_SHAPE;
   if (!workspace || workspace_bytes < ptamd_attention_workspace_bytes(B, L, H, dk)) return PTAMD_ERR_WORKSPACE;
@@ -519,7 +520,9 @@ int ptamd_attention_bwd(const float *qkv, const int64_t *seq, const float *out, 
   hipStream_t st = (hipStream_t)stream;
   float *delta = static_cast<float *>(workspace);
   if ((dk == 64 || dk == 32) && (arith == PTAMD_GEMM_AUTO || arith == PTAMD_GEMM_F16X2))
-    return pt_attention_bwd_f16x2(qkv, seq, out, dout, lse, delta, B, L, H, dk, dropout_p, seed, stream_id, dqkv, st);
+    return pt_attention_bwd_f16x2(qkv, seq, out, dout, lse, delta, B, L, H, dk, dropout_p, seed, stream_id, dqkv, row_scale,
+                                  row_scale ? row_scale_min : nullptr, st);
+  if (row_scale || row_scale_min) return PTAMD_ERR_BAD_SHAPE;  // the scales are a by-product of the f16x2 kernels only
   if ((dk == 64 || dk == 32) && arith != PTAMD_GEMM_F32)
     return pt_attention_bwd_split(qkv, seq, out, dout, lse, delta, B, L, H, dk, dropout_p, seed, stream_id, dqkv, st);
   switch (dk) {

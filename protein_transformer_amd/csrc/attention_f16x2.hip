@@ -182,6 +182,27 @@ __device__ __forceinline__ float online_scale(float m, float &bscale) {
   }
   return ratio;
 }
+// Row scales of dqkv for the f16x2 products that consume it (ptamd_gemm a_scale / uniform scale), so that no pass over
+// dqkv is needed: a lane pair holds one row of one head's block; the f16x2 row scale is a decreasing function of the
+// row maximum, so the blocks of a row combine by atomicMin on targets the caller preset to 0x7F000000.  row_min[0..3]
+// receive the smallest scale of all rows (the uniform scale of dqkv as an operand of the weight-gradient product).
+__device__ __forceinline__ void publish_row_scale(float amax, bool ok, int row, int tid, uint32_t *__restrict__ row_scale,
+                                                  uint32_t *__restrict__ row_min, unsigned int *__restrict__ s_min) {
+  const int lane = tid & 63;
+  amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+  uint32_t sb = ok ? pt_row_scale_bits(__float_as_uint(amax)) : 0x7F000000u;
+  if (ok && lane < 32) atomicMin(row_scale + row, sb);
+  if (row_min) {  // one global atomic per workgroup and copy: the wavefronts meet in LDS first
+    if (tid == 0) *s_min = 0x7F000000u;
+    __syncthreads();
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) sb = min(sb, (uint32_t)__shfl_xor((int)sb, o, 64));
+    if (lane == 0) atomicMin(s_min, sb);
+    __syncthreads();
+    if (tid < 4) atomicMin(row_min + tid, *s_min);
+  }
+}
+
 constexpr float BSCALE0 = 1.329227995784916e36f;  // 2^120
 
 constexpr int BUF = 2 * Tile2::ELEMS;  // f16 elements of one {A, B} tile buffer
@@ -350,7 +371,8 @@ template <int DK>
 __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq_f16x2_kernel(
     const float *__restrict__ qkv, const int64_t *__restrict__ seq, const float *__restrict__ o_fwd,
     const float *__restrict__ d_o, const float *__restrict__ lse, float *__restrict__ delta, int L, int H, float p_drop,
-    uint64_t seed, uint32_t stream_id, float *__restrict__ dqkv) {
+    uint64_t seed, uint32_t stream_id, float *__restrict__ dqkv, uint32_t *__restrict__ row_scale,
+    uint32_t *__restrict__ row_min) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   __shared__ unsigned int sMask[2];
   __shared__ __attribute__((aligned(16))) float sInvK[2][8], sInvV[2][8];
@@ -490,8 +512,8 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
     stV = nxV;
     __syncthreads();
   }
+  const float un = inv_pow2(bscale);
   if (q_ok) {
-    const float un = inv_pow2(bscale);
     float *op = dqkv + (size_t)(b * L + q) * D3 + h * DK;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -502,6 +524,14 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
             make_float4(dq[t][4 * g] * un, dq[t][4 * g + 1] * un, dq[t][4 * g + 2] * un, dq[t][4 * g + 3] * un);
       }
   }
+  if (row_scale) {
+    float am = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) am = fmaxf(am, fabsf(dq[t][r]));
+    publish_row_scale(am * un, q_ok, b * L + q, tid, row_scale, row_min, &sMask[0]);
+  }
 }
 
 // dK, dV: one workgroup = 256 keys of one (protein, head); lane column = key.  The scaled K and V rows of a lane's key
@@ -511,10 +541,11 @@ template <int DK>
 __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv_f16x2_kernel(
     const float *__restrict__ qkv, const int64_t *__restrict__ seq, const float *__restrict__ d_o,
     const float *__restrict__ lse, const float *__restrict__ delta, int L, int H, float p_drop, uint64_t seed,
-    uint32_t stream_id, float *__restrict__ dqkv) {
+    uint32_t stream_id, float *__restrict__ dqkv, uint32_t *__restrict__ row_scale, uint32_t *__restrict__ row_min) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   __shared__ __attribute__((aligned(16))) float sLse[2][TR], sDel[2][TR];
   __shared__ __attribute__((aligned(16))) float sInvQ[2][8], sInvG[2][8];
+  __shared__ unsigned int sMin;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * QB + wave * 32;
   const int D = H * DK, D3 = 3 * D;
@@ -669,8 +700,19 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
     stG = nxG;
     __syncthreads();
   }
+  const float uk = inv_pow2(bscale), uv = ks * g_run * INV_TWO14;
+  if (row_scale) {
+    float ak = 0.f, av = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        ak = fmaxf(ak, fabsf(dk[t][r]));
+        av = fmaxf(av, fabsf(dv[t][r]));
+      }
+    publish_row_scale(fmaxf(ak * uk, av * uv), k_ok, b * L + key, tid, row_scale, row_min, &sMin);
+  }
   if (k_ok) {
-    const float uk = inv_pow2(bscale), uv = ks * g_run * INV_TWO14;
     float *okp = dqkv + (size_t)(b * L + key) * D3 + D + h * DK, *ovp = okp + D;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -713,25 +755,25 @@ int pt_attention_fwd_f16x2(const float *qkv, const int64_t *seq, int B, int L, i
 
 int pt_attention_bwd_f16x2(const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse,
                            float *delta, int B, int L, int H, int dk, float p, uint64_t seed, uint32_t sid, float *dqkv,
-                           hipStream_t st) {
+                           uint32_t *row_scale, uint32_t *row_min, hipStream_t st) {
   using namespace ptattn16;
   const dim3 grid((L + QB - 1) / QB, H, B);
   if (dk == 64) {
     if (int rc = set_lds(attn_bwd_dq_f16x2_kernel<64>)) return rc;
     if (int rc = set_lds(attn_bwd_dkv_f16x2_kernel<64>)) return rc;
     hipLaunchKernelGGL(attn_bwd_dq_f16x2_kernel<64>, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, o_fwd, d_o, lse, delta, L, H, p,
-                       seed, sid, dqkv);
+                       seed, sid, dqkv, row_scale, row_min);
     if (int rc = pt_check_launch()) return rc;
     hipLaunchKernelGGL(attn_bwd_dkv_f16x2_kernel<64>, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, d_o, lse, delta, L, H, p, seed,
-                       sid, dqkv);
+                       sid, dqkv, row_scale, row_min);
   } else {
     if (int rc = set_lds(attn_bwd_dq_f16x2_kernel<32>)) return rc;
     if (int rc = set_lds(attn_bwd_dkv_f16x2_kernel<32>)) return rc;
     hipLaunchKernelGGL(attn_bwd_dq_f16x2_kernel<32>, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, o_fwd, d_o, lse, delta, L, H, p,
-                       seed, sid, dqkv);
+                       seed, sid, dqkv, row_scale, row_min);
     if (int rc = pt_check_launch()) return rc;
     hipLaunchKernelGGL(attn_bwd_dkv_f16x2_kernel<32>, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, d_o, lse, delta, L, H, p, seed,
-                       sid, dqkv);
+                       sid, dqkv, row_scale, row_min);
   }
   return pt_check_launch();
 }

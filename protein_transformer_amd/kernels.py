@@ -299,16 +299,22 @@ def attention_fwd(qkv, seq, H, dropout_p, seed, stream_id, arith=None):
     return out, lse
 
 
-def attention_bwd(qkv, seq, out, dout, lse, H, dropout_p, seed, stream_id, arith=None):
+def attention_bwd(qkv, seq, out, dout, lse, H, dropout_p, seed, stream_id, arith=None, row_scale=None, row_scale_min=None):
+    """row_scale [T] / row_scale_min [4] (int32, preset to 0x7F000000): f16x2 scales of the rows of dqkv as a by-product
+    (f16x2 arithmetic and head size 32 / 64 only - `attention_row_scales_available`)."""
     B, L = seq.shape
     D = qkv.shape[1] // 3
     dqkv = torch.empty_like(qkv)
     ws = workspace("attn", lib().ptamd_attention_workspace_bytes(B, L, H, D // H), qkv.device)
     check(lib().ptamd_attention_bwd(ptr(qkv), ptr(seq), ptr(out), ptr(dout), ptr(lse), B, L, H, D // H,
                                     float(dropout_p), int(seed), int(stream_id),
-                                    int(_DEFAULT_ARITH if arith is None else arith), ptr(dqkv), ptr(ws), ws.numel(),
-                                    stream()), "attention_bwd")
+                                    int(_DEFAULT_ARITH if arith is None else arith), ptr(dqkv), ptr(row_scale),
+                                    ptr(row_scale_min), ptr(ws), ws.numel(), stream()), "attention_bwd")
     return dqkv
+
+
+def attention_row_scales_available(dk, arith):
+    return dk in (32, 64) and int(arith) in (GEMM_AUTO, GEMM_F16X2)
 
 
 def relu_dropout_bwd(dy, y, dropout_p):

@@ -147,6 +147,7 @@ class _TransformerBase(nn.Module):
         self.dropout_seed = 0x5DEECE66D
         self._step_counter = 0
         self.grad_hook = None                        # called with (offset, numel) as soon as a gradient slice is final
+        self.attn_row_scales = True                  # dqkv row scales from the attention backward kernels (False: a pass; ablation)
         self.attn_mode = None                        # arithmetic of the attention kernels alone (ablations); None = gemm_mode
         self.gemm_mode = None                        # kernels.GEMM_* arithmetic of THIS model; None = kernels.get_gemm_mode()
         self._init_parameters()
@@ -274,7 +275,7 @@ class _TransformerBase(nn.Module):
             factor = torch.zeros(self.nlayers, dtype=torch.float32, device=dev)
             ones = torch.tensor([1.0, 1.0, 1.0, 0.0], dtype=torch.float32, device=dev)     # a stats record for "no weight"
             layers, wjobs, bjobs, o = [], [], [], 0
-            minbuf = torch.zeros(self.nlayers, 12, dtype=torch.int32, device=dev)   # atomicMin targets, preset before every backward pass
+            minbuf = torch.zeros(self.nlayers, 16, dtype=torch.int32, device=dev)   # atomicMin targets, preset before every backward pass
 
             def take(n):
                 nonlocal o
@@ -288,7 +289,7 @@ class _TransformerBase(nn.Module):
                 L = dict(rs_qkv=take(3 * D), cs_qkv=take(D), rs_o=take(D), cs_o=take(D), rs_1=take(F), cs_1=take(D),
                          rs_2=take(D), cs_2=take(F), att_scale=take(4), f1_scale=take(4), h1_scale=take(4), h2_scale=take(4),
                          dqkv_scale=take(4), dz1_factor=factor[i:i + 1])
-                L.update(dy2_min=minbuf[i, 0:4], dz1_min=minbuf[i, 4:8], dyo_min=minbuf[i, 8:12])
+                L.update(dy2_min=minbuf[i, 0:4], dz1_min=minbuf[i, 4:8], dyo_min=minbuf[i, 8:12], dqkv_min=minbuf[i, 12:16])
                 st = stats[i]
                 wjobs += [dict(w=wqkv, row_scale=L["rs_qkv"], col_scale=L["cs_qkv"]),
                           dict(w=wqkv[2 * D:], stats=st[0]),                                     # W_v: row norms
@@ -449,6 +450,8 @@ class _EncoderFn(torch.autograd.Function):
         fuse = D <= 1024                                   # LayerNorm backward + the dropout backward behind it in one kernel
         i32 = lambda: torch.empty(B * L, dtype=torch.int32, device=dx.device)                 # noqa: E731
         dy2 = s_dy2 = bs_dz1 = None                        # dropout'(dx) of the FFN output site, made by the layer above
+        attn_ar = ar if m.attn_mode is None else int(m.attn_mode)
+        s_dqkv_all = None
         have_min = False                                   # ... together with the uniform scales of dy2 / dz1 for the dW products
         if scales is not None:
             scales[0]["minbuf"].fill_(0x7F000000)          # atomicMin targets of this backward pass (largest scale)
@@ -485,15 +488,23 @@ class _EncoderFn(torch.autograd.Function):
             K.linear_bwd_weight(dyo, att, G(b + "self_attn.wo.weight"), G(b + "self_attn.wo.bias"), arith=ar,
                                 dy_scale=sc["dyo_min"] if uni_o else None, x_scale=sc["att_scale"] if uni_o else None)
             datt = K.linear_bwd_input(dyo, W(b + "self_attn.wo.weight"), arith=ar, a_scale=s_dyo, b_scale=sc and sc["cs_o"])
-            dqkv = K.attention_bwd(qkv, seq, att, datt, lse, H, pa, seed, sid + _SITE_ATTN,
-                                    arith=ar if m.attn_mode is None else m.attn_mode)
+            # the f16x2 attention kernels leave the row scales of dqkv (A of the dX product) and the smallest of them (the
+            # uniform scale of dqkv as operand of the dW product) behind; other arithmetics: one pass over dqkv
+            attn_scales = sc is not None and m.attn_row_scales and K.attention_row_scales_available(D // H, attn_ar)
+            if attn_scales and s_dqkv_all is None:
+                s_dqkv_all = torch.full((m.nlayers, B * L), 0x7F000000, dtype=torch.int32, device=dpred.device)
+            s_dqkv = s_dqkv_all[i] if attn_scales else None
+            dqkv = K.attention_bwd(qkv, seq, att, datt, lse, H, pa, seed, sid + _SITE_ATTN, arith=attn_ar,
+                                    row_scale=s_dqkv, row_scale_min=sc["dqkv_min"] if attn_scales else None)
             gw, gb = m._qkv(gflat, i)
             wqkv, _ = m._qkv(flat, i)
-            if sc is not None:   # one pass over dqkv gives its row scales (A of the dX product) and its largest |value| (-> the
-                s_dqkv = i32()   # uniform scale of dqkv as operand of the dW product): the pass ptamd_gemm would run anyway
-                K.weight_scales([dict(w=dqkv, row_scale=s_dqkv, stats=sc["dqkv_stats"], rows_only=True)])
-                K.bound_scales([dict(w=sc["dqkv_stats"], w_index=2, out_scale=sc["dqkv_scale"])])
-                K.linear_bwd_weight(dqkv, h1, gw, gb, arith=ar, dy_scale=sc["dqkv_scale"], x_scale=sc["h1_scale"])
+            if sc is not None:
+                dq_uni = sc["dqkv_min"]
+                if not attn_scales:
+                    s_dqkv, dq_uni = i32(), sc["dqkv_scale"]
+                    K.weight_scales([dict(w=dqkv, row_scale=s_dqkv, stats=sc["dqkv_stats"], rows_only=True)])
+                    K.bound_scales([dict(w=sc["dqkv_stats"], w_index=2, out_scale=sc["dqkv_scale"])])
+                K.linear_bwd_weight(dqkv, h1, gw, gb, arith=ar, dy_scale=dq_uni, x_scale=sc["h1_scale"])
                 dh1 = K.linear_bwd_input(dqkv, wqkv, arith=ar, a_scale=s_dqkv, b_scale=sc["cs_qkv"])
             else:
                 K.linear_bwd_weight(dqkv, h1, gw, gb, arith=ar)

@@ -198,3 +198,29 @@ def test_weight_gradient_product_with_uniform_scales(dev):
     rel = float((dw_u.double() - ref).norm() / ref.norm())
     assert rel < 1e-6
     assert torch.allclose(db_u, db_b, rtol=1e-5, atol=1e-3 * float(db_b.abs().max()))      # the fused bias gradient is fp32 either way
+
+
+@pytest.mark.parametrize("B,L,H,dk", [(3, 300, 4, 64), (2, 130, 8, 32)])
+def test_attention_bwd_row_scales(dev, B, L, H, dk):
+    """ptamd_attention_bwd (f16x2 arithmetic) leaves the f16x2 row scales of dqkv and the smallest of them behind: exactly
+    those of a pass over the dqkv it wrote; other arithmetics refuse the request."""
+    from protein_transformer_amd import kernels as K
+    g = torch.Generator().manual_seed(3)
+    D = H * dk
+    qkv = torch.randn(B * L, 3 * D, generator=g).to(dev)
+    dout = (torch.randn(B * L, D, generator=g) * torch.exp(2 * torch.randn(B * L, 1, generator=g))).to(dev) * 1e-3
+    seq = torch.randint(0, 20, (B, L), generator=g)
+    seq[0, L - 40:] = 20
+    seq = seq.to(dev)
+    o, lse = K.attention_fwd(qkv, seq, H, 0.1, 5, 2, arith=K.GEMM_F16X2)
+    rs = torch.full((B * L,), 0x7F000000, dtype=torch.int32, device=dev)
+    mn = torch.full((4,), 0x7F000000, dtype=torch.int32, device=dev)
+    dq = K.attention_bwd(qkv, seq, o, dout, lse, H, 0.1, 5, 2, arith=K.GEMM_F16X2, row_scale=rs, row_scale_min=mn)
+    dq0 = K.attention_bwd(qkv, seq, o, dout, lse, H, 0.1, 5, 2, arith=K.GEMM_F16X2)
+    assert torch.equal(dq, dq0)                                                  # the by-product does not touch the result
+    want = scale_of(dq.abs().amax(dim=1).cpu().numpy())
+    assert np.array_equal(as_float(rs), want)
+    assert np.array_equal(as_float(mn), np.full(4, want.min()))
+    assert K.attention_row_scales_available(dk, K.GEMM_AUTO) and not K.attention_row_scales_available(dk, K.GEMM_BF16X3)
+    with pytest.raises(RuntimeError):
+        K.attention_bwd(qkv, seq, o, dout, lse, H, 0.1, 5, 2, arith=K.GEMM_BF16X3, row_scale=rs, row_scale_min=mn)
