@@ -86,10 +86,23 @@ def parse():
 
 # ----------------------------------------------------------------------------- CPU baseline (the checker, timed)
 def _cpu_leg(a, batch_cpu, params, n, pool):
+    """One timed oracle step on n proteins of the batch.  The oracle keeps the reference's assertion on the bond angle
+    (Structure.py:42, theta in [-pi, pi] against the DOUBLE pi): a float32 angle within 9e-8 below pi rounds to
+    float32(pi) > pi and trips it - about once in 1e7 angles, on the reference as on the oracle.  Such a sample says
+    nothing about speed: the leg moves on to the next n proteins of the batch (at most 4 attempts)."""
     from oracle import step as ostep
-    trainer = ostep.CpuTrainer(params, a.n_head, loss=a.loss, optimizer=a.optimizer, lr=1e-4, clip=1.0, pool=pool)
-    seq, ang, crd = (batch_cpu[k][:n] for k in ("seq", "true_ang", "true_crd"))
-    return ostep.time_cpu_steps(trainer, (seq, ang, crd), n_steps=1)
+    avail = batch_cpu["seq"].shape[0]
+    last = None
+    for attempt in range(4):
+        idx = [(attempt * n + i) % avail for i in range(n)]
+        trainer = ostep.CpuTrainer({k: v.clone() for k, v in params.items()}, a.n_head, loss=a.loss, optimizer=a.optimizer,
+                                   lr=1e-4, clip=1.0, pool=pool)
+        seq, ang, crd = (batch_cpu[k][idx] for k in ("seq", "true_ang", "true_crd"))
+        try:
+            return ostep.time_cpu_steps(trainer, (seq, ang, crd), n_steps=1)
+        except AssertionError as e:                      # the reference's own input assertion, see above
+            last = e
+    raise last
 
 
 def cpu_baseline(a, batch_cpu, params):
@@ -356,7 +369,11 @@ def main():
             pick = min(range(nb), key=lambda i: abs(host_batches[i][0].shape[1] - 200)) if a.ragged == "binned" else 0
             cpu_batch = dict(zip(keys, (t.clone() for t in host_batches[pick])))
             params = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}   # the same model, reference keys
-            out["cpu_baseline"] = cpu_baseline(a, cpu_batch, params)
+            try:
+                out["cpu_baseline"] = cpu_baseline(a, cpu_batch, params)
+            except Exception as e:                       # the bench line must not depend on the checker's health
+                out["cpu_baseline"] = {"value": None, "unit": "residues/s", "cores": 0, "kind": "port",
+                                       "sample": f"failed: {type(e).__name__}: {e}"}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -638,7 +638,7 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
           dv[t][r] = v;
         }
     }
-    const float gn = inv_pow2(g_run) * TWO14;
+    const float gn = inv_pow2(g_run);  // (2^127 while every dO group seen so far is zero: multiplied LAST, after 0 * 2^14)
     const float4 igh = lh ? igb : iga;
     const float iq[4] = {iq4.x, iq4.y, iq4.z, iq4.w}, ig[4] = {igh.x, igh.y, igh.z, igh.w};
     float cu[4], ug[4], wq[4], fp[4];
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
       cu[j] = ck * iq[j];
       ug[j] = gk * ig[j];
       wq[j] = scale * iq[j];
-      fp[j] = ig[j] * gn;  // <= 2^14
+      fp[j] = ig[j] * TWO14 * gn;  // <= 2^14
     }
     f32x16 pd;  // dropped probabilities (operand of dV), without the 1 / (1 - p): that is applied to dV at the end
     const uint32_t keepbits = p_drop > 0.f ? attn_keep_bits_queries_in_rows(dk_, (uint32_t)key, qq0, lh) : 0xffffu;

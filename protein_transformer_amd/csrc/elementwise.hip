@@ -144,7 +144,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restr
   }
 }
 
-constexpr int LN_BWD_BLOCKS = 512;  // 2 per CU, 4 wavefronts each; one partial row of (dgamma, dbeta) per block
+#ifndef PT_LN_BWD_BLOCKS
+#define PT_LN_BWD_BLOCKS 512
+#endif
+constexpr int LN_BWD_BLOCKS = PT_LN_BWD_BLOCKS;  // 2 per CU, 4 wavefronts each; one partial row of (dgamma, dbeta) per block
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                             const float *__restrict__ gamma,

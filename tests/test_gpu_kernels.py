@@ -490,6 +490,16 @@ def test_attention_f16x2_degenerate_rows(dev):
         res[mode] = (o.double().cpu(), dq.double().cpu(), lse.double().cpu())
     for a, b in zip(res[K_.GEMM_F32], res[K_.GEMM_F16X2]):
         assert ((a - b).norm() / b.norm()).item() < 3e-6
+    # no gradient at all (the top layer of a freshly initialised model), and none for one protein: zeros, not NaN
+    for dz in (torch.zeros(B, L, D), torch.cat([torch.zeros(1, L, D), torch.randn(1, L, D, generator=g)])):
+        o, lse = K_.attention_fwd(qd, seq.to(dev), H, 0.1, 3, 1, arith=K_.GEMM_F16X2)
+        dq = K_.attention_bwd(qd, seq.to(dev), o, dz.view(B * L, D).to(dev), lse, H, 0.1, 3, 1, arith=K_.GEMM_F16X2)
+        assert torch.isfinite(dq).all()
+        assert (dq.view(B, L, 3 * D)[0] == 0).all()
+    vz = qkv.clone()
+    vz[:, :, 2 * D:] = 0.0                       # V == 0 everywhere: the forward pass never sees a non-zero scale group
+    o, lse = K_.attention_fwd(vz.view(B * L, 3 * D).to(dev), seq.to(dev), H, 0.0, 0, 0, arith=K_.GEMM_F16X2)
+    assert torch.isfinite(o).all() and (o == 0).all()
 
 
 # ------------------------------------------------------------------------------------------------ optimizer
