@@ -290,6 +290,12 @@ def main():
         model.gemm_mode = modes[a.gemm_mode]
     gc.enable()
 
+    # a step whose numbers are NaN runs FASTER (the matrix pipe draws less power on constant data): a throughput measured on
+    # a diverged model is not a measurement.  Checked on every rank after the last timed loop, fatal.
+    flat_p, flat_g = model.flat_parameters()
+    if not (bool(torch.isfinite(flat_p).all()) and bool(torch.isfinite(flat_g).all())):
+        sys.exit("bench.py: non-finite parameters / gradients after the timed steps - the measurement is invalid")
+
     traffic = None          # HBM bytes per GEMM launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
     tpath = os.path.join(ROOT, "profiles", "r02_gemm_hbm_traffic.json")
     if os.path.exists(tpath) and a.config == 4 and a.batch == 32 and a.gemm_mode == "auto":
