@@ -64,16 +64,11 @@ __device__ __forceinline__ f32x16 mfma3(const f16x8 (&a)[2], const f16x8 (&b)[2]
 }
 // eight f32 -> the two f16x8 MFMA operands of (x[0..3] s0, x[4..7] s1)
 __device__ __forceinline__ void split8g(const float (&x)[8], float s0, float s1, f16x8 (&f)[2]) {
-  uint32_t t[2][4];
-  split_pair_f16(x[0], x[1], s0, s0, t[0][0], t[1][0]);
-  split_pair_f16(x[2], x[3], s0, s0, t[0][1], t[1][1]);
-  split_pair_f16(x[4], x[5], s1, s1, t[0][2], t[1][2]);
-  split_pair_f16(x[6], x[7], s1, s1, t[0][3], t[1][3]);
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const u32x4 u = {t[k][0], t[k][1], t[k][2], t[k][3]};
-    f[k] = __builtin_bit_cast(f16x8, u);
-  }
+  uint2 a1, a2, b1, b2;
+  split_quad_f16(x[0], x[1], x[2], x[3], s0, s0, s0, s0, a1, a2);
+  split_quad_f16(x[4], x[5], x[6], x[7], s1, s1, s1, s1, b1, b2);
+  f[0] = __builtin_bit_cast(f16x8, (u32x4){a1.x, a1.y, b1.x, b1.y});
+  f[1] = __builtin_bit_cast(f16x8, (u32x4){a2.x, a2.y, b2.x, b2.y});
 }
 
 // ---- LDS image of a [32][64] f32 tile as two f16 planes: row format and swizzle of split_bf16.h (Tile64)
@@ -86,8 +81,7 @@ struct Tile2 {
   }
   static __device__ __forceinline__ void store4(unsigned short *__restrict__ s, int row, int d, const float4 &v, float sc) {
     uint2 t1, t2;
-    split_pair_f16(v.x, v.y, sc, sc, t1.x, t2.x);
-    split_pair_f16(v.z, v.w, sc, sc, t1.y, t2.y);
+    split_quad_f16(v.x, v.y, v.z, v.w, sc, sc, sc, sc, t1, t2);
     const int off = offset(row, d);
     *reinterpret_cast<uint2 *>(s + off) = t1;
     *reinterpret_cast<uint2 *>(s + PLANE + off) = t2;

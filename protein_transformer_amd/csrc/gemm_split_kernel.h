@@ -151,8 +151,8 @@ __device__ __forceinline__ void store_split_f16(unsigned short *__restrict__ s, 
   for (int i = 0; i < ROWS / 64; ++i) {
     const int kl = KMAJOR ? pt / LPK + (NPRODUCER / LPK) * i : 4 * (pt % 4);
     uint2 t1, t2;
-    split_pair_f16(v[i].x, v[i].y, KMAJOR ? sc[0] : sc[i], KMAJOR ? sc[1] : sc[i], t1.x, t2.x);
-    split_pair_f16(v[i].z, v[i].w, KMAJOR ? sc[2] : sc[i], KMAJOR ? sc[3] : sc[i], t1.y, t2.y);
+    split_quad_f16(v[i].x, v[i].y, v[i].z, v[i].w, KMAJOR ? sc[0] : sc[i], KMAJOR ? sc[1] : sc[i], KMAJOR ? sc[2] : sc[i],
+                   KMAJOR ? sc[3] : sc[i], t1, t2);
     const int off = KMAJOR ? kl * LD_KR + 4 * (pt % LPK) : (pt / 4 + 64 * i) * LD_RK + kl;
     *reinterpret_cast<uint2 *>(s + off) = t1;
     *reinterpret_cast<uint2 *>(s + PLANE + off) = t2;

@@ -53,6 +53,34 @@ __device__ __forceinline__ void split_pair_f16(float x0, float x1, float s0, flo
   t1 = __builtin_bit_cast(uint32_t, h);
   t2 = __builtin_bit_cast(uint32_t, g);
 }
+// Four values at once, each with its own scale.  PT_MIX_SPLIT (ablation, slower: profiles/r02_f16_split_mix_ablation.txt):
+// EIGHT vector instructions instead of twelve - v_fma_mixlo/mixhi_f16 round the f32 product x s straight into one half of
+// a packed register and take the f16 half back as the addend of the residual fma(x, s, -h) - same results, bit for bit.
+// The two pairs are interleaved so that no instruction reads a half-register write of the instruction before it
+// (gfx940+ destination-select forwarding hazard, which the compiler cannot see inside an asm block), and one s_nop
+// separates the last write from whatever the compiler schedules next.
+__device__ __forceinline__ void split_quad_f16(float x0, float x1, float x2, float x3, float s0, float s1, float s2,
+                                               float s3, uint2 &t1, uint2 &t2) {
+#ifndef PT_MIX_SPLIT
+  split_pair_f16(x0, x1, s0, s1, t1.x, t2.x);
+  split_pair_f16(x2, x3, s2, s3, t1.y, t2.y);
+#else
+  uint32_t ha, hb, ga, gb;
+  asm("v_fma_mixlo_f16 %0, %4, %8, 0\n\t"
+      "v_fma_mixhi_f16 %0, %5, %9, 0\n\t"
+      "v_fma_mixlo_f16 %1, %6, %10, 0\n\t"
+      "v_fma_mixhi_f16 %1, %7, %11, 0\n\t"
+      "v_fma_mixlo_f16 %2, %4, %8, -%0 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %2, %5, %9, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %3, %6, %10, -%1 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %3, %7, %11, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "s_nop 0"
+      : "=&v"(ha), "=&v"(hb), "=&v"(ga), "=&v"(gb)
+      : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(s0), "v"(s1), "v"(s2), "v"(s3));
+  t1 = make_uint2(ha, hb);
+  t2 = make_uint2(ga, gb);
+#endif
+}
 // eight f32 -> the three bf16x8 MFMA operands
 __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 (&f)[3]) {
   uint32_t t[3][4];
