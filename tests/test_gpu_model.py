@@ -304,7 +304,8 @@ def test_full_size_step_is_additive_over_proteins(dev):
         SUM all-reduce exact, dp.py), and the per-protein losses of the halves are those of the whole batch;
       * a protein's loss does not depend on what else is in the batch (no cross-protein leakage through padding,
         attention masking or the tile decomposition of the kernels);
-      * the exact-f32 MFMA kernels and the default split-bf16 kernels agree on losses and gradients.
+      * the exact-f32 MFMA kernels, the three-term bf16 kernels and the default (AUTO: two-term f16) agree on losses and
+        gradients.
     """
     import types
     from protein_transformer_amd import kernels as K_
@@ -340,6 +341,9 @@ def test_full_size_step_is_additive_over_proteins(dev):
         g_a, d_a, ln_a = grads(slice(0, B // 2), K_.GEMM_BF16X3)
         g_b, d_b, ln_b = grads(slice(B // 2, B), K_.GEMM_BF16X3)
         g_f32, d_f32, ln_f32 = grads(slice(0, B), K_.GEMM_F32)
+        g_auto, d_auto, ln_auto = grads(slice(0, B), K_.GEMM_AUTO)          # the default: f16x2 GEMMs and attention
+        g_auto_a, _, _ = grads(slice(0, B // 2), K_.GEMM_AUTO)
+        g_auto_b, _, _ = grads(slice(B // 2, B), K_.GEMM_AUTO)
     finally:
         K_.set_gemm_mode(old)
     norm = g_all.norm().item()
@@ -351,6 +355,13 @@ def test_full_size_step_is_additive_over_proteins(dev):
     # chains (5.6e-4 measured; each of them is closer than that to an fp64 evaluation, see the next test)
     assert (g_f32 - g_all).norm().item() <= 2e-3 * norm
     assert d_f32 == pytest.approx(d_all, rel=1e-5) and ln_f32 == pytest.approx(ln_all, rel=1e-5)
+    # the default arithmetic (PTAMD_GEMM_AUTO: two-term f16 products with power-of-two scales in the GEMMs and in attention)
+    # at full size: same losses, gradients as close to the exact-f32 kernels' as the three-term bf16 ones are, additive
+    # over the halves of the batch (the uniform scales of the weight-gradient products depend on the batch: rounding only)
+    assert torch.isfinite(g_auto).all()
+    assert d_auto == pytest.approx(d_f32, rel=1e-5) and ln_auto == pytest.approx(ln_f32, rel=1e-5)
+    assert (g_auto - g_f32).norm().item() <= 2e-3 * norm
+    assert (g_auto_a + g_auto_b - g_auto).norm().item() <= 2e-3 * norm
 
 
 def test_arithmetic_modes_against_fp64_step(dev):
