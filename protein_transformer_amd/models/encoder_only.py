@@ -369,6 +369,7 @@ class _EncoderFn(torch.autograd.Function):
         pa = m.attn_dropout if train else 0.0
         W = lambda name: m._slice(flat, name)                                      # noqa: E731
         ar = K.get_gemm_mode() if m.gemm_mode is None else int(m.gemm_mode)        # every launch below carries it
+        attn_default = ar                 # the attention kernels find their f16x2 scales themselves: AUTO stays AUTO for them
         if ar == K.GEMM_AUTO and B * L * D < AUTO_F16X2_MIN_WORK:
             ar = K.GEMM_BF16X3         # launch-bound step: the scale bookkeeping of f16x2 costs more than its products save
         pe = m.encoder.positional_enc.pe[0]
@@ -401,7 +402,8 @@ class _EncoderFn(torch.autograd.Function):
             h1, mean1, rstd1 = K.layernorm_fwd(x, W(b + "sublayer_connections.0.norm.weight"),
                                                W(b + "sublayer_connections.0.norm.bias"), row_scale=s_h1)
             qkv = K.linear_fwd(h1, wqkv, bqkv, arith=ar, a_scale=s_h1, b_scale=sc and sc["rs_qkv"])
-            att, lse = K.attention_fwd(qkv, seq, H, pa, seed, sid + _SITE_ATTN, arith=ar if m.attn_mode is None else m.attn_mode)
+            att, lse = K.attention_fwd(qkv, seq, H, pa, seed, sid + _SITE_ATTN,
+                                        arith=attn_default if m.attn_mode is None else m.attn_mode)
             x2 = K.linear_fwd(att, W(b + "self_attn.wo.weight"), W(b + "self_attn.wo.bias"), residual=x, ldr=D,
                               dropout_p=p, seed=seed, stream_id=sid + _SITE_ATTN_OUT, arith=ar,
                               a_scale=sc and sc["att_scale"], a_scale_stride=0, b_scale=sc and sc["rs_o"])
@@ -418,7 +420,7 @@ class _EncoderFn(torch.autograd.Function):
             x = x3
         pred = K.linear_fwd(x, W("output_projection.weight"), W("output_projection.bias"), flags=K.EPI_TANH,
                             arith=ar)
-        ctx.model, ctx.seed, ctx.seq, ctx.flat, ctx.arith = m, seed, seq, flat, ar
+        ctx.model, ctx.seed, ctx.seq, ctx.flat, ctx.arith, ctx.attn_arith = m, seed, seq, flat, ar, attn_default
         ctx.p, ctx.pa = p, pa
         ctx.saved, ctx.conv_saved, ctx.scales = saved, conv_saved, scales
         ctx.x_last, ctx.pred = x, pred
@@ -450,7 +452,7 @@ class _EncoderFn(torch.autograd.Function):
         fuse = D <= 1024                                   # LayerNorm backward + the dropout backward behind it in one kernel
         i32 = lambda: torch.empty(B * L, dtype=torch.int32, device=dx.device)                 # noqa: E731
         dy2 = s_dy2 = bs_dz1 = None                        # dropout'(dx) of the FFN output site, made by the layer above
-        attn_ar = ar if m.attn_mode is None else int(m.attn_mode)
+        attn_ar = ctx.attn_arith if m.attn_mode is None else int(m.attn_mode)
         s_dqkv_all = None
         have_min = False                                   # ... together with the uniform scales of dy2 / dz1 for the dW products
         if scales is not None:
