@@ -644,7 +644,7 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
       fp[j] = ig[j] * TWO14 * gn;  // <= 2^14
     }
     f32x16 pd;  // dropped probabilities (operand of dV), without the 1 / (1 - p): that is applied to dV at the end
-    const uint32_t keepbits = p_drop > 0.f ? attn_keep_bits_queries_in_rows(dk_, (uint32_t)key, qq0, lh) : 0xffffu;
+    const uint32_t keepbits = p_drop > 0.f ? attn_keep_bits_queries_in_rows_paired(dk_, (uint32_t)key, qq0, lh) : 0xffffu;
     float wmax = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {

@@ -60,3 +60,22 @@ __device__ __forceinline__ uint32_t attn_keep_bits_queries_in_rows(const AttnDro
   }
   return bits;
 }
+
+// The same bits at half the generator calls, for kernels whose lanes 2k and 2k + 1 hold the keys 2m and 2m + 1 of one
+// pair (even first key of the wavefront, same q0 and lh in both lanes): the two lanes need the SAME 16 words, one its
+// low and the other its high halves.  The even lane draws the words of registers 0..7, the odd lane those of 8..15, both
+// decide both halves, and one DPP exchange between neighbours hands over the eight decisions the partner needs.
+__device__ __forceinline__ uint32_t attn_keep_bits_queries_in_rows_paired(const AttnDrop &d, uint32_t key, int q0, int lh) {
+  const uint32_t kp_part = attn_kp_part(d, key >> 1), odd = key & 1u;
+  const uint32_t base = attn_q_part(d, (uint32_t)(q0 + 4 * lh) + 16u * odd);
+  uint32_t lo_bits = 0, hi_bits = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t w = attn_word(base + (uint32_t)((i & 3) + 8 * (i >> 2)) * ATTN_C_Q, kp_part);
+    lo_bits |= ((w & 0xffffu) >= d.thr16 ? 1u : 0u) << i;
+    hi_bits |= ((w >> 16) >= d.thr16 ? 1u : 0u) << i;
+  }
+  const uint32_t mine = odd ? hi_bits : lo_bits, give = odd ? lo_bits : hi_bits;
+  const uint32_t got = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+  return odd ? (got | (mine << 8)) : (mine | (got << 8));
+}
