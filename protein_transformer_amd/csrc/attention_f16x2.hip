@@ -208,7 +208,7 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const float *__restrict__ qkv, const int64_t *__restrict__ seq, int L, int H, float p_drop, uint64_t seed,
     uint32_t stream_id, float *__restrict__ out, float *__restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-  __shared__ unsigned int sMask[2];
+  __shared__ __attribute__((aligned(16))) float sBias[2][TR];
   __shared__ __attribute__((aligned(16))) float sInvK[2][8], sInvV[2][8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB + wave * 32;
@@ -236,11 +236,12 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
   Stage<DK> stK, stV;
   const int ntiles = (L + TR - 1) / TR;
+  // key mask of a tile as an ADDITIVE term of the soft-max argument (0 or -inf per key), read back one float4 per register
+  // quadruple: no bit extraction and no select per element
   auto publish_mask = [&](int k0, int buf) __attribute__((always_inline)) {
-    if (wave == 0) {
-      const int key = k0 + l31;
-      const unsigned long long mk = __ballot(lh == 0 && key < L && sq[key < L ? key : 0] != PTAMD_PAD_ID);
-      if (lane == 0) sMask[buf] = (unsigned int)mk;
+    if (tid < TR) {
+      const int key = k0 + tid;
+      sBias[buf][tid] = (key < L && sq[key < L ? key : 0] != PTAMD_PAD_ID) ? 0.f : -INFINITY;
     }
   };
   stK.load(base + D, D3, 0, L, tid);
@@ -259,7 +260,6 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const unsigned short *sK = smem + cur * BUF, *sV = sK + Tile2::ELEMS;
     nxK.load(base + D, D3, k0 + 2 * TR, L, tid);
     nxV.load(base + 2 * D, D3, k0 + 2 * TR, L, tid);
-    const unsigned int mask = sMask[cur];
     const float4 ik4 = *reinterpret_cast<const float4 *>(&sInvK[cur][4 * lh]);  // the four key groups of this lane half
     const float4 iva = *reinterpret_cast<const float4 *>(&sInvV[cur][0]), ivb = *reinterpret_cast<const float4 *>(&sInvV[cur][4]);
     f32x16 s;
@@ -280,11 +280,14 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const float cu[4] = {cq * ik4.x, cq * ik4.y, cq * ik4.z, cq * ik4.w};
     float mt = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const bool valid = (mask >> crow(r, lh)) & 1u;
-      const float t = s[r] * cu[r >> 2];  // (the product first: a masked group of zero rows has cu = 0)
-      s[r] = valid ? t : -INFINITY;
-      mt = fmaxf(mt, s[r]);
+    for (int j = 0; j < 4; ++j) {
+      const float4 b4 = *reinterpret_cast<const float4 *>(&sBias[cur][8 * j + 4 * lh]);
+      const float bias[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {  // (s cu is finite - a masked group of zero rows has s = cu = 0 - so the sum is -inf, not NaN)
+        s[4 * j + e] = fmaf(s[4 * j + e], cu[j], bias[e]);
+        mt = fmaxf(mt, s[4 * j + e]);
+      }
     }
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float m_new = fmaxf(m_run, mt);
@@ -368,7 +371,8 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
     uint64_t seed, uint32_t stream_id, float *__restrict__ dqkv, uint32_t *__restrict__ row_scale,
     uint32_t *__restrict__ row_min) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-  __shared__ unsigned int sMask[2];
+  __shared__ __attribute__((aligned(16))) float sBias[2][TR];
+  __shared__ unsigned int sMin;
   __shared__ __attribute__((aligned(16))) float sInvK[2][8], sInvV[2][8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB + wave * 32;
@@ -413,11 +417,12 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
   Stage<DK> stK, stV;
   const int ntiles = (L + TR - 1) / TR;
+  // key mask of a tile as an ADDITIVE term of the soft-max argument (0 or -inf per key), read back one float4 per register
+  // quadruple: no bit extraction and no select per element
   auto publish_mask = [&](int k0, int buf) __attribute__((always_inline)) {
-    if (wave == 0) {
-      const int key = k0 + l31;
-      const unsigned long long mk = __ballot(lh == 0 && key < L && sq[key < L ? key : 0] != PTAMD_PAD_ID);
-      if (lane == 0) sMask[buf] = (unsigned int)mk;
+    if (tid < TR) {
+      const int key = k0 + tid;
+      sBias[buf][tid] = (key < L && sq[key < L ? key : 0] != PTAMD_PAD_ID) ? 0.f : -INFINITY;
     }
   };
   stK.load(base + D, D3, 0, L, tid);
@@ -436,7 +441,6 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const unsigned short *sK = smem + cur * BUF, *sV = sK + Tile2::ELEMS;
     nxK.load(base + D, D3, k0 + 2 * TR, L, tid);
     nxV.load(base + 2 * D, D3, k0 + 2 * TR, L, tid);
-    const unsigned int mask = sMask[cur];
     const float4 ik4 = *reinterpret_cast<const float4 *>(&sInvK[cur][4 * lh]);
     const float4 iv4 = *reinterpret_cast<const float4 *>(&sInvV[cur][4 * lh]);
     f32x16 s, dp;
@@ -468,10 +472,11 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
     float wmax = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int kk = crow(r, lh), j = r >> 2;
-      const bool valid = (mask >> kk) & 1u;
-      // (the mask goes into the ARGUMENT, exp2(-inf) = 0: a select around the exp would become a branch per element)
-      const float p = __builtin_amdgcn_exp2f(valid ? fmaf(s[r], cu[j], -my_lse2) : -INFINITY);
+      const int j = r >> 2;
+      // (the mask goes into the ARGUMENT, exp2(-inf) = 0: 0 or -inf per key, added to -lse)
+      const float4 b4 = *reinterpret_cast<const float4 *>(&sBias[cur][8 * j + 4 * lh]);
+      const float nb = ((r & 3) == 0 ? b4.x : (r & 3) == 1 ? b4.y : (r & 3) == 2 ? b4.z : b4.w) - my_lse2;
+      const float p = __builtin_amdgcn_exp2f(fmaf(s[r], cu[j], nb));
       float g = dp[r] * ug[j];
       if (p_drop > 0.f) g = (keep >> r) & 1u ? g : 0.f;
       s[r] = p * (g - my_delta) * wk[j];
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) am = fmaxf(am, fabsf(dq[t][r]));
-    publish_row_scale(am * un, q_ok, b * L + q, tid, row_scale, row_min, &sMask[0]);
+    publish_row_scale(am * un, q_ok, b * L + q, tid, row_scale, row_min, &sMin);
   }
 }
 
@@ -575,7 +580,7 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
   stQ.store(smem, sInvQ[0], 0, L, tid);
   stG.store(smem + Tile2::ELEMS, sInvG[0], 0, L, tid);
   if (tid < TR) {
-    sLse[0][tid] = tid < L ? lse_b[tid] * LOG2E : 0.f;
+    sLse[0][tid] = tid < L ? lse_b[tid] * LOG2E : INFINITY;
     sDel[0][tid] = tid < L ? del_b[tid] : 0.f;
   }
   Stage<DK> nxQ, nxG;
@@ -592,7 +597,7 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (more) {
       if (tid < TR) {
         const int qn = qq0 + TR + tid;
-        r_lse = qn < L ? lse_b[qn] * LOG2E : 0.f;
+        r_lse = qn < L ? lse_b[qn] * LOG2E : INFINITY;
         r_del = qn < L ? del_b[qn] : 0.f;
       }
     }
@@ -648,10 +653,14 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
     float wmax = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int qi = crow(r, lh), qg = qq0 + qi, j = r >> 2;
-      const bool ok = k_valid && qg < L;
-      const float my_l = sLse[cur][qi], my_d = sDel[cur][qi];  // (LDS broadcast reads: registers are the scarce resource here)
-      const float p = __builtin_amdgcn_exp2f(ok ? fmaf(s[r], cu[j], -my_l) : -INFINITY);
+      const int j = r >> 2;
+      // (LDS broadcast reads, one float4 per register quadruple: registers are the scarce resource here; query rows beyond
+      // L carry lse = +inf, so the row mask costs nothing per element and the key mask is a loop-invariant select)
+      const float4 l4 = *reinterpret_cast<const float4 *>(&sLse[cur][8 * j + 4 * lh]);
+      const float4 d4 = *reinterpret_cast<const float4 *>(&sDel[cur][8 * j + 4 * lh]);
+      const float my_l = (r & 3) == 0 ? l4.x : (r & 3) == 1 ? l4.y : (r & 3) == 2 ? l4.z : l4.w;
+      const float my_d = (r & 3) == 0 ? d4.x : (r & 3) == 1 ? d4.y : (r & 3) == 2 ? d4.z : d4.w;
+      const float p = __builtin_amdgcn_exp2f(k_valid ? fmaf(s[r], cu[j], -my_l) : -INFINITY);
       float g = dp[r] * ug[j], pk = p;
       if (p_drop > 0.f) {
         const bool keep = (keepbits >> r) & 1u;
