@@ -118,9 +118,8 @@ template <int DK>
 struct Stage {
   static constexpr int CPR = DK / 4;  // float4 per tile row
   float4 v;
-  __device__ __forceinline__ void load(const float *__restrict__ base, int ld, int row0, int nrows, int tid) {
-    const int row = min(row0 + min(tid / CPR, TR - 1), nrows - 1);
-    v = *reinterpret_cast<const float4 *>(base + (size_t)row * ld + (tid % CPR) * 4);
+  __device__ __forceinline__ void load(const float *__restrict__ base, uint32_t off) {
+    v = *reinterpret_cast<const float4 *>(base + off);
   }
   __device__ __forceinline__ void store(unsigned short *__restrict__ s, float *__restrict__ inv, int row0, int nrows,
                                         int tid) const {
@@ -136,6 +135,25 @@ struct Stage {
         inv[(g & 1) * 4 + (g >> 1)] = __uint_as_float((254u << 23) - sbits);
       }
     }
+  }
+};
+
+// Element offset of a thread's float4 in consecutive 32-row tiles of a [nrows, ld] block (rows clamped to the last one):
+// an add and a min per tile instead of a 64-bit multiply per load; tiles that share rows (K and V, same ld) share it.
+template <int DK>
+struct TileRows {
+  uint32_t u, lim, col, step;
+  __device__ __forceinline__ TileRows(int ld, int nrows, int tid) {
+    constexpr int CPR = DK / 4;
+    u = (uint32_t)min(tid / CPR, TR - 1) * (uint32_t)ld;
+    lim = (uint32_t)(nrows - 1) * (uint32_t)ld;
+    col = (uint32_t)(tid % CPR) * 4u;
+    step = (uint32_t)TR * (uint32_t)ld;
+  }
+  __device__ __forceinline__ uint32_t next() {
+    const uint32_t off = min(u, lim) + col;
+    u += step;
+    return off;
   }
 };
 
@@ -244,22 +262,26 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
       sBias[buf][tid] = (key < L && sq[key < L ? key : 0] != PTAMD_PAD_ID) ? 0.f : -INFINITY;
     }
   };
-  stK.load(base + D, D3, 0, L, tid);
-  stV.load(base + 2 * D, D3, 0, L, tid);
+  TileRows<DK> rows(D3, L, tid);
+  uint32_t toff = rows.next();
+  stK.load(base + D, toff);
+  stV.load(base + 2 * D, toff);
   stK.store(smem, sInvK[0], 0, L, tid);
   stV.store(smem + Tile2::ELEMS, sInvV[0], 0, L, tid);
   publish_mask(0, 0);
   Stage<DK> nxK, nxV;  // loads run two tiles ahead of the arithmetic (attention_split.hip)
-  stK.load(base + D, D3, TR, L, tid);
-  stV.load(base + 2 * D, D3, TR, L, tid);
+  toff = rows.next();
+  stK.load(base + D, toff);
+  stV.load(base + 2 * D, toff);
   __syncthreads();
 
   for (int kt = 0; kt < ntiles; ++kt) {
     const int k0 = kt * TR, cur = kt & 1;
     const bool more = kt + 1 < ntiles;
     const unsigned short *sK = smem + cur * BUF, *sV = sK + Tile2::ELEMS;
-    nxK.load(base + D, D3, k0 + 2 * TR, L, tid);
-    nxV.load(base + 2 * D, D3, k0 + 2 * TR, L, tid);
+    toff = rows.next();
+    nxK.load(base + D, toff);
+    nxV.load(base + 2 * D, toff);
     const float4 ik4 = *reinterpret_cast<const float4 *>(&sInvK[cur][4 * lh]);  // the four key groups of this lane half
     const float4 iva = *reinterpret_cast<const float4 *>(&sInvV[cur][0]), ivb = *reinterpret_cast<const float4 *>(&sInvV[cur][4]);
     f32x16 s;
@@ -425,22 +447,26 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
       sBias[buf][tid] = (key < L && sq[key < L ? key : 0] != PTAMD_PAD_ID) ? 0.f : -INFINITY;
     }
   };
-  stK.load(base + D, D3, 0, L, tid);
-  stV.load(base + 2 * D, D3, 0, L, tid);
+  TileRows<DK> rows(D3, L, tid);
+  uint32_t toff = rows.next();
+  stK.load(base + D, toff);
+  stV.load(base + 2 * D, toff);
   stK.store(smem, sInvK[0], 0, L, tid);
   stV.store(smem + Tile2::ELEMS, sInvV[0], 0, L, tid);
   publish_mask(0, 0);
   Stage<DK> nxK, nxV;
-  stK.load(base + D, D3, TR, L, tid);
-  stV.load(base + 2 * D, D3, TR, L, tid);
+  toff = rows.next();
+  stK.load(base + D, toff);
+  stV.load(base + 2 * D, toff);
   __syncthreads();
 
   for (int kt = 0; kt < ntiles; ++kt) {
     const int k0 = kt * TR, cur = kt & 1;
     const bool more = kt + 1 < ntiles;
     const unsigned short *sK = smem + cur * BUF, *sV = sK + Tile2::ELEMS;
-    nxK.load(base + D, D3, k0 + 2 * TR, L, tid);
-    nxV.load(base + 2 * D, D3, k0 + 2 * TR, L, tid);
+    toff = rows.next();
+    nxK.load(base + D, toff);
+    nxV.load(base + 2 * D, toff);
     const float4 ik4 = *reinterpret_cast<const float4 *>(&sInvK[cur][4 * lh]);
     const float4 iv4 = *reinterpret_cast<const float4 *>(&sInvV[cur][4 * lh]);
     f32x16 s, dp;
@@ -575,8 +601,9 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
   Stage<DK> stQ, stG;
   const int ntiles = (L + TR - 1) / TR;
   float r_lse = 0.f, r_del = 0.f;
-  stQ.load(base, D3, 0, L, tid);
-  stG.load(gbase, D, 0, L, tid);
+  TileRows<DK> rows_q(D3, L, tid), rows_g(D, L, tid);
+  stQ.load(base, rows_q.next());
+  stG.load(gbase, rows_g.next());
   stQ.store(smem, sInvQ[0], 0, L, tid);
   stG.store(smem + Tile2::ELEMS, sInvG[0], 0, L, tid);
   if (tid < TR) {
@@ -584,16 +611,16 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
     sDel[0][tid] = tid < L ? del_b[tid] : 0.f;
   }
   Stage<DK> nxQ, nxG;
-  stQ.load(base, D3, TR, L, tid);
-  stG.load(gbase, D, TR, L, tid);
+  stQ.load(base, rows_q.next());
+  stG.load(gbase, rows_g.next());
   __syncthreads();
 
   for (int qt = 0; qt < ntiles; ++qt) {
     const int qq0 = qt * TR, cur = qt & 1;
     const bool more = qt + 1 < ntiles;
     const unsigned short *sQ = smem + cur * BUF, *sG = sQ + Tile2::ELEMS;
-    nxQ.load(base, D3, qq0 + 2 * TR, L, tid);
-    nxG.load(gbase, D, qq0 + 2 * TR, L, tid);
+    nxQ.load(base, rows_q.next());
+    nxG.load(gbase, rows_g.next());
     if (more) {
       if (tid < TR) {
         const int qn = qq0 + TR + tid;
