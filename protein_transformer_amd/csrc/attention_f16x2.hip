@@ -56,6 +56,12 @@ __device__ __forceinline__ uint32_t group_umax(uint32_t v) {
   return v;
 }
 
+// x where bit r of `keep` is set, +0 elsewhere: a sign-extending 1-bit field extract (0 or ~0) and an AND - two
+// instructions per element instead of bit test + compare + select
+__device__ __forceinline__ float keep_or_zero(float x, uint32_t keep, int r) {
+  return __uint_as_float(__float_as_uint(x) & (uint32_t)__builtin_amdgcn_sbfe((int)keep, r, 1));
+}
+
 __device__ __forceinline__ f32x16 mfma3(const f16x8 (&a)[2], const f16x8 (&b)[2], f32x16 c) {
   c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], c, 0, 0, 0);
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (p_drop > 0.f) {
       const uint32_t keep = attn_keep_bits_keys_in_rows(dk_, q_part, k0, lh);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = (keep >> r) & 1u ? s[r] : 0.f;  // the 1 / (1 - p) is applied to O at the end
+      for (int r = 0; r < 16; ++r) s[r] = keep_or_zero(s[r], keep, r);  // the 1 / (1 - p) is applied to O at the end
     }
     // O^T[d][q] += V^T[d][key] P^T[key][q]: the accumulator rows of s are already in the k order of frag_cols
 #pragma unroll
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
       const float nb = ((r & 3) == 0 ? b4.x : (r & 3) == 1 ? b4.y : (r & 3) == 2 ? b4.z : b4.w) - my_lse2;
       const float p = __builtin_amdgcn_exp2f(fmaf(s[r], cu[j], nb));
       float g = dp[r] * ug[j];
-      if (p_drop > 0.f) g = (keep >> r) & 1u ? g : 0.f;
+      if (p_drop > 0.f) g = keep_or_zero(g, keep, r);
       s[r] = p * (g - my_delta) * wk[j];
       wmax = fmaxf(wmax, fabsf(s[r]));
     }
@@ -690,9 +696,8 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
       const float p = __builtin_amdgcn_exp2f(k_valid ? fmaf(s[r], cu[j], -my_l) : -INFINITY);
       float g = dp[r] * ug[j], pk = p;
       if (p_drop > 0.f) {
-        const bool keep = (keepbits >> r) & 1u;
-        g = keep ? g : 0.f;
-        pk = keep ? p : 0.f;
+        g = keep_or_zero(g, keepbits, r);
+        pk = keep_or_zero(p, keepbits, r);
       }
       pd[r] = pk;
       s[r] = p * (g - my_d) * wq[j];  // dS[q][key] / (Q group scale)
