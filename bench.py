@@ -297,7 +297,7 @@ def main():
         sys.exit("bench.py: non-finite parameters / gradients after the timed steps - the measurement is invalid")
 
     traffic = None          # HBM bytes per GEMM launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-    tpath = os.path.join(ROOT, "profiles", "r02_gemm_hbm_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r02", "r02_gemm_hbm_traffic.json")
     if os.path.exists(tpath) and a.config == 4 and a.batch == 32 and a.gemm_mode == "auto":
         with open(tpath) as f:
             traffic = round(json.load(f)["hbm_bytes_per_launch"])
@@ -335,7 +335,7 @@ def main():
                     "mfma_flops_issued_tflops": round(issued, 1),
                     "mfma_instruction_peak_tflops": BF16_MFMA_PEAK_TFLOPS if products > 1 else F32_MFMA_PEAK_TFLOPS,
                     "launch_mix": mix,
-                    "traffic_unit": "HBM bytes per launch (PMC, profiles/r02_gemm_hbm_traffic.json)",
+                    "traffic_unit": "HBM bytes per launch (PMC, profiles/r02/r02_gemm_hbm_traffic.json)",
                     "algorithmic_bytes_per_launch": round(sum(b for b in gemm_bytes) / max(len(gemm_bytes), 1)),
                     "launches_per_step": round(len(timing) / a.steps, 1), "avg_launch_us": round(1e3 * ms / len(timing), 2),
                     "gflop_per_step": round(flops / a.steps / 1e9, 1),

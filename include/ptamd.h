@@ -140,7 +140,7 @@ typedef struct {
   /* F16X2 arithmetic only, optional: the row scales of the operands (uint32 bits of a power of two s with
    * max |x_row| * s < 2^15, see PTAMD_GEMM_F16X2) when the caller already has them - written by the kernel that
    * produced the operand (ptamd_layernorm_fwd, ptamd_layernorm_bwd_dropout) or derived from a bound of the row maxima
-   * (ptamd_encoder_bounds).  NULL: ptamd_gemm finds them with a pass over the operand (needs the workspace).
+   * (ptamd_weight_scales, ptamd_bound_scales).  NULL: ptamd_gemm finds them with a pass over the operand (needs the workspace).
    * a_scale_stride / b_scale_stride: 1 = one scale per operand row (A: per m, B: per n); 0 = ONE scale for every row of
    * the operand - the array then holds FOUR copies of it (row-contiguous operands load the scales of four rows at once).
    * With uniform scales on both sides the weight-gradient products (k-major A and B) can run in F16X2 without any pass:
@@ -222,6 +222,28 @@ typedef struct {
 } ptamd_gemm_hp_args;
 size_t ptamd_gemm_hp_workspace_bytes(int M, int N, int split_k);
 int ptamd_gemm_hp(const ptamd_gemm_hp_args *args, void *stream);
+
+/* ptamd_gemm_hp_dw: the weight-gradient product of a torch.nn.Linear (what autograd derives from `F.linear(x, W, b)` in
+ * Attention.py:38-41,49,69 / Sublayers.py:28-34: dW = dy^T x, db = sum_t dy) from TOKEN-MAJOR pre-split operands - the same
+ * hp buffers the forward / dX products read as their A operand:
+ *     C[M, N] (+)= sum_t Y[t, m] X[t, n],      colsum[m] += sum_t Y[t, m]   (colsum may be NULL)
+ * Y = hp [T, M] with one scale per token, X = hp [T, N] likewise (csrc/gemm_hp_dw.hip: transpose reads of the token-major
+ * blocks; the per-token scales are folded into one f16 power of two per token, error model of a uniform-scale f16x2
+ * product).  split_k cuts the token range; slabs are summed in a fixed order.  accumulate != 0: C += (else C =).
+ * The workspace is always needed (per-token factors live there). */
+typedef struct {
+  int M, N, T;
+  const void *Y; const float *Y_scale;
+  const void *X; const float *X_scale;
+  float *C; int ldc;
+  int accumulate;
+  float *colsum;
+  int split_k;
+  void *workspace; size_t workspace_bytes;
+  int reserved_cus;
+} ptamd_gemm_hp_dw_args;
+size_t ptamd_gemm_hp_dw_workspace_bytes(int M, int N, int T, int split_k);
+int ptamd_gemm_hp_dw(const ptamd_gemm_hp_dw_args *args, void *stream);
 
 /* ------------------------------------------------------------------ f16x2 bookkeeping without passes over activations
  * (csrc/scales.hip).  Scales are uint32 bit patterns of powers of two, as ptamd_gemm_args.a_scale / b_scale take them.

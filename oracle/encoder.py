@@ -87,7 +87,7 @@ def attention(p, base, x, key_mask, nhead):
     return F.linear(o, p[base + "wo.weight"], p[base + "wo.bias"])
 
 
-def encoder_forward(p, seq, nhead, return_hidden=False):
+def encoder_forward(p, seq, nhead, return_hidden=False, use_tanh_out=True):
     """[B,L] int64 -> [B,L,24] tanh'ed (cos,sin) predictions.
 
     enc-only: encoder_only.py:36-42.  conv-enc (keys `encoder.conv_layers.j.*` present, possibly without an
@@ -124,5 +124,7 @@ def encoder_forward(p, seq, nhead, return_hidden=False):
         h = F.linear(torch.relu(F.linear(h, p[base + "pwff.layer1.weight"], p[base + "pwff.layer1.bias"])),
                      p[base + "pwff.layer2.weight"], p[base + "pwff.layer2.bias"])   # Sublayers.py:34
         x = x + h
-    out = torch.tanh(F.linear(x, p["output_projection.weight"], p["output_projection.bias"]))
+    out = F.linear(x, p["output_projection.weight"], p["output_projection.bias"])
+    if use_tanh_out:                                           # encoder_only.py:40-41; False = `-m conv-enc-linear-out`
+        out = torch.tanh(out)
     return (out, x) if return_hidden else out

@@ -6,7 +6,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libptamd.so")
+# PTAMD_LIB_TAG selects an ablation build made with PTAMD_BUILD_TAG (profiles/tools); unset = the product library
+_TAG = os.environ.get("PTAMD_LIB_TAG", "")
+LIB_PATH = os.path.join(_HERE, "csrc", f"libptamd_{_TAG}.so" if _TAG else "libptamd.so")
 
 OK = 0
 ERRORS = {-1: "bad shape", -2: "sequence too long for the NeRF LDS staging", -3: "workspace missing or too small",
@@ -60,6 +62,18 @@ class GemmHpArgs(C.Structure):
                 ("reserved_cus", _i)]
 
 
+class GemmHpDwArgs(C.Structure):
+    _fields_ = [("M", _i), ("N", _i), ("T", _i),
+                ("Y", _p), ("Y_scale", _p),
+                ("X", _p), ("X_scale", _p),
+                ("C", _p), ("ldc", _i),
+                ("accumulate", _i),
+                ("colsum", _p),
+                ("split_k", _i),
+                ("workspace", _p), ("workspace_bytes", _sz),
+                ("reserved_cus", _i)]
+
+
 # name -> (restype, argtypes); mirrors include/ptamd.h one to one
 SIGNATURES = {
     "ptamd_version": (C.c_char_p, []),
@@ -86,6 +100,8 @@ SIGNATURES = {
     "ptamd_hp_split": (_i, [_p, _i, _i, _i, _i, _p, _p, _p]),
     "ptamd_gemm_hp_workspace_bytes": (_sz, [_i, _i, _i]),
     "ptamd_gemm_hp": (_i, [C.POINTER(GemmHpArgs), _p]),
+    "ptamd_gemm_hp_dw_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "ptamd_gemm_hp_dw": (_i, [C.POINTER(GemmHpDwArgs), _p]),
     "ptamd_weight_scales": (_i, [C.POINTER(WScaleJob), _i, _p]),
     "ptamd_bound_scales": (_i, [C.POINTER(BoundJob), _i, _p]),
     "ptamd_layernorm_fwd": (_i, [_p, _p, _p, _i64, _i, _p, _p, _p, _p, _p]),

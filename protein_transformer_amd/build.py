@@ -17,8 +17,11 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
-LIB = os.path.join(CSRC, "libptamd.so")
-OBJ_DIR = os.path.join(CSRC, "build")
+# PTAMD_BUILD_TAG=<tag>: an ablation build (with PTAMD_EXTRA_FLAGS) next to the product library, loaded by setting
+# PTAMD_LIB_TAG=<tag> (protein_transformer_amd/_lib.py); the product library and its objects are left alone
+_TAG = os.environ.get("PTAMD_BUILD_TAG", "")
+LIB = os.path.join(CSRC, f"libptamd_{_TAG}.so" if _TAG else "libptamd.so")
+OBJ_DIR = os.path.join(CSRC, f"build_{_TAG}" if _TAG else "build")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", f"-I{INCLUDE}"]

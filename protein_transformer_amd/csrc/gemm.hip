@@ -285,11 +285,29 @@ __global__ void gemm_splitk_reduce_kernel(const GemmParams p, const float *__res
 
 }  // namespace
 
-int persistent_grid(int reserved_cus) {  // CUs of the current device (a cheap attribute query: no state kept between calls)
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-      cus <= 0)
-    cus = 256;
+namespace {
+// CU counts of the visible devices: immutable facts about the hardware, queried once (thread-safe static initialisation) so
+// that the ~100 GEMM launches of a step do not each pay a hipDeviceGetAttribute - not state: nothing a call does changes it
+constexpr int MAX_DEVICES = 64;
+struct CuTable {
+  int cus[MAX_DEVICES];
+  CuTable() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    for (int d = 0; d < MAX_DEVICES; ++d) {
+      int c = 0;
+      if (d >= n || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || c <= 0) c = 256;
+      cus[d] = c;
+    }
+  }
+};
+}  // namespace
+
+int persistent_grid(int reserved_cus) {  // CUs of the current device minus the reserve, at least 1
+  static const CuTable table;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
+  int cus = table.cus[dev];
   if (reserved_cus > 0) cus -= reserved_cus;
   return cus > 0 ? cus : 1;
 }

@@ -157,7 +157,11 @@ __device__ __forceinline__ void tile_epilogue_vec(const GemmParams &p, const f32
       const int row = row0 + i * 32 + rr, col = col0 + c4;
       float4 v = *reinterpret_cast<const float4 *>(scratch + rr * 64 + c4);
       if (VEC) {
+#ifdef PT_ABLATE_NOSTORE   // ablation build: everything but the global store of the tile (the condition is never true)
+        if (row < p.M && col < p.N && p.M < 0) {
+#else
         if (row < p.M && col < p.N) {
+#endif
           if (EPI != EPI_PLAIN && !partial) {
             if (p.residual) {
               const f32x4 r4 = pre4[t];

@@ -83,7 +83,12 @@ __global__ __launch_bounds__(G::THREADS, G::WG_PER_CU * G::NW / 4) void gemm_hp_
   constexpr int TI = G::TI, KB = G::KB, BK = G::BK;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *const scratch = reinterpret_cast<float *>(smem + 2 * G::STAGE_BYTES);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // the wavefront index as a SCALAR: everything derived from it (which DMA piece, which operand, LDS destinations) is then
+  // computed on the scalar unit and the operand base pointer is a scalar select - left as a vector value the compiler
+  // re-loaded the selected pointer from the kernel-argument segment inside every DMA slot and waited vmcnt(0) for it,
+  // draining the LDS-DMA queue in the middle of the stage
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const ptgemm::WorkRange work(p.g, G::TILE_M, HBN);
   if (work.begin >= work.end) return;
@@ -235,7 +240,7 @@ int launch_hp_g(const HpParams &p, int splits, hipStream_t st) {
 }
 
 // The geometry in use: 8 wavefronts x (64 x 64) = 256 x 128 tile, 32 k per stage, one workgroup per CU, DMA pieces between
-// the MFMA groups.  Measured alternatives (profiles/r02_hp_gemm_ablations.txt): the DMA burst behind the barrier
+// the MFMA groups.  Measured alternatives (profiles/r02/r02_hp_gemm_ablations.txt): the DMA burst behind the barrier
 // (HpGeom<4, 2, 2, false>) is 5-8 % slower; two workgroups of 4 wavefronts x (128 x 64) per CU (HpGeom<2, 4, 1, true>) 20-40 %
 // slower and at the 256-VGPR limit; 128 x 128 tiles (HpGeom<2, 2, 2, true>) 30-50 % slower.
 typedef HpGeom<4, 2, 2, true> Geom;

@@ -53,7 +53,7 @@ __device__ __forceinline__ void split_pair_f16(float x0, float x1, float s0, flo
   t1 = __builtin_bit_cast(uint32_t, h);
   t2 = __builtin_bit_cast(uint32_t, g);
 }
-// Four values at once, each with its own scale.  PT_MIX_SPLIT (ablation, slower: profiles/r02_f16_split_mix_ablation.txt):
+// Four values at once, each with its own scale.  PT_MIX_SPLIT (ablation, slower: profiles/r02/r02_f16_split_mix_ablation.txt):
 // EIGHT vector instructions instead of twelve - v_fma_mixlo/mixhi_f16 round the f32 product x s straight into one half of
 // a packed register and take the f16 half back as the addend of the residual fma(x, s, -h) - same results, bit for bit.
 // The two pairs are interleaved so that no instruction reads a half-register write of the instruction before it

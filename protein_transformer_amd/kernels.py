@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import GemmArgs, GemmHpArgs, check, lib, ptr, stream, workspace
+from ._lib import GemmArgs, GemmHpArgs, GemmHpDwArgs, check, lib, ptr, stream, workspace
 
 EPI_RELU, EPI_TANH, EPI_ACCUM, EPI_GATE = 1, 2, 4, 8
 
@@ -130,6 +130,35 @@ def gemm_hp(a, b, C_out, *, bias=None, residual=None, ldr=0, flags=0, dropout_p=
         GEMM_TIMING.append((2.0 * M * N * a.K, e0, e1, 3))
         GEMM_BYTES.append(4 * (M * a.K + N * a.K + M * N * (1 + (residual is not None) + bool(flags & EPI_ACCUM))))
     return C_out
+
+
+def pick_split_k_dw(M, N, T, slots=256):
+    """Token splits of ptamd_gemm_hp_dw: (256 x 128 tile, split) items for one round of the persistent grid, at least
+    8 stages (256 tokens) per item."""
+    tiles = ((M + 255) // 256) * ((N + 127) // 128)
+    return max(1, min(T // 256, slots // tiles))
+
+
+def gemm_hp_dw(y, x, dw, dbias=None, accumulate=True, split_k=None):
+    """dw[M,N] (+)= y^T x, dbias[M] += column sums of y, from token-major pre-split operands y = hp [T,M], x = hp [T,N]."""
+    assert y.rows == x.rows
+    T, M, N = y.rows, y.K, x.K
+    sk = pick_split_k_dw(M, N, T) if split_k is None else int(split_k)
+    ws = workspace("gemm_hp_dw", lib().ptamd_gemm_hp_dw_workspace_bytes(M, N, T, sk), dw.device)
+    args = GemmHpDwArgs(M=M, N=N, T=T, Y=y.planes.data_ptr(), Y_scale=y.scale.data_ptr(), X=x.planes.data_ptr(),
+                        X_scale=x.scale.data_ptr(), C=dw.data_ptr(), ldc=dw.stride(0), accumulate=int(accumulate),
+                        colsum=dbias.data_ptr() if dbias is not None else None, split_k=sk, workspace=ws.data_ptr(),
+                        workspace_bytes=ws.numel(), reserved_cus=int(GEMM_RESERVED_CUS))
+    if GEMM_TIMING is None:
+        check(lib().ptamd_gemm_hp_dw(C.byref(args), stream()), "gemm_hp_dw")
+    else:
+        e0, e1 = GEMM_EVENT_POOL.pop(), GEMM_EVENT_POOL.pop()
+        e0.record()
+        check(lib().ptamd_gemm_hp_dw(C.byref(args), stream()), "gemm_hp_dw")
+        e1.record()
+        GEMM_TIMING.append((2.0 * M * N * T, e0, e1, 3))
+        GEMM_BYTES.append(4 * (T * M + T * N + 2 * M * N))
+    return dw
 
 
 def pick_split_k(M, N, K, slots=512):

@@ -171,7 +171,9 @@ class LossReport:
     A rank whose shard is empty passes None for everything and still takes part in the reduction.
     """
 
-    _NVEC = 18  # [0:4] sums of drmsd, ln, bb, bb-ln  [4] proteins  [5] sum rmsd  [6:12] mse sums  [12:16] status bits  [16] residues  [17] proteins with rmsd
+    # [0:4] sums of drmsd, ln, bb, bb-ln  [4] proteins  [5] sum rmsd  [6:12] mse sums  [12:16] status bits  [16] residues
+    # [17] proteins with rmsd  [18] ranks that passed a residue count (0: nobody counted - n_res stays None like on one rank)
+    _NVEC = 19
 
     def __init__(self, device, stats=None, status=None, mse_sums_local=None, rmsd=None, n_res=None):
         from . import dp
@@ -206,6 +208,7 @@ class LossReport:
             if status is not None:
                 v[12:16] = ((status.to(torch.int64) >> torch.arange(4, device=device)) & 1).double()
             v[16] = float(n_res or 0)
+            v[18] = 0.0 if n_res is None else 1.0
             dp.all_reduce_sum_(v)
             self.global_mse_sums = v[6:12].float()
             buf = _pinned("report64", self._NVEC, torch.float64, device)
@@ -238,7 +241,8 @@ class LossReport:
             n = max(v[4], 1.0)
             out.update({"drmsd": v[0] / n, "lndrmsd": v[1] / n, "drmsd-bb": v[2] / n, "lndrmsd-bb": v[3] / n,
                         "n_proteins": int(v[4]), "mse": v[6:12],
-                        "status": sum((1 << k) for k in range(4) if v[12 + k] > 0), "n_res": int(v[16])})
+                        "status": sum((1 << k) for k in range(4) if v[12 + k] > 0),
+                        "n_res": int(v[16]) if v[18] > 0 else None})
             if v[17] > 0:
                 out["rmsd"] = v[5] / v[17]
         return out

@@ -105,8 +105,6 @@ class _TransformerBase(nn.Module):
     def __init__(self, nlayers, nhead, dmodel, dff, max_seq_len, vocab, angle_means, use_tanh_out, dropout=0.1,
                  conv_kernel_sizes=None, conv_dim_reductions=(), use_embedding=True, conv_out_matches_dm=True):
         super().__init__()
-        if not use_tanh_out:
-            raise NotImplementedError("use_tanh_out=False is unreachable from the reference CLI (SURVEY.md A-1.7)")
         self.angle_means = angle_means
         self.vocab = vocab
         self.nlayers, self.nhead, self.dmodel, self.dff, self.max_seq_len = nlayers, nhead, dmodel, dff, max_seq_len
@@ -193,7 +191,11 @@ class _TransformerBase(nn.Module):
             else:
                 fan_in = self.dff if "layer2" in name else self.dlayer
                 nn.init.uniform_(p, -1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
-        am = np.arctanh(np.asarray(self.angle_means, dtype=np.float64))
+        # encoder_only.py:28-33 / convolutional_encoder.py:33-36: `-m conv-enc-linear-out` (use_tanh_out=False, reachable
+        # through train.py:289-298) starts the bias at the angle means themselves, there is no tanh to undo
+        am = np.asarray(self.angle_means, dtype=np.float64)
+        if self.use_tanh_out:
+            am = np.arctanh(am)
         with torch.no_grad():
             self.output_projection.bias.copy_(torch.tensor(am, dtype=torch.float32))
             self.output_projection.weight.zero_()
@@ -218,6 +220,7 @@ class _TransformerBase(nn.Module):
                 params[n].data = view
             self._flat = flat
             self._flat_grad = torch.zeros_like(flat)
+            self.__dict__.pop("_scale_caches", None)     # they hold views of the old flat buffer (keyed by its address)
         gbase = self._flat_grad.data_ptr()
         for n, (off, shape) in self._layout.items():
             p = params[n]
@@ -418,8 +421,8 @@ class _EncoderFn(torch.autograd.Function):
                               a_scale=sc and sc["f1_scale"], a_scale_stride=0, b_scale=sc and sc["rs_2"])
             saved.append((x, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, f1))
             x = x3
-        pred = K.linear_fwd(x, W("output_projection.weight"), W("output_projection.bias"), flags=K.EPI_TANH,
-                            arith=ar)
+        pred = K.linear_fwd(x, W("output_projection.weight"), W("output_projection.bias"),
+                            flags=K.EPI_TANH if m.use_tanh_out else 0, arith=ar)
         ctx.model, ctx.seed, ctx.seq, ctx.flat, ctx.arith, ctx.attn_arith = m, seed, seq, flat, ar, attn_default
         ctx.p, ctx.pa = p, pa
         ctx.saved, ctx.conv_saved, ctx.scales = saved, conv_saved, scales
@@ -443,7 +446,7 @@ class _EncoderFn(torch.autograd.Function):
                 m.grad_hook(o0, o1 + int(np.prod(s1)) - o0)
 
         dpred = dpred.contiguous().view(-1, NUM_PREDICTED_ANGLES * 2)
-        dpre = K.tanh_bwd(dpred, ctx.pred)
+        dpre = K.tanh_bwd(dpred, ctx.pred) if m.use_tanh_out else dpred
         K.linear_bwd_weight(dpre, ctx.x_last, G("output_projection.weight"), G("output_projection.bias"),
                             arith=ar)
         dx = K.linear_bwd_input(dpre, W("output_projection.weight"), arith=ar)
@@ -547,7 +550,7 @@ class _EncoderFn(torch.autograd.Function):
 
 
 # tokens x d_model below which AUTO runs the whole step in bf16x3 (measured: 2.9 against 3.2 ms/step at 4096 x 256,
-# 10.2 against 9.8 at 16384 x 256 - profiles/r02_v2_bench_cfg2.json, cfg3)
+# 10.2 against 9.8 at 16384 x 256 - profiles/r02/r02_v2_bench_cfg2.json, cfg3)
 AUTO_F16X2_MIN_WORK = 1 << 21
 
 

@@ -295,10 +295,15 @@ def g10(rng):
     for tag, kw in (("emb", dict(conv_kernel_sizes=[3, 5, 3], conv_dim_reductions=[2, 2, 2], use_embedding=True,
                                  conv_out_matches_dm=True)),
                     ("onehot", dict(conv_kernel_sizes=[3, 5], conv_dim_reductions=[0.5, 1], use_embedding=False,
+                                    conv_out_matches_dm=True)),
+                    # `-m conv-enc-linear-out` (train.py:289-298): no tanh, bias initialised to the angle means themselves
+                    ("linear", dict(conv_kernel_sizes=[5], conv_dim_reductions=[1], use_embedding=True,
                                     conv_out_matches_dm=True))):
         torch.manual_seed(int(rng.integers(0, 2 ** 31)))
         model = ConvEncoderOnlyTransformer(nlayers=1, nhead=4, dmodel=32, dff=64, max_seq_len=500, vocab=VOCAB,
-                                           angle_means=am, use_tanh_out=True, dropout=0.0, **kw)
+                                           angle_means=am, use_tanh_out=tag != "linear", dropout=0.0, **kw)
+        if tag == "linear":
+            out["linear/init_bias"] = model.output_projection.bias.detach().numpy().copy()
         for m in model.modules():
             if isinstance(m, torch.nn.Dropout):
                 m.p = 0.0

@@ -157,16 +157,18 @@ def test_conv1d_vs_torch(dev, B, L, C, Co, k, mode):
 
 
 # ------------------------------------------------------------------------------------------------ golden G10
-def conv_model(sd, nhead, am, kernels, reducs, use_embedding, dev, max_seq_len=500, dmodel=None):
+def conv_model(sd, nhead, am, kernels, reducs, use_embedding, dev, use_tanh_out=True, max_seq_len=500, dmodel=None):
     from protein_transformer_amd.models.convolutional_encoder import ConvEncoderOnlyTransformer
     from protein_transformer_amd.protein.Sequence import VOCAB
     dl = sd["output_projection.weight"].shape[1]
     dff = sd["encoder.enc_layers.0.pwff.layer1.weight"].shape[0]
     nl = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("encoder.enc_layers."))
     m = ConvEncoderOnlyTransformer(nlayers=nl, nhead=nhead, dmodel=dmodel or dl, dff=dff, max_seq_len=max_seq_len, vocab=VOCAB,
-                                   angle_means=am, use_tanh_out=True, conv_kernel_sizes=kernels,
+                                   angle_means=am, use_tanh_out=use_tanh_out, conv_kernel_sizes=kernels,
                                    conv_dim_reductions=reducs, use_embedding=use_embedding, conv_out_matches_dm=True,
                                    dropout=0.0)
+    if not use_tanh_out:     # encoder_only.py:31-33: the bias starts at the angle means, no arctanh
+        assert np.allclose(m.output_projection.bias.detach().numpy(), np.asarray(am, dtype=np.float32))
     missing, unexpected = m.load_state_dict({k: v for k, v in sd.items() if not k.endswith(".pe")}, strict=False)
     assert missing == ["encoder.positional_enc.pe"] and not unexpected       # the reference's keys, nothing else
     m.set_dropout(0.0)
@@ -174,9 +176,10 @@ def conv_model(sd, nhead, am, kernels, reducs, use_embedding, dev, max_seq_len=5
 
 
 @pytest.mark.parametrize("mode", ["f32", "auto"])
-@pytest.mark.parametrize("tag", ["emb", "onehot"])
+@pytest.mark.parametrize("tag", ["emb", "onehot", "linear"])
 def test_conv_encoder_golden(golden, dev, tag, mode):
-    """The reference's own ConvEncoderOnlyTransformer outputs and gradients (G10) through the HIP path."""
+    """The reference's own ConvEncoderOnlyTransformer outputs and gradients (G10) through the HIP path; "linear" is
+    `-m conv-enc-linear-out` (use_tanh_out=False, train.py:289-298 of the reference)."""
     from protein_transformer_amd import kernels as K
     g = golden("g10_convenc")
     pre = tag + "/sd/"
@@ -185,7 +188,7 @@ def test_conv_encoder_golden(golden, dev, tag, mode):
     K.set_gemm_mode(K.GEMM_F32 if mode == "f32" else K.GEMM_AUTO)
     try:
         m = conv_model(sd, 4, g["angle_means"], [int(k) for k in g[tag + "/kernels"]], [float(r) for r in g[tag + "/reducs"]],
-                       tag == "emb", dev)
+                       tag != "onehot", dev, use_tanh_out=tag != "linear")
         assert set(m.state_dict().keys()) == set(sd) | {"encoder.positional_enc.pe"}
         m.train()
         m.zero_grad()

@@ -202,16 +202,19 @@ def test_sidechain_program_consistency():
 
 
 # ---------------------------------------------------------------- G10: conv-enc front end
-@pytest.mark.parametrize("tag", ["emb", "onehot"])
+@pytest.mark.parametrize("tag", ["emb", "onehot", "linear"])
 def test_conv_encoder_golden(golden, tag):
     g = golden("g10_convenc")
     pre = tag + "/sd/"
     sd = {k[len(pre):]: T(v).clone().requires_grad_() for k, v in g.items() if k.startswith(pre)}
     dl = sd["output_projection.weight"].shape[1]
-    d_pe = sd["encoder.input_embedding.emb.weight"].shape[1] if tag == "emb" else dl
+    d_pe = sd["encoder.input_embedding.emb.weight"].shape[1] if tag != "onehot" else dl
     params = {**sd, "encoder.positional_enc.pe": encoder.positional_table(500, d_pe)}
-    pred = encoder.encoder_forward(params, T(g["seq"]), 4)
+    pred = encoder.encoder_forward(params, T(g["seq"]), 4, use_tanh_out=tag != "linear")   # "linear": -m conv-enc-linear-out
     assert np.allclose(pred.detach().numpy(), g[tag + "/pred"], atol=2e-6)
+    if tag == "linear":      # no tanh: predictions leave [-1, 1]; the bias starts at the angle means themselves
+        assert np.abs(g[tag + "/pred"]).max() > 1.0
+        assert np.allclose(g["linear/init_bias"], g["angle_means"].astype(np.float32))
     (pred * T(g["w"])).sum().backward()
     gmax = max(np.abs(g[k]).max() for k in g if k.startswith(tag + "/grad/"))
     for k in g:
