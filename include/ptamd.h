@@ -206,6 +206,13 @@ int ptamd_gemm_products(const ptamd_gemm_args *args);
 size_t ptamd_hp_bytes(int rows, int K);
 int ptamd_hp_padded_rows(int rows);
 int ptamd_hp_split(const float *x, int ld, int rows, int K, int transposed, void *planes, float *scale, void *stream);
+/* ptamd_hp_split_rows: up to 16 K-contiguous matrices [rows, K] (K % 4 == 0, K <= 2048) -> planes + scales in ONE launch
+ * (one wavefront per row: maximum, scale, split): the weight matrices of a model once per step. */
+typedef struct {
+  const float *x; int ld, rows, K;
+  void *planes; float *scale;
+} ptamd_hp_split_job;
+int ptamd_hp_split_rows(const ptamd_hp_split_job *jobs_host, int njobs, void *stream);
 typedef struct {
   int M, N, K;
   const void *A; const float *A_scale;
@@ -222,28 +229,6 @@ typedef struct {
 } ptamd_gemm_hp_args;
 size_t ptamd_gemm_hp_workspace_bytes(int M, int N, int split_k);
 int ptamd_gemm_hp(const ptamd_gemm_hp_args *args, void *stream);
-
-/* ptamd_gemm_hp_dw: the weight-gradient product of a torch.nn.Linear (what autograd derives from `F.linear(x, W, b)` in
- * Attention.py:38-41,49,69 / Sublayers.py:28-34: dW = dy^T x, db = sum_t dy) from TOKEN-MAJOR pre-split operands - the same
- * hp buffers the forward / dX products read as their A operand:
- *     C[M, N] (+)= sum_t Y[t, m] X[t, n],      colsum[m] += sum_t Y[t, m]   (colsum may be NULL)
- * Y = hp [T, M] with one scale per token, X = hp [T, N] likewise (csrc/gemm_hp_dw.hip: transpose reads of the token-major
- * blocks; the per-token scales are folded into one f16 power of two per token, error model of a uniform-scale f16x2
- * product).  split_k cuts the token range; slabs are summed in a fixed order.  accumulate != 0: C += (else C =).
- * The workspace is always needed (per-token factors live there). */
-typedef struct {
-  int M, N, T;
-  const void *Y; const float *Y_scale;
-  const void *X; const float *X_scale;
-  float *C; int ldc;
-  int accumulate;
-  float *colsum;
-  int split_k;
-  void *workspace; size_t workspace_bytes;
-  int reserved_cus;
-} ptamd_gemm_hp_dw_args;
-size_t ptamd_gemm_hp_dw_workspace_bytes(int M, int N, int T, int split_k);
-int ptamd_gemm_hp_dw(const ptamd_gemm_hp_dw_args *args, void *stream);
 
 /* ------------------------------------------------------------------ f16x2 bookkeeping without passes over activations
  * (csrc/scales.hip).  Scales are uint32 bit patterns of powers of two, as ptamd_gemm_args.a_scale / b_scale take them.
@@ -273,9 +258,11 @@ typedef struct {
 int ptamd_bound_scales(const ptamd_bound_job *jobs_host, int njobs, void *stream);
 
 /* torch.nn.LayerNorm(D, eps=1e-5) (Sublayers.py:13,17): y = (x-mean)*rstd*gamma+beta; saves mean,rstd [T];
- * row_scale [T] (may be NULL): the f16x2 scale of every row of y, for the GEMM that reads y as its A operand */
+ * row_scale [T] (may be NULL): the f16x2 scale of every row of y, for the GEMM that reads y as its A operand;
+ * planes (may be NULL; needs row_scale and D % 32 == 0): y once more in the pre-split hp format (ptamd_hp_bytes(T, D)
+ * bytes), scaled by row_scale - the A operand of ptamd_gemm_hp for the product behind the LayerNorm (QKV, FFN layer 1) */
 int ptamd_layernorm_fwd(const float *x, const float *gamma, const float *beta, int64_t T, int D, float *y,
-                        float *mean, float *rstd, uint32_t *row_scale, void *stream);
+                        float *mean, float *rstd, uint32_t *row_scale, void *planes, void *stream);
 /* dx [T,D] = LN'(dy) + dres (dres: gradient of the residual branch, may be NULL; dx may alias dres);
  * dgamma, dbeta [D] accumulated (+=) through fixed-order partials in workspace */
 size_t ptamd_layernorm_bwd_workspace_bytes(int D);

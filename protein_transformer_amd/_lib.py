@@ -47,6 +47,10 @@ class BoundJob(C.Structure):
                 ("sqrt_d", _f), ("post_scale", _f), ("out_scale", _p), ("out_value", _p)]
 
 
+class HpSplitJob(C.Structure):
+    _fields_ = [("x", _p), ("ld", _i), ("rows", _i), ("K", _i), ("planes", _p), ("scale", _p)]
+
+
 class GemmHpArgs(C.Structure):
     _fields_ = [("M", _i), ("N", _i), ("K", _i),
                 ("A", _p), ("A_scale", _p),
@@ -59,18 +63,6 @@ class GemmHpArgs(C.Structure):
                 ("split_k", _i),
                 ("workspace", _p), ("workspace_bytes", _sz),
                 ("gate_scale", _f),
-                ("reserved_cus", _i)]
-
-
-class GemmHpDwArgs(C.Structure):
-    _fields_ = [("M", _i), ("N", _i), ("T", _i),
-                ("Y", _p), ("Y_scale", _p),
-                ("X", _p), ("X_scale", _p),
-                ("C", _p), ("ldc", _i),
-                ("accumulate", _i),
-                ("colsum", _p),
-                ("split_k", _i),
-                ("workspace", _p), ("workspace_bytes", _sz),
                 ("reserved_cus", _i)]
 
 
@@ -98,13 +90,12 @@ SIGNATURES = {
     "ptamd_hp_bytes": (_sz, [_i, _i]),
     "ptamd_hp_padded_rows": (_i, [_i]),
     "ptamd_hp_split": (_i, [_p, _i, _i, _i, _i, _p, _p, _p]),
+    "ptamd_hp_split_rows": (_i, [C.POINTER(HpSplitJob), _i, _p]),
     "ptamd_gemm_hp_workspace_bytes": (_sz, [_i, _i, _i]),
     "ptamd_gemm_hp": (_i, [C.POINTER(GemmHpArgs), _p]),
-    "ptamd_gemm_hp_dw_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "ptamd_gemm_hp_dw": (_i, [C.POINTER(GemmHpDwArgs), _p]),
     "ptamd_weight_scales": (_i, [C.POINTER(WScaleJob), _i, _p]),
     "ptamd_bound_scales": (_i, [C.POINTER(BoundJob), _i, _p]),
-    "ptamd_layernorm_fwd": (_i, [_p, _p, _p, _i64, _i, _p, _p, _p, _p, _p]),
+    "ptamd_layernorm_fwd": (_i, [_p, _p, _p, _i64, _i, _p, _p, _p, _p, _p, _p]),
     "ptamd_layernorm_bwd_dropout": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _u64, _u32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "ptamd_layernorm_bwd_workspace_bytes": (_sz, [_i]),
     "ptamd_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _p, _p, _p, _p, _sz, _p]),

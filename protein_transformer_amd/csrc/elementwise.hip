@@ -8,6 +8,7 @@
 //   torch.nn.LayerNorm(D)         .../Sublayers.py:13,17   (eps 1e-5, biased variance, affine)
 //   Dropout / ReLU / tanh backward: autograd of Sublayers.py:17,34 and encoder_only.py:41
 #include "common.h"
+#include "hp_format.h"
 
 namespace {
 
@@ -99,7 +100,8 @@ template <int NV>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                             const float *__restrict__ beta, int64_t T, int D,
                                                             float *__restrict__ y, float *__restrict__ mean_out,
-                                                            float *__restrict__ rstd_out, uint32_t *__restrict__ row_scale) {
+                                                            float *__restrict__ rstd_out, uint32_t *__restrict__ row_scale,
+                                                            char *__restrict__ planes) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= T) return;
@@ -133,14 +135,24 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restr
       const float4 o = make_float4((v[j].x - mean) * rstd * g.x + b.x, (v[j].y - mean) * rstd * g.y + b.y,
                                    (v[j].z - mean) * rstd * g.z + b.z, (v[j].w - mean) * rstd * g.w + b.w);
       *reinterpret_cast<float4 *>(yr + c) = o;
+      v[j] = o;
       amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
   }
   if (row_scale) amax = wave_max(amax);  // the f16x2 row scale of y as a GEMM operand (include/ptamd.h), for free here
+  const uint32_t sbits = pt_row_scale_bits(__float_as_uint(amax));
+  if (planes) {   // y a second time, pre-split for ptamd_gemm_hp (csrc/hp_format.h): the A operand of the product behind
+    const float sc = __uint_as_float(sbits);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = (j * 64 + lane) * 4;
+      if (c < D) pthp::store4_split(planes, D >> 4, row, c, v[j], sc);
+    }
+  }
   if (lane == 0) {
     mean_out[row] = mean;
     rstd_out[row] = rstd;
-    if (row_scale) row_scale[row] = pt_row_scale_bits(__float_as_uint(amax));
+    if (row_scale) row_scale[row] = sbits;
   }
 }
 
@@ -478,14 +490,16 @@ int ptamd_embed_bwd(const int64_t *seq, const float *dout, int B, int L, int D, 
 }
 
 int ptamd_layernorm_fwd(const float *x, const float *gamma, const float *beta, int64_t T, int D, float *y, float *mean,
-                        float *rstd, uint32_t *row_scale, void *stream) {
+                        float *rstd, uint32_t *row_scale, void *planes_out, void *stream) {
   if (T <= 0 || D <= 0 || (D & 3) || D > 2048) return PTAMD_ERR_BAD_SHAPE;
+  if (planes_out && (!row_scale || (D & 31) || !pt_aligned16(planes_out))) return PTAMD_ERR_BAD_SHAPE;
+  char *planes = static_cast<char *>(planes_out);
   const dim3 grid((unsigned)((T + 3) / 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (D <= 256) hipLaunchKernelGGL(layernorm_fwd_kernel<1>, grid, block, 0, st, x, gamma, beta, T, D, y, mean, rstd, row_scale);
-  else if (D <= 512) hipLaunchKernelGGL(layernorm_fwd_kernel<2>, grid, block, 0, st, x, gamma, beta, T, D, y, mean, rstd, row_scale);
-  else if (D <= 1024) hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, block, 0, st, x, gamma, beta, T, D, y, mean, rstd, row_scale);
-  else hipLaunchKernelGGL(layernorm_fwd_kernel<8>, grid, block, 0, st, x, gamma, beta, T, D, y, mean, rstd, row_scale);
+  if (D <= 256) hipLaunchKernelGGL(layernorm_fwd_kernel<1>, grid, block, 0, st, x, gamma, beta, T, D, y, mean, rstd, row_scale, planes);
+  else if (D <= 512) hipLaunchKernelGGL(layernorm_fwd_kernel<2>, grid, block, 0, st, x, gamma, beta, T, D, y, mean, rstd, row_scale, planes);
+  else if (D <= 1024) hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, block, 0, st, x, gamma, beta, T, D, y, mean, rstd, row_scale, planes);
+  else hipLaunchKernelGGL(layernorm_fwd_kernel<8>, grid, block, 0, st, x, gamma, beta, T, D, y, mean, rstd, row_scale, planes);
   return pt_check_launch();
 }
 

@@ -328,6 +328,44 @@ __global__ __launch_bounds__(256) void hp_write_kernel(const float *__restrict__
   *reinterpret_cast<uint4 *>(dst + BLK_BYTES) = lo;
 }
 
+// ---- several K-contiguous matrices in one launch: one wavefront per (padded) row, the row held in registers
+constexpr int MAX_SPLIT_JOBS = 16;
+struct SplitJobs {
+  const float *x[MAX_SPLIT_JOBS];
+  char *planes[MAX_SPLIT_JOBS];
+  float *scale[MAX_SPLIT_JOBS];
+  int ld[MAX_SPLIT_JOBS], rows[MAX_SPLIT_JOBS], K[MAX_SPLIT_JOBS];
+  int first_block[MAX_SPLIT_JOBS + 1];   // blocks of 4 rows
+  int njobs;
+};
+template <int NV>
+__global__ __launch_bounds__(256) void hp_split_rows_kernel(const SplitJobs j) {
+  int job = 0;
+#pragma unroll 1
+  while (job + 1 < j.njobs && (int)blockIdx.x >= j.first_block[job + 1]) ++job;
+  const int lane = threadIdx.x & 63;
+  const int row = ((int)blockIdx.x - j.first_block[job]) * 4 + (threadIdx.x >> 6);
+  const int rows = j.rows[job], K = j.K[job], rows_p = round_up(rows, 32), Kp = round_up(K, 32);
+  if (row >= rows_p) return;
+  float4 v[NV];
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    v[i] = (row < rows && c < K) ? *reinterpret_cast<const float4 *>(j.x[job] + (size_t)row * j.ld[job] + c)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+  }
+  m = wave_max(m);
+  const float s = row < rows ? __uint_as_float(scale_bits_of(__float_as_uint(m))) : 1.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < Kp) store4_split(j.planes[job], Kp >> 4, row, c, v[i], s);
+  }
+  if (lane == 0) j.scale[job][row] = s;
+}
+
 size_t slab_bytes(int M, int N, int split_k) {
   if (split_k <= 1) return 0;
   return ((size_t)split_k * M * N * sizeof(float) + 15) & ~(size_t)15;
@@ -364,6 +402,30 @@ int ptamd_hp_split(const float *x, int ld, int rows, int K, int transposed, void
     hipLaunchKernelGGL(hp_amax_to_scale_kernel, dim3((rows_p + 255) / 256), dim3(256), 0, st, reinterpret_cast<uint32_t *>(scale),
                        rows, rows_p);
   }
+  return pt_check_launch();
+}
+
+int ptamd_hp_split_rows(const ptamd_hp_split_job *jobs, int njobs, void *stream) {
+  if (!jobs || njobs <= 0 || njobs > MAX_SPLIT_JOBS) return PTAMD_ERR_BAD_SHAPE;
+  SplitJobs j;
+  int blocks = 0, kmax = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const ptamd_hp_split_job &q = jobs[i];
+    if (!q.x || !q.planes || !q.scale || q.rows <= 0 || q.K <= 0 || (q.K & 3) || (q.ld & 3) || q.K > 2048) return PTAMD_ERR_BAD_SHAPE;
+    if (!pt_aligned16(q.x) || !pt_aligned16(q.planes)) return PTAMD_ERR_ALIGN;
+    j.x[i] = q.x; j.planes[i] = static_cast<char *>(q.planes); j.scale[i] = q.scale;
+    j.ld[i] = q.ld; j.rows[i] = q.rows; j.K[i] = q.K;
+    j.first_block[i] = blocks;
+    blocks += round_up(q.rows, 32) / 4;
+    kmax = q.K > kmax ? q.K : kmax;
+  }
+  for (int i = njobs; i <= MAX_SPLIT_JOBS; ++i) j.first_block[i] = blocks;
+  j.njobs = njobs;
+  hipStream_t st = (hipStream_t)stream;
+  if (kmax <= 256) hipLaunchKernelGGL(hp_split_rows_kernel<1>, dim3(blocks), dim3(256), 0, st, j);
+  else if (kmax <= 512) hipLaunchKernelGGL(hp_split_rows_kernel<2>, dim3(blocks), dim3(256), 0, st, j);
+  else if (kmax <= 1024) hipLaunchKernelGGL(hp_split_rows_kernel<4>, dim3(blocks), dim3(256), 0, st, j);
+  else hipLaunchKernelGGL(hp_split_rows_kernel<8>, dim3(blocks), dim3(256), 0, st, j);
   return pt_check_launch();
 }
 

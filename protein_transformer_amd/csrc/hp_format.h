@@ -46,4 +46,21 @@ __host__ __device__ inline void chunk_coords(int c, int &r, int &h) {
 __device__ __forceinline__ uint32_t scale_bits_of(uint32_t amax) { return min(268u - (amax >> 23), 254u) << 23; }
 __device__ __forceinline__ float inverse_of_scale(float scale) { return __uint_as_float((254u << 23) - __float_as_uint(scale)); }
 
+#ifdef __HIPCC__
+// Four consecutive columns c .. c + 3 (c multiple of 4) of row `row`, already multiplied by nothing: x * s is split here
+// into the two planes (8 bytes each).  Writers that hold a row in float4 pieces (LayerNorm, the weight splitter) use this.
+__device__ __forceinline__ void store4_split(char *__restrict__ planes, int KB16, int64_t row, int c, float4 v, float s) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const float a0 = v.x * s, a1 = v.y * s, a2 = v.z * s, a3 = v.w * s;               // exact: s is a power of two
+  const h2 h01 = __builtin_convertvector((f2){a0, a1}, h2), h23 = __builtin_convertvector((f2){a2, a3}, h2);
+  const h2 l01 = __builtin_convertvector((f2){a0 - (float)h01[0], a1 - (float)h01[1]}, h2);
+  const h2 l23 = __builtin_convertvector((f2){a2 - (float)h23[0], a3 - (float)h23[1]}, h2);
+  const int r = (int)(row & 31), h = (c >> 3) & 1;
+  char *dst = planes + block_offset((int)(row >> 5), c >> 4, 0, KB16) + chunk_index(r, h) * 16 + ((c >> 2) & 1) * 8;
+  *reinterpret_cast<uint2 *>(dst) = make_uint2(__builtin_bit_cast(uint32_t, h01), __builtin_bit_cast(uint32_t, h23));
+  *reinterpret_cast<uint2 *>(dst + BLK_BYTES) = make_uint2(__builtin_bit_cast(uint32_t, l01), __builtin_bit_cast(uint32_t, l23));
+}
+#endif
+
 }  // namespace pthp

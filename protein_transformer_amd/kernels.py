@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import GemmArgs, GemmHpArgs, GemmHpDwArgs, check, lib, ptr, stream, workspace
+from ._lib import GemmArgs, GemmHpArgs, check, lib, ptr, stream, workspace
 
 EPI_RELU, EPI_TANH, EPI_ACCUM, EPI_GATE = 1, 2, 4, 8
 
@@ -132,35 +132,6 @@ def gemm_hp(a, b, C_out, *, bias=None, residual=None, ldr=0, flags=0, dropout_p=
     return C_out
 
 
-def pick_split_k_dw(M, N, T, slots=256):
-    """Token splits of ptamd_gemm_hp_dw: (256 x 128 tile, split) items for one round of the persistent grid, at least
-    8 stages (256 tokens) per item."""
-    tiles = ((M + 255) // 256) * ((N + 127) // 128)
-    return max(1, min(T // 256, slots // tiles))
-
-
-def gemm_hp_dw(y, x, dw, dbias=None, accumulate=True, split_k=None):
-    """dw[M,N] (+)= y^T x, dbias[M] += column sums of y, from token-major pre-split operands y = hp [T,M], x = hp [T,N]."""
-    assert y.rows == x.rows
-    T, M, N = y.rows, y.K, x.K
-    sk = pick_split_k_dw(M, N, T) if split_k is None else int(split_k)
-    ws = workspace("gemm_hp_dw", lib().ptamd_gemm_hp_dw_workspace_bytes(M, N, T, sk), dw.device)
-    args = GemmHpDwArgs(M=M, N=N, T=T, Y=y.planes.data_ptr(), Y_scale=y.scale.data_ptr(), X=x.planes.data_ptr(),
-                        X_scale=x.scale.data_ptr(), C=dw.data_ptr(), ldc=dw.stride(0), accumulate=int(accumulate),
-                        colsum=dbias.data_ptr() if dbias is not None else None, split_k=sk, workspace=ws.data_ptr(),
-                        workspace_bytes=ws.numel(), reserved_cus=int(GEMM_RESERVED_CUS))
-    if GEMM_TIMING is None:
-        check(lib().ptamd_gemm_hp_dw(C.byref(args), stream()), "gemm_hp_dw")
-    else:
-        e0, e1 = GEMM_EVENT_POOL.pop(), GEMM_EVENT_POOL.pop()
-        e0.record()
-        check(lib().ptamd_gemm_hp_dw(C.byref(args), stream()), "gemm_hp_dw")
-        e1.record()
-        GEMM_TIMING.append((2.0 * M * N * T, e0, e1, 3))
-        GEMM_BYTES.append(4 * (T * M + T * N + 2 * M * N))
-    return dw
-
-
 def pick_split_k(M, N, K, slots=512):
     """K splits for a reduction-heavy product with few output tiles: as many (tile, split) items as fit in ONE round
     of the persistent grid (2 workgroups x 256 CUs) - one item more than that would cost a whole second round."""
@@ -232,15 +203,38 @@ def colsum(x, out, accumulate=True):
     return out
 
 
-def layernorm_fwd(x, gamma, beta, row_scale=None):
-    """y, mean, rstd; `row_scale` (uint32-as-int32 [T], optional) receives the f16x2 scale of every row of y."""
+def layernorm_fwd(x, gamma, beta, row_scale=None, planes=None):
+    """y, mean, rstd; `row_scale` (uint32-as-int32 [T], optional) receives the f16x2 scale of every row of y; `planes`
+    (uint8 buffer of ptamd_hp_bytes(T, D), optional, needs row_scale) receives y once more in the pre-split hp format."""
     T, D = x.shape
     y = torch.empty_like(x)
     mean = torch.empty(T, dtype=torch.float32, device=x.device)
     rstd = torch.empty(T, dtype=torch.float32, device=x.device)
     check(lib().ptamd_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), T, D, ptr(y), ptr(mean), ptr(rstd), ptr(row_scale),
-                                    stream()), "layernorm_fwd")
+                                    ptr(planes), stream()), "layernorm_fwd")
     return y, mean, rstd
+
+
+def hp_view(planes, scale, rows, K):
+    """HpOperand over existing buffers (planes: uint8, scale: float32 / int32 bits of powers of two, one per row)."""
+    op = HpOperand.__new__(HpOperand)
+    op.rows, op.K, op.planes = int(rows), int(K), planes
+    op.scale = scale.view(torch.float32) if scale.dtype != torch.float32 else scale
+    return op
+
+
+def hp_split_rows(mats, outs):
+    """K-contiguous matrices -> HpOperands `outs` (allocated by the caller) in one launch per 16 matrices."""
+    from ._lib import HpSplitJob
+    for i in range(0, len(mats), 16):
+        chunk = list(zip(mats[i:i + 16], outs[i:i + 16]))
+        arr = (HpSplitJob * len(chunk))()
+        for k, (w, o) in enumerate(chunk):
+            assert w.dim() == 2 and w.stride(1) == 1 and (o.rows, o.K) == tuple(w.shape)
+            arr[k] = HpSplitJob(x=w.data_ptr(), ld=w.stride(0), rows=w.shape[0], K=w.shape[1], planes=o.planes.data_ptr(),
+                                scale=o.scale.data_ptr())
+        check(lib().ptamd_hp_split_rows(arr, len(chunk), stream()), "hp_split_rows")
+    return outs
 
 
 def layernorm_bwd_dropout(dy, x, gamma, mean, rstd, dgamma, dbeta, dres, dropout_p, seed, stream_id, row_scale=None,

@@ -148,6 +148,7 @@ class _TransformerBase(nn.Module):
         self.attn_row_scales = True                  # dqkv row scales from the attention backward kernels (False: a pass; ablation)
         self.attn_mode = None                        # arithmetic of the attention kernels alone (ablations); None = gemm_mode
         self.gemm_mode = None                        # kernels.GEMM_* arithmetic of THIS model; None = kernels.get_gemm_mode()
+        self.hp_forward = True                       # QKV / FFN-layer-1 products on ptamd_gemm_hp from LayerNorm-written planes
         self._init_parameters()
 
     # ------------------------------------------------------------------ parameters
@@ -321,8 +322,19 @@ class _TransformerBase(nn.Module):
                 L["dqkv_stats"] = dq_stats[i]
                 L["minbuf"] = minbuf
             cache = caches[key] = dict(layers=layers, wjobs=wjobs, bjobs=bjobs, keep=(ints, stats, factor, ones, dq_stats, minbuf))
+            # the two weight matrices that sit behind a LayerNorm, pre-split once per forward pass for ptamd_gemm_hp
+            cache["hp_mats"], cache["hp_outs"] = [], []
+            if self.hp_forward and D % 32 == 0 and D <= 2048:
+                for i, L in enumerate(layers):
+                    wqkv, _ = self._qkv(flat, i)
+                    w1 = W(f"encoder.enc_layers.{i}.pwff.layer1.weight")
+                    L["hp_qkv"], L["hp_1"] = K.HpOperand(3 * D, D, dev), K.HpOperand(F, D, dev)
+                    cache["hp_mats"] += [wqkv, w1]
+                    cache["hp_outs"] += [L["hp_qkv"], L["hp_1"]]
         K.weight_scales(cache["wjobs"])
         K.bound_scales(cache["bjobs"])
+        if cache["hp_mats"]:
+            K.hp_split_rows(cache["hp_mats"], cache["hp_outs"])
         return cache["layers"]
 
     def _slice(self, buf, name):
@@ -396,6 +408,10 @@ class _EncoderFn(torch.autograd.Function):
         # outputs from the LayerNorm kernel itself (None: the arithmetic of this pass does not use them)
         scales = m._step_scales(flat, ar, p, pa)
         Tn = B * L
+        # The products right behind a LayerNorm (QKV, FFN layer 1) run on ptamd_gemm_hp: the LayerNorm kernel writes its
+        # output a second time as pre-split planes (one buffer, consumed at once), the weights were split above.
+        use_hp = scales is not None and "hp_qkv" in scales[0]
+        hplanes = torch.empty(K.lib().ptamd_hp_bytes(Tn, D), dtype=torch.uint8, device=x.device) if use_hp else None
         for i in range(m.nlayers):
             b = f"encoder.enc_layers.{i}."
             sid = i * 8
@@ -403,8 +419,12 @@ class _EncoderFn(torch.autograd.Function):
             wqkv, bqkv = m._qkv(flat, i)
             s_h1 = torch.empty(Tn, dtype=torch.int32, device=x.device) if sc else None
             h1, mean1, rstd1 = K.layernorm_fwd(x, W(b + "sublayer_connections.0.norm.weight"),
-                                               W(b + "sublayer_connections.0.norm.bias"), row_scale=s_h1)
-            qkv = K.linear_fwd(h1, wqkv, bqkv, arith=ar, a_scale=s_h1, b_scale=sc and sc["rs_qkv"])
+                                               W(b + "sublayer_connections.0.norm.bias"), row_scale=s_h1, planes=hplanes)
+            if use_hp:
+                qkv = K.gemm_hp(K.hp_view(hplanes, s_h1, Tn, D), sc["hp_qkv"],
+                                torch.empty(Tn, 3 * D, dtype=torch.float32, device=x.device), bias=bqkv)
+            else:
+                qkv = K.linear_fwd(h1, wqkv, bqkv, arith=ar, a_scale=s_h1, b_scale=sc and sc["rs_qkv"])
             att, lse = K.attention_fwd(qkv, seq, H, pa, seed, sid + _SITE_ATTN,
                                         arith=attn_default if m.attn_mode is None else m.attn_mode)
             x2 = K.linear_fwd(att, W(b + "self_attn.wo.weight"), W(b + "self_attn.wo.bias"), residual=x, ldr=D,
@@ -412,10 +432,15 @@ class _EncoderFn(torch.autograd.Function):
                               a_scale=sc and sc["att_scale"], a_scale_stride=0, b_scale=sc and sc["rs_o"])
             s_h2 = torch.empty(Tn, dtype=torch.int32, device=x.device) if sc else None
             h2, mean2, rstd2 = K.layernorm_fwd(x2, W(b + "sublayer_connections.1.norm.weight"),
-                                               W(b + "sublayer_connections.1.norm.bias"), row_scale=s_h2)
-            f1 = K.linear_fwd(h2, W(b + "pwff.layer1.weight"), W(b + "pwff.layer1.bias"), flags=K.EPI_RELU,
-                              dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_HID, arith=ar,
-                              a_scale=s_h2, b_scale=sc and sc["rs_1"])
+                                               W(b + "sublayer_connections.1.norm.bias"), row_scale=s_h2, planes=hplanes)
+            if use_hp:
+                f1 = K.gemm_hp(K.hp_view(hplanes, s_h2, Tn, D), sc["hp_1"],
+                               torch.empty(Tn, m.dff, dtype=torch.float32, device=x.device), bias=W(b + "pwff.layer1.bias"),
+                               flags=K.EPI_RELU, dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_HID)
+            else:
+                f1 = K.linear_fwd(h2, W(b + "pwff.layer1.weight"), W(b + "pwff.layer1.bias"), flags=K.EPI_RELU,
+                                  dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_HID, arith=ar,
+                                  a_scale=s_h2, b_scale=sc and sc["rs_1"])
             x3 = K.linear_fwd(f1, W(b + "pwff.layer2.weight"), W(b + "pwff.layer2.bias"), residual=x2, ldr=D,
                               dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_OUT, arith=ar,
                               a_scale=sc and sc["f1_scale"], a_scale_stride=0, b_scale=sc and sc["rs_2"])

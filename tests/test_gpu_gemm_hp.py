@@ -110,50 +110,33 @@ def test_gemm_hp_epilogues_split_and_masks(dev):
     assert float((c1 - c2).abs().max()) < 2e-5 * float(c2.abs().max())
 
 
-# ------------------------------------------------------------------------------------------------ ptamd_gemm_hp_dw
-@pytest.mark.parametrize("T,M,N,split", [(64, 256, 128, 1), (512, 512, 512, None), (300, 200, 72, 3), (4096, 512, 2048, None),
-                                         (2048, 1536, 512, None), (1000, 24, 512, 4), (97, 132, 48, 1), (8192, 2048, 512, 16)])
-def test_gemm_hp_dw_matches_fp64(dev, T, M, N, split):
-    """dW = dy^T x and dbias = column sums of dy from token-major pre-split operands (csrc/gemm_hp_dw.hip): token rows of
-    very different size (per-token scales inside the contraction), a zero row, accumulation into dW / dbias."""
+def test_layernorm_writes_planes_and_weights_split_in_one_launch(dev):
+    """The two writers behind the hp forward products of the model: ptamd_layernorm_fwd(planes=...) and ptamd_hp_split_rows
+    produce exactly what ptamd_hp_split makes of the same fp32 matrix, and the product from them equals the fp64 product."""
     from protein_transformer_amd import kernels as K_
-    g = torch.Generator().manual_seed(T + M + N)
-    dy = torch.randn(T, M, generator=g) * torch.exp(torch.randn(T, 1, generator=g) * 2)      # ~5 decades between tokens
-    x = torch.randn(T, N, generator=g) * torch.exp(torch.randn(T, 1, generator=g) * 0.5)
-    dy[T // 3] = 0
-    Y, X = K_.hp_split(dy.to(dev)), K_.hp_split(x.to(dev))
-    dw0, db0 = torch.randn(M, N, generator=g), torch.randn(M, generator=g)
-    dw, db = dw0.to(dev), db0.to(dev)
-    K_.gemm_hp_dw(Y, X, dw, db, accumulate=True, split_k=split)
-    ref = dy.double().t() @ x.double()
-    bound = dy.double().abs().t() @ x.double().abs()
-    err = (dw.cpu().double() - dw0.double() - ref).abs()
-    # norm-wise bound of a uniform-scale f16x2 product (include/ptamd.h): 2^-20 sum|x||y| + what the tokens far below the
-    # largest lose; measured 2-4e-7 of the bound, plus the rounding of the accumulation into dw0
-    assert float((err / (bound + dw0.double().abs())).max()) < 2e-6, float((err / (bound + dw0.double().abs())).max())
-    assert float(err.norm() / ref.norm()) < 5e-7
-    cref = dy.double().sum(0)
-    cerr = (db.cpu().double() - db0.double() - cref).abs()
-    assert float((cerr / (dy.double().abs().sum(0) + db0.double().abs())).max()) < 2e-6
-    # overwrite instead of accumulate, no bias gradient
-    dw2 = torch.full((M, N), float("nan"), device=dev)
-    K_.gemm_hp_dw(Y, X, dw2, None, accumulate=False, split_k=split)
-    assert float((dw2.cpu().double() - ref).norm() / ref.norm()) < 5e-7
-    # against the uniform-scale f16x2 product of ptamd_gemm on the fp32 operands: same error class
-    if M % 4 == 0 and N % 4 == 0:
-        dw3 = torch.zeros(M, N, device=dev)
-        K_.linear_bwd_weight(dy.to(dev), x.to(dev), dw3, None, arith=K_.GEMM_BF16X3)
-        assert float((dw3.cpu().double() - ref).norm() / ref.norm()) < 5e-7
-
-
-def test_gemm_hp_dw_uniform_rows_is_fp32_grade(dev):
-    """Tokens of similar size (LayerNorm outputs x gradients within a few binades): element-wise fp32-fma-chain level."""
-    from protein_transformer_amd import kernels as K_
-    g = torch.Generator().manual_seed(5)
-    T, M, N = 2048, 256, 384
-    dy, x = torch.randn(T, M, generator=g), torch.randn(T, N, generator=g)
-    dw = torch.zeros(M, N, device=dev)
-    K_.gemm_hp_dw(K_.hp_split(dy.to(dev)), K_.hp_split(x.to(dev)), dw, None, accumulate=False)
-    ref = dy.double().t() @ x.double()
-    bound = dy.double().abs().t() @ x.double().abs()
-    assert float(((dw.cpu().double() - ref).abs() / bound).max()) < 6e-7
+    g = torch.Generator().manual_seed(11)
+    T, D, N = 200, 96, 160                                   # T not a multiple of 32: the last block row is partly unused
+    x = (torch.randn(T, D, generator=g) * torch.exp(torch.randn(T, 1, generator=g))).to(dev)
+    gamma, beta = (1 + 0.2 * torch.randn(D, generator=g)).to(dev), (0.1 * torch.randn(D, generator=g)).to(dev)
+    scale = torch.empty(T, dtype=torch.int32, device=dev)
+    planes = torch.zeros(K_.lib().ptamd_hp_bytes(T, D), dtype=torch.uint8, device=dev)
+    y, _, _ = K_.layernorm_fwd(x, gamma, beta, row_scale=scale, planes=planes)
+    y2, _, _ = K_.layernorm_fwd(x, gamma, beta)
+    assert torch.equal(y, y2)
+    ref_op = K_.hp_split(y)
+    got = K_.hp_view(planes, scale, T, D)
+    assert torch.equal(got.scale[:T], ref_op.scale[:T])
+    back_ref, _, _ = unpack(ref_op, dev)
+    back_got = unpack(K_.hp_view(planes, torch.cat([got.scale, torch.ones(24, device=dev)]), T, D), dev)[0]
+    assert np.array_equal(back_got[:T], back_ref[:T])
+    # weights: several matrices, one launch
+    ws = [torch.randn(N, D, generator=g).to(dev) * 0.05, torch.randn(64, D, generator=g).to(dev), torch.randn(40, 32, generator=g).to(dev)]
+    outs = K_.hp_split_rows(ws, [K_.HpOperand(w.shape[0], w.shape[1], dev) for w in ws])
+    for w, o in zip(ws, outs):
+        r = K_.hp_split(w)
+        assert torch.equal(o.planes, r.planes) and torch.equal(o.scale, r.scale)
+    C = torch.empty(T, N, device=dev)
+    K_.gemm_hp(got, outs[0], C)
+    ref = y.cpu().double() @ ws[0].cpu().double().t()
+    bound = y.cpu().double().abs() @ ws[0].cpu().double().abs().t()
+    assert float(((C.cpu().double() - ref).abs() / bound).max()) < 6e-7
