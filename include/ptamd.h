@@ -266,6 +266,11 @@ int ptamd_layernorm_fwd(const float *x, const float *gamma, const float *beta, i
 /* dx [T,D] = LN'(dy) + dres (dres: gradient of the residual branch, may be NULL; dx may alias dres);
  * dgamma, dbeta [D] accumulated (+=) through fixed-order partials in workspace */
 size_t ptamd_layernorm_bwd_workspace_bytes(int D);
+/* dgamma == dbeta == NULL in the two calls below: the kernel leaves its fixed-order partial sums in `workspace` and the caller
+ * finishes up to 16 such sites with ONE launch of ptamd_layernorm_bwd_reduce (dgamma / dbeta += their column sums) - e.g.
+ * both LayerNorms of an encoder layer, or all of a backward pass; every pending site needs a workspace of its own. */
+typedef struct { const void *partials; int D; float *dgamma; float *dbeta; } ptamd_ln_reduce_job;
+int ptamd_layernorm_bwd_reduce(const ptamd_ln_reduce_job *jobs_host, int njobs, void *stream);
 int ptamd_layernorm_bwd(const float *dy, const float *x, const float *gamma, const float *mean, const float *rstd,
                         const float *dres, int64_t T, int D, float *dx, float *dgamma, float *dbeta, void *workspace,
                         size_t workspace_bytes, void *stream);

@@ -47,6 +47,10 @@ class BoundJob(C.Structure):
                 ("sqrt_d", _f), ("post_scale", _f), ("out_scale", _p), ("out_value", _p)]
 
 
+class LnReduceJob(C.Structure):
+    _fields_ = [("partials", _p), ("D", _i), ("dgamma", _p), ("dbeta", _p)]
+
+
 class HpSplitJob(C.Structure):
     _fields_ = [("x", _p), ("ld", _i), ("rows", _i), ("K", _i), ("planes", _p), ("scale", _p)]
 
@@ -98,6 +102,7 @@ SIGNATURES = {
     "ptamd_layernorm_fwd": (_i, [_p, _p, _p, _i64, _i, _p, _p, _p, _p, _p, _p]),
     "ptamd_layernorm_bwd_dropout": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _u64, _u32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "ptamd_layernorm_bwd_workspace_bytes": (_sz, [_i]),
+    "ptamd_layernorm_bwd_reduce": (_i, [C.POINTER(LnReduceJob), _i, _p]),
     "ptamd_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _p, _p, _p, _p, _sz, _p]),
     "ptamd_embed_fwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _u64, _p, _p]),
     "ptamd_embed_bwd_workspace_bytes": (_sz, [_i]),

@@ -376,13 +376,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dropout_kernel(
     }
   }
 }
-// LN_BWD_BLOCKS partial rows -> [D]: one block per 64 columns, 16 waves each summing every 16th row (256 B reads)
-__global__ __launch_bounds__(1024) void layernorm_bwd_reduce_kernel(const float *__restrict__ part, int D,
-                                                                    float *__restrict__ dgamma,
-                                                                    float *__restrict__ dbeta) {
+// LN_BWD_BLOCKS partial rows -> [D]: one block per 64 columns, 16 waves each summing every 16th row (256 B reads).
+// Several LayerNorm sites per launch (blockIdx.y = site): the backward kernels of a layer (or of the whole pass) leave
+// their partial rows in separate workspaces and ONE reduce launch finishes them (ptamd_layernorm_bwd_reduce).
+constexpr int LN_MAX_REDUCE_JOBS = 16;
+struct LnReduceJobs {
+  const float *part[LN_MAX_REDUCE_JOBS];
+  float *dgamma[LN_MAX_REDUCE_JOBS], *dbeta[LN_MAX_REDUCE_JOBS];
+  int D[LN_MAX_REDUCE_JOBS];
+};
+__global__ __launch_bounds__(1024) void layernorm_bwd_reduce_kernel(const LnReduceJobs jobs) {
   __shared__ float s_a[16][64], s_b[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
+  const int c = blockIdx.x * 64 + lane, D = jobs.D[blockIdx.y];
+  const float *__restrict__ part = jobs.part[blockIdx.y];
+  if ((int)blockIdx.x * 64 >= D) return;
   float a = 0.f, b = 0.f;
   if (c < D)
     for (int w = wave; w < LN_BWD_BLOCKS; w += 16) {
@@ -399,9 +407,15 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_reduce_kernel(const float 
       ta += s_a[w][lane];
       tb += s_b[w][lane];
     }
-    dgamma[c] += ta;
-    dbeta[c] += tb;
+    jobs.dgamma[blockIdx.y][c] += ta;
+    jobs.dbeta[blockIdx.y][c] += tb;
   }
+}
+int launch_ln_reduce(const float *part, int D, float *dgamma, float *dbeta, hipStream_t st) {
+  LnReduceJobs j;
+  for (int i = 0; i < LN_MAX_REDUCE_JOBS; ++i) { j.part[i] = part; j.dgamma[i] = dgamma; j.dbeta[i] = dbeta; j.D[i] = D; }
+  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((D + 63) / 64, 1), dim3(1024), 0, st, j);
+  return pt_check_launch();
 }
 
 // ------------------------------------------------------------------------------------------------ column sums
@@ -520,9 +534,9 @@ int ptamd_layernorm_bwd(const float *dy, const float *x, const float *gamma, con
   else if (D <= 1024) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, st, dy, x, gamma, mean, rstd, dres, T, D, dx, part);
   else hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, block, 0, st, dy, x, gamma, mean, rstd, dres, T, D, dx, part);
   int rc = pt_check_launch();
-  if (rc) return rc;
-  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((D + 63) / 64), dim3(1024), 0, st, part, D, dgamma, dbeta);
-  return pt_check_launch();
+  if (rc || (!dgamma && !dbeta)) return rc;   // no destinations: the partial rows stay in the workspace (ptamd_layernorm_bwd_reduce)
+  if (!dgamma || !dbeta) return PTAMD_ERR_BAD_SHAPE;
+  return launch_ln_reduce(part, D, dgamma, dbeta, st);
 }
 
 int ptamd_layernorm_bwd_dropout(const float *dy, const float *x, const float *gamma, const float *mean, const float *rstd,
@@ -545,8 +559,23 @@ int ptamd_layernorm_bwd_dropout(const float *dy, const float *x, const float *ga
   else PT_LN_FUSED(4);
 #undef PT_LN_FUSED
   int rc = pt_check_launch();
-  if (rc) return rc;
-  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((D + 63) / 64), dim3(1024), 0, st, part, D, dgamma, dbeta);
+  if (rc || (!dgamma && !dbeta)) return rc;
+  if (!dgamma || !dbeta) return PTAMD_ERR_BAD_SHAPE;
+  return launch_ln_reduce(part, D, dgamma, dbeta, st);
+}
+
+int ptamd_layernorm_bwd_reduce(const ptamd_ln_reduce_job *jobs, int njobs, void *stream) {
+  if (!jobs || njobs <= 0 || njobs > LN_MAX_REDUCE_JOBS) return PTAMD_ERR_BAD_SHAPE;
+  LnReduceJobs j;
+  int dmax = 0;
+  for (int i = 0; i < njobs; ++i) {
+    if (!jobs[i].partials || !jobs[i].dgamma || !jobs[i].dbeta || jobs[i].D <= 0) return PTAMD_ERR_BAD_SHAPE;
+    j.part[i] = static_cast<const float *>(jobs[i].partials); j.dgamma[i] = jobs[i].dgamma; j.dbeta[i] = jobs[i].dbeta;
+    j.D[i] = jobs[i].D;
+    dmax = jobs[i].D > dmax ? jobs[i].D : dmax;
+  }
+  for (int i = njobs; i < LN_MAX_REDUCE_JOBS; ++i) { j.part[i] = j.part[0]; j.dgamma[i] = j.dgamma[0]; j.dbeta[i] = j.dbeta[0]; j.D[i] = 0; }
+  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((dmax + 63) / 64, njobs), dim3(1024), 0, (hipStream_t)stream, j);
   return pt_check_launch();
 }
 

@@ -237,18 +237,42 @@ def hp_split_rows(mats, outs):
     return outs
 
 
+def _ln_workspace(D, device, pending):
+    """Workspace of one LayerNorm backward; with a `pending` list (deferred reduction) every pending site gets its own."""
+    tag = "ln" if pending is None else f"ln{len(pending)}"
+    return workspace(tag, lib().ptamd_layernorm_bwd_workspace_bytes(D), device)
+
+
+def layernorm_bwd_flush(pending):
+    """Finish the deferred (dgamma, dbeta) reductions in `pending` with one launch per 16 sites; empties the list."""
+    from ._lib import LnReduceJob
+    for i in range(0, len(pending), 16):
+        chunk = pending[i:i + 16]
+        arr = (LnReduceJob * len(chunk))()
+        for k, (ws, D, dg, db) in enumerate(chunk):
+            arr[k] = LnReduceJob(partials=ws.data_ptr(), D=D, dgamma=dg.data_ptr(), dbeta=db.data_ptr())
+        check(lib().ptamd_layernorm_bwd_reduce(arr, len(chunk), stream()), "layernorm_bwd_reduce")
+    del pending[:]
+
+
 def layernorm_bwd_dropout(dy, x, gamma, mean, rstd, dgamma, dbeta, dres, dropout_p, seed, stream_id, row_scale=None,
-                          bound_factor=None, bound_scale=None, row_scale_min=None, bound_scale_min=None):
+                          bound_factor=None, bound_scale=None, row_scale_min=None, bound_scale_min=None, pending=None):
     """LayerNorm backward fused with the dropout backward of its output (ptamd_layernorm_bwd_dropout): returns
     (dx, dropped); dropped is dx itself when dropout_p == 0.  Fills row_scale / bound_scale [T] when given."""
     T, D = x.shape
     dx = torch.empty_like(x)
     dropped = torch.empty_like(x) if dropout_p > 0 else None
-    ws = workspace("ln", lib().ptamd_layernorm_bwd_workspace_bytes(D), x.device)
+    if pending is not None and len(pending) >= 16:
+        layernorm_bwd_flush(pending)
+    ws = _ln_workspace(D, x.device, pending)
+    defer = pending is not None
     check(lib().ptamd_layernorm_bwd_dropout(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), T, D, float(dropout_p),
                                             int(seed), int(stream_id), ptr(dx), ptr(dropped), ptr(row_scale),
                                             ptr(bound_factor), ptr(bound_scale), ptr(row_scale_min), ptr(bound_scale_min),
-                                            ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(), stream()), "layernorm_bwd_dropout")
+                                            None if defer else ptr(dgamma), None if defer else ptr(dbeta), ptr(ws), ws.numel(),
+                                            stream()), "layernorm_bwd_dropout")
+    if defer:
+        pending.append((ws, D, dgamma, dbeta))
     return dx, (dropped if dropped is not None else dx)
 
 
@@ -285,13 +309,20 @@ def bound_scales(jobs):
         check(lib().ptamd_bound_scales(arr, len(chunk), stream()), "bound_scales")
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None):
-    """dx = LayerNorm'(dy) (+ dres, the gradient that bypassed the sublayer through the residual add)."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, pending=None):
+    """dx = LayerNorm'(dy) (+ dres, the gradient that bypassed the sublayer through the residual add).  `pending`: a list
+    that collects the (dgamma, dbeta) reduction of this site for `layernorm_bwd_flush` instead of launching it here."""
     T, D = x.shape
     dx = torch.empty_like(x)
-    ws = workspace("ln", lib().ptamd_layernorm_bwd_workspace_bytes(D), x.device)
-    check(lib().ptamd_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), T, D, ptr(dx), ptr(dgamma),
-                                    ptr(dbeta), ptr(ws), ws.numel(), stream()), "layernorm_bwd")
+    if pending is not None and len(pending) >= 16:
+        layernorm_bwd_flush(pending)
+    ws = _ln_workspace(D, x.device, pending)
+    defer = pending is not None
+    check(lib().ptamd_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), T, D, ptr(dx),
+                                    None if defer else ptr(dgamma), None if defer else ptr(dbeta), ptr(ws), ws.numel(), stream()),
+          "layernorm_bwd")
+    if defer:
+        pending.append((ws, D, dgamma, dbeta))
     return dx
 
 

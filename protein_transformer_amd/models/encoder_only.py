@@ -464,8 +464,11 @@ class _EncoderFn(torch.autograd.Function):
         W = lambda name: m._slice(flat, name)                                      # noqa: E731
         G = lambda name: m._slice(gflat, name)                                     # noqa: E731
 
+        ln_pending = []      # deferred (dgamma, dbeta) reductions of the LayerNorm backward kernels: one launch per flush
+
         def done(first, last):
             if m.grad_hook is not None:
+                K.layernorm_bwd_flush(ln_pending)     # a slice handed to the all-reduce must be final
                 o0, _ = m._layout[first]
                 o1, s1 = m._layout[last]
                 m.grad_hook(o0, o1 + int(np.prod(s1)) - o0)
@@ -509,10 +512,11 @@ class _EncoderFn(torch.autograd.Function):
                 s_dyo = i32() if sc else None
                 dx2, dyo = K.layernorm_bwd_dropout(dh2, x2, W(b + "sublayer_connections.1.norm.weight"), mean2, rstd2, g2w, g2b,
                                                    dx, p, seed, sid + _SITE_ATTN_OUT, row_scale=s_dyo,
-                                                   row_scale_min=sc["dyo_min"] if sc else None)
+                                                   row_scale_min=sc["dyo_min"] if sc else None, pending=ln_pending)
             else:
                 s_dyo = None
-                dx2 = K.layernorm_bwd(dh2, x2, W(b + "sublayer_connections.1.norm.weight"), mean2, rstd2, g2w, g2b, dres=dx)
+                dx2 = K.layernorm_bwd(dh2, x2, W(b + "sublayer_connections.1.norm.weight"), mean2, rstd2, g2w, g2b, dres=dx,
+                                      pending=ln_pending)
                 dyo = K.dropout_bwd(dx2, p, seed, sid + _SITE_ATTN_OUT) if p > 0 else dx2
             uni_o = sc is not None and fuse
             K.linear_bwd_weight(dyo, att, G(b + "self_attn.wo.weight"), G(b + "self_attn.wo.bias"), arith=ar,
@@ -547,14 +551,16 @@ class _EncoderFn(torch.autograd.Function):
                                                   dx2, p, seed, (i - 1) * 8 + _SITE_FFN_OUT, row_scale=s_dy2,
                                                   bound_factor=below["dz1_factor"] if below else None, bound_scale=bs_dz1,
                                                   row_scale_min=below["dy2_min"] if below else None,
-                                                  bound_scale_min=below["dz1_min"] if below else None)
+                                                  bound_scale_min=below["dz1_min"] if below else None, pending=ln_pending)
                 have_min = below is not None
             else:
-                dx = K.layernorm_bwd(dh1, x, W(b + "sublayer_connections.0.norm.weight"), mean1, rstd1, g1w, g1b, dres=dx2)
+                dx = K.layernorm_bwd(dh1, x, W(b + "sublayer_connections.0.norm.weight"), mean1, rstd1, g1w, g1b, dres=dx2,
+                                     pending=ln_pending)
                 dy2 = s_dy2 = bs_dz1 = None
                 have_min = False
             done(b + "self_attn.wq.weight", b + "sublayer_connections.1.norm.bias")
             ctx.saved[i] = None
+        K.layernorm_bwd_flush(ln_pending)
         # ---- front end
         if not m.use_embedding:
             dx = K.posenc_add_bwd(dx, p, seed)
