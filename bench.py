@@ -272,6 +272,22 @@ def main():
     gc.disable()                # a generation-2 collection over the event pool costs ~60 ms when it lands in the timed steps
     dt, losses = timed(step, a.warmup)                               # THE timed region: K steps, nothing else on the host
     n_res_timed = sum(res_of[(a.warmup + i) % nb] for i in range(a.steps))
+    comm = None
+    if world > 1:
+        # the same K steps with two events per step around the tail wait of the gradient all-reduce: how much of the
+        # reduction the overlap with backward did NOT hide (a pass of its own, like the GEMM events below)
+        dp.comm_meter_start()
+        dt_comm, _ = timed(step, a.warmup)
+        wait_ms, nbytes = dp.comm_meter_stop()
+        wt = torch.tensor([wait_ms], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(wt, op=torch.distributed.ReduceOp.MAX)     # the slowest rank's wait
+        wait_ms = float(wt.item())
+        comm = {"allreduce_wait_ms": round(wait_ms, 4), "comm_bytes": nbytes,
+                "ms_per_step_in_this_pass": round(1e3 * dt_comm / a.steps, 3),
+                "what": "per step and rank: time the compute stream waited for the SUM all-reduce of the flat gradient (issued per "
+                        "encoder layer from the backward pass, RCCL stream) after backward had been enqueued; bytes all-reduced "
+                        "(+ one 19-entry fp64 vector of loss statistics)",
+                "reserved_cus": int(kernels.GEMM_RESERVED_CUS)}
     dt_h2d, _ = timed(step_h2d, a.warmup)
     dt_inst = None
     if timing is not None:
@@ -371,6 +387,8 @@ def main():
             "arithmetic_modes": {a.gemm_mode: {"ms_per_step": round(1e3 * dt / a.steps, 3)}, **sweep},
             "roofline": roofline,
         }
+        if comm is not None:
+            out["communication"] = comm
         if world == 1 and not a.no_cpu_baseline:
             keys = ("seq", "true_ang", "true_crd")
             pick = min(range(nb), key=lambda i: abs(host_batches[i][0].shape[1] - 200)) if a.ragged == "binned" else 0

@@ -22,10 +22,11 @@ VALID_SPLITS = [10, 20, 30, 40, 50, 70, 90]
 MAX_SEQ_LEN = 500
 
 
-def collate_fn(insts, coords=False, sequences=False, max_seq_len=None):
+def collate_fn(insts, coords=False, sequences=False, max_seq_len=None, min_len=0):
     """Pad every instance to the longest in the batch (pad id 20 for sequences, zeros otherwise), then
-    truncate to max_seq_len residues (x14 atoms for coordinates)."""
-    longest = max(len(inst) for inst in insts)
+    truncate to max_seq_len residues (x14 atoms for coordinates).  `min_len` (residues): pad at least that far - a
+    data-parallel shard is padded to the longest protein of the GLOBAL batch (ShardedBatchSampler)."""
+    longest = max(max(len(inst) for inst in insts), min_len * (NUM_PREDICTED_COORDS if coords else 1))
     rows = []
     for inst in insts:
         inst = np.asarray(inst)
@@ -43,10 +44,12 @@ def make_paired_collate_fn(max_seq_len=MAX_SEQ_LEN):
     def paired(insts):
         if len(insts) == 0:      # this rank's shard of a batch with fewer proteins than ranks (dp.shard_indices)
             return (torch.zeros(0, 0, dtype=torch.int64), torch.zeros(0, 0, 24), torch.zeros(0, 0, 3))
-        sequences, angles, coords = list(zip(*insts))
-        return (collate_fn(sequences, sequences=True, max_seq_len=max_seq_len),
-                collate_fn(angles, max_seq_len=max_seq_len),
-                collate_fn(coords, coords=True, max_seq_len=max_seq_len))
+        fields = list(zip(*insts))
+        sequences, angles, coords = fields[:3]
+        pad_to = max(fields[3]) if len(fields) > 3 else 0       # the global batch's longest protein (data parallel)
+        return (collate_fn(sequences, sequences=True, max_seq_len=max_seq_len, min_len=pad_to),
+                collate_fn(angles, max_seq_len=max_seq_len, min_len=pad_to),
+                collate_fn(coords, coords=True, max_seq_len=max_seq_len, min_len=pad_to))
     return paired
 
 
@@ -86,6 +89,8 @@ class ProteinDataset(torch.utils.data.Dataset):
         return self.n_insts
 
     def __getitem__(self, idx):
+        if isinstance(idx, tuple):               # (index, pad_to) from ShardedBatchSampler: the length travels with the item
+            return (*self[idx[0]], idx[1])
         if self._angs is not None:
             return self._seqs[idx], self._angs[idx], self._crds[idx]
         return self._seqs[idx]
@@ -119,6 +124,8 @@ class BinnedProteinDataset(torch.utils.data.Dataset):
         return self.n_insts
 
     def __getitem__(self, idx):
+        if isinstance(idx, tuple):               # (index, pad_to) from ShardedBatchSampler
+            return (*self[idx[0]], idx[1])
         if self._angs is not None:
             return self._seqs[idx], self._angs[idx], self._crds[idx]
         return self._seqs[idx]
@@ -210,12 +217,15 @@ class DevicePrefetcher:
 
 class ShardedBatchSampler(torch.utils.data.Sampler):
     """Data-parallel view of a batch sampler: yields, for every batch of the wrapped sampler, the indices that THIS rank
-    takes (serpentine deal by length, dp.shard_indices) - so each rank collates, pads (to its own longest protein) and
-    uploads only its shard.  Every rank draws the same global batches (same seed, same numpy stream: train.seed_rngs)."""
+    takes (serpentine deal by length, dp.shard_indices) - so each rank collates, pads and uploads only its shard.  Every
+    rank draws the same global batches (same seed, same numpy stream: train.seed_rngs).  With `pad_to_global` (default)
+    the indices travel as (index, longest protein of the GLOBAL batch) and the collate function pads that far: a
+    conv-enc model then sees the same columns behind a protein's end (pad-token embeddings, not the Conv1d zero padding)
+    as in the single-process batch, so the sum of the ranks' gradients is the single-process gradient for every model."""
 
-    def __init__(self, batch_sampler, lengths, world=None, rank=None):
+    def __init__(self, batch_sampler, lengths, world=None, rank=None, pad_to_global=True):
         self.batch_sampler, self.lengths = batch_sampler, lengths
-        self.world, self.rank = world, rank
+        self.world, self.rank, self.pad_to_global = world, rank, pad_to_global
 
     def __len__(self):
         return len(self.batch_sampler)
@@ -224,8 +234,9 @@ class ShardedBatchSampler(torch.utils.data.Sampler):
         from . import dp
         for batch in self.batch_sampler:
             batch = [int(i) for i in batch]
-            keep = dp.shard_indices([self.lengths[i] for i in batch], self.world, self.rank)
-            yield [batch[k] for k in keep]
+            lens = [int(self.lengths[i]) for i in batch]
+            keep = dp.shard_indices(lens, self.world, self.rank)
+            yield [(batch[k], max(lens)) for k in keep] if self.pad_to_global else [batch[k] for k in keep]
 
 
 def prepare_dataloaders(data, args, max_seq_len, num_workers=1):
@@ -263,7 +274,7 @@ def prepare_dataloaders(data, args, max_seq_len, num_workers=1):
         if world == 1:
             return torch.utils.data.DataLoader(ds, batch_size=args.batch_size, **common)
         batches = torch.utils.data.BatchSampler(torch.utils.data.SequentialSampler(ds), args.batch_size, drop_last=False)
-        lengths = [min(len(ds[i][0]), max_seq_len) for i in range(len(ds))]
+        lengths = [min(len(q), max_seq_len) for q in ds._seqs]      # from the raw sequences, no __getitem__ per item
         return torch.utils.data.DataLoader(ds, batch_sampler=sharded(batches, lengths), **common)
 
     valid_loaders = {split: plain(f'valid-{split}') for split in VALID_SPLITS if f'valid-{split}' in data}

@@ -132,22 +132,52 @@ def reserve_cus_for_collectives(n=None):
     kernels.GEMM_RESERVED_CUS = max(0, int(n))
 
 
+# Exposed-communication meter (bench.py --gpus N): when COMM_METER is a list, every `all_reduce_gradients` brackets its
+# waits with two events on the COMPUTE stream - the interval is the time the compute stream stood still for the
+# reduction, i.e. what the overlap with backward did NOT hide - and appends (event, event, bytes reduced this step).
+COMM_METER = None
+
+
+def comm_meter_start():
+    global COMM_METER
+    COMM_METER = []
+
+
+def comm_meter_stop():
+    """-> (mean exposed wait per step in ms, bytes reduced per step) of the steps since `comm_meter_start`."""
+    global COMM_METER
+    rec, COMM_METER = COMM_METER or [], None
+    if not rec:
+        return 0.0, 0
+    torch.cuda.synchronize()
+    return sum(e0.elapsed_time(e1) for e0, e1, _ in rec) / len(rec), int(sum(b for _, _, b in rec) / len(rec))
+
+
 def all_reduce_gradients(model, empty=False):
     """Finish the step's gradient exchange.  With `attach(model)` this only waits for the slices already
     in flight; without it the whole flat buffer is reduced here in one call.  `empty`: this rank had no proteins in
     the step (its gradient buffer is zero and no backward ran): it issues the same reductions, in the same order."""
     if world_size() == 1:
         return
+    meter = COMM_METER is not None and torch.cuda.is_available()
+    if meter:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     if getattr(model, "grad_hook", None) is None:
         _, g = model.flat_parameters()
         dist.all_reduce(g, op=dist.ReduceOp.SUM)
-        return
-    if empty:
-        for off, n in model.grad_slices():
-            model.grad_hook(off, n)
-    for work in model._dp_pending:
-        work.wait()
-    model._dp_pending.clear()
+        nbytes = 4 * g.numel()
+    else:
+        if empty:
+            for off, n in model.grad_slices():
+                model.grad_hook(off, n)
+        for work in model._dp_pending:
+            work.wait()
+        model._dp_pending.clear()
+        nbytes = 4 * sum(n for _, n in model.grad_slices())
+    if meter:
+        e1.record()
+        COMM_METER.append((e0, e1, nbytes))
 
 
 def all_reduce_sum_(t):

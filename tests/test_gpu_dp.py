@@ -29,8 +29,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _make(dev, loss, case):
+def _make(dev, loss, case, conv=False):
     from protein_transformer_amd import synthetic
+    from protein_transformer_amd.models.convolutional_encoder import ConvEncoderOnlyTransformer
     from protein_transformer_amd.models.encoder_only import EncoderOnlyTransformer
     from protein_transformer_amd.optim import FusedSGD
     from protein_transformer_amd.protein.Sequence import VOCAB
@@ -39,7 +40,10 @@ def _make(dev, loss, case):
     batch = synthetic.make_batch(LENS[case], L_pad=48, seed=9, build_coords=build, frac_missing=0.05)
     am = synthetic.angle_means(batch["true_ang"])
     torch.manual_seed(123)
-    model = EncoderOnlyTransformer(2, 4, 64, 128, 64, VOCAB, am, True, dropout=0.0)
+    if conv:     # `-m "conv-enc|3,5|2,2"`: the Conv1d windows reach across a protein's end into the padding
+        model = ConvEncoderOnlyTransformer(2, 4, 64, 128, 64, VOCAB, am, True, [3, 5], [2, 2], True, True, dropout=0.0)
+    else:
+        model = EncoderOnlyTransformer(2, 4, 64, 128, 64, VOCAB, am, True, dropout=0.0)
     with torch.no_grad():
         model.output_projection.weight.normal_(0, 0.05)
     model.set_dropout(0.0)
@@ -49,13 +53,14 @@ def _make(dev, loss, case):
     return model, opt, args, tuple(batch[k] for k in ("seq", "true_ang", "true_crd")), LENS[case]
 
 
-def _shard(batch, lens, world, rank):
-    """What dataset.ShardedBatchSampler + collate hand to a rank: its proteins, padded to its own longest one."""
+def _shard(batch, lens, world, rank, pad_to_global=False):
+    """What dataset.ShardedBatchSampler + collate hand to a rank: its proteins, padded to its own longest one or (the
+    sampler's default, `pad_to_global`) to the longest protein of the global batch."""
     from protein_transformer_amd import dp
     keep = dp.shard_indices(lens, world, rank)
     if not keep:
         return (torch.zeros(0, 0, dtype=torch.int64), torch.zeros(0, 0, 24), torch.zeros(0, 0, 3)), 0
-    Lr = max(lens[i] for i in keep)
+    Lr = max(lens) if pad_to_global else max(lens[i] for i in keep)
     seq, ang, crd = batch
     return (seq[keep, :Lr].contiguous(), ang[keep, :Lr].contiguous(), crd[keep, :Lr * 14].contiguous()), sum(lens[i] for i in keep)
 
@@ -71,9 +76,11 @@ def _worker(rank, world, port, out_dir, loss, case):
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     dp.init_from_env()
-    model, opt, args, batch, lens = _make(dev, loss, case)
+    conv = case.startswith("conv-")
+    case = case[5:] if conv else case
+    model, opt, args, batch, lens = _make(dev, loss, case, conv)
     dp.attach(model)
-    (seq, ang, crd), n_res = _shard(batch, lens, world, rank)
+    (seq, ang, crd), n_res = _shard(batch, lens, world, rank, pad_to_global=conv)
     if case == "ragged":
         assert seq.shape[0] == (3 if rank == 0 else 2)
     if case == "single":
@@ -93,14 +100,19 @@ def _worker(rank, world, port, out_dir, loss, case):
 
 
 @pytest.mark.parametrize("loss,case", [("drmsd", "ragged"), ("combined", "ragged"), ("mse", "ragged"), ("lndrmsd", "equal"),
-                                       ("combined", "single")])
+                                       ("combined", "single"), ("combined", "conv-ragged")])
 def test_two_rank_step_equals_full_batch(tmp_path, loss, case):
+    """`conv-ragged`: a conv-enc model (Conv1d windows cross the end of a protein) with the shards padded to the longest
+    protein of the GLOBAL batch, as dataset.ShardedBatchSampler does: only then does a rank's longest protein see the same
+    columns behind its end as in the single-process batch."""
     assert torch.cuda.is_available()
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), loss, case), nprocs=2, join=True)
     from protein_transformer_amd.log import init_metrics
     from protein_transformer_amd.train import eval_epoch, train_step
     dev = torch.device("cuda:0")
-    model, opt, args, batch, lens = _make(dev, loss, case)
+    conv = case.startswith("conv-")
+    case = case[5:] if conv else case
+    model, opt, args, batch, lens = _make(dev, loss, case, conv)
     start = model.flat_parameters()[0].cpu().numpy().copy()
     data = tuple(t.to(dev) for t in batch)
     losses = train_step(model, opt, args, *data)
