@@ -11,24 +11,22 @@
 // Three launches per batch:
 //   compact   NaN-mask compaction of (pred, true) atoms per protein; backbone atoms (slots 0..2) are packed
 //             FIRST so the backbone-only dRMSD falls out of the same sweep (dRMSD is permutation invariant).
-//   pairs     grid (row block, protein): each lane owns one atom i, column tiles of 256 atoms are staged in
-//             LDS and read as broadcasts; per pair 2 transcendentals (one v_rsq_f32 each for the predicted and the true
-//             distance; the predicted one doubles as 1/d for the gradient).  ALU/transcendental bound, O(n) bytes.
-//   finalize  fixed-order fp64 reduction of the block partials, loss statistics, gradient scale and scatter
-//             back to the [L*14,3] slot layout.
+//   pairs     the UPPER TRIANGLE of the pair matrix, every unordered pair once (drmsd_tri_kernel below): each lane owns one
+//             row atom i, column tiles of 64 atoms are staged in LDS and read as broadcasts; per pair 2 transcendentals
+//             (one v_rsq_f32 each for the predicted and the true distance; the predicted one doubles as 1/d for the
+//             gradient); the column atoms' share of the gradient comes from a transposed re-read of the coefficient
+//             tile through LDS.  ALU/transcendental bound, O(n) bytes + O(n^2 / 256) partial-sum bytes.
+//   finalize  fixed-order fp64 reduction of the block partials, loss statistics, gradient assembly (row + column
+//             partials, fixed order), scale and scatter back to the [L*14,3] slot layout.
 #include "common.h"
 
 namespace {
 
 constexpr int CB = 256;  // threads per block of the compaction / finalize kernels
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-#ifndef PT_DRMSD_PB
-#define PT_DRMSD_PB 128
-#endif
 #ifndef PT_DRMSD_UNROLL
 #define PT_DRMSD_UNROLL 4
 #endif
-constexpr int PB = PT_DRMSD_PB;  // rows (= threads) per block of the pair sweep: ~34 blocks per protein keep 256 CUs balanced
 
 struct Counts {
   int n, n_bb, len, pad;
@@ -99,37 +97,75 @@ __global__ __launch_bounds__(CB) void drmsd_compact_kernel(const float *__restri
   if (tid == 0) counts[b] = Counts{tot_bb + tot_ot, tot_bb, len, 0};
 }
 
+// ---- the pair sweep over the UPPER TRIANGLE: every unordered pair {i, j} is evaluated ONCE.
+// Atoms are cut into tiles of 64 (one wavefront's lanes); a workgroup of 4 wavefronts owns a STRIP of 4 row tiles
+// (256 atoms) and walks a CHUNK of up to 16 column tiles J >= its first tile (the chunks of a strip are separate work
+// items: a strip's work shrinks with its index, 16-tile chunks keep the items balanced - 1824 items of <= 16 tile steps at
+// 32 proteins x 4275 atoms).  For a column tile J above a wavefront's row tile I (I < J) the wavefront
+//   phase 1  walks 16 columns like the old two-sided kernel did (lane = row atom i, column coordinates broadcast from
+//            LDS, one v_rsq_f32 each for the predicted and the true distance), adds e^2 to the loss, cf (x_i - x_j) to
+//            its row gradient - and leaves the coefficient cf_ij = e / d in LDS, row-major with a 17-word row stride;
+//   phase 2  re-reads that 64 x 16 coefficient tile TRANSPOSED (lane = column j = lane & 15 and a quarter lane >> 4 of the
+//            rows; conflict-free both ways thanks to the odd stride), accumulates S_j = sum_i cf_ij and
+//            V_j = sum_i cf_ij x_i over its 16 rows and folds the four quarters with two lane exchanges: 4 fma + one LDS
+//            read per pair instead of the ~17 instructions and two transcendentals of a second visit.  The column atom's
+//            gradient contribution is x_j S_j - V_j.  (A 64-column coefficient tile would be 16.6 KB per wavefront and
+//            hold the kernel at 2 wavefronts per SIMD: measured 510 us, latency-bound, against 576 for the old kernel.)
+// The four wavefronts' (S, V) of a column tile are summed in a fixed order through LDS and written to a per-(strip,
+// column tile) slot; the finalize kernel adds, per atom and in a fixed order, the row partials of its strip's chunks and
+// the column partials of all strips at or above it: no atomics anywhere, bit-reproducible.  The diagonal tile (I == J) is
+// still swept from both sides inside the tile (its loss terms count half).
+constexpr int TS = 64, STRIP_TILES = 4, RS = TS * STRIP_TILES, CHUNK_TILES = 16;
+constexpr int SUB = 16, CF_LD = SUB + 1;   // the coefficient tile is kept for 16 columns at a time: 4.3 KB per wavefront, 5 workgroups per CU
+
+struct TriLayout {  // per protein: strips x chunks work items, column tiles
+  int strips, chunks, tiles;
+};
+__host__ __device__ inline TriLayout tri_layout(int nmax) {
+  TriLayout t;
+  t.tiles = (nmax + TS - 1) / TS;
+  t.strips = (t.tiles + STRIP_TILES - 1) / STRIP_TILES;
+  t.chunks = (t.tiles + CHUNK_TILES - 1) / CHUNK_TILES;
+  return t;
+}
+
 template <bool WITH_GRAD>
-__global__ __launch_bounds__(PB) void drmsd_pairs_kernel(const float4 *__restrict__ pred4,
-                                                         const float4 *__restrict__ true4,
-                                                         const Counts *__restrict__ counts, int L, int row_blocks,
-                                                         float4 *__restrict__ gcomp, double *__restrict__ partials) {
-  // column tile in LDS, predicted and true coordinate side by side: (px, tx, py, ty) and (pz, tz), so that the two
-  // distance computations of a pair run as ONE stream of packed f32 instructions (v_pk_add / v_pk_fma_f32: two lanes'
-  // worth of arithmetic per issue slot - the pair loop is VALU-bound, not memory-bound)
-  __shared__ float4 s_xy[PB];
-  __shared__ float2 s_z[PB];
-  __shared__ double s_red[2 * (PB / 64)];
-  const int b = blockIdx.y, tid = threadIdx.x;
+__global__ __launch_bounds__(RS) void drmsd_tri_kernel(const float4 *__restrict__ pred4, const float4 *__restrict__ true4,
+                                                       const Counts *__restrict__ counts, int L,
+                                                       float4 *__restrict__ rowpart, float4 *__restrict__ colpart,
+                                                       double *__restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  float *const s_cf = s_dyn;                                                  // [4][64][17] coefficient tiles
+  float4 *const s_xy = reinterpret_cast<float4 *>(s_dyn + STRIP_TILES * TS * CF_LD);   // column tile: (px, tx, py, ty)
+  float2 *const s_z = reinterpret_cast<float2 *>(s_xy + TS);                  //              (pz, tz)
+  float4 *const s_row = reinterpret_cast<float4 *>(s_z + TS);                 // [4][64] predicted coordinates of the rows
+  float4 *const s_cs = s_row + RS;                                            // [4][64] (S, Vx, Vy, Vz) per wavefront
+  __shared__ double s_red[2 * STRIP_TILES];
+  const size_t nmax = (size_t)L * 14;
+  const TriLayout tl = tri_layout((int)nmax);
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int strip = blockIdx.x / tl.chunks, chunk = blockIdx.x % tl.chunks;
   const Counts cn = counts[b];
-  const int n = cn.n, nbb = cn.n_bb;
-  double *part = partials + ((size_t)b * row_blocks + blockIdx.x) * 2;
-  const int row0 = blockIdx.x * PB;
-  if (row0 >= n) {  // block-uniform
+  const int n = cn.n, nbb = cn.n_bb, nT = (n + TS - 1) / TS;
+  double *part = partials + ((size_t)b * tl.strips * tl.chunks + blockIdx.x) * 2;
+  const int J0 = max(STRIP_TILES * strip, CHUNK_TILES * chunk), J1 = min(nT, CHUNK_TILES * (chunk + 1));
+  if (STRIP_TILES * strip >= nT || J0 >= J1) {  // block-uniform: nothing to do (the finalize kernel skips these items too)
     if (tid == 0) part[0] = part[1] = 0.0;
     return;
   }
-  const size_t nmax = (size_t)L * 14;
   pred4 += (size_t)b * nmax;
   true4 += (size_t)b * nmax;
-  const int i = row0 + tid;
+  const int I = STRIP_TILES * strip + w, i = I * TS + lane;
   const bool live = i < n;
   const float4 pi = live ? pred4[i] : make_float4(0, 0, 0, 0);
   const float4 ti = live ? true4[i] : make_float4(0, 0, 0, 0);
+  s_row[w * TS + lane] = pi;
   const f32x2 ix = {pi.x, ti.x}, iy = {pi.y, ti.y}, iz = {pi.z, ti.z};
-  float accA = 0.f, accB = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+  float offA = 0.f, offB = 0.f, diagA = 0.f, diagB = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+  float *const cf_row = s_cf + (w * TS + lane) * CF_LD;     // phase 1: this lane's row of coefficients
 
-  auto pair = [&](int j, float &acc) {
+  // one pair: e^2 into acc, cf (x_i - x_j) into the row gradient; returns cf (0 for a dead row)
+  auto pair = [&](int j, float &acc) __attribute__((always_inline)) {
     const float4 a = s_xy[j];  // same address in every lane: LDS broadcast
     const float2 c = s_z[j];
     const f32x2 dx = ix - (f32x2){a.x, a.y}, dy = iy - (f32x2){a.z, a.w}, dz = iz - (f32x2){c.x, c.y};  // (pred, true)
@@ -140,120 +176,192 @@ __global__ __launch_bounds__(PB) void drmsd_pairs_kernel(const float4 *__restric
     const float inv = __builtin_amdgcn_rsqf(d2), invt = __builtin_amdgcn_rsqf(t2);
     f32x2 dt = (f32x2){d2, t2} * (f32x2){inv, invt};  // (d, tau)
     asm("" : "+v"(dt));  // keep the rounded products: no FMA contraction into e, so pred == true gives e == 0 exactly
-    const float e = dt[0] - dt[1];
+    const float e = live ? dt[0] - dt[1] : 0.f;
     acc = fmaf(e, e, acc);
+    const float cf = e * inv;
     if (WITH_GRAD) {
-      const float cf = e * inv;
       gx = fmaf(cf, dx[0], gx);
       gy = fmaf(cf, dy[0], gy);
       gz = fmaf(cf, dz[0], gz);
     }
+    return cf;
   };
 
-  for (int c0 = 0; c0 < n; c0 += PB) {
-    __syncthreads();
-    if (c0 + tid < n) {
-      const float4 pj = pred4[c0 + tid], tj = true4[c0 + tid];
-      s_xy[tid] = make_float4(pj.x, tj.x, pj.y, tj.y);
-      s_z[tid] = make_float2(pj.z, tj.z);
+  for (int J = J0; J < J1; ++J) {
+    __syncthreads();  // everybody is done with the previous column tile and its (S, V) slots
+    if (w == 0) {
+      const int jj = J * TS + lane;
+      const float4 pj = jj < n ? pred4[jj] : make_float4(0, 0, 0, 0), tj = jj < n ? true4[jj] : make_float4(0, 0, 0, 0);
+      s_xy[lane] = make_float4(pj.x, tj.x, pj.y, tj.y);
+      s_z[lane] = make_float2(pj.z, tj.z);
     }
     __syncthreads();
-    const int cnt = min(PB, n - c0);
-    const int ja = max(0, min(cnt, nbb - c0));
-    // four pairs per iteration, written out by hand (the optimizer declines to unroll this loop by itself): the loop
-    // bookkeeping is shared and the next pairs' LDS reads are in flight under the current pair's arithmetic
-    int j = 0;
-    constexpr int U = PT_DRMSD_UNROLL;
-    for (; j + U - 1 < ja; j += U) {
+    const int cnt = min(TS, n - J * TS);
+    const int ja = max(0, min(cnt, nbb - J * TS));   // columns below ja are backbone atoms (then so is every row i < j)
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);   // (S, Vx, Vy, Vz) of column lane of the tile, in lanes 0..cnt-1
+    if (I < J) {  // wavefront-uniform: a full tile above the diagonal
+      constexpr int U = PT_DRMSD_UNROLL;
+      const float4 *rows = s_row + w * TS + (lane >> 4) * SUB;          // phase 2: this lane's quarter of the rows
+      const float *cf_q = s_cf + (w * TS + (lane >> 4) * SUB) * CF_LD + (lane & (SUB - 1));
+      for (int j0 = 0; j0 < cnt; j0 += SUB) {
+        const int j1 = min(cnt, j0 + SUB), jb = max(j0, min(j1, ja));   // [j0, jb) backbone columns, [jb, j1) the rest
+        int j = j0;
+        for (; j + U - 1 < jb; j += U) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) pair(j + u, accA);
-    }
-    for (; j < ja; ++j) pair(j, accA);
-    for (; j + U - 1 < cnt; j += U) {
+          for (int u = 0; u < U; ++u) {
+            const float cf = pair(j + u, offA);
+            if (WITH_GRAD) cf_row[j + u - j0] = cf;
+          }
+        }
+        for (; j < jb; ++j) {
+          const float cf = pair(j, offA);
+          if (WITH_GRAD) cf_row[j - j0] = cf;
+        }
+        for (; j + U - 1 < j1; j += U) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) pair(j + u, accB);
+          for (int u = 0; u < U; ++u) {
+            const float cf = pair(j + u, offB);
+            if (WITH_GRAD) cf_row[j + u - j0] = cf;
+          }
+        }
+        for (; j < j1; ++j) {
+          const float cf = pair(j, offB);
+          if (WITH_GRAD) cf_row[j - j0] = cf;
+        }
+        if (WITH_GRAD) {  // phase 2 for these 16 columns (LDS is in order per wavefront); columns >= j1 read stale finite data
+          float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (j0 + (lane & (SUB - 1)) < j1) {
+#pragma unroll
+            for (int r = 0; r < SUB; ++r) {
+              const float c = cf_q[r * CF_LD];
+              const float4 xr = rows[r];
+              q.x += c;
+              q.y = fmaf(c, xr.x, q.y);
+              q.z = fmaf(c, xr.y, q.z);
+              q.w = fmaf(c, xr.z, q.w);
+            }
+          }
+          // fold the four row quarters (lanes l, l ^ 16, l ^ 32, l ^ 48) in a fixed order: every lane ends with the sum
+          q.x += __shfl_xor(q.x, 16, 64); q.y += __shfl_xor(q.y, 16, 64); q.z += __shfl_xor(q.z, 16, 64); q.w += __shfl_xor(q.w, 16, 64);
+          q.x += __shfl_xor(q.x, 32, 64); q.y += __shfl_xor(q.y, 32, 64); q.z += __shfl_xor(q.z, 32, 64); q.w += __shfl_xor(q.w, 32, 64);
+          if ((lane >> 4) == (j0 >> 4)) cs = q;   // lane l keeps column l of the tile: quarter j0 / 16 holds columns j0 .. j0 + 15
+        }
+      }
+    } else if (I == J) {  // the diagonal tile: both sides inside the tile, j == i contributes exactly 0
+      int j = 0;
+      for (; j < ja; ++j) pair(j, diagA);
+      for (; j < cnt; ++j) pair(j, diagB);
     }
-    for (; j < cnt; ++j) pair(j, accB);
+    if (WITH_GRAD) {
+      s_cs[w * TS + lane] = cs;
+      __syncthreads();
+      if (w == 0) {  // fixed order over the four wavefronts
+        const float4 a0 = s_cs[lane], a1 = s_cs[TS + lane], a2 = s_cs[2 * TS + lane], a3 = s_cs[3 * TS + lane];
+        const float4 t = make_float4(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y,
+                                     ((a0.z + a1.z) + a2.z) + a3.z, ((a0.w + a1.w) + a2.w) + a3.w);
+        colpart[(((size_t)b * tl.strips + strip) * tl.tiles + J) * TS + lane] = t;
+      }
+    }
   }
-  if (WITH_GRAD && live) gcomp[(size_t)b * nmax + i] = make_float4(gx, gy, gz, 0.f);
-  // every pair (i,j), i != j, was visited twice over the grid; j == i contributes exactly 0 to everything
-  // (dx = 0 -> d = 1e-15, true distance 1e-15, e = 0).
-  double all = live ? (double)accA + (double)accB : 0.0;
-  double bbp = (live && i < nbb) ? (double)accA : 0.0;
+  if (WITH_GRAD) rowpart[(((size_t)b * tl.strips + strip) * tl.chunks + chunk) * RS + tid] = make_float4(gx, gy, gz, 0.f);
+  // loss terms: off-diagonal tiles saw every pair once, the diagonal tile twice
+  double all = (double)offA + (double)offB + 0.5 * ((double)diagA + (double)diagB);
+  double bbp = (double)offA + ((live && i < nbb) ? 0.5 * (double)diagA : 0.0);
   all = wave_sum_d(all);
   bbp = wave_sum_d(bbp);
-  if ((tid & 63) == 0) {
-    s_red[(tid >> 6) * 2] = all;
-    s_red[(tid >> 6) * 2 + 1] = bbp;
+  if (lane == 0) {
+    s_red[w * 2] = all;
+    s_red[w * 2 + 1] = bbp;
   }
   __syncthreads();
   if (tid == 0) {
     double a = 0, c = 0;
-    for (int w = 0; w < PB / 64; ++w) {
-      a += s_red[w * 2];
-      c += s_red[w * 2 + 1];
+    for (int k = 0; k < STRIP_TILES; ++k) {
+      a += s_red[k * 2];
+      c += s_red[k * 2 + 1];
     }
     part[0] = a;
     part[1] = c;
   }
 }
+constexpr size_t TRI_LDS = (size_t)(STRIP_TILES * TS * CF_LD) * 4 + TS * 16 + TS * 8 + RS * 16 + RS * 16;
 
+// statistics, gradient assembly and scatter back to the slot layout: grid (ceil(nmax / 256), B); dcrd was zeroed before
 __global__ __launch_bounds__(CB) void drmsd_finalize_kernel(const Counts *__restrict__ counts,
-                                                            const double *__restrict__ partials, int row_blocks,
-                                                            const float4 *__restrict__ gcomp,
+                                                            const double *__restrict__ partials,
+                                                            const float4 *__restrict__ pred4,
+                                                            const float4 *__restrict__ rowpart,
+                                                            const float4 *__restrict__ colpart,
                                                             const int *__restrict__ idx, int L,
                                                             float *__restrict__ stats, float *__restrict__ dcrd) {
   __shared__ float s_scale;
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.y, tid = threadIdx.x;
   const Counts cn = counts[b];
+  const size_t nmax = (size_t)L * 14;
+  const TriLayout tl = tri_layout((int)nmax);
+  if ((int)blockIdx.x * CB >= max(cn.n, 1)) return;
   if (tid == 0) {
     double all = 0, bbp = 0;
-    for (int r = 0; r < row_blocks; ++r) {
-      all += partials[((size_t)b * row_blocks + r) * 2];
-      bbp += partials[((size_t)b * row_blocks + r) * 2 + 1];
+    const int items = tl.strips * tl.chunks;
+    for (int r = 0; r < items; ++r) {
+      all += partials[((size_t)b * items + r) * 2];
+      bbp += partials[((size_t)b * items + r) * 2 + 1];
     }
     const double n = cn.n, nb = cn.n_bb;
     const double P = n * (n - 1) * 0.5, Pb = nb * (nb - 1) * 0.5;
     // mse_loss over an empty pair set is NaN in the reference as well
-    float D = (float)sqrt((all * 0.5) / P);
-    float Db = (float)sqrt((bbp * 0.5) / Pb);
-    float *st = stats + (size_t)b * 8;
-    st[0] = D;
-    st[1] = D / (float)cn.n;
-    st[2] = Db;
-    st[3] = Db / (float)cn.n_bb;
-    st[4] = (float)cn.n;
-    st[5] = (float)cn.n_bb;
-    st[6] = 0.f;
-    st[7] = 0.f;
+    const float D = (float)sqrt(all / P);
+    const float Db = (float)sqrt(bbp / Pb);
+    if (blockIdx.x == 0) {
+      float *st = stats + (size_t)b * 8;
+      st[0] = D;
+      st[1] = D / (float)cn.n;
+      st[2] = Db;
+      st[3] = Db / (float)cn.n_bb;
+      st[4] = (float)cn.n;
+      st[5] = (float)cn.n_bb;
+      st[6] = 0.f;
+      st[7] = 0.f;
+    }
     s_scale = (float)(1.0 / (n * P * (double)D));
   }
   if (dcrd == nullptr) return;
   __syncthreads();
+  const int j = blockIdx.x * CB + tid;
+  if (j >= cn.n) return;
   const float scale = s_scale;
-  const size_t nmax = (size_t)L * 14;
-  float *out = dcrd + (size_t)b * nmax * 3;
-  for (size_t k = tid; k < nmax * 3; k += CB) out[k] = 0.f;
-  __syncthreads();
-  gcomp += (size_t)b * nmax;
-  idx += (size_t)b * nmax;
-  for (int j = tid; j < cn.n; j += CB) {
-    const float4 g = gcomp[j];
-    const int s = idx[j];
-    out[s * 3 + 0] = scale * g.x;
-    out[s * 3 + 1] = scale * g.y;
-    out[s * 3 + 2] = scale * g.z;
+  const int nT = (cn.n + TS - 1) / TS, J = j / TS, sJ = J / STRIP_TILES;
+  float gx = 0.f, gy = 0.f, gz = 0.f;
+  // row side: the chunks of this atom's strip that had work, in order
+  for (int c = 0; c < tl.chunks; ++c) {
+    const int J0 = max(STRIP_TILES * sJ, CHUNK_TILES * c), J1 = min(nT, CHUNK_TILES * (c + 1));
+    if (J0 >= J1) continue;
+    const float4 r = rowpart[(((size_t)b * tl.strips + sJ) * tl.chunks + c) * RS + (j - sJ * RS)];
+    gx += r.x; gy += r.y; gz += r.z;
   }
+  // column side: every strip at or above this atom's tile, in order: g_j += x_j S - V
+  const float4 xj = pred4[(size_t)b * nmax + j];
+  for (int s = 0; s <= sJ; ++s) {
+    const float4 cp = colpart[(((size_t)b * tl.strips + s) * tl.tiles + J) * TS + (j & (TS - 1))];
+    gx += fmaf(xj.x, cp.x, -cp.y);
+    gy += fmaf(xj.y, cp.x, -cp.z);
+    gz += fmaf(xj.z, cp.x, -cp.w);
+  }
+  const int sl = idx[(size_t)b * nmax + j];
+  float *out = dcrd + (size_t)b * nmax * 3;
+  out[sl * 3 + 0] = scale * gx;
+  out[sl * 3 + 1] = scale * gy;
+  out[sl * 3 + 2] = scale * gz;
 }
 
 struct Layout {
-  size_t pred4, true4, gcomp, idx, counts, partials, total;
-  int row_blocks;
+  size_t pred4, true4, rowpart, colpart, idx, counts, partials, total;
+  TriLayout tl;
 };
 Layout layout(int B, int L) {
   Layout l;
   const size_t nmax = (size_t)L * 14, BN = (size_t)B * nmax;
-  l.row_blocks = (int)((nmax + PB - 1) / PB);
+  l.tl = tri_layout((int)nmax);
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o = off;
@@ -262,10 +370,11 @@ Layout layout(int B, int L) {
   };
   l.pred4 = take(BN * sizeof(float4));
   l.true4 = take(BN * sizeof(float4));
-  l.gcomp = take(BN * sizeof(float4));
+  l.rowpart = take((size_t)B * l.tl.strips * l.tl.chunks * RS * sizeof(float4));
+  l.colpart = take((size_t)B * l.tl.strips * l.tl.tiles * TS * sizeof(float4));
   l.idx = take(BN * sizeof(int));
   l.counts = take((size_t)B * sizeof(Counts));
-  l.partials = take((size_t)B * l.row_blocks * 2 * sizeof(double));
+  l.partials = take((size_t)B * l.tl.strips * l.tl.chunks * 2 * sizeof(double));
   l.total = off;
   return l;
 }
@@ -287,7 +396,7 @@ int ptamd_drmsd_fwd_bwd(const float *pred_crd, const float *true_crd, const int6
   if (!pt_aligned16(workspace)) return PTAMD_ERR_ALIGN;
   char *ws = static_cast<char *>(workspace);
   float4 *pred4 = reinterpret_cast<float4 *>(ws + l.pred4), *true4 = reinterpret_cast<float4 *>(ws + l.true4),
-         *gcomp = reinterpret_cast<float4 *>(ws + l.gcomp);
+         *rowpart = reinterpret_cast<float4 *>(ws + l.rowpart), *colpart = reinterpret_cast<float4 *>(ws + l.colpart);
   int *idx = reinterpret_cast<int *>(ws + l.idx);
   Counts *counts = reinterpret_cast<Counts *>(ws + l.counts);
   double *partials = reinterpret_cast<double *>(ws + l.partials);
@@ -296,16 +405,21 @@ int ptamd_drmsd_fwd_bwd(const float *pred_crd, const float *true_crd, const int6
                      counts);
   int rc = pt_check_launch();
   if (rc) return rc;
-  if (dcrd)
-    hipLaunchKernelGGL(drmsd_pairs_kernel<true>, dim3(l.row_blocks, B), dim3(PB), 0, st, pred4, true4, counts, L,
-                       l.row_blocks, gcomp, partials);
-  else
-    hipLaunchKernelGGL(drmsd_pairs_kernel<false>, dim3(l.row_blocks, B), dim3(PB), 0, st, pred4, true4, counts, L,
-                       l.row_blocks, gcomp, partials);
+  const dim3 grid(l.tl.strips * l.tl.chunks, B);
+  if (dcrd) {
+    PT_HIP_TRY(hipMemsetAsync(dcrd, 0, (size_t)B * L * 14 * 3 * sizeof(float), st));   // slots of absent atoms stay 0
+    auto kern = drmsd_tri_kernel<true>;
+    PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRI_LDS));
+    hipLaunchKernelGGL(kern, grid, dim3(RS), TRI_LDS, st, pred4, true4, counts, L, rowpart, colpart, partials);
+  } else {
+    auto kern = drmsd_tri_kernel<false>;
+    PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRI_LDS));
+    hipLaunchKernelGGL(kern, grid, dim3(RS), TRI_LDS, st, pred4, true4, counts, L, rowpart, colpart, partials);
+  }
   rc = pt_check_launch();
   if (rc) return rc;
-  hipLaunchKernelGGL(drmsd_finalize_kernel, dim3(B), dim3(CB), 0, st, counts, partials, l.row_blocks, gcomp, idx, L,
-                     stats, dcrd);
+  hipLaunchKernelGGL(drmsd_finalize_kernel, dim3((unsigned)(((size_t)L * 14 + CB - 1) / CB), B), dim3(CB), 0, st, counts,
+                     partials, pred4, rowpart, colpart, idx, L, stats, dcrd);
   return pt_check_launch();
 }
 

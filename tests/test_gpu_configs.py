@@ -135,6 +135,59 @@ def test_config4_full_size_auto_mode(dev):
     assert err < 5e-4, err
 
 
+def test_config3_full_size_additivity_and_auto_vs_f32(dev):
+    """BASELINE configs[2] at FULL size: `-m "conv-enc|3,7,11|2,2,2"` d_model 256, 6 layers, 8 heads (dk = 32), 32 proteins x
+    L = 512, `-l combined` (reference: models/convolutional_encoder.py:106-123, train.py:78-97).  (i) the gradient of the
+    batch is the sum of the gradients of its two halves - the dRMSD part is a sum over proteins, the MSE part a mean over
+    the selected angles, so the halves are weighted by their angle counts; (ii) the default AUTO arithmetic against the
+    exact-f32 MFMA on the same inputs; (iii) losses independent of the arithmetic."""
+    from protein_transformer_amd import kernels as K_
+    from protein_transformer_amd import synthetic
+    from protein_transformer_amd.models.convolutional_encoder import ConvEncoderOnlyTransformer
+    from protein_transformer_amd.protein.Sequence import VOCAB
+    from protein_transformer_amd.protein.Structure import nerf_forward
+    from protein_transformer_amd.train import get_losses
+    B, L = 32, 512
+    lens = [L] * 24 + [300, 411, 77, 512, 129, 256, 499, 64]
+    build = lambda ang, seq: nerf_forward(ang.to(dev), seq.to(dev))[0]  # noqa: E731
+    batch = synthetic.make_batch(lens, L_pad=L, seed=17, build_coords=build)
+    seq, ang, crd = (batch[k].to(dev) for k in ("seq", "true_ang", "true_crd"))
+    torch.manual_seed(4)
+    model = ConvEncoderOnlyTransformer(6, 8, 256, 2048, L, VOCAB, synthetic.angle_means(batch["true_ang"]), True, [3, 7, 11],
+                                       [2, 2, 2], True, True, dropout=0.0)
+    model.set_dropout(0.0)
+    model = model.to(dev).train()
+    with torch.no_grad():
+        dict(model.named_parameters())["output_projection.weight"].normal_(0, 0.02)
+    args = types.SimpleNamespace(loss="drmsd", combined_drmsd_weight=0.5, backbone_loss=False, clip=None)
+
+    def run(sl, mode, loss="drmsd"):
+        K_.set_gemm_mode(mode)
+        args.loss = loss
+        model.zero_grad()
+        losses = get_losses(args, model(seq[sl], ang[sl]), ang[sl], crd[sl], seq[sl])
+        _, g = model.flat_parameters()
+        return g.clone(), {k: float(losses[k]) for k in ("drmsd-full", "lndrmsd-full", "mse-full", "combined-full")}
+
+    old = K_.get_gemm_mode()
+    try:
+        g_all, l_all = run(slice(0, B), K_.GEMM_AUTO)
+        g_a, l_a = run(slice(0, B // 2), K_.GEMM_AUTO)
+        g_b, l_b = run(slice(B // 2, B), K_.GEMM_AUTO)
+        g_f32, l_f32 = run(slice(0, B), K_.GEMM_F32)
+        g_comb, l_comb = run(slice(0, B), K_.GEMM_AUTO, "combined")      # the loss of config 3: finite, larger than dRMSD's
+    finally:
+        K_.set_gemm_mode(old)
+    norm = g_all.norm().item()
+    assert norm > 0 and torch.isfinite(g_all).all() and torch.isfinite(g_comb).all()
+    assert (g_a + g_b - g_all).norm().item() <= 2e-3 * norm                   # (i) sum over proteins (SURVEY A-7)
+    assert (g_f32 - g_all).norm().item() <= 2e-3 * norm                       # (ii)
+    for k in ("drmsd-full", "lndrmsd-full", "mse-full"):                      # (iii)
+        assert l_f32[k] == pytest.approx(l_all[k], rel=2e-5), k
+    assert l_all["drmsd-full"] == pytest.approx(0.5 * (l_a["drmsd-full"] + l_b["drmsd-full"]), rel=1e-5)
+    assert (g_comb - g_all).norm().item() > 1e-3 * norm                       # the MSE term is in the `combined` gradient
+
+
 def test_config5_ragged_long_step(dev):
     """BASELINE configs[4]: enc-only d_model 512 on a ragged batch with lengths up to 1500 (> the reference's 500),
     `-l lndrmsd`.  (i) gradient additivity over sub-batches, (ii) losses independent of the padding / batch context,

@@ -96,15 +96,43 @@ def test_parity_record(case):
     cfg, model_s, dm, nl, nh, dff, lens, loss = case
     dev = torch.device("cuda:0")
     L = max(lens)
-    build = lambda ang, seq: nerf_forward(ang.to(dev), seq.to(dev))[0]  # noqa: E731
-    batch = synthetic.make_batch(lens, L_pad=L, seed=100 + cfg, build_coords=build, frac_missing=0.02)
-    seq, ang, crd = (batch[k].to(dev) for k in ("seq", "true_ang", "true_crd"))
     B = len(lens)
-    model = _make_model(dev, model_s, dm, nl, nh, dff, L, synthetic.angle_means(batch["true_ang"]), seed=7 + cfg)
+    build = lambda ang, seq: nerf_forward(ang.to(dev), seq.to(dev))[0]  # noqa: E731
     # the gradient the reference back-propagates is that of sum_i lndrmsd_i whatever the reported loss (SURVEY A-7); the MSE
     # term of `combined` is covered by the G7 / G8 goldens - the record uses the dRMSD path for every config
     args = types.SimpleNamespace(loss="drmsd" if loss == "combined" else loss, combined_drmsd_weight=0.5, backbone_loss=False,
                                  clip=None)
+    coord_unit = np.array([1e-3 * max(1.0, n / 128) for n in lens])
+    # A freshly initialised model predicts ARBITRARY angles, and now and then a bond angle lands within ~1e-3 of 0 or pi:
+    # three atoms in a line, the NeRF frame of the next atom is a normalised near-zero cross product and ANY fp32 chain -
+    # the reference's own included - is off by 5 - 40 times the section-8(d) unit for that protein, its gradient with it.
+    # Such a draw measures the conditioning of the input, not the kernels: it is recorded (`skipped_draws`) and the next
+    # seed is taken.  Criterion (implementation-independent, fp64 only): moving every angle by one fp32 rounding of an
+    # O(1) angle (6e-8 rad, random sign) moves some coordinate by more than one unit of 1e-3 A * max(1, L / 128).
+    # (Found with config 4, seed 104: a predicted C-N-CA angle of -4.8e-5 rad; every atom behind it was fine on the
+    # device - backbone within 2e-5 A of fp64 - but the one side-chain atom built on the collinear triple was 8.9e-3 A off,
+    # and the oracle's fp32 chain 1 - 4e-3 A off from there to the end of the chain.)
+    skipped = []
+    gen = torch.Generator().manual_seed(1234 + cfg)
+    for attempt in range(8):
+        seed = 100 + cfg + 1000 * attempt
+        batch = synthetic.make_batch(lens, L_pad=L, seed=seed, build_coords=build, frac_missing=0.02)
+        seq, ang, crd = (batch[k].to(dev) for k in ("seq", "true_ang", "true_crd"))
+        model = _make_model(dev, model_s, dm, nl, nh, dff, L, synthetic.angle_means(batch["true_ang"]), seed=7 + cfg + attempt)
+        rad_probe = angles_forward(model(seq, ang).detach()).cpu().double()
+        c64 = obat.generate_coords_batched(rad_probe, seq.cpu(), torch.float64).numpy()
+        sign = torch.randint(0, 2, rad_probe.shape, generator=gen).double() * 2 - 1
+        c64p = obat.generate_coords_batched(rad_probe + 6e-8 * sign, seq.cpu(), torch.float64).numpy()
+        resp = np.array([np.abs(c64p[b, :n * 14] - c64[b, :n * 14]).max() for b, n in enumerate(lens)]) / coord_unit
+        # ... or three backbone atoms within 5e-4 rad of a straight line (angles 3..5 = N-CA-C, CA-C-N, C-N-CA): the direction
+        # of the 1e-4 A component that defines the next frame is then at the mercy of the 1e-7 A rounding of the coordinates
+        sin_bond = np.array([np.abs(np.sin(rad_probe[b, :n, 3:6].numpy())).min() for b, n in enumerate(lens)])
+        if resp.max() <= 1.0 and sin_bond.min() >= 5e-4:
+            break
+        skipped.append({"seed": seed, "response_to_6e-8_rad_on_every_angle_units": [float(x) for x in resp],
+                        "smallest_abs_sin_of_a_backbone_bond_angle": [float(x) for x in sin_bond]})
+    else:
+        pytest.fail("no well-conditioned draw in 8 seeds")
 
     # ---- fp64 on the CPU: the oracle's formulas end to end
     params = {k: v.detach().cpu().double() for k, v in model.state_dict().items()}
@@ -117,11 +145,10 @@ def test_parity_record(case):
     rad64.backward(dang64)
     ref = {n: v.grad for n, v in leaf.items()}
     mask = (np.arange(L)[None, :] < np.asarray(lens)[:, None])
-    coord_unit = np.array([1e-3 * max(1.0, n / 128) for n in lens])
 
     rec = {"config": cfg, "model": f"{model_s} d_model={dm} n_layers={nl} n_head={nh} d_ff={dff}", "lengths": lens,
            "loss": loss, "dropout": 0.0, "reference": "fp64 evaluation of the oracle (oracle.encoder + oracle.batched)",
-           "modes": {}}
+           "seed": seed, "skipped_draws": skipped, "modes": {}}
     old = K_.get_gemm_mode()
     try:
         for mode in MODES:
