@@ -1,0 +1,19 @@
+#!/bin/bash
+# round-3 measurement set on one MI355X box: headline bench line, rocprofv3 kernel stats of the same command, PMC traffic
+# passes (separate runs, --kernel-trace only), the other BASELINE configurations.   usage: r03_collect.sh <tag> [full]
+set -x
+tag=${1:-x}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+out=gpurun_out/r3_$tag
+mkdir -p $out
+python bench.py --steps 20 --warmup 3 > $out/bench_cfg4.json 2> $out/bench_cfg4.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o r3 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-mode-sweep > $out/bench_under_rocprof.json 2> $out/prof.err
+rm -f $out/prof/*/r3_kernel_trace.csv $out/prof/r3_kernel_trace.csv
+if [ "$2" = "full" ]; then
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-mode-sweep > $out/pmc_fetch.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-mode-sweep > $out/pmc_write.log 2>&1
+  rm -f $out/pmc_*/p_kernel_trace.csv $out/pmc_*/*/p_kernel_trace.csv
+  for c in 1 2 3 5; do python bench.py --config $c --steps 20 --warmup 3 > $out/bench_cfg$c.json 2> $out/bench_cfg$c.err; done
+  for b in 4 8 16; do python bench.py --batch $b --steps 20 --warmup 3 --no-cpu-baseline --no-mode-sweep --no-kernel-timing > $out/bench_batch$b.json 2>/dev/null; done
+fi
+find $out -name "*.csv" | head -20
