@@ -386,6 +386,7 @@ int resolve_mode(const ptamd_gemm_args *a) {
   if (mode == PTAMD_GEMM_AUTO) mode = a->a_kmajor ? PTAMD_GEMM_BF16X3 : PTAMD_GEMM_F16X2;
   const size_t a_bytes = (size_t)(a->a_kmajor ? a->K : a->M) * a->lda * sizeof(float);
   const size_t b_bytes = (size_t)(a->b_kmajor ? a->K : a->N) * a->ldb * sizeof(float);
+  if (mode == PTAMD_GEMM_F16X2 && a->K < 32) mode = PTAMD_GEMM_BF16X3;   // the f16x2 kernel stages 32 k at a time
   if (a->K < 16 || a_bytes >= ((size_t)1 << 32) || b_bytes >= ((size_t)1 << 32)) mode = PTAMD_GEMM_F32;
   return mode;
 }

@@ -52,19 +52,44 @@ namespace {
 using namespace ptsplit;  // bf16x8, split_pair (x = t1 + t2 + t3 exactly, scalar subtractions), LDS transpose-read types
 
 constexpr int TBM = 256, TBN = 128;  // output tile of a workgroup
-constexpr int SBK = 16;              // f32 k per stage = one bf16 MFMA k step
 constexpr int NTHREADS = 512, NPRODUCER = 256;
-constexpr int NSETS = 4;             // register sets of a producer = stages of global loads in flight (even)
-constexpr int LD_RK = 24;            // bf16 per row of a [row][k] plane: 48 B = odd multiple of 16 B
 constexpr int KR_PAD = 32;           // a [k][rows + 32] plane: 4 consecutive k hit 4 different 64-B bank groups
-constexpr int PLANE_A = TBM * LD_RK, PLANE_B = TBN * LD_RK;   // 6144 / 3072 bf16 (the [k][row] forms are smaller)
-constexpr int STAGE = 3 * (PLANE_A + PLANE_B);                // 27648 bf16 = 55296 B
 constexpr int SCRATCH_FLOATS = 4 * 2048;                      // epilogue transpose scratch of the 4 consumers
 constexpr int COLSUM_AREAS = 3;                               // see the producers' publish / the consumers' read below
 constexpr int COLSUM_FLOATS = COLSUM_AREAS * 4 * TBM;         // rotating [4 k groups][256 rows] partial sums
-constexpr size_t LDS_BYTES = (size_t)2 * STAGE * sizeof(unsigned short) + (SCRATCH_FLOATS + COLSUM_FLOATS) * sizeof(float);
-static_assert(PLANE_A >= SBK * (TBM + KR_PAD) && PLANE_B >= SBK * (TBN + KR_PAD), "plane must hold either layout");
-static_assert(LDS_BYTES <= 160 * 1024, "LDS budget of a CU");
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+// Geometry of a stage by arithmetic.
+//   three bf16 planes (NPROD 6 / 9): 16 k per stage, K-contiguous planes [row][16 + 8 pad] (48-byte rows: conflict-free
+//     ds_read_b128), four register sets of global loads in flight;
+//   two f16 planes (NPROD 3): 32 k per stage - ONE barrier and one round of the producer / consumer hand-off per 32 k
+//     instead of per 16 (the barrier structure cost 0.28 us of a 0.93-us 16-k stage, profiles/r02/r02_gemm_occupancy.txt), whole
+//     128-byte lines per K-contiguous operand row and load (16 k touched one 64-byte half of every line).  Two planes of
+//     32 k only fit LDS unpadded: K-contiguous planes are [row][32] f16 = four 16-byte chunks per row, chunk c of row r
+//     stored at c ^ ((r >> 2) & 3) - any 16 rows x one chunk column cover 16 different 16-byte slots of the 256-byte bank
+//     row, so the fragment reads stay conflict-free; two register sets of twice the size keep the same 64 k in flight.
+template <int NPROD>
+struct Geo {
+  static constexpr bool F16 = NPROD == 3;
+  static constexpr int NPLANES = F16 ? 2 : 3;
+  static constexpr int SBK = F16 ? 32 : 16;              // f32 k per stage
+  static constexpr int QK = SBK / 4;                     // float4 per K-contiguous operand row and stage
+  static constexpr int NSETS = F16 ? 2 : 4;              // register sets of a producer = stages of global loads in flight (even)
+  static constexpr int LD_RK = F16 ? SBK : SBK + 8;      // f16 / bf16 per row of a [row][k] plane
+  static constexpr bool SWZ = F16;                       // chunk swizzle instead of padding
+  static constexpr int PLANE_A = cmax(TBM * LD_RK, SBK * (TBM + KR_PAD));
+  static constexpr int PLANE_B = cmax(TBN * LD_RK, SBK * (TBN + KR_PAD));
+  static constexpr int STAGE = NPLANES * (PLANE_A + PLANE_B);
+  static constexpr size_t LDS_BYTES = (size_t)2 * STAGE * sizeof(unsigned short) + (SCRATCH_FLOATS + COLSUM_FLOATS) * sizeof(float);
+  static constexpr int NVA = TBM * SBK / (4 * NPRODUCER), NVB = TBN * SBK / (4 * NPRODUCER);   // float4 per producer thread and stage
+  template <int ROWS> static constexpr int nv() { return ROWS * SBK / (4 * NPRODUCER); }
+  template <int ROWS> static constexpr int plane() { return ROWS == TBM ? PLANE_A : PLANE_B; }
+  // element offset of (row, k) in a [row][k] plane, k multiple of 4
+  static __device__ __forceinline__ int rk_offset(int row, int k) {
+    return SWZ ? row * LD_RK + ((((k >> 3) ^ (row >> 2)) & 3) << 3) + (k & 7) : row * LD_RK + k;
+  }
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget of a CU");
+};
 
 // One stage of one operand (ROWS tile rows x 16 k), global -> registers of the 256 producer threads: ROWS / 64
 // float4 per thread, each from  (scalar base of the stage) + (32-bit per-thread byte offset of the work item),
@@ -74,12 +99,15 @@ static_assert(LDS_BYTES <= 160 * 1024, "LDS budget of a CU");
 // the prefetch distance collapses.  Rows beyond the operand are clamped (they only feed output rows that are never
 // stored); a K tail is handled by starting the last stage of an item 16 k before its end and zeroing the k that
 // were already consumed (store_split's `kskip`).
-template <bool KMAJOR, int ROWS>
-__device__ __forceinline__ void item_offsets(int ld, int rows, int r0, int pt, uint32_t (&voff)[ROWS / 64]) {
-  constexpr int LPK = ROWS / 4;  // lanes per k of a row-contiguous operand
+// Geometry helpers: G = Geo<NPROD>.  A K-contiguous operand row holds G::QK float4 of a stage; thread pt takes k quad
+// pt % QK of the rows pt / QK + (256 / QK) i.  A row-contiguous operand: thread pt takes the row quad pt % LPK of the k
+// rows pt / LPK + (256 / LPK) i.
+template <typename G, bool KMAJOR, int ROWS>
+__device__ __forceinline__ void item_offsets(int ld, int rows, int r0, int pt, uint32_t (&voff)[G::template nv<ROWS>()]) {
+  constexpr int LPK = ROWS / 4, NV = G::template nv<ROWS>();  // lanes per k of a row-contiguous operand
 #pragma unroll
-  for (int i = 0; i < ROWS / 64; ++i) {
-    if (!KMAJOR) voff[i] = ((uint32_t)min(r0 + pt / 4 + 64 * i, rows - 1) * (uint32_t)ld + 4 * (pt % 4)) * 4u;
+  for (int i = 0; i < NV; ++i) {
+    if (!KMAJOR) voff[i] = ((uint32_t)min(r0 + pt / G::QK + (NPRODUCER / G::QK) * i, rows - 1) * (uint32_t)ld + 4 * (pt % G::QK)) * 4u;
     else voff[i] = ((uint32_t)(pt / LPK + (NPRODUCER / LPK) * i) * (uint32_t)ld + min(r0 + 4 * (pt % LPK), rows - 4)) * 4u;
   }
 }
@@ -90,30 +118,34 @@ __device__ __forceinline__ void load_raw(const float *__restrict__ stage_base, c
     v[i] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(stage_base) + voff[i]);
 }
 
-// the first kskip k of a stage are zeroed (only the last stage of an item whose K range is not a multiple of 16)
-template <bool KMAJOR, int ROWS>
-__device__ __forceinline__ void mask_tail(int pt, float4 (&v)[ROWS / 64], int kskip) {
-  constexpr int LPK = ROWS / 4;
+// the first kskip k of a stage are zeroed (only the last stage of an item whose K range is not a multiple of the stage)
+template <typename G, bool KMAJOR, int ROWS>
+__device__ __forceinline__ void mask_tail(int pt, float4 (&v)[G::template nv<ROWS>()], int kskip) {
+  constexpr int LPK = ROWS / 4, NV = G::template nv<ROWS>();
   if (kskip > 0) {  // uniform
 #pragma unroll
-    for (int i = 0; i < ROWS / 64; ++i) {
-      const int kl = KMAJOR ? pt / LPK + (NPRODUCER / LPK) * i : 4 * (pt % 4);
-      if (kl < kskip) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < NV; ++i) {
+      const int kl = KMAJOR ? pt / LPK + (NPRODUCER / LPK) * i : 4 * (pt % G::QK);
+      if (KMAJOR) {
+        if (kl < kskip) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {  // a float4 = 4 consecutive k: kskip is a multiple of 4 (K, k_per_split are)
+        if (kl < kskip) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   }
 }
 // registers of one stage -> the three LDS planes of the operand at `s`
-template <bool KMAJOR, int ROWS>
-__device__ __forceinline__ void store_split(unsigned short *__restrict__ s, int pt, const float4 (&v)[ROWS / 64]) {
-  constexpr int LPK = ROWS / 4, PLANE = ROWS * LD_RK, LD_KR = ROWS + KR_PAD;
+template <typename G, bool KMAJOR, int ROWS>
+__device__ __forceinline__ void store_split(unsigned short *__restrict__ s, int pt, const float4 (&v)[G::template nv<ROWS>()]) {
+  constexpr int LPK = ROWS / 4, PLANE = G::template plane<ROWS>(), LD_KR = ROWS + KR_PAD, NV = G::template nv<ROWS>();
 #pragma unroll
-  for (int i = 0; i < ROWS / 64; ++i) {
-    const int kl = KMAJOR ? pt / LPK + (NPRODUCER / LPK) * i : 4 * (pt % 4);
+  for (int i = 0; i < NV; ++i) {
+    const int kl = KMAJOR ? pt / LPK + (NPRODUCER / LPK) * i : 4 * (pt % G::QK);
     uint2 t1, t2, t3;
     split_pair(v[i].x, v[i].y, t1.x, t2.x, t3.x);
     split_pair(v[i].z, v[i].w, t1.y, t2.y, t3.y);
-    const int off = KMAJOR ? kl * LD_KR + 4 * (pt % LPK)          // 4 consecutive rows of one k
-                           : (pt / 4 + 64 * i) * LD_RK + kl;      // 4 consecutive k of one row
+    const int off = KMAJOR ? kl * LD_KR + 4 * (pt % LPK)                                   // 4 consecutive rows of one k
+                           : G::rk_offset(pt / G::QK + (NPRODUCER / G::QK) * i, kl);       // 4 consecutive k of one row
     *reinterpret_cast<uint2 *>(s + off) = t1;
     *reinterpret_cast<uint2 *>(s + PLANE + off) = t2;
     *reinterpret_cast<uint2 *>(s + 2 * PLANE + off) = t3;
@@ -123,37 +155,39 @@ __device__ __forceinline__ void store_split(unsigned short *__restrict__ s, int 
 // ---- f16x2 arithmetic (NPROD == 3): every operand row carries a power-of-two scale (gemm_row_scale_kernel below);
 // the producers load it with the stage (unconditionally, like the operand itself), multiply and split into TWO f16
 // planes, and the consumers undo the two scales on the accumulators before the epilogue.
-template <bool KMAJOR, int ROWS>
-__device__ __forceinline__ void scale_offsets(int rows, int r0, int pt, uint32_t (&soff)[4], int stride = 1) {
-  constexpr int LPK = ROWS / 4;
+constexpr int MAX_NV = 8;   // float4 (and, for a K-contiguous operand, row scales) per producer thread and stage
+template <typename G, bool KMAJOR, int ROWS>
+__device__ __forceinline__ void scale_offsets(int rows, int r0, int pt, uint32_t (&soff)[MAX_NV], int stride = 1) {
+  constexpr int LPK = ROWS / 4, NV = G::template nv<ROWS>();
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (!KMAJOR) soff[i] = (uint32_t)min(r0 + pt / 4 + 64 * (i < ROWS / 64 ? i : 0), rows - 1) * 4u * (uint32_t)stride;  // the row of v[i]
+  for (int i = 0; i < MAX_NV; ++i) {
+    if (!KMAJOR) soff[i] = (uint32_t)min(r0 + pt / G::QK + (NPRODUCER / G::QK) * (i < NV ? i : 0), rows - 1) * 4u * (uint32_t)stride;  // the row of v[i]
     else soff[i] = (uint32_t)min(r0 + 4 * (pt % LPK), rows - 4) * 4u * (uint32_t)stride;              // the 4 rows of every v[i]
   }
 }
-template <bool KMAJOR, int ROWS>
-__device__ __forceinline__ void load_scales(const uint32_t *__restrict__ scale, const uint32_t (&soff)[4], float (&sc)[4]) {
+template <typename G, bool KMAJOR, int ROWS>
+__device__ __forceinline__ void load_scales(const uint32_t *__restrict__ scale, const uint32_t (&soff)[MAX_NV], float (&sc)[MAX_NV]) {
   const char *base = reinterpret_cast<const char *>(scale);
+  constexpr int NV = G::template nv<ROWS>();
   if (!KMAJOR) {
 #pragma unroll
-    for (int i = 0; i < ROWS / 64; ++i) sc[i] = *reinterpret_cast<const float *>(base + soff[i]);
+    for (int i = 0; i < NV; ++i) sc[i] = *reinterpret_cast<const float *>(base + soff[i]);
   } else {
     const float4 v = *reinterpret_cast<const float4 *>(base + soff[0]);
     sc[0] = v.x; sc[1] = v.y; sc[2] = v.z; sc[3] = v.w;
   }
 }
-template <bool KMAJOR, int ROWS>
-__device__ __forceinline__ void store_split_f16(unsigned short *__restrict__ s, int pt, const float4 (&v)[ROWS / 64],
-                                                const float (&sc)[4]) {
-  constexpr int LPK = ROWS / 4, PLANE = ROWS * LD_RK, LD_KR = ROWS + KR_PAD;
+template <typename G, bool KMAJOR, int ROWS>
+__device__ __forceinline__ void store_split_f16(unsigned short *__restrict__ s, int pt, const float4 (&v)[G::template nv<ROWS>()],
+                                                const float (&sc)[MAX_NV]) {
+  constexpr int LPK = ROWS / 4, PLANE = G::template plane<ROWS>(), LD_KR = ROWS + KR_PAD, NV = G::template nv<ROWS>();
 #pragma unroll
-  for (int i = 0; i < ROWS / 64; ++i) {
-    const int kl = KMAJOR ? pt / LPK + (NPRODUCER / LPK) * i : 4 * (pt % 4);
+  for (int i = 0; i < NV; ++i) {
+    const int kl = KMAJOR ? pt / LPK + (NPRODUCER / LPK) * i : 4 * (pt % G::QK);
     uint2 t1, t2;
     split_quad_f16(v[i].x, v[i].y, v[i].z, v[i].w, KMAJOR ? sc[0] : sc[i], KMAJOR ? sc[1] : sc[i], KMAJOR ? sc[2] : sc[i],
                    KMAJOR ? sc[3] : sc[i], t1, t2);
-    const int off = KMAJOR ? kl * LD_KR + 4 * (pt % LPK) : (pt / 4 + 64 * i) * LD_RK + kl;
+    const int off = KMAJOR ? kl * LD_KR + 4 * (pt % LPK) : G::rk_offset(pt / G::QK + (NPRODUCER / G::QK) * i, kl);
     *reinterpret_cast<uint2 *>(s + off) = t1;
     *reinterpret_cast<uint2 *>(s + PLANE + off) = t2;
   }
@@ -163,18 +197,19 @@ __device__ __forceinline__ void store_split_f16(unsigned short *__restrict__ s, 
 __device__ __forceinline__ uint32_t row_scale_bits(uint32_t amax) { return min(268u - (amax >> 23), 254u) << 23; }
 __device__ __forceinline__ float inverse_scale(uint32_t scale_bits) { return __uint_as_float((254u << 23) - scale_bits); }
 
-// MFMA operand of the 32 tile rows starting at r0, plane t: lane l holds row r0 + (l & 31), k = 8 (l >> 5) + 0..7
-template <bool KMAJOR, int ROWS>
-__device__ __forceinline__ bf16x8 read_frag(const unsigned short *__restrict__ s, int r0, int lane, int t) {
-  constexpr int PLANE = ROWS * LD_RK, LD_KR = ROWS + KR_PAD;
+// MFMA operand of the 32 tile rows starting at r0, plane t, k step ks of the stage: lane l holds row r0 + (l & 31),
+// k = 16 ks + 8 (l >> 5) + 0..7
+template <typename G, bool KMAJOR, int ROWS>
+__device__ __forceinline__ bf16x8 read_frag(const unsigned short *__restrict__ s, int r0, int lane, int t, int ks) {
+  constexpr int PLANE = G::template plane<ROWS>(), LD_KR = ROWS + KR_PAD;
   if (!KMAJOR) {
-    return *reinterpret_cast<const bf16x8 *>(s + t * PLANE + (r0 + (lane & 31)) * LD_RK + 8 * (lane >> 5));
+    return *reinterpret_cast<const bf16x8 *>(s + t * PLANE + G::rk_offset(r0 + (lane & 31), 16 * ks + 8 * (lane >> 5)));
   } else {
     // ds_read_b64_tr_b16: within a 16-lane group, lane q supplies the address of 4 contiguous bf16 = columns
     // 4 (q & 3) .. +3 of matrix row (q >> 2) and receives column q of the 4 rows.  Rows = 4 consecutive k,
     // columns = 16 consecutive tile rows.
     const int q16 = lane & 15;
-    const unsigned short *q = s + t * PLANE + (8 * (lane >> 5) + (q16 >> 2)) * LD_KR + r0 + (lane & 16) + 4 * (q16 & 3);
+    const unsigned short *q = s + t * PLANE + (16 * ks + 8 * (lane >> 5) + (q16 >> 2)) * LD_KR + r0 + (lane & 16) + 4 * (q16 & 3);
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)q);
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(q + 4 * LD_KR));
     const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -197,6 +232,8 @@ template <bool A_KMAJOR, bool B_KMAJOR, int NPROD, int EPI>
 __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16x3_mfma_kernel(
     const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  using G = Geo<NPROD>;
+  constexpr int SBK = G::SBK, NSETS = G::NSETS, STAGE = G::STAGE, PLANE_A = G::PLANE_A, NVA = G::NVA, NVB = G::NVB;
   float *const scratch = reinterpret_cast<float *>(smem + 2 * STAGE);
   float *const cs_area = scratch + SCRATCH_FLOATS;
 
@@ -245,59 +282,61 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
     // ================================================================ producers
     const int pt = tid - NPRODUCER;
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
-    float cs_w[4] = {0.f, 0.f, 0.f, 0.f};  // weight of this thread's k rows (pt / 64 + 4 i) for the item under `st`
+    float cs_w[NVA];  // weight of this thread's k rows (pt / 64 + 4 i) for the item under `st`
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) cs_w[i] = 0.f;
     int cs_parity = 0;
     auto colsum_weights = [&](const Item &it) __attribute__((always_inline)) {
       const bool on = colsum_on(it);
       const int first = colsum_first(it);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) cs_w[i] = (on && ((pt / 64 + 4 * i) & (cs_share - 1)) == first) ? 1.f : 0.f;
+      for (int i = 0; i < NVA; ++i) cs_w[i] = (on && ((pt / 64 + 4 * i) & (cs_share - 1)) == first) ? 1.f : 0.f;
     };
 
     Cursor ld = {work.begin, 0, item_at(work.begin), false};  // next stage to fetch
     ld.k0 = ld.it.kbeg;
     Cursor st = ld;                                    // next stage to convert and store
     colsum_weights(st.it);
-    uint32_t voa[4], vob[2];                           // per-thread byte offsets of the item under `ld`
-    item_offsets<A_KMAJOR, TBM>(p.lda, p.M, ld.it.bm0, pt, voa);
-    item_offsets<B_KMAJOR, TBN>(p.ldb, p.N, ld.it.bn0, pt, vob);
-    float4 ra[NSETS][4], rb[NSETS][2];                 // NSETS stages in flight (registers)
-    float rsa[NSETS][4], rsb[NSETS][4];                // f16x2 only: the row scales that go with them
-    uint32_t soa[4], sob[4];
+    uint32_t voa[NVA], vob[NVB];                       // per-thread byte offsets of the item under `ld`
+    item_offsets<G, A_KMAJOR, TBM>(p.lda, p.M, ld.it.bm0, pt, voa);
+    item_offsets<G, B_KMAJOR, TBN>(p.ldb, p.N, ld.it.bn0, pt, vob);
+    float4 ra[NSETS][NVA], rb[NSETS][NVB];             // NSETS stages in flight (registers)
+    float rsa[NSETS][MAX_NV], rsb[NSETS][MAX_NV];      // f16x2 only: the row scales that go with them
+    uint32_t soa[MAX_NV], sob[MAX_NV];
     if (F16) {
-      scale_offsets<A_KMAJOR, TBM>(p.M, ld.it.bm0, pt, soa, p.scale_a_stride);
-      scale_offsets<B_KMAJOR, TBN>(p.N, ld.it.bn0, pt, sob, p.scale_b_stride);
+      scale_offsets<G, A_KMAJOR, TBM>(p.M, ld.it.bm0, pt, soa, p.scale_a_stride);
+      scale_offsets<G, B_KMAJOR, TBN>(p.N, ld.it.bn0, pt, sob, p.scale_b_stride);
     }
     int rskip[NSETS];
-    auto fetch = [&](float4 (&a)[4], float4 (&b)[2], int &kskip, float (&sa_)[4], float (&sb_)[4]) __attribute__((always_inline)) {
+    auto fetch = [&](float4 (&a)[NVA], float4 (&b)[NVB], int &kskip, float (&sa_)[MAX_NV], float (&sb_)[MAX_NV]) __attribute__((always_inline)) {
       const int klim = ld.it.kend - ld.k0;
       const int ks = klim >= SBK ? ld.k0 : ld.it.kend - SBK;  // the last stage of an item may start early
       kskip = ld.k0 - ks;
       load_raw(p.A + (A_KMAJOR ? (size_t)ks * p.lda : (size_t)ks), voa, a);
       load_raw(p.B + (B_KMAJOR ? (size_t)ks * p.ldb : (size_t)ks), vob, b);
       if (F16) {
-        load_scales<A_KMAJOR, TBM>(p.scale_a, soa, sa_);
-        load_scales<B_KMAJOR, TBN>(p.scale_b, sob, sb_);
+        load_scales<G, A_KMAJOR, TBM>(p.scale_a, soa, sa_);
+        load_scales<G, B_KMAJOR, TBN>(p.scale_b, sob, sb_);
       }
       const int w_before = ld.w;
       advance(ld);
       if (ld.w != w_before) {  // uniform, no memory access inside
-        item_offsets<A_KMAJOR, TBM>(p.lda, p.M, ld.it.bm0, pt, voa);
-        item_offsets<B_KMAJOR, TBN>(p.ldb, p.N, ld.it.bn0, pt, vob);
+        item_offsets<G, A_KMAJOR, TBM>(p.lda, p.M, ld.it.bm0, pt, voa);
+        item_offsets<G, B_KMAJOR, TBN>(p.ldb, p.N, ld.it.bn0, pt, vob);
         if (F16) {
-          scale_offsets<A_KMAJOR, TBM>(p.M, ld.it.bm0, pt, soa, p.scale_a_stride);
-          scale_offsets<B_KMAJOR, TBN>(p.N, ld.it.bn0, pt, sob, p.scale_b_stride);
+          scale_offsets<G, A_KMAJOR, TBM>(p.M, ld.it.bm0, pt, soa, p.scale_a_stride);
+          scale_offsets<G, B_KMAJOR, TBN>(p.N, ld.it.bn0, pt, sob, p.scale_b_stride);
         }
       }
     };
     // convert + store the stage under `st` into LDS buffer `buf`, then refill the registers two stages ahead
-    auto produce = [&](float4 (&a)[4], float4 (&b)[2], int &kskip, float (&sa_)[4], float (&sb_)[4], int buf) __attribute__((always_inline)) {
-      unsigned short *sa = smem + buf * STAGE, *sb = sa + 3 * PLANE_A;
-      mask_tail<A_KMAJOR, TBM>(pt, a, kskip);
-      mask_tail<B_KMAJOR, TBN>(pt, b, kskip);
+    auto produce = [&](float4 (&a)[NVA], float4 (&b)[NVB], int &kskip, float (&sa_)[MAX_NV], float (&sb_)[MAX_NV], int buf) __attribute__((always_inline)) {
+      unsigned short *sa = smem + buf * STAGE, *sb = sa + G::NPLANES * PLANE_A;
+      mask_tail<G, A_KMAJOR, TBM>(pt, a, kskip);
+      mask_tail<G, B_KMAJOR, TBN>(pt, b, kskip);
       if (has_colsum) {  // kernel-uniform; the weights are zero where this workgroup has nothing to add
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {  // scalar fmas, kept apart: a v_pk_fma_f32 beside the consumer's MFMAs stalls the pipe
+        for (int i = 0; i < NVA; ++i) {  // scalar fmas, kept apart: a v_pk_fma_f32 beside the consumer's MFMAs stalls the pipe
           csum.x = fmaf(cs_w[i], a[i].x, csum.x); asm volatile("" : "+v"(csum.x));
           csum.y = fmaf(cs_w[i], a[i].y, csum.y); asm volatile("" : "+v"(csum.y));
           csum.z = fmaf(cs_w[i], a[i].z, csum.z); asm volatile("" : "+v"(csum.z));
@@ -305,11 +344,11 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
         }
       }
       if (F16) {
-        store_split_f16<A_KMAJOR, TBM>(sa, pt, a, sa_);
-        store_split_f16<B_KMAJOR, TBN>(sb, pt, b, sb_);
+        store_split_f16<G, A_KMAJOR, TBM>(sa, pt, a, sa_);
+        store_split_f16<G, B_KMAJOR, TBN>(sb, pt, b, sb_);
       } else {
-        store_split<A_KMAJOR, TBM>(sa, pt, a);
-        store_split<B_KMAJOR, TBN>(sb, pt, b);
+        store_split<G, A_KMAJOR, TBM>(sa, pt, a);
+        store_split<G, B_KMAJOR, TBN>(sb, pt, b);
       }
       if (has_colsum && !st.end && st.k0 + SBK >= st.it.kend) {  // last stage of its item: publish (LDS only)
         if (colsum_on(st.it)) {
@@ -326,7 +365,10 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
         const bool was_end = st.end;
         advance(st);
         if (st.w != w_before) colsum_weights(st.it);
-        if (st.end && !was_end) cs_w[0] = cs_w[1] = cs_w[2] = cs_w[3] = 0.f;  // past the end the last stage is re-fetched
+        if (st.end && !was_end) {  // past the end the last stage is re-fetched
+#pragma unroll
+          for (int i = 0; i < NVA; ++i) cs_w[i] = 0.f;
+        }
       }
       // the refill must not be scheduled above the conversion: old and new contents of the registers would overlap,
       // the set could not stay in place across the loop and the copies (each waiting for its load) would drain the
@@ -376,15 +418,16 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
         __syncthreads();
         continue;
       }
-      const unsigned short *sa = smem + (g & 1) * STAGE, *sb = sa + 3 * PLANE_A;
+      const unsigned short *sa = smem + (g & 1) * STAGE, *sb = sa + G::NPLANES * PLANE_A;
       bf16x8 fa[4][3], fb[2][3];
+      int ks = 0;  // 16-k step of the stage
       auto read_a = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i][t] = read_frag<A_KMAJOR, TBM>(sa, wm * 128 + 32 * i, lane, t);
+        for (int i = 0; i < 4; ++i) fa[i][t] = read_frag<G, A_KMAJOR, TBM>(sa, wm * 128 + 32 * i, lane, t, ks);
       };
       auto read_b = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) fb[j][t] = read_frag<B_KMAJOR, TBN>(sb, wn * 64 + 32 * j, lane, t);
+        for (int j = 0; j < 2; ++j) fb[j][t] = read_frag<G, B_KMAJOR, TBN>(sb, wn * 64 + 32 * j, lane, t, ks);
       };
       auto mul = [&](int ta, int tb) __attribute__((always_inline)) {
 #pragma unroll
@@ -397,9 +440,13 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
       };
       // smallest products first; fragments are read in the order the products need them
       if (NPROD == 3) {
-        read_a(1); read_b(0); mul(1, 0);
-        read_a(0); read_b(1); mul(0, 1);
-        mul(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < SBK / 16; ++kk) {
+          ks = kk;
+          read_a(1); read_b(0); mul(1, 0);
+          read_a(0); read_b(1); mul(0, 1);
+          mul(0, 0);
+        }
       } else if (NPROD == 9) {
         read_a(2); read_b(2); mul(2, 2);
         read_b(1); mul(2, 1);
@@ -457,10 +504,10 @@ int launch(const GemmParams &p, int splits, hipStream_t st) {
   const int work = ((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN) * splits;
   auto kern = gemm_bf16x3_mfma_kernel<AK, BKM, NPROD, EPI>;
   PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)LDS_BYTES));  // idempotent, host-only: no state kept between calls
+                                 (int)Geo<NPROD>::LDS_BYTES));  // idempotent, host-only: no state kept between calls
   const int slots = persistent_grid(p.reserved_cus);  // one workgroup per CU
   const int grid = work < slots ? work : slots;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), LDS_BYTES, st, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), Geo<NPROD>::LDS_BYTES, st, p);
   return pt_check_launch();
 }
 
