@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-mode-sweep", action="store_true", help="skip the bf16x3 / f32 re-runs of the timed loop")
     ap.add_argument("--no-attn-row-scales", action="store_true", help="ablation: dqkv row scales by a pass over dqkv")
+    ap.add_argument("--no-side-stream", action="store_true", help="ablation: weight-gradient products of small batches on the main stream")
+    ap.add_argument("--no-hp-forward", action="store_true", help="ablation: QKV / FFN-layer-1 forward products on ptamd_gemm instead of ptamd_gemm_hp")
     ap.add_argument("--attn-mode", default=None, choices=["f32", "bf16x3", "f16x2"],
                     help="arithmetic of the attention kernels alone (ablation; default: that of --gemm-mode)")
     ap.add_argument("--gemm-mode", default="auto", choices=["f32", "bf16x3", "bf16x3full", "f16x2", "auto"],
@@ -228,6 +230,8 @@ def main():
     model.gemm_mode = modes[a.gemm_mode]
     model.attn_mode = None if a.attn_mode is None else modes[a.attn_mode]
     model.attn_row_scales = not a.no_attn_row_scales
+    model.side_stream_dw = not a.no_side_stream
+    model.hp_forward = not a.no_hp_forward
     model.dropout_seed += 7919 * rank
     dp.attach(model)
     opt = (FusedAdam(model, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=10e-3) if a.optimizer == "adam"

@@ -149,6 +149,7 @@ class _TransformerBase(nn.Module):
         self.attn_mode = None                        # arithmetic of the attention kernels alone (ablations); None = gemm_mode
         self.gemm_mode = None                        # kernels.GEMM_* arithmetic of THIS model; None = kernels.get_gemm_mode()
         self.hp_forward = True                       # QKV / FFN-layer-1 products on ptamd_gemm_hp from LayerNorm-written planes
+        self.side_stream_dw = True                   # small batches: weight-gradient products on a side stream
         self._init_parameters()
 
     # ------------------------------------------------------------------ parameters
@@ -385,7 +386,7 @@ class _EncoderFn(torch.autograd.Function):
         W = lambda name: m._slice(flat, name)                                      # noqa: E731
         ar = K.get_gemm_mode() if m.gemm_mode is None else int(m.gemm_mode)        # every launch below carries it
         attn_default = ar                 # the attention kernels find their f16x2 scales themselves: AUTO stays AUTO for them
-        if ar == K.GEMM_AUTO and B * L * D < AUTO_F16X2_MIN_WORK:
+        if ar == K.GEMM_AUTO and B * L * D < (AUTO_F16X2_MIN_WORK >> 1 if D >= 512 else AUTO_F16X2_MIN_WORK):
             ar = K.GEMM_BF16X3         # launch-bound step: the scale bookkeeping of f16x2 costs more than its products save
         pe = m.encoder.positional_enc.pe[0]
         # ---- front end: embedding (+ doubled positional add) or one-hot, then the optional Conv1d stack
@@ -465,9 +466,32 @@ class _EncoderFn(torch.autograd.Function):
         G = lambda name: m._slice(gflat, name)                                     # noqa: E731
 
         ln_pending = []      # deferred (dgamma, dbeta) reductions of the LayerNorm backward kernels: one launch per flush
+        # Small batches: the weight-gradient products (independent of the dX chain, 40 % of the backward GEMM time) go to a
+        # side stream; the main stream waits for it before a gradient slice is handed on and at the end of the pass.
+        main = torch.cuda.current_stream(dpred.device)
+        side = None
+        if m.side_stream_dw and D >= 512 and B * L >= 2048 and B * L * D <= SIDE_STREAM_MAX_WORK:
+            side = m.__dict__.get("_side_stream")
+            if side is None or side.device != dpred.device:
+                side = m.__dict__["_side_stream"] = torch.cuda.Stream(device=dpred.device)
+
+        def dw(*tensors_then_kwargs, **kw):
+            """K.linear_bwd_weight(dy, x, dw, db, ...) - on the side stream when there is one."""
+            if side is None:
+                return K.linear_bwd_weight(*tensors_then_kwargs, **kw)
+            side.wait_stream(main)                       # the operands were produced on the main stream
+            for t in tensors_then_kwargs[:2]:
+                t.record_stream(side)                    # allocated on the main stream, read on the side stream
+            with torch.cuda.stream(side):
+                return K.linear_bwd_weight(*tensors_then_kwargs, **kw)
+
+        def join():
+            if side is not None:
+                main.wait_stream(side)
 
         def done(first, last):
             if m.grad_hook is not None:
+                join()
                 K.layernorm_bwd_flush(ln_pending)     # a slice handed to the all-reduce must be final
                 o0, _ = m._layout[first]
                 o1, s1 = m._layout[last]
@@ -497,12 +521,12 @@ class _EncoderFn(torch.autograd.Function):
             if dy2 is None:
                 dy2 = K.dropout_bwd(dx, p, seed, sid + _SITE_FFN_OUT) if p > 0 else dx
             uni = sc is not None and have_min              # uniform scales of both operands: the dW product runs in f16x2
-            K.linear_bwd_weight(dy2, f1, G(b + "pwff.layer2.weight"), G(b + "pwff.layer2.bias"), arith=ar,
+            dw(dy2, f1, G(b + "pwff.layer2.weight"), G(b + "pwff.layer2.bias"), arith=ar,
                                 dy_scale=sc["dy2_min"] if uni else None, x_scale=sc["f1_scale"] if uni else None)
             # backward of layer2 and, in its epilogue, of the ReLU + dropout in front of it (gate = saved f1)
             dz1 = K.linear_bwd_input(dy2, W(b + "pwff.layer2.weight"), gate=f1, gate_dropout_p=p, arith=ar,
                                      a_scale=s_dy2 if sc else None, b_scale=sc and sc["cs_2"])
-            K.linear_bwd_weight(dz1, h2, G(b + "pwff.layer1.weight"), G(b + "pwff.layer1.bias"), arith=ar,
+            dw(dz1, h2, G(b + "pwff.layer1.weight"), G(b + "pwff.layer1.bias"), arith=ar,
                                 dy_scale=sc["dz1_min"] if uni else None, x_scale=sc["h2_scale"] if uni else None)
             dh2 = K.linear_bwd_input(dz1, W(b + "pwff.layer1.weight"), arith=ar,
                                      a_scale=bs_dz1 if sc else None, b_scale=sc and sc["cs_1"])
@@ -519,7 +543,7 @@ class _EncoderFn(torch.autograd.Function):
                                       pending=ln_pending)
                 dyo = K.dropout_bwd(dx2, p, seed, sid + _SITE_ATTN_OUT) if p > 0 else dx2
             uni_o = sc is not None and fuse
-            K.linear_bwd_weight(dyo, att, G(b + "self_attn.wo.weight"), G(b + "self_attn.wo.bias"), arith=ar,
+            dw(dyo, att, G(b + "self_attn.wo.weight"), G(b + "self_attn.wo.bias"), arith=ar,
                                 dy_scale=sc["dyo_min"] if uni_o else None, x_scale=sc["att_scale"] if uni_o else None)
             datt = K.linear_bwd_input(dyo, W(b + "self_attn.wo.weight"), arith=ar, a_scale=s_dyo, b_scale=sc and sc["cs_o"])
             # the f16x2 attention kernels leave the row scales of dqkv (A of the dX product) and the smallest of them (the
@@ -538,10 +562,10 @@ class _EncoderFn(torch.autograd.Function):
                     s_dqkv, dq_uni = i32(), sc["dqkv_scale"]
                     K.weight_scales([dict(w=dqkv, row_scale=s_dqkv, stats=sc["dqkv_stats"], rows_only=True)])
                     K.bound_scales([dict(w=sc["dqkv_stats"], w_index=2, out_scale=sc["dqkv_scale"])])
-                K.linear_bwd_weight(dqkv, h1, gw, gb, arith=ar, dy_scale=dq_uni, x_scale=sc["h1_scale"])
+                dw(dqkv, h1, gw, gb, arith=ar, dy_scale=dq_uni, x_scale=sc["h1_scale"])
                 dh1 = K.linear_bwd_input(dqkv, wqkv, arith=ar, a_scale=s_dqkv, b_scale=sc["cs_qkv"])
             else:
-                K.linear_bwd_weight(dqkv, h1, gw, gb, arith=ar)
+                dw(dqkv, h1, gw, gb, arith=ar)
                 dh1 = K.linear_bwd_input(dqkv, wqkv, arith=ar)
             g1w, g1b = G(b + "sublayer_connections.0.norm.weight"), G(b + "sublayer_connections.0.norm.bias")
             if fuse and i > 0:      # the gradient enters layer i - 1 through ITS FFN-output dropout: made here, with its scales
@@ -561,6 +585,7 @@ class _EncoderFn(torch.autograd.Function):
             done(b + "self_attn.wq.weight", b + "sublayer_connections.1.norm.bias")
             ctx.saved[i] = None
         K.layernorm_bwd_flush(ln_pending)
+        join()
         # ---- front end
         if not m.use_embedding:
             dx = K.posenc_add_bwd(dx, p, seed)
@@ -581,8 +606,14 @@ class _EncoderFn(torch.autograd.Function):
 
 
 # tokens x d_model below which AUTO runs the whole step in bf16x3 (measured: 2.9 against 3.2 ms/step at 4096 x 256,
-# 10.2 against 9.8 at 16384 x 256 - profiles/r02/r02_v2_bench_cfg2.json, cfg3)
+# 10.2 against 9.8 at 16384 x 256 - profiles/r02/r02_v2_bench_cfg2.json, cfg3); half of it for d_model >= 512, where the
+# f16x2 path (with the LDS-DMA forward products) wins from 2048 tokens on (4.92 against 5.34 ms at 2048 x 512, round 3)
 AUTO_F16X2_MIN_WORK = 1 << 21
+# tokens x d_model below which the weight-gradient products of the backward pass run on a SIDE stream next to the dX chain
+# (few output tiles per product: the persistent kernels leave CUs idle that the other stream's kernel can take).  Only for
+# d_model >= 512 and >= 2048 tokens: measured -0..4 % at 4, -5 % at 8, -3 % at 16 proteins x 512 (profiles/r03), but +14 % on
+# config 2 (4096 x 256) and +12 % on config 1, where the step is bound by host-side launches and the stream joins add to them
+SIDE_STREAM_MAX_WORK = 1 << 23
 
 
 class EncoderOnlyTransformer(_TransformerBase):

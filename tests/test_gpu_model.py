@@ -419,3 +419,27 @@ def test_arithmetic_modes_against_fp64_step(dev):
     assert err[K_.GEMM_F32] < 5e-4 and err[K_.GEMM_BF16X3] < 5e-4 and err[K_.GEMM_F16X2] < 5e-4, err
     for m in got:
         assert got[m][1] == pytest.approx(ln64, rel=2e-5)
+    # Per parameter GROUP (a norm over the whole vector cannot see a wrong or dropped gradient in a small group -
+    # LayerNorm gains and biases, the bias vectors): every group of every arithmetic inside 2e-3 of its own norm, and the
+    # default f16x2 arithmetic in no group worse than 3 x the worse of the two strictly fp32-grade ones (floor 2e-4: below
+    # that the comparison is between two draws of the same rounding noise).
+    def group_of(n):
+        kind = "weight" if n.endswith("weight") else "bias"
+        for tag, name in (("input_embedding", "embedding"), ("output_projection", "out"), ("norm", "layernorm"),
+                          ("self_attn", "attention"), ("pwff", "ffn")):
+            if tag in n:
+                return f"{name}.{kind}"
+        return n
+    per = {}
+    for m in got:
+        acc = {}
+        for n in leaf:
+            e2, r2 = ((got[m][0][n] - leaf[n].grad) ** 2).sum().item(), (leaf[n].grad ** 2).sum().item()
+            a = acc.setdefault(group_of(n), [0.0, 0.0])
+            a[0] += e2
+            a[1] += r2
+        per[m] = {k: (v[0] / v[1]) ** 0.5 for k, v in acc.items() if v[1] > 0}
+        assert all(e < 2e-3 for e in per[m].values()), (m, per[m])
+    assert set(per[K_.GEMM_F16X2]) >= {"layernorm.weight", "layernorm.bias", "attention.bias", "ffn.bias", "out.bias"}
+    for k, e in per[K_.GEMM_F16X2].items():
+        assert e < max(3.0 * max(per[K_.GEMM_F32][k], per[K_.GEMM_BF16X3][k]), 2e-4), (k, e, per[K_.GEMM_F32][k], per[K_.GEMM_BF16X3][k])
