@@ -231,6 +231,8 @@ def main():
     model.attn_mode = None if a.attn_mode is None else modes[a.attn_mode]
     model.attn_row_scales = not a.no_attn_row_scales
     model.side_stream_dw = not a.no_side_stream
+    if os.environ.get("PTAMD_DW_SLOTS"):
+        kernels.DW_SLOTS = int(os.environ["PTAMD_DW_SLOTS"])
     model.hp_forward = not a.no_hp_forward
     model.dropout_seed += 7919 * rank
     dp.attach(model)

@@ -1,5 +1,6 @@
 #!/bin/bash
-# round-3 measurement set on one MI355X box: headline bench line, rocprofv3 kernel stats of the same command, PMC traffic
+# round-3 measurement set on one MI355X box: headline bench line, rocprofv3 kernel stats of the same command (with --no-side-stream:
+# kernels of two streams that overlap report durations that include their waiting for CUs), PMC traffic
 # passes (separate runs, --kernel-trace only), the other BASELINE configurations.   usage: r03_collect.sh <tag> [full]
 set -x
 tag=${1:-x}
@@ -7,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/r3_$tag
 mkdir -p $out
 python bench.py --steps 20 --warmup 3 > $out/bench_cfg4.json 2> $out/bench_cfg4.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o r3 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-mode-sweep > $out/bench_under_rocprof.json 2> $out/prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o r3 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-mode-sweep --no-side-stream > $out/bench_under_rocprof.json 2> $out/prof.err
 rm -f $out/prof/*/r3_kernel_trace.csv $out/prof/r3_kernel_trace.csv
 if [ "$2" = "full" ]; then
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-mode-sweep > $out/pmc_fetch.log 2>&1

@@ -265,6 +265,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dropout_kernel(
   }
   const uint32_t t16 = dropout_threshold(p) >> 16;
   const float ks = 1.f / (1.f - p), bf = bound_factor ? *bound_factor : 0.f;
+  const float *__restrict__ rsrc = dres ? dres : dy;   // no residual gradient: the loads stay (unconditional), their weight is 0
+  const float rflag = dres ? 1.f : 0.f;
   const int64_t ngroups = ((T + 31) / 32) * 4;
   for (int64_t cr = wid; cr < ngroups; cr += LN_BWD_BLOCKS * 4) {  // cr = call row (4 I + 2 h + gp)
     const int64_t r0 = ((cr >> 2) << 5) + 16 * (cr & 1) + 4 * ((cr >> 1) & 1);
@@ -278,26 +280,45 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dropout_kernel(
           rnd[j][k] = pt_rand4(seed, (uint64_t)cr * (uint64_t)D + (uint64_t)(c < D ? c : 0), stream_id);
         }
     }
+    // The eight rows of the group, software-pipelined: the loads of row f + 1 (x, dy, dres, mean, rstd: UNCONDITIONAL, the
+    // row index clamped, columns beyond D clamped and masked afterwards) are issued before row f is reduced and written.
+    // Written with predicated loads the compiler turned every `if` into a branch, issued the loads two at a time and
+    // waited for each pair: four dependent memory round trips per row, 3.3 TB/s (profiles/r03).
+    float4 xa[2][NV], da[2][NV], ra[2][NV];
+    float mua[2], rsa[2];
+    auto fetch = [&](int f, int set) __attribute__((always_inline)) {
+      const int64_t row = min(r0 + 8 * (f >> 2) + (f & 3), T - 1);
+      mua[set] = mean[row];
+      rsa[set] = rstd[row];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int c = min((j * 64 + lane) * 4, D - 4);
+        xa[set][j] = *reinterpret_cast<const float4 *>(x + row * D + c);
+        da[set][j] = *reinterpret_cast<const float4 *>(dy + row * D + c);
+        ra[set][j] = *reinterpret_cast<const float4 *>(rsrc + row * D + c);
+      }
+    };
+    fetch(0, 0);
 #pragma unroll
     for (int f = 0; f < 8; ++f) {
       const int64_t row = r0 + 8 * (f >> 2) + (f & 3);
-      if (row >= T) continue;  // wavefront-uniform
-      const float mu = mean[row], rs = rstd[row];
+      if (f < 7) fetch(f + 1, (f + 1) & 1);
+      if (row >= T) continue;  // wavefront-uniform (no loads behind it)
+      const float mu = mua[f & 1], rs = rsa[f & 1];
       float4 xh[NV], gy[NV];
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
         const int c = (j * 64 + lane) * 4;
-        if (c < D) {
-          const float4 xv = *reinterpret_cast<const float4 *>(x + row * D + c);
-          const float4 d = *reinterpret_cast<const float4 *>(dy + row * D + c);
-          xh[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-          gy[j] = make_float4(d.x * g[j].x, d.y * g[j].y, d.z * g[j].z, d.w * g[j].w);
-          s1 += (gy[j].x + gy[j].y) + (gy[j].z + gy[j].w);
-          s2 += (gy[j].x * xh[j].x + gy[j].y * xh[j].y) + (gy[j].z * xh[j].z + gy[j].w * xh[j].w);
-          dg[j].x += d.x * xh[j].x; dg[j].y += d.y * xh[j].y; dg[j].z += d.z * xh[j].z; dg[j].w += d.w * xh[j].w;
-          db[j].x += d.x; db[j].y += d.y; db[j].z += d.z; db[j].w += d.w;
-        }
+        const float live = c < D ? 1.f : 0.f;   // lanes beyond D hold a clamped copy of the last columns: weight 0
+        const float4 xv = xa[f & 1][j];
+        const float4 d = make_float4(da[f & 1][j].x * live, da[f & 1][j].y * live, da[f & 1][j].z * live, da[f & 1][j].w * live);
+        xh[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+        gy[j] = make_float4(d.x * g[j].x, d.y * g[j].y, d.z * g[j].z, d.w * g[j].w);
+        s1 += (gy[j].x + gy[j].y) + (gy[j].z + gy[j].w);
+        s2 += (gy[j].x * xh[j].x + gy[j].y * xh[j].y) + (gy[j].z * xh[j].z + gy[j].w * xh[j].w);
+        dg[j].x += d.x * xh[j].x; dg[j].y += d.y * xh[j].y; dg[j].z += d.z * xh[j].z; dg[j].w += d.w * xh[j].w;
+        db[j].x += d.x; db[j].y += d.y; db[j].z += d.z; db[j].w += d.w;
       }
       const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
       float amax = 0.f, sq = 0.f;
@@ -305,12 +326,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dropout_kernel(
       for (int j = 0; j < NV; ++j) {
         const int c = (j * 64 + lane) * 4;
         if (c < D) {
-          float4 o = make_float4(rs * (gy[j].x - m1 - xh[j].x * m2), rs * (gy[j].y - m1 - xh[j].y * m2),
-                                 rs * (gy[j].z - m1 - xh[j].z * m2), rs * (gy[j].w - m1 - xh[j].w * m2));
-          if (dres) {
-            const float4 r = *reinterpret_cast<const float4 *>(dres + row * D + c);
-            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-          }
+          // rs * (..) + r as ONE fma each, like the compiler contracts `o += r` in layernorm_bwd_kernel (the two kernels are
+          // compared bit for bit); r * rflag is exact (rflag is 0 or 1: no residual gradient -> + 0)
+          const float4 r = ra[f & 1][j];
+          float4 o = make_float4(fmaf(rs, gy[j].x - m1 - xh[j].x * m2, r.x * rflag), fmaf(rs, gy[j].y - m1 - xh[j].y * m2, r.y * rflag),
+                                 fmaf(rs, gy[j].z - m1 - xh[j].z * m2, r.z * rflag), fmaf(rs, gy[j].w - m1 - xh[j].w * m2, r.w * rflag));
           *reinterpret_cast<float4 *>(dx + row * D + c) = o;
           if (p > 0.f) {
             o.x = drop_field_value(rnd[j][0], f) >= t16 ? o.x * ks : 0.f;

@@ -132,9 +132,13 @@ def gemm_hp(a, b, C_out, *, bias=None, residual=None, ldr=0, flags=0, dropout_p=
     return C_out
 
 
-def pick_split_k(M, N, K, slots=512):
+DW_SLOTS = 512           # knob of pick_split_k (profiles/tools/r03_ab_dw_slots.sh)
+
+
+def pick_split_k(M, N, K, slots=None):
     """K splits for a reduction-heavy product with few output tiles: as many (tile, split) items as fit in ONE round
     of the persistent grid (2 workgroups x 256 CUs) - one item more than that would cost a whole second round."""
+    slots = DW_SLOTS if slots is None else slots
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if tiles >= slots // 2 or K <= 512:
         return 1

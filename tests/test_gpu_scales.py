@@ -85,11 +85,15 @@ def test_layernorm_bwd_dropout_equals_separate_kernels(dev, T, D, p):
     factor = torch.tensor([3.5], device=dev)
     dx1, dr1 = K.layernorm_bwd_dropout(dy, x, gam, mean, rstd, dg1, db1, dres, p, 1234, 13, row_scale=rs, bound_factor=factor,
                                        bound_scale=bs)
-    assert torch.equal(dx1, dx0) and torch.equal(dr1, dr0)
+    # the two kernels evaluate the same formulas with different fma contractions (the fused one loads unconditionally and
+    # software-pipelines its rows): equal to rounding relative to the size of the row, identical dropout pattern
+    tol = 2e-6 * dx0.abs().max(1, keepdim=True).values
+    assert bool(((dx1 - dx0).abs() <= tol).all()) and bool(((dr1 - dr0).abs() <= tol / (1 - p)).all())
+    assert bool((((dr1 == 0) == (dr0 == 0)) | (dx0.abs() <= tol)).all())       # (a dx that cancels to exactly 0 in one of them)
     # (rows are dealt to the wavefronts in another order: the partial sums differ in their rounding)
     assert float((dg1 - dg0).abs().max()) <= 2e-5 * float(dg0.abs().max()) and float((db1 - db0).abs().max()) <= 2e-5 * float(db0.abs().max())
-    assert np.array_equal(as_float(rs), scale_of(dr0.abs().max(1).values.cpu().numpy()))
-    nrm = np.sqrt((dr0.cpu().double().numpy() ** 2).sum(1)) * 3.5
+    assert np.array_equal(as_float(rs), scale_of(dr1.abs().max(1).values.cpu().numpy()))     # exact maxima of what was written
+    nrm = np.sqrt((dr1.cpu().double().numpy() ** 2).sum(1)) * 3.5
     got = as_float(bs)
     want = scale_of(nrm.astype(np.float32))
     assert np.all((got == want) | (got == want * 2) | (got * 2 == want))                 # fp32 rounding of the norm at a binade edge
