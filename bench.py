@@ -299,8 +299,12 @@ def main():
     if timing is not None:
         # the same K steps once more with two HIP events around every ptamd_gemm call (150 event records per step cost
         # ~0.4 ms of host time per step, which is why this pass is not the one `value` is taken from)
+        # (the weight-gradient products go back to the main stream for this pass: two kernels that share the chip from two
+        # streams each report a duration that includes waiting for CUs, and the sum would no longer be GEMM time)
         kernels.GEMM_TIMING = timing
+        side, model.side_stream_dw = model.side_stream_dw, False
         dt_inst, _ = timed(step, a.warmup)
+        model.side_stream_dw = side
         kernels.GEMM_TIMING = None
     sweep = {}
     if not a.no_mode_sweep and a.gemm_mode == "auto":
@@ -319,7 +323,7 @@ def main():
         sys.exit("bench.py: non-finite parameters / gradients after the timed steps - the measurement is invalid")
 
     traffic = None          # HBM bytes per GEMM launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-    tpath = os.path.join(ROOT, "profiles", "r02", "r02_gemm_hbm_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r03", "r03_gemm_hbm_traffic.json")
     if os.path.exists(tpath) and a.config == 4 and a.batch == 32 and a.gemm_mode == "auto":
         with open(tpath) as f:
             traffic = round(json.load(f)["hbm_bytes_per_launch"])
@@ -349,21 +353,28 @@ def main():
                           "ms_per_step": round(v[2] / a.steps, 3)} for k, v in sorted(by_products.items())}
         kern = "ptamd_gemm: " + " + ".join(f"{round(v[0] / a.steps, 1)} x NPROD={k}" for k, v in sorted(by_products.items()))
         products = issued / achieved
+        pipe_peak = BF16_MFMA_PEAK_TFLOPS if products > 1 else F32_MFMA_PEAK_TFLOPS
         roofline = {"bound": "mfma", "kernel": kern,
-                    "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": traffic,
-                    "achieved_is": "algorithmic fp32 FLOP (2*M*N*K) per second of GEMM kernel time (HIP events around every ptamd_gemm call)",
-                    "peak_is": "f32-equivalent ceiling of the launch mix: sum(flop) / sum(flop_i * products_i / dense MFMA peak_i)",
-                    "mfma_flops_issued_tflops": round(issued, 1),
-                    "mfma_instruction_peak_tflops": BF16_MFMA_PEAK_TFLOPS if products > 1 else F32_MFMA_PEAK_TFLOPS,
+                    "achieved": round(issued, 1), "peak": pipe_peak, "unit": "TFLOP/s",
+                    "frac": round(issued / pipe_peak, 4), "traffic": traffic,
+                    "achieved_is": "matrix-pipe FLOP ISSUED per second of GEMM kernel time: algorithmic 2*M*N*K of every launch x the "
+                                   "matrix-pipe products its arithmetic spends per fp32 product (3: two f16 terms, 6 / 9: three bf16 "
+                                   "terms, 1: f32 MFMA), HIP events around every ptamd_gemm / ptamd_gemm_hp call",
+                    "peak_is": "dense f16 / bf16 MFMA peak of MI355X (MI355X_MICROARCH.md); 157.3 when every product runs on the f32 MFMA",
+                    "f32_equivalent": {"achieved_tflops": round(achieved, 2), "ceiling_of_the_launch_mix_tflops": round(peak, 1),
+                                       "frac": round(achieved / peak, 4),
+                                       "what": "algorithmic fp32 FLOP per second, and the rate at which the launch mix would run with "
+                                               "the matrix pipe at its dense peak throughout: sum(flop) / sum(flop_i * products_i / peak)"},
                     "launch_mix": mix,
-                    "traffic_unit": "HBM bytes per launch (PMC, profiles/r02/r02_gemm_hbm_traffic.json)",
+                    "traffic_unit": "HBM bytes per launch (PMC, profiles/r03/r03_gemm_hbm_traffic.json: separate --pmc FETCH_SIZE / "
+                                    "WRITE_SIZE passes, FETCH x 2 per the gfx950 correction of the guide)",
                     "algorithmic_bytes_per_launch": round(sum(b for b in gemm_bytes) / max(len(gemm_bytes), 1)),
                     "launches_per_step": round(len(timing) / a.steps, 1), "avg_launch_us": round(1e3 * ms / len(timing), 2),
                     "gflop_per_step": round(flops / a.steps / 1e9, 1),
-                    "share_of_step_time": round(ms / (dt * 1e3), 3),
-                    "measured_in": f"a second pass of the same {a.steps} steps with HIP events around every ptamd_gemm call "
-                                   f"({round(1e3 * dt_inst / a.steps, 3)} ms/step with the instrumentation)"}
+                    "share_of_step_time": round(ms / (1e3 * dt_inst), 3),
+                    "measured_in": f"a second pass of the same {a.steps} steps with HIP events around every GEMM call and the "
+                                   f"weight-gradient products on the main stream ({round(1e3 * dt_inst / a.steps, 3)} ms/step in that pass; "
+                                   f"the value of this line comes from the un-instrumented pass)"}
 
     dtype = {"f32": "f32",
              "f16x2": "f32 (GEMM and attention operands scaled by powers of two and split into 2 f16 terms on the f16 MFMA pipe, "

@@ -4,6 +4,7 @@
   python profiles/summarize.py stats  <kernel_stats.csv> <steps_in_run>         -> per-step table on stdout
   python profiles/summarize.py traffic <fetch_counter_collection.csv> <write_counter_collection.csv> \
          <algorithmic_bytes_per_launch> <out.json>                              -> HBM bytes per GEMM launch
+  python profiles/summarize.py step_traffic <fetch csv> <write csv> <steps>     -> HBM bytes per step by kernel
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB.  On gfx950 FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane
 coalesced reads as 64 bytes (MI355X_MICROARCH.md, HBM section), hence the x2 on the fetch side; WRITE_SIZE is taken
@@ -13,7 +14,7 @@ import csv
 import json
 import sys
 
-KERNEL = "_mfma_kernel"     # gemm_bf16x3_mfma_kernel<.., NPROD, ..> (NPROD = 3: f16x2, 6: bf16x3) or gemm_f32_mfma_kernel (PTAMD_GEMM_MODE=0)
+KERNEL = ("_mfma_kernel", "gemm_hp_kernel")   # gemm_bf16x3_mfma_kernel<.., NPROD, ..> (NPROD = 3: f16x2, 6: bf16x3), gemm_f32_mfma_kernel, and the LDS-DMA kernel
 
 
 def stats(path, steps):
@@ -29,7 +30,8 @@ def stats(path, steps):
 
 def counter_avg(path, name, kernel=KERNEL):
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-            if "gemm_" in r["Kernel_Name"] and kernel in r["Kernel_Name"] and r["Counter_Name"] == name]
+            if "gemm_" in r["Kernel_Name"] and any(k in r["Kernel_Name"] for k in ((kernel,) if isinstance(kernel, str) else kernel))
+            and r["Counter_Name"] == name]
     return (sum(vals) / len(vals), len(vals)) if vals else (0.0, 0)
 
 
@@ -41,7 +43,7 @@ def traffic(fetch_csv, write_csv, algorithmic, out):
     fs, ns = counter_avg(fetch_csv, "FETCH_SIZE", "row_scale_kernel")
     ws, _ = counter_avg(write_csv, "WRITE_SIZE", "row_scale_kernel")
     rec = {
-        "kernel": "gemm_*" + KERNEL, "launches_profiled": n, "fetch_size_kb_avg": f, "write_size_kb_avg": w,
+        "kernel": "gemm_*" + " | ".join(KERNEL), "launches_profiled": n, "fetch_size_kb_avg": f, "write_size_kb_avg": w,
         "fetch_correction": "x2: on gfx950 FETCH_SIZE tallies 128-B requests as 64 B for 16-B/lane coalesced reads "
                             "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncorrected",
         "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": float(algorithmic),
@@ -57,10 +59,32 @@ def traffic(fetch_csv, write_csv, algorithmic, out):
     print(json.dumps(rec, indent=1))
 
 
+def step_traffic(fetch_csv, write_csv, steps):
+    """HBM-side bytes per step by kernel from the two PMC passes (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes)."""
+    import collections
+    import re
+    tot, calls = collections.defaultdict(float), collections.Counter()
+    for path, name, mult in ((fetch_csv, "FETCH_SIZE", 2.0), (write_csv, "WRITE_SIZE", 1.0)):
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] != name:
+                continue
+            k = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
+            k = re.sub(r"^void ", "", k).split("(")[0].split("<")[0]
+            tot[k] += mult * float(r["Counter_Value"]) * 1024.0
+            if name == "FETCH_SIZE":
+                calls[k] += 1
+    print(f"# HBM-side bytes per step by kernel (2 x FETCH_SIZE + WRITE_SIZE, separate PMC passes; {steps} steps profiled)")
+    for k, v in sorted(tot.items(), key=lambda kv: -kv[1])[:20]:
+        print(f"{v / steps / 1e6:10.1f} MB/step {calls[k] / steps:7.1f} calls/step  {k}")
+    print(f"total {sum(tot.values()) / steps / 1e9:.3f} GB/step")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], int(sys.argv[3]))
     elif sys.argv[1] == "traffic":
         traffic(*sys.argv[2:6])
+    elif sys.argv[1] == "step_traffic":
+        step_traffic(sys.argv[2], sys.argv[3], int(sys.argv[4]))
     else:
         sys.exit(__doc__)

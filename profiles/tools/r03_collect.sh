@@ -14,7 +14,7 @@ if [ "$2" = "full" ]; then
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-mode-sweep > $out/pmc_fetch.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-mode-sweep > $out/pmc_write.log 2>&1
   rm -f $out/pmc_*/p_kernel_trace.csv $out/pmc_*/*/p_kernel_trace.csv
-  for c in 1 2 3 5; do python bench.py --config $c --steps 20 --warmup 3 > $out/bench_cfg$c.json 2> $out/bench_cfg$c.err; done
+  for c in 1 2 3 5; do python bench.py --config $c --steps 20 --warmup 20 > $out/bench_cfg$c.json 2> $out/bench_cfg$c.err; done   # (20 warm-up steps: the launch-bound configs 1 and 2 speed up by 10 % over the first passes of a process)
   for b in 4 8 16; do python bench.py --batch $b --steps 20 --warmup 3 --no-cpu-baseline --no-mode-sweep --no-kernel-timing > $out/bench_batch$b.json 2>/dev/null; done
 fi
 find $out -name "*.csv" | head -20
