@@ -470,7 +470,7 @@ class _EncoderFn(torch.autograd.Function):
         # side stream; the main stream waits for it before a gradient slice is handed on and at the end of the pass.
         main = torch.cuda.current_stream(dpred.device)
         side = None
-        if m.side_stream_dw and D >= 512 and B * L >= 2048 and B * L * D <= SIDE_STREAM_MAX_WORK:
+        if m.side_stream_dw and D >= 512 and B * L >= 4096 and B * L * D <= SIDE_STREAM_MAX_WORK:
             side = m.__dict__.get("_side_stream")
             if side is None or side.device != dpred.device:
                 side = m.__dict__["_side_stream"] = torch.cuda.Stream(device=dpred.device)
@@ -611,8 +611,9 @@ class _EncoderFn(torch.autograd.Function):
 AUTO_F16X2_MIN_WORK = 1 << 21
 # tokens x d_model below which the weight-gradient products of the backward pass run on a SIDE stream next to the dX chain
 # (few output tiles per product: the persistent kernels leave CUs idle that the other stream's kernel can take).  Only for
-# d_model >= 512 and >= 2048 tokens: measured -0..4 % at 4, -5 % at 8, -3 % at 16 proteins x 512 (profiles/r03), but +14 % on
-# config 2 (4096 x 256) and +12 % on config 1, where the step is bound by host-side launches and the stream joins add to them
+# d_model >= 512 and >= 4096 tokens: measured -5 % at 8, -3 % at 16, -1.2 % at 32 proteins x 512, +-3 % at 4
+# (profiles/r03/r03_ab_side_stream.txt), but +14 % on config 2 (4096 x 256) and +12 % on config 1, where the step is bound by
+# host-side launches and the stream joins add to them
 SIDE_STREAM_MAX_WORK = 1 << 23
 
 
