@@ -204,7 +204,15 @@ class _TransformerBase(nn.Module):
 
     def _ensure_flat(self):
         """(Re)build the flat parameter / gradient buffers on the parameters' device and alias every
-        named parameter (and its .grad) into them.  Idempotent; survives .to(device) and load_state_dict."""
+        named parameter (and its .grad) into them.  Idempotent; survives .to(device) and load_state_dict.
+        Called several times per step: the fast path checks the two ends of the layout only (a `.to()` / `_apply` replaces
+        every parameter's storage, anything that re-points single parameters by hand must call `_invalidate_flat`)."""
+        fast = self.__dict__.get("_flat_fast")
+        if fast is not None:
+            flat, first, last, off_last, gfirst = fast
+            if (first.data_ptr() == flat.data_ptr() and last.data_ptr() == flat.data_ptr() + 4 * off_last
+                    and first.grad is not None and first.grad.data_ptr() == gfirst):
+                return self._flat, self._flat_grad
         params = dict(self.named_parameters())
         dev = next(iter(params.values())).device
         if dev.type != "cuda":
@@ -223,12 +231,23 @@ class _TransformerBase(nn.Module):
             self._flat = flat
             self._flat_grad = torch.zeros_like(flat)
             self.__dict__.pop("_scale_caches", None)     # they hold views of the old flat buffer (keyed by its address)
+            self.__dict__["_view_cache"] = {}
         gbase = self._flat_grad.data_ptr()
         for n, (off, shape) in self._layout.items():
             p = params[n]
             if p.grad is None or p.grad.data_ptr() != gbase + 4 * off:
                 p.grad = self._flat_grad[off:off + int(np.prod(shape))].view(shape)
+        names = list(self._layout)
+        self.__dict__["_flat_fast"] = (self._flat, params[names[0]], params[names[-1]], self._layout[names[-1]][0],
+                                       params[names[0]].grad.data_ptr())
         return self._flat, self._flat_grad
+
+    def _invalidate_flat(self):
+        self.__dict__.pop("_flat_fast", None)
+
+    def _apply(self, fn, *a, **kw):          # .to() / .cuda() / .float(): every parameter gets a new storage
+        self._invalidate_flat()
+        return super()._apply(fn, *a, **kw)
 
     def flat_parameters(self):
         """(flat parameter buffer, flat gradient buffer): what the fused optimizer / all-reduce operate on."""
@@ -339,15 +358,36 @@ class _TransformerBase(nn.Module):
         return cache["layers"]
 
     def _slice(self, buf, name):
-        off, shape = self._layout[name]
-        return buf[off:off + int(np.prod(shape))].view(shape)
+        """View of parameter `name` in a flat buffer (the parameters or the gradients); the views of the two long-lived
+        buffers are cached (46 view constructions per step were 5 % of the host time of a launch-bound step)."""
+        cache = self.__dict__.setdefault("_view_cache", {})
+        ptr = buf.data_ptr()
+        key = (ptr, name)
+        v = cache.get(key)
+        if v is None:
+            off, shape = self._layout[name]
+            v = buf[off:off + int(np.prod(shape))].view(shape)
+            # (the autograd anchor of a forward pass is a detached alias of the flat buffer: same address, same views)
+            if (self._flat is not None and ptr == self._flat.data_ptr()) or \
+                    (self._flat_grad is not None and ptr == self._flat_grad.data_ptr()):
+                cache[key] = v.detach()
+                v = cache[key]
+        return v
 
     def _qkv(self, buf, i):
-        b = f"encoder.enc_layers.{i}.self_attn."
-        off_w, _ = self._layout[b + "wq.weight"]
-        off_b, _ = self._layout[b + "wq.bias"]
-        D = self.dlayer
-        return buf[off_w:off_w + 3 * D * D].view(3 * D, D), buf[off_b:off_b + 3 * D]
+        cache = self.__dict__.setdefault("_view_cache", {})
+        key = (buf.data_ptr(), "qkv", i)
+        v = cache.get(key)
+        if v is None:
+            b = f"encoder.enc_layers.{i}.self_attn."
+            off_w, _ = self._layout[b + "wq.weight"]
+            off_b, _ = self._layout[b + "wq.bias"]
+            D = self.dlayer
+            v = (buf[off_w:off_w + 3 * D * D].view(3 * D, D).detach(), buf[off_b:off_b + 3 * D].detach())
+            if (self._flat is not None and key[0] == self._flat.data_ptr()) or \
+                    (self._flat_grad is not None and key[0] == self._flat_grad.data_ptr()):
+                cache[key] = v
+        return v
 
     # ------------------------------------------------------------------ forward
     def forward(self, enc_input, dec_input=None):
