@@ -51,12 +51,12 @@ namespace {
 
 using namespace ptsplit;  // bf16x8, split_pair (x = t1 + t2 + t3 exactly, scalar subtractions), LDS transpose-read types
 
-constexpr int TBM = 256, TBN = 128;  // output tile of a workgroup
+constexpr int TBN = 128;             // output tile of a workgroup: (64 TI) x 128, TI = 4 (256 rows) or 2 (128 rows, below)
 constexpr int NTHREADS = 512, NPRODUCER = 256;
 constexpr int KR_PAD = 32;           // a [k][rows + 32] plane: 4 consecutive k hit 4 different 64-B bank groups
 constexpr int SCRATCH_FLOATS = 4 * 2048;                      // epilogue transpose scratch of the 4 consumers
 constexpr int COLSUM_AREAS = 3;                               // see the producers' publish / the consumers' read below
-constexpr int COLSUM_FLOATS = COLSUM_AREAS * 4 * TBM;         // rotating [4 k groups][256 rows] partial sums
+constexpr int COLSUM_FLOATS = COLSUM_AREAS * 4 * 256;         // rotating [4 k groups][256 rows] partial sums (256-row tiles only)
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 // Geometry of a stage by arithmetic.
@@ -68,8 +68,13 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 //     32 k only fit LDS unpadded: K-contiguous planes are [row][32] f16 = four 16-byte chunks per row, chunk c of row r
 //     stored at c ^ ((r >> 2) & 3) - any 16 rows x one chunk column cover 16 different 16-byte slots of the 256-byte bank
 //     row, so the fragment reads stay conflict-free; two register sets of twice the size keep the same 64 k in flight.
-template <int NPROD>
+// TI = 32-row MFMA tiles per consumer: 4 = the 256 x 128 workgroup tile; 2 = a 128 x 128 tile for products whose 256-row
+// tiles would leave most of the chip idle (few tokens: small batches, the per-GPU share of a strongly scaled batch) - the
+// latency floor of such a product is ONE tile's time, which halves with the tile (K-contiguous A only: the weight-gradient
+// products split their long K instead).
+template <int NPROD, int TI = 4>
 struct Geo {
+  static constexpr int TBM = 64 * TI;
   static constexpr bool F16 = NPROD == 3;
   static constexpr int NPLANES = F16 ? 2 : 3;
   static constexpr int SBK = F16 ? 32 : 16;              // f32 k per stage
@@ -228,11 +233,13 @@ struct Cursor {
   bool end;  // set once the cursor was asked to step past the last stage (it then stays on that stage)
 };
 
-template <bool A_KMAJOR, bool B_KMAJOR, int NPROD, int EPI>
+template <bool A_KMAJOR, bool B_KMAJOR, int NPROD, int EPI, int TI = 4>
 __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16x3_mfma_kernel(
     const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-  using G = Geo<NPROD>;
+  using G = Geo<NPROD, TI>;
+  constexpr int TBM = G::TBM;
+  static_assert(TI == 4 || !A_KMAJOR, "the fused bias gradient of k-major A assumes 256-row tiles");
   constexpr int SBK = G::SBK, NSETS = G::NSETS, STAGE = G::STAGE, PLANE_A = G::PLANE_A, NVA = G::NVA, NVB = G::NVB;
   float *const scratch = reinterpret_cast<float *>(smem + 2 * STAGE);
   float *const cs_area = scratch + SCRATCH_FLOATS;
@@ -398,10 +405,10 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
     const int wm = wave >> 1, wn = wave & 1;
     const uint32_t thr = dropout_threshold(p.dropout_p);
     const float keep_scale = 1.f / (1.f - p.dropout_p);
-    f32x16 acc[4][2];
+    f32x16 acc[TI][2];
     auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -419,11 +426,11 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
         continue;
       }
       const unsigned short *sa = smem + (g & 1) * STAGE, *sb = sa + G::NPLANES * PLANE_A;
-      bf16x8 fa[4][3], fb[2][3];
+      bf16x8 fa[TI][3], fb[2][3];
       int ks = 0;  // 16-k step of the stage
       auto read_a = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i][t] = read_frag<G, A_KMAJOR, TBM>(sa, wm * 128 + 32 * i, lane, t, ks);
+        for (int i = 0; i < TI; ++i) fa[i][t] = read_frag<G, A_KMAJOR, TBM>(sa, wm * (32 * TI) + 32 * i, lane, t, ks);
       };
       auto read_b = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
       };
       auto mul = [&](int ta, int tb) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             acc[i][j] = F16 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][ta]),
@@ -463,14 +470,14 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
       if (cc.k0 + SBK >= cc.it.kend) {  // that was the item's last stage
         float *C = p.C + (partial ? (size_t)cc.it.z * p.slab : 0);
         const int ldc = partial ? p.N : p.ldc;
-        const int row0 = cc.it.bm0 + wm * 128, col0 = cc.it.bn0 + wn * 64;
+        const int row0 = cc.it.bm0 + wm * (32 * TI), col0 = cc.it.bn0 + wn * 64;
         if (F16) {  // back from the scaled operands: acc / (scale_a[row] scale_b[col]), exact (powers of two)
           const int l31 = lane & 31, lh = lane >> 5;
           float ib[2];
 #pragma unroll
           for (int j = 0; j < 2; ++j) ib[j] = inverse_scale(p.scale_b[min(col0 + j * 32 + l31, p.N - 1) * p.scale_b_stride]);
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -480,8 +487,8 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
                 for (int j = 0; j < 2; ++j) acc[i][j][g * 4 + e] = acc[i][j][g * 4 + e] * ia * ib[j];
               }
         }
-        if (p.vec_epilogue) tile_epilogue_vec<4, true, EPI>(p, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 2048);
-        else tile_epilogue_vec<4, false, EPI>(p, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 2048);
+        if (p.vec_epilogue) tile_epilogue_vec<TI, true, EPI>(p, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 2048);
+        else tile_epilogue_vec<TI, false, EPI>(p, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 2048);
         zero_acc();
         if (colsum_on(cc.it)) {  // the producers published this item's sums before the barrier above: one row per lane
           const float *q = cs_area + cs_parity * 4 * TBM;
@@ -499,16 +506,32 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
   }
 }
 
-template <bool AK, bool BKM, int NPROD, int EPI>
-int launch(const GemmParams &p, int splits, hipStream_t st) {
-  const int work = ((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN) * splits;
-  auto kern = gemm_bf16x3_mfma_kernel<AK, BKM, NPROD, EPI>;
+constexpr int TI2_COST_NUM = 3, TI2_COST_DEN = 5;  // cost of a 128-row tile / a 256-row tile: 0.55 - 0.64 measured (profiles/r03/r03_tile_height.txt)
+template <bool AK, bool BKM, int NPROD, int EPI, int TI>
+int launch_ti(const GemmParams &p, int splits, hipStream_t st) {
+  using G = Geo<NPROD, TI>;
+  const int work = ((p.M + G::TBM - 1) / G::TBM) * ((p.N + TBN - 1) / TBN) * splits;
+  auto kern = gemm_bf16x3_mfma_kernel<AK, BKM, NPROD, EPI, TI>;
   PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)Geo<NPROD>::LDS_BYTES));  // idempotent, host-only: no state kept between calls
+                                 (int)G::LDS_BYTES));  // idempotent, host-only: no state kept between calls
   const int slots = persistent_grid(p.reserved_cus);  // one workgroup per CU
   const int grid = work < slots ? work : slots;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), Geo<NPROD>::LDS_BYTES, st, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), G::LDS_BYTES, st, p);
   return pt_check_launch();
+}
+template <bool AK, bool BKM, int NPROD, int EPI>
+int launch(const GemmParams &p, int splits, hipStream_t st) {
+  // 128-row tiles where they finish sooner: rounds of tiles over the CUs x the cost of a tile (K-contiguous A only).
+  if (!AK && NPROD != 9 && p.M > 128) {
+    const int slots = persistent_grid(p.reserved_cus), nt = (p.N + TBN - 1) / TBN * splits;
+    const int rounds4 = (((p.M + 255) / 256) * nt + slots - 1) / slots, rounds2 = (((p.M + 127) / 128) * nt + slots - 1) / slots;
+#if defined(PT_FORCE_TI)
+    if (PT_FORCE_TI == 2) return launch_ti<false, BKM, NPROD, EPI, 2>(p, splits, st);
+#else
+    if (TI2_COST_NUM * rounds2 < TI2_COST_DEN * rounds4) return launch_ti<false, BKM, NPROD, EPI, 2>(p, splits, st);
+#endif
+  }
+  return launch_ti<AK, BKM, NPROD, EPI, 4>(p, splits, st);
 }
 
 template <int NPROD, int EPI>

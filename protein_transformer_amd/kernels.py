@@ -149,10 +149,11 @@ SPLIT_K_ROWS = True      # knob of pick_split_k_rows (tests compare both setting
 
 
 def pick_split_k_rows(M, N, K, slots=256):
-    """K splits for an activation x weight product whose 256 x 128 output tiles do not fill the chip (few tokens: small
-    batches, the per-GPU share of a strongly scaled batch) and whose reduction is long enough to be worth cutting: the
-    slabs are summed in a fixed order by the reduce kernel, which also applies the epilogue (same dropout masks)."""
-    tiles = ((M + 255) // 256) * ((N + 127) // 128)
+    """K splits for an activation x weight product whose output tiles (128 x 128: the staging GEMM halves its 256-row tile
+    when that finishes sooner) do not fill the chip (few tokens: small batches, the per-GPU share of a strongly scaled
+    batch) and whose reduction is long enough to be worth cutting: the slabs are summed in a fixed order by the reduce
+    kernel, which also applies the epilogue (same dropout masks)."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if not SPLIT_K_ROWS or tiles * 2 > slots or K < 1024:
         return 1
     return max(1, min(K // 512, slots // tiles))

@@ -278,7 +278,7 @@ class _TransformerBase(nn.Module):
         return out
 
     # ------------------------------------------------------------------ f16x2 bookkeeping (csrc/scales.hip)
-    def _step_scales(self, flat, arith, p, pa):
+    def _step_scales(self, flat, arith, p, pa, hp=True):
         """Row / column scales of every encoder weight matrix and the weight-derived bounds of the attention output, the
         FFN hidden layer and its gradient - computed on the device in three small launches per forward pass, so that no
         GEMM of the step has to run a pass over its operands for them.  Returns a list of per-layer dicts (or None when the
@@ -353,7 +353,7 @@ class _TransformerBase(nn.Module):
                     cache["hp_outs"] += [L["hp_qkv"], L["hp_1"]]
         K.weight_scales(cache["wjobs"])
         K.bound_scales(cache["bjobs"])
-        if cache["hp_mats"]:
+        if cache["hp_mats"] and hp:
             K.hp_split_rows(cache["hp_mats"], cache["hp_outs"])
         return cache["layers"]
 
@@ -447,11 +447,13 @@ class _EncoderFn(torch.autograd.Function):
         saved = []
         # f16x2 row scales without passes over the operands: weights and weight-derived bounds once per forward, LayerNorm
         # outputs from the LayerNorm kernel itself (None: the arithmetic of this pass does not use them)
-        scales = m._step_scales(flat, ar, p, pa)
         Tn = B * L
+        # (below HP_MIN_TOKENS the staging GEMM with 128-row tiles is the faster of the two: profiles/r03/r03_tile_height.txt)
+        want_hp = Tn >= HP_MIN_TOKENS
+        scales = m._step_scales(flat, ar, p, pa, hp=want_hp)
         # The products right behind a LayerNorm (QKV, FFN layer 1) run on ptamd_gemm_hp: the LayerNorm kernel writes its
         # output a second time as pre-split planes (one buffer, consumed at once), the weights were split above.
-        use_hp = scales is not None and "hp_qkv" in scales[0]
+        use_hp = want_hp and scales is not None and "hp_qkv" in scales[0]
         hplanes = torch.empty(K.lib().ptamd_hp_bytes(Tn, D), dtype=torch.uint8, device=x.device) if use_hp else None
         for i in range(m.nlayers):
             b = f"encoder.enc_layers.{i}."
@@ -655,6 +657,8 @@ AUTO_F16X2_MIN_WORK = 1 << 21
 # (profiles/r03/r03_ab_side_stream.txt), but +14 % on config 2 (4096 x 256) and +12 % on config 1, where the step is bound by
 # host-side launches and the stream joins add to them
 SIDE_STREAM_MAX_WORK = 1 << 23
+# tokens from which the products behind a LayerNorm run on ptamd_gemm_hp (below: ptamd_gemm, 128-row tiles)
+HP_MIN_TOKENS = 4096
 
 
 class EncoderOnlyTransformer(_TransformerBase):
