@@ -29,8 +29,9 @@
 namespace ptattn16 {
 using namespace ptsplit;
 
-constexpr int NTHR = 512;        // 8 wavefronts
-constexpr int QB = NTHR / 2;     // queries (or keys) per workgroup: 32 per wavefront
+// NW wavefronts per workgroup, 32 queries (or keys) each: 8 (256 per workgroup) or, when that leaves half of the CUs
+// without a workgroup (few proteins), 4 - the same wavefronts then run one per SIMD instead of two, which is what
+// bounds a workgroup (VALU issue), at the price of staging twice the share of every tile.
 constexpr int TR = 32;           // rows (keys or queries) of an LDS tile
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float TWO14 = 16384.f, INV_TWO14 = 1.f / 16384.f;
@@ -120,44 +121,62 @@ struct Tile2 {
 // A group of four rows is held by 4 DK / 4 adjacent lanes (one wavefront for DK = 64, half of one for DK = 32); its
 // inverse scale goes to inv[(g & 1) * 4 + (g >> 1)], g = row >> 2, so that a lane half reads ITS four groups
 // (g = 2 j + lh) as one float4.  Loads are unconditional (row clamped); rows beyond nrows are zeroed when stored.
-template <int DK>
+template <int DK, int NW>
+struct StageGeo {
+  static constexpr int CPR = DK / 4;               // float4 per tile row
+  static constexpr int RPP = 64 * NW / CPR;        // tile rows the workgroup covers with one float4 per thread
+  static constexpr int NI = RPP >= TR ? 1 : TR / RPP;  // float4 per thread and tile
+};
+template <int NI>
+struct TileOff {
+  uint32_t o[NI];
+};
+template <int DK, int NW>
 struct Stage {
-  static constexpr int CPR = DK / 4;  // float4 per tile row
-  float4 v;
-  __device__ __forceinline__ void load(const float *__restrict__ base, uint32_t off) {
-    v = *reinterpret_cast<const float4 *>(base + off);
+  using G = StageGeo<DK, NW>;
+  static constexpr int CPR = G::CPR, NI = G::NI;
+  float4 v[NI];
+  __device__ __forceinline__ void load(const float *__restrict__ base, const TileOff<NI> &off) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) v[i] = *reinterpret_cast<const float4 *>(base + off.o[i]);
   }
   __device__ __forceinline__ void store(unsigned short *__restrict__ s, float *__restrict__ inv, int row0, int nrows,
                                         int tid) const {
-    const int row = tid / CPR;
-    const bool ok = row < TR && row0 + row < nrows;
-    const float4 x = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
-    const uint32_t amax = group_umax<4 * CPR>(umax4(x));
-    const uint32_t sbits = pt_row_scale_bits(amax);
-    if (row < TR) {  // (wavefront-uniform)
-      Tile2::store4(s, row, (tid % CPR) * 4, x, __uint_as_float(sbits));
-      if ((tid % (4 * CPR)) == 0) {
-        const int g = row >> 2;
-        inv[(g & 1) * 4 + (g >> 1)] = __uint_as_float((254u << 23) - sbits);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int row = tid / CPR + i * G::RPP;
+      const bool ok = row < TR && row0 + row < nrows;
+      const float4 x = make_float4(ok ? v[i].x : 0.f, ok ? v[i].y : 0.f, ok ? v[i].z : 0.f, ok ? v[i].w : 0.f);
+      const uint32_t amax = group_umax<4 * CPR>(umax4(x));
+      const uint32_t sbits = pt_row_scale_bits(amax);
+      if (row < TR) {  // (wavefront-uniform)
+        Tile2::store4(s, row, (tid % CPR) * 4, x, __uint_as_float(sbits));
+        if ((tid % (4 * CPR)) == 0) {
+          const int g = row >> 2;
+          inv[(g & 1) * 4 + (g >> 1)] = __uint_as_float((254u << 23) - sbits);
+        }
       }
     }
   }
 };
 
-// Element offset of a thread's float4 in consecutive 32-row tiles of a [nrows, ld] block (rows clamped to the last one):
-// an add and a min per tile instead of a 64-bit multiply per load; tiles that share rows (K and V, same ld) share it.
-template <int DK>
+// Element offsets of a thread's float4 in consecutive 32-row tiles of a [nrows, ld] block (rows clamped to the last one):
+// an add and a min per load instead of a 64-bit multiply; tiles that share rows (K and V, same ld) share them.
+template <int DK, int NW>
 struct TileRows {
-  uint32_t u, lim, col, step;
+  using G = StageGeo<DK, NW>;
+  uint32_t u, lim, col, step, pass;
   __device__ __forceinline__ TileRows(int ld, int nrows, int tid) {
-    constexpr int CPR = DK / 4;
-    u = (uint32_t)min(tid / CPR, TR - 1) * (uint32_t)ld;
+    u = (uint32_t)min(tid / G::CPR, TR - 1) * (uint32_t)ld;
     lim = (uint32_t)(nrows - 1) * (uint32_t)ld;
-    col = (uint32_t)(tid % CPR) * 4u;
+    col = (uint32_t)(tid % G::CPR) * 4u;
     step = (uint32_t)TR * (uint32_t)ld;
+    pass = (uint32_t)G::RPP * (uint32_t)ld;
   }
-  __device__ __forceinline__ uint32_t next() {
-    const uint32_t off = min(u, lim) + col;
+  __device__ __forceinline__ TileOff<G::NI> next() {
+    TileOff<G::NI> off;
+#pragma unroll
+    for (int i = 0; i < G::NI; ++i) off.o[i] = min(u + (uint32_t)i * pass, lim) + col;
     u += step;
     return off;
   }
@@ -227,15 +246,15 @@ constexpr int BUF = 2 * Tile2::ELEMS;  // f16 elements of one {A, B} tile buffer
 constexpr size_t ATTN_LDS = (size_t)2 * BUF * sizeof(unsigned short);
 
 // =================================================================================================== forward
-template <int DK>
-__global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_f16x2_kernel(
+template <int DK, int NW>
+__global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_f16x2_kernel(
     const float *__restrict__ qkv, const int64_t *__restrict__ seq, int L, int H, float p_drop, uint64_t seed,
     uint32_t stream_id, float *__restrict__ out, float *__restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   __shared__ __attribute__((aligned(16))) float sBias[2][TR];
   __shared__ __attribute__((aligned(16))) float sInvK[2][8], sInvV[2][8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB + wave * 32;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (32 * NW) + wave * 32;
   const int D = H * DK, D3 = 3 * D;
   const float *base = qkv + (size_t)b * L * D3 + h * DK;  // Q block of this head; K at +D, V at +2D
   const int64_t *sq = seq + (size_t)b * L;
@@ -258,7 +277,7 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
   float m_run = -INFINITY, l_run = 0.f;  // running maximum in log2 units
   float v_run = 0.f;                     // largest inverse V group scale so far (a power of two; wavefront-uniform)
 
-  Stage<DK> stK, stV;
+  Stage<DK, NW> stK, stV;
   const int ntiles = (L + TR - 1) / TR;
   // key mask of a tile as an ADDITIVE term of the soft-max argument (0 or -inf per key), read back one float4 per register
   // quadruple: no bit extraction and no select per element
@@ -268,14 +287,14 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
       sBias[buf][tid] = (key < L && sq[key < L ? key : 0] != PTAMD_PAD_ID) ? 0.f : -INFINITY;
     }
   };
-  TileRows<DK> rows(D3, L, tid);
-  uint32_t toff = rows.next();
+  TileRows<DK, NW> rows(D3, L, tid);
+  auto toff = rows.next();
   stK.load(base + D, toff);
   stV.load(base + 2 * D, toff);
   stK.store(smem, sInvK[0], 0, L, tid);
   stV.store(smem + Tile2::ELEMS, sInvV[0], 0, L, tid);
   publish_mask(0, 0);
-  Stage<DK> nxK, nxV;  // loads run two tiles ahead of the arithmetic (attention_split.hip)
+  Stage<DK, NW> nxK, nxV;  // loads run two tiles ahead of the arithmetic (attention_split.hip)
   toff = rows.next();
   stK.load(base + D, toff);
   stV.load(base + 2 * D, toff);
@@ -392,8 +411,8 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
 // =================================================================================================== backward
 // dQ: same decomposition as the forward kernel.  Also computes delta[q] = sum_d dO[q,d] O[q,d] and publishes it for the
 // dK/dV kernel, which runs after this one on the same stream.
-template <int DK>
-__global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq_f16x2_kernel(
+template <int DK, int NW>
+__global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq_f16x2_kernel(
     const float *__restrict__ qkv, const int64_t *__restrict__ seq, const float *__restrict__ o_fwd,
     const float *__restrict__ d_o, const float *__restrict__ lse, float *__restrict__ delta, int L, int H, float p_drop,
     uint64_t seed, uint32_t stream_id, float *__restrict__ dqkv, uint32_t *__restrict__ row_scale,
@@ -403,7 +422,7 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
   __shared__ unsigned int sMin;
   __shared__ __attribute__((aligned(16))) float sInvK[2][8], sInvV[2][8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB + wave * 32;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (32 * NW) + wave * 32;
   const int D = H * DK, D3 = 3 * D;
   const float *base = qkv + (size_t)b * L * D3 + h * DK;
   const int64_t *sq = seq + (size_t)b * L;
@@ -443,7 +462,7 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
     for (int r = 0; r < 16; ++r) dq[t][r] = 0.f;
   float bscale = BSCALE0;  // common power of two of the dS operand (per query = per accumulator column)
 
-  Stage<DK> stK, stV;
+  Stage<DK, NW> stK, stV;
   const int ntiles = (L + TR - 1) / TR;
   // key mask of a tile as an ADDITIVE term of the soft-max argument (0 or -inf per key), read back one float4 per register
   // quadruple: no bit extraction and no select per element
@@ -453,14 +472,14 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
       sBias[buf][tid] = (key < L && sq[key < L ? key : 0] != PTAMD_PAD_ID) ? 0.f : -INFINITY;
     }
   };
-  TileRows<DK> rows(D3, L, tid);
-  uint32_t toff = rows.next();
+  TileRows<DK, NW> rows(D3, L, tid);
+  auto toff = rows.next();
   stK.load(base + D, toff);
   stV.load(base + 2 * D, toff);
   stK.store(smem, sInvK[0], 0, L, tid);
   stV.store(smem + Tile2::ELEMS, sInvV[0], 0, L, tid);
   publish_mask(0, 0);
-  Stage<DK> nxK, nxV;
+  Stage<DK, NW> nxK, nxV;
   toff = rows.next();
   stK.load(base + D, toff);
   stV.load(base + 2 * D, toff);
@@ -568,8 +587,8 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
 // dK, dV: one workgroup = 256 keys of one (protein, head); lane column = key.  The scaled K and V rows of a lane's key
 // stay in registers as B operands; Q and dO tiles of 32 queries stream through LDS and serve both as row fragments
 // (S = Q K^T, dP = dO V^T) and as transposed fragments (dK^T += Q^T dS, dV^T += dO^T Pd).
-template <int DK>
-__global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv_f16x2_kernel(
+template <int DK, int NW>
+__global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv_f16x2_kernel(
     const float *__restrict__ qkv, const int64_t *__restrict__ seq, const float *__restrict__ d_o,
     const float *__restrict__ lse, const float *__restrict__ delta, int L, int H, float p_drop, uint64_t seed,
     uint32_t stream_id, float *__restrict__ dqkv, uint32_t *__restrict__ row_scale, uint32_t *__restrict__ row_min) {
@@ -578,7 +597,7 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
   __shared__ __attribute__((aligned(16))) float sInvQ[2][8], sInvG[2][8];
   __shared__ unsigned int sMin;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * QB + wave * 32;
+  const int b = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * (32 * NW) + wave * 32;
   const int D = H * DK, D3 = 3 * D;
   const float *base = qkv + (size_t)b * L * D3 + h * DK;
   const float *gbase = d_o + (size_t)b * L * D + h * DK;
@@ -604,10 +623,10 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
   float bscale = BSCALE0;  // common power of two of the dS operand (per key = per accumulator column)
   float g_run = 0.f;       // largest inverse dO group scale so far (wavefront-uniform)
 
-  Stage<DK> stQ, stG;
+  Stage<DK, NW> stQ, stG;
   const int ntiles = (L + TR - 1) / TR;
   float r_lse = 0.f, r_del = 0.f;
-  TileRows<DK> rows_q(D3, L, tid), rows_g(D, L, tid);
+  TileRows<DK, NW> rows_q(D3, L, tid), rows_g(D, L, tid);
   stQ.load(base, rows_q.next());
   stG.load(gbase, rows_g.next());
   stQ.store(smem, sInvQ[0], 0, L, tid);
@@ -616,7 +635,7 @@ __global__ __launch_bounds__(NTHR, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
     sLse[0][tid] = tid < L ? lse_b[tid] * LOG2E : INFINITY;
     sDel[0][tid] = tid < L ? del_b[tid] : 0.f;
   }
-  Stage<DK> nxQ, nxG;
+  Stage<DK, NW> nxQ, nxG;
   stQ.load(base, rows_q.next());
   stG.load(gbase, rows_g.next());
   __syncthreads();
@@ -774,41 +793,57 @@ static int set_lds(K kernel) {
 }
 }  // namespace ptattn16
 
+namespace ptgemm {
+int persistent_grid(int reserved_cus);  // CUs of the current device (gemm.hip: a table filled once, no per-launch query)
+}
+namespace ptattn16 {
+namespace {
+// 4-wavefront workgroups when the 8-wavefront ones would cover at most half of the CUs
+inline bool small_launch(int B, int L, int H) { return (size_t)((L + 255) / 256) * H * B * 2 <= (size_t)ptgemm::persistent_grid(0); }
+
+template <int DK, int NW>
+int launch_fwd(const float *qkv, const int64_t *seq, int B, int L, int H, float p, uint64_t seed, uint32_t sid, float *out,
+               float *lse, hipStream_t st) {
+  const dim3 grid((L + 32 * NW - 1) / (32 * NW), H, B);
+  if (int rc = set_lds(attn_fwd_f16x2_kernel<DK, NW>)) return rc;  // idempotent, host-only: no state kept between calls
+  hipLaunchKernelGGL((attn_fwd_f16x2_kernel<DK, NW>), grid, dim3(64 * NW), ATTN_LDS, st, qkv, seq, L, H, p, seed, sid, out, lse);
+  return pt_check_launch();
+}
+template <int DK, int NW>
+int launch_bwd(const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse, float *delta,
+               int B, int L, int H, float p, uint64_t seed, uint32_t sid, float *dqkv, uint32_t *row_scale, uint32_t *row_min,
+               hipStream_t st) {
+  const dim3 grid((L + 32 * NW - 1) / (32 * NW), H, B);
+  if (int rc = set_lds(attn_bwd_dq_f16x2_kernel<DK, NW>)) return rc;
+  if (int rc = set_lds(attn_bwd_dkv_f16x2_kernel<DK, NW>)) return rc;
+  hipLaunchKernelGGL((attn_bwd_dq_f16x2_kernel<DK, NW>), grid, dim3(64 * NW), ATTN_LDS, st, qkv, seq, o_fwd, d_o, lse, delta, L, H,
+                     p, seed, sid, dqkv, row_scale, row_min);
+  if (int rc = pt_check_launch()) return rc;
+  hipLaunchKernelGGL((attn_bwd_dkv_f16x2_kernel<DK, NW>), grid, dim3(64 * NW), ATTN_LDS, st, qkv, seq, d_o, lse, delta, L, H, p,
+                     seed, sid, dqkv, row_scale, row_min);
+  return pt_check_launch();
+}
+}  // namespace
+}  // namespace ptattn16
+
 int pt_attention_fwd_f16x2(const float *qkv, const int64_t *seq, int B, int L, int H, int dk, float p, uint64_t seed,
                            uint32_t sid, float *out, float *lse, hipStream_t st) {
   using namespace ptattn16;
-  const dim3 grid((L + QB - 1) / QB, H, B);
-  if (dk == 64) {
-    if (int rc = set_lds(attn_fwd_f16x2_kernel<64>)) return rc;  // idempotent, host-only: no state kept between calls
-    hipLaunchKernelGGL(attn_fwd_f16x2_kernel<64>, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, L, H, p, seed, sid, out, lse);
-  } else {
-    if (int rc = set_lds(attn_fwd_f16x2_kernel<32>)) return rc;
-    hipLaunchKernelGGL(attn_fwd_f16x2_kernel<32>, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, L, H, p, seed, sid, out, lse);
-  }
-  return pt_check_launch();
+  const bool small = small_launch(B, L, H);
+  if (dk == 64) return small ? launch_fwd<64, 4>(qkv, seq, B, L, H, p, seed, sid, out, lse, st)
+                             : launch_fwd<64, 8>(qkv, seq, B, L, H, p, seed, sid, out, lse, st);
+  return small ? launch_fwd<32, 4>(qkv, seq, B, L, H, p, seed, sid, out, lse, st)
+               : launch_fwd<32, 8>(qkv, seq, B, L, H, p, seed, sid, out, lse, st);
 }
 
 int pt_attention_bwd_f16x2(const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse,
                            float *delta, int B, int L, int H, int dk, float p, uint64_t seed, uint32_t sid, float *dqkv,
                            uint32_t *row_scale, uint32_t *row_min, hipStream_t st) {
   using namespace ptattn16;
-  const dim3 grid((L + QB - 1) / QB, H, B);
-  if (dk == 64) {
-    if (int rc = set_lds(attn_bwd_dq_f16x2_kernel<64>)) return rc;
-    if (int rc = set_lds(attn_bwd_dkv_f16x2_kernel<64>)) return rc;
-    hipLaunchKernelGGL(attn_bwd_dq_f16x2_kernel<64>, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, o_fwd, d_o, lse, delta, L, H, p,
-                       seed, sid, dqkv, row_scale, row_min);
-    if (int rc = pt_check_launch()) return rc;
-    hipLaunchKernelGGL(attn_bwd_dkv_f16x2_kernel<64>, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, d_o, lse, delta, L, H, p, seed,
-                       sid, dqkv, row_scale, row_min);
-  } else {
-    if (int rc = set_lds(attn_bwd_dq_f16x2_kernel<32>)) return rc;
-    if (int rc = set_lds(attn_bwd_dkv_f16x2_kernel<32>)) return rc;
-    hipLaunchKernelGGL(attn_bwd_dq_f16x2_kernel<32>, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, o_fwd, d_o, lse, delta, L, H, p,
-                       seed, sid, dqkv, row_scale, row_min);
-    if (int rc = pt_check_launch()) return rc;
-    hipLaunchKernelGGL(attn_bwd_dkv_f16x2_kernel<32>, grid, dim3(NTHR), ATTN_LDS, st, qkv, seq, d_o, lse, delta, L, H, p, seed,
-                       sid, dqkv, row_scale, row_min);
-  }
-  return pt_check_launch();
+  const bool small = small_launch(B, L, H);
+  if (dk == 64)
+    return small ? launch_bwd<64, 4>(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st)
+                 : launch_bwd<64, 8>(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
+  return small ? launch_bwd<32, 4>(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st)
+               : launch_bwd<32, 8>(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
 }

@@ -467,6 +467,32 @@ def test_attention_f16x2_wide_row_ranges(dev, B, L, H, dk):
         assert rel(dq.view(B, L, 3 * D)[:, :, i * D:(i + 1) * D], gr[:, :, i * D:(i + 1) * D]) < 2e-6, name
 
 
+@pytest.mark.parametrize("dk", [64, 32])
+def test_attention_f16x2_workgroup_sizes_agree(dev, dk):
+    """Launches that would cover at most half of the CUs with 8-wavefront workgroups use 4-wavefront ones
+    (attention_f16x2.hip, small_launch).  A wavefront does the same arithmetic in the same order in both, so a big batch
+    (8 wavefronts) and its first proteins alone (4) must agree BIT FOR BIT - forward, dropout masks and all gradients."""
+    from protein_transformer_amd import kernels as K_
+    B, Bs, L, H, p, seed, sid = 17, 3, 300, 8, 0.1, 99, 7
+    D = H * dk
+    g = torch.Generator().manual_seed(41)
+    seq = torch.randint(0, 20, (B, L), generator=g)
+    seq[1, 200:] = 20
+    seq[2, 33:] = 20
+    qkv = torch.randn(B * L, 3 * D, generator=g).to(dev)
+    dout = torch.randn(B * L, D, generator=g).to(dev)
+    seq = seq.to(dev)
+    o, lse = K_.attention_fwd(qkv, seq, H, p, seed, sid, arith=K_.GEMM_F16X2)
+    dq = K_.attention_bwd(qkv, seq, o, dout, lse, H, p, seed, sid, arith=K_.GEMM_F16X2)
+    n = Bs * L
+    o2, lse2 = K_.attention_fwd(qkv[:n].contiguous(), seq[:Bs].contiguous(), H, p, seed, sid, arith=K_.GEMM_F16X2)
+    dq2 = K_.attention_bwd(qkv[:n].contiguous(), seq[:Bs].contiguous(), o2, dout[:n].contiguous(), lse2, H, p, seed, sid,
+                           arith=K_.GEMM_F16X2)
+    assert torch.equal(o[:n], o2) and torch.equal(lse.view(B, -1)[:Bs], lse2.view(Bs, -1))
+    assert torch.equal(dq[:n], dq2)
+    assert torch.isfinite(dq).all() and dq.abs().max() > 0
+
+
 def test_attention_f16x2_degenerate_rows(dev):
     """All-zero K / V rows (scale groups with maximum 0), a fully padded 32-key tile and huge / tiny magnitudes: finite
     results equal to the exact-f32 kernels' to rounding."""
