@@ -32,6 +32,11 @@ using namespace ptsplit;
 // NW wavefronts per workgroup, 32 queries (or keys) each: 8 (256 per workgroup) or, when that leaves half of the CUs
 // without a workgroup (few proteins), 4 - the same wavefronts then run one per SIMD instead of two, which is what
 // bounds a workgroup (VALU issue), at the price of staging twice the share of every tile.
+// PARTS = 2 (with NW = 4, when even those cover at most half of the CUs): the streamed dimension (keys in the forward /
+// dQ kernels, queries in the dK/dV kernel) is cut in two halves, wavefronts 0-1 walk the first, 2-3 the second - half
+// the serial tile loop per wavefront, which is what a launch of few workgroups is bound by - and the two partial
+// results of a query (key) group are combined through LDS at the end: soft-max statistics and accumulator scales for
+// the forward pass, plain sums (after the accumulator scales) for the gradients.  Fixed order: deterministic.
 constexpr int TR = 32;           // rows (keys or queries) of an LDS tile
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float TWO14 = 16384.f, INV_TWO14 = 1.f / 16384.f;
@@ -166,8 +171,8 @@ template <int DK, int NW>
 struct TileRows {
   using G = StageGeo<DK, NW>;
   uint32_t u, lim, col, step, pass;
-  __device__ __forceinline__ TileRows(int ld, int nrows, int tid) {
-    u = (uint32_t)min(tid / G::CPR, TR - 1) * (uint32_t)ld;
+  __device__ __forceinline__ void init(int ld, int nrows, int tid, int first_row = 0) {
+    u = (uint32_t)(first_row + min(tid / G::CPR, TR - 1)) * (uint32_t)ld;
     lim = (uint32_t)(nrows - 1) * (uint32_t)ld;
     col = (uint32_t)(tid % G::CPR) * 4u;
     step = (uint32_t)TR * (uint32_t)ld;
@@ -246,15 +251,17 @@ constexpr int BUF = 2 * Tile2::ELEMS;  // f16 elements of one {A, B} tile buffer
 constexpr size_t ATTN_LDS = (size_t)2 * BUF * sizeof(unsigned short);
 
 // =================================================================================================== forward
-template <int DK, int NW>
+template <int DK, int NW, int PARTS>
 __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_f16x2_kernel(
     const float *__restrict__ qkv, const int64_t *__restrict__ seq, int L, int H, float p_drop, uint64_t seed,
     uint32_t stream_id, float *__restrict__ out, float *__restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-  __shared__ __attribute__((aligned(16))) float sBias[2][TR];
-  __shared__ __attribute__((aligned(16))) float sInvK[2][8], sInvV[2][8];
+  __shared__ __attribute__((aligned(16))) float sBias[2][PARTS][TR];
+  __shared__ __attribute__((aligned(16))) float sInvK[2][PARTS][8], sInvV[2][PARTS][8];
+  constexpr int NG = NW / PARTS;  // query groups of the workgroup
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (32 * NW) + wave * 32;
+  const int grp = PARTS == 1 ? wave : wave % NG, part = PARTS == 1 ? 0 : wave / NG;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (32 * NG) + grp * 32;
   const int D = H * DK, D3 = 3 * D;
   const float *base = qkv + (size_t)b * L * D3 + h * DK;  // Q block of this head; K at +D, V at +2D
   const int64_t *sq = seq + (size_t)b * L;
@@ -277,38 +284,46 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2
   float m_run = -INFINITY, l_run = 0.f;  // running maximum in log2 units
   float v_run = 0.f;                     // largest inverse V group scale so far (a power of two; wavefront-uniform)
 
-  Stage<DK, NW> stK, stV;
-  const int ntiles = (L + TR - 1) / TR;
+  Stage<DK, NW> stK[PARTS], stV[PARTS];
+  const int ntiles = ((L + TR - 1) / TR + PARTS - 1) / PARTS;  // tiles of one part: part p walks tiles p ntiles ..
+  auto tile = [&](int buf, int pt) __attribute__((always_inline)) { return smem + (buf * PARTS + pt) * BUF; };
   // key mask of a tile as an ADDITIVE term of the soft-max argument (0 or -inf per key), read back one float4 per register
   // quadruple: no bit extraction and no select per element
-  auto publish_mask = [&](int k0, int buf) __attribute__((always_inline)) {
+  auto publish_mask = [&](int k0, int buf, int pt) __attribute__((always_inline)) {
     if (tid < TR) {
       const int key = k0 + tid;
-      sBias[buf][tid] = (key < L && sq[key < L ? key : 0] != PTAMD_PAD_ID) ? 0.f : -INFINITY;
+      sBias[buf][pt][tid] = (key < L && sq[key < L ? key : 0] != PTAMD_PAD_ID) ? 0.f : -INFINITY;
     }
   };
-  TileRows<DK, NW> rows(D3, L, tid);
-  auto toff = rows.next();
-  stK.load(base + D, toff);
-  stV.load(base + 2 * D, toff);
-  stK.store(smem, sInvK[0], 0, L, tid);
-  stV.store(smem + Tile2::ELEMS, sInvV[0], 0, L, tid);
-  publish_mask(0, 0);
-  Stage<DK, NW> nxK, nxV;  // loads run two tiles ahead of the arithmetic (attention_split.hip)
-  toff = rows.next();
-  stK.load(base + D, toff);
-  stV.load(base + 2 * D, toff);
+  TileRows<DK, NW> rows[PARTS];
+  Stage<DK, NW> nxK[PARTS], nxV[PARTS];  // loads run two tiles ahead of the arithmetic (attention_split.hip)
+#pragma unroll
+  for (int pt = 0; pt < PARTS; ++pt) {
+    rows[pt].init(D3, L, tid, pt * ntiles * TR);
+    const auto toff = rows[pt].next();
+    stK[pt].load(base + D, toff);
+    stV[pt].load(base + 2 * D, toff);
+    stK[pt].store(tile(0, pt), sInvK[0][pt], pt * ntiles * TR, L, tid);
+    stV[pt].store(tile(0, pt) + Tile2::ELEMS, sInvV[0][pt], pt * ntiles * TR, L, tid);
+    publish_mask(pt * ntiles * TR, 0, pt);
+    const auto toff2 = rows[pt].next();
+    stK[pt].load(base + D, toff2);
+    stV[pt].load(base + 2 * D, toff2);
+  }
   __syncthreads();
 
   for (int kt = 0; kt < ntiles; ++kt) {
-    const int k0 = kt * TR, cur = kt & 1;
+    const int k0 = (part * ntiles + kt) * TR, cur = kt & 1;
     const bool more = kt + 1 < ntiles;
-    const unsigned short *sK = smem + cur * BUF, *sV = sK + Tile2::ELEMS;
-    toff = rows.next();
-    nxK.load(base + D, toff);
-    nxV.load(base + 2 * D, toff);
-    const float4 ik4 = *reinterpret_cast<const float4 *>(&sInvK[cur][4 * lh]);  // the four key groups of this lane half
-    const float4 iva = *reinterpret_cast<const float4 *>(&sInvV[cur][0]), ivb = *reinterpret_cast<const float4 *>(&sInvV[cur][4]);
+    const unsigned short *sK = tile(cur, part), *sV = sK + Tile2::ELEMS;
+#pragma unroll
+    for (int pt = 0; pt < PARTS; ++pt) {
+      const auto toff = rows[pt].next();
+      nxK[pt].load(base + D, toff);
+      nxV[pt].load(base + 2 * D, toff);
+    }
+    const float4 ik4 = *reinterpret_cast<const float4 *>(&sInvK[cur][part][4 * lh]);  // the four key groups of this lane half
+    const float4 iva = *reinterpret_cast<const float4 *>(&sInvV[cur][part][0]), ivb = *reinterpret_cast<const float4 *>(&sInvV[cur][part][4]);
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -318,17 +333,20 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2
       Tile2::frag_rows(sK, st, lane, kf);
       s = mfma3(kf, qf[st], s);
     }
-    if (more) {  // scale + split + store the next tile into the other buffer while the soft-max runs
-      unsigned short *nK = smem + (cur ^ 1) * BUF;
-      stK.store(nK, sInvK[cur ^ 1], k0 + TR, L, tid);
-      stV.store(nK + Tile2::ELEMS, sInvV[cur ^ 1], k0 + TR, L, tid);
-      publish_mask(k0 + TR, cur ^ 1);
+    if (more) {  // scale + split + store the next tile(s) into the other buffer while the soft-max runs
+#pragma unroll
+      for (int pt = 0; pt < PARTS; ++pt) {
+        const int kn = (pt * ntiles + kt + 1) * TR;
+        stK[pt].store(tile(cur ^ 1, pt), sInvK[cur ^ 1][pt], kn, L, tid);
+        stV[pt].store(tile(cur ^ 1, pt) + Tile2::ELEMS, sInvV[cur ^ 1][pt], kn, L, tid);
+        publish_mask(kn, cur ^ 1, pt);
+      }
     }
     const float cu[4] = {cq * ik4.x, cq * ik4.y, cq * ik4.z, cq * ik4.w};
     float mt = -INFINITY;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float4 b4 = *reinterpret_cast<const float4 *>(&sBias[cur][8 * j + 4 * lh]);
+      const float4 b4 = *reinterpret_cast<const float4 *>(&sBias[cur][part][8 * j + 4 * lh]);
       const float bias[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {  // (s cu is finite - a masked group of zero rows has s = cu = 0 - so the sum is -inf, not NaN)
@@ -386,11 +404,42 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2
         o[t] = mfma3(vf, pf, o[t]);
       }
     }
-    stK = nxK;
-    stV = nxV;
+#pragma unroll
+    for (int pt = 0; pt < PARTS; ++pt) {
+      stK[pt] = nxK[pt];
+      stV[pt] = nxV[pt];
+    }
     __syncthreads();  // the other buffer is complete; nobody reads this one any more
   }
 
+  if (PARTS == 2) {
+    // the second key half hands its soft-max state (running maximum, row sum of its lane half, V scale) and its
+    // accumulators to the wavefront of the same queries that walked the first half: [slot][lane] floats in the tile area
+    float *xch = reinterpret_cast<float *>(smem) + grp * (NT * 16 + 3) * 64 + lane;
+    if (part == 1) {
+      xch[0] = m_run;
+      xch[64] = l_run;
+      xch[128] = v_run;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[(3 + t * 16 + r) * 64] = o[t][r];
+    }
+    __syncthreads();
+    if (part == 1) return;
+    const float m1 = xch[0], l1 = xch[64], v1 = xch[128];
+    const float m = fmaxf(m_run, m1), ms = m == -INFINITY ? 0.f : m;
+    const float a0 = __builtin_amdgcn_exp2f(m_run - ms), a1 = __builtin_amdgcn_exp2f(m1 - ms);
+    const float vm = fmaxf(v_run, v1), ivm = inv_pow2(vm);  // common V scale (powers of two; 0 only if both are)
+    const float f0 = a0 * (v_run * ivm), f1 = a1 * (v1 * ivm);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[t][r] = o[t][r] * f0 + xch[(3 + t * 16 + r) * 64] * f1;
+    l_run = l_run * a0 + l1 * a1;
+    m_run = m;
+    v_run = vm;
+  }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   // soft-max normalisation, dropout scale and the common V scale in one factor
   const float inv = (p_drop > 0.f ? dk_.ks : 1.f) * v_run * INV_TWO14 / l_tot;
@@ -411,18 +460,20 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2
 // =================================================================================================== backward
 // dQ: same decomposition as the forward kernel.  Also computes delta[q] = sum_d dO[q,d] O[q,d] and publishes it for the
 // dK/dV kernel, which runs after this one on the same stream.
-template <int DK, int NW>
+template <int DK, int NW, int PARTS>
 __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq_f16x2_kernel(
     const float *__restrict__ qkv, const int64_t *__restrict__ seq, const float *__restrict__ o_fwd,
     const float *__restrict__ d_o, const float *__restrict__ lse, float *__restrict__ delta, int L, int H, float p_drop,
     uint64_t seed, uint32_t stream_id, float *__restrict__ dqkv, uint32_t *__restrict__ row_scale,
     uint32_t *__restrict__ row_min) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-  __shared__ __attribute__((aligned(16))) float sBias[2][TR];
+  __shared__ __attribute__((aligned(16))) float sBias[2][PARTS][TR];
   __shared__ unsigned int sMin;
-  __shared__ __attribute__((aligned(16))) float sInvK[2][8], sInvV[2][8];
+  __shared__ __attribute__((aligned(16))) float sInvK[2][PARTS][8], sInvV[2][PARTS][8];
+  constexpr int NG = NW / PARTS;  // query groups of the workgroup
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (32 * NW) + wave * 32;
+  const int grp = PARTS == 1 ? wave : wave % NG, part = PARTS == 1 ? 0 : wave / NG;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (32 * NG) + grp * 32;
   const int D = H * DK, D3 = 3 * D;
   const float *base = qkv + (size_t)b * L * D3 + h * DK;
   const int64_t *sq = seq + (size_t)b * L;
@@ -450,7 +501,7 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2
       }
     my_delta += __shfl_xor(my_delta, 32, 64);
     if (!q_ok) my_delta = 0.f;
-    if (q_ok && lh == 0) delta[((size_t)b * H + h) * L + q] = my_delta;
+    if (q_ok && lh == 0 && part == 0) delta[((size_t)b * H + h) * L + q] = my_delta;
   }
   const float cq = scale * LOG2E * iq;
   const float gq = ig * (p_drop > 0.f ? dk_.ks : 1.f);
@@ -462,38 +513,46 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2
     for (int r = 0; r < 16; ++r) dq[t][r] = 0.f;
   float bscale = BSCALE0;  // common power of two of the dS operand (per query = per accumulator column)
 
-  Stage<DK, NW> stK, stV;
-  const int ntiles = (L + TR - 1) / TR;
+  Stage<DK, NW> stK[PARTS], stV[PARTS];
+  const int ntiles = ((L + TR - 1) / TR + PARTS - 1) / PARTS;  // tiles of one part: part p walks tiles p ntiles ..
+  auto tile = [&](int buf, int pt) __attribute__((always_inline)) { return smem + (buf * PARTS + pt) * BUF; };
   // key mask of a tile as an ADDITIVE term of the soft-max argument (0 or -inf per key), read back one float4 per register
   // quadruple: no bit extraction and no select per element
-  auto publish_mask = [&](int k0, int buf) __attribute__((always_inline)) {
+  auto publish_mask = [&](int k0, int buf, int pt) __attribute__((always_inline)) {
     if (tid < TR) {
       const int key = k0 + tid;
-      sBias[buf][tid] = (key < L && sq[key < L ? key : 0] != PTAMD_PAD_ID) ? 0.f : -INFINITY;
+      sBias[buf][pt][tid] = (key < L && sq[key < L ? key : 0] != PTAMD_PAD_ID) ? 0.f : -INFINITY;
     }
   };
-  TileRows<DK, NW> rows(D3, L, tid);
-  auto toff = rows.next();
-  stK.load(base + D, toff);
-  stV.load(base + 2 * D, toff);
-  stK.store(smem, sInvK[0], 0, L, tid);
-  stV.store(smem + Tile2::ELEMS, sInvV[0], 0, L, tid);
-  publish_mask(0, 0);
-  Stage<DK, NW> nxK, nxV;
-  toff = rows.next();
-  stK.load(base + D, toff);
-  stV.load(base + 2 * D, toff);
+  TileRows<DK, NW> rows[PARTS];
+  Stage<DK, NW> nxK[PARTS], nxV[PARTS];
+#pragma unroll
+  for (int pt = 0; pt < PARTS; ++pt) {
+    rows[pt].init(D3, L, tid, pt * ntiles * TR);
+    const auto toff = rows[pt].next();
+    stK[pt].load(base + D, toff);
+    stV[pt].load(base + 2 * D, toff);
+    stK[pt].store(tile(0, pt), sInvK[0][pt], pt * ntiles * TR, L, tid);
+    stV[pt].store(tile(0, pt) + Tile2::ELEMS, sInvV[0][pt], pt * ntiles * TR, L, tid);
+    publish_mask(pt * ntiles * TR, 0, pt);
+    const auto toff2 = rows[pt].next();
+    stK[pt].load(base + D, toff2);
+    stV[pt].load(base + 2 * D, toff2);
+  }
   __syncthreads();
 
   for (int kt = 0; kt < ntiles; ++kt) {
-    const int k0 = kt * TR, cur = kt & 1;
+    const int k0 = (part * ntiles + kt) * TR, cur = kt & 1;
     const bool more = kt + 1 < ntiles;
-    const unsigned short *sK = smem + cur * BUF, *sV = sK + Tile2::ELEMS;
-    toff = rows.next();
-    nxK.load(base + D, toff);
-    nxV.load(base + 2 * D, toff);
-    const float4 ik4 = *reinterpret_cast<const float4 *>(&sInvK[cur][4 * lh]);
-    const float4 iv4 = *reinterpret_cast<const float4 *>(&sInvV[cur][4 * lh]);
+    const unsigned short *sK = tile(cur, part), *sV = sK + Tile2::ELEMS;
+#pragma unroll
+    for (int pt = 0; pt < PARTS; ++pt) {
+      const auto toff = rows[pt].next();
+      nxK[pt].load(base + D, toff);
+      nxV[pt].load(base + 2 * D, toff);
+    }
+    const float4 ik4 = *reinterpret_cast<const float4 *>(&sInvK[cur][part][4 * lh]);
+    const float4 iv4 = *reinterpret_cast<const float4 *>(&sInvV[cur][part][4 * lh]);
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
@@ -506,10 +565,13 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2
       dp = mfma3(vf, gf[st], dp);   // dP^T[key][q] = V dO^T
     }
     if (more) {
-      unsigned short *nK = smem + (cur ^ 1) * BUF;
-      stK.store(nK, sInvK[cur ^ 1], k0 + TR, L, tid);
-      stV.store(nK + Tile2::ELEMS, sInvV[cur ^ 1], k0 + TR, L, tid);
-      publish_mask(k0 + TR, cur ^ 1);
+#pragma unroll
+      for (int pt = 0; pt < PARTS; ++pt) {
+        const int kn = (pt * ntiles + kt + 1) * TR;
+        stK[pt].store(tile(cur ^ 1, pt), sInvK[cur ^ 1][pt], kn, L, tid);
+        stV[pt].store(tile(cur ^ 1, pt) + Tile2::ELEMS, sInvV[cur ^ 1][pt], kn, L, tid);
+        publish_mask(kn, cur ^ 1, pt);
+      }
     }
     const float ik[4] = {ik4.x, ik4.y, ik4.z, ik4.w}, iv[4] = {iv4.x, iv4.y, iv4.z, iv4.w};
     float cu[4], ug[4], wk[4];
@@ -525,7 +587,7 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2
     for (int r = 0; r < 16; ++r) {
       const int j = r >> 2;
       // (the mask goes into the ARGUMENT, exp2(-inf) = 0: 0 or -inf per key, added to -lse)
-      const float4 b4 = *reinterpret_cast<const float4 *>(&sBias[cur][8 * j + 4 * lh]);
+      const float4 b4 = *reinterpret_cast<const float4 *>(&sBias[cur][part][8 * j + 4 * lh]);
       const float nb = ((r & 3) == 0 ? b4.x : (r & 3) == 1 ? b4.y : (r & 3) == 2 ? b4.z : b4.w) - my_lse2;
       const float p = __builtin_amdgcn_exp2f(fmaf(s[r], cu[j], nb));
       float g = dp[r] * ug[j];
@@ -558,12 +620,33 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2
         dq[t] = mfma3(kt_, df, dq[t]);
       }
     }
-    stK = nxK;
-    stV = nxV;
+#pragma unroll
+    for (int pt = 0; pt < PARTS; ++pt) {
+      stK[pt] = nxK[pt];
+      stV[pt] = nxV[pt];
+    }
     __syncthreads();
   }
-  const float un = inv_pow2(bscale);
-  if (q_ok) {
+  float un = inv_pow2(bscale);
+  if (PARTS == 2) {  // dQ of the second key half, brought to its true scale, is added to the first half's
+    float *xch = reinterpret_cast<float *>(smem) + grp * (NT * 16) * 64 + lane;
+    if (part == 1) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[(t * 16 + r) * 64] = dq[t][r] * un;
+    }
+    __syncthreads();
+    if (part == 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[t][r] = dq[t][r] * un + xch[(t * 16 + r) * 64];
+      un = 1.f;
+    }
+  }
+  const bool writer = part == 0;
+  if (q_ok && writer) {
     float *op = dqkv + (size_t)(b * L + q) * D3 + h * DK;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -580,24 +663,26 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) am = fmaxf(am, fabsf(dq[t][r]));
-    publish_row_scale(am * un, q_ok, b * L + q, tid, row_scale, row_min, &sMin);
+    publish_row_scale(am * un, q_ok && writer, b * L + q, tid, row_scale, row_min, &sMin);
   }
 }
 
 // dK, dV: one workgroup = 256 keys of one (protein, head); lane column = key.  The scaled K and V rows of a lane's key
 // stay in registers as B operands; Q and dO tiles of 32 queries stream through LDS and serve both as row fragments
 // (S = Q K^T, dP = dO V^T) and as transposed fragments (dK^T += Q^T dS, dV^T += dO^T Pd).
-template <int DK, int NW>
+template <int DK, int NW, int PARTS>
 __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv_f16x2_kernel(
     const float *__restrict__ qkv, const int64_t *__restrict__ seq, const float *__restrict__ d_o,
     const float *__restrict__ lse, const float *__restrict__ delta, int L, int H, float p_drop, uint64_t seed,
     uint32_t stream_id, float *__restrict__ dqkv, uint32_t *__restrict__ row_scale, uint32_t *__restrict__ row_min) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-  __shared__ __attribute__((aligned(16))) float sLse[2][TR], sDel[2][TR];
-  __shared__ __attribute__((aligned(16))) float sInvQ[2][8], sInvG[2][8];
+  __shared__ __attribute__((aligned(16))) float sLse[2][PARTS][TR], sDel[2][PARTS][TR];
+  __shared__ __attribute__((aligned(16))) float sInvQ[2][PARTS][8], sInvG[2][PARTS][8];
   __shared__ unsigned int sMin;
+  constexpr int NG = NW / PARTS;  // key groups of the workgroup
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * (32 * NW) + wave * 32;
+  const int grp = PARTS == 1 ? wave : wave % NG, part = PARTS == 1 ? 0 : wave / NG;
+  const int b = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * (32 * NG) + grp * 32;
   const int D = H * DK, D3 = 3 * D;
   const float *base = qkv + (size_t)b * L * D3 + h * DK;
   const float *gbase = d_o + (size_t)b * L * D + h * DK;
@@ -623,38 +708,47 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2
   float bscale = BSCALE0;  // common power of two of the dS operand (per key = per accumulator column)
   float g_run = 0.f;       // largest inverse dO group scale so far (wavefront-uniform)
 
-  Stage<DK, NW> stQ, stG;
-  const int ntiles = (L + TR - 1) / TR;
-  float r_lse = 0.f, r_del = 0.f;
-  TileRows<DK, NW> rows_q(D3, L, tid), rows_g(D, L, tid);
-  stQ.load(base, rows_q.next());
-  stG.load(gbase, rows_g.next());
-  stQ.store(smem, sInvQ[0], 0, L, tid);
-  stG.store(smem + Tile2::ELEMS, sInvG[0], 0, L, tid);
-  if (tid < TR) {
-    sLse[0][tid] = tid < L ? lse_b[tid] * LOG2E : INFINITY;
-    sDel[0][tid] = tid < L ? del_b[tid] : 0.f;
+  Stage<DK, NW> stQ[PARTS], stG[PARTS];
+  const int ntiles = ((L + TR - 1) / TR + PARTS - 1) / PARTS;  // query tiles of one part: part p walks tiles p ntiles ..
+  auto tile = [&](int buf, int pt) __attribute__((always_inline)) { return smem + (buf * PARTS + pt) * BUF; };
+  float r_lse[PARTS], r_del[PARTS];
+  TileRows<DK, NW> rows_q[PARTS], rows_g[PARTS];
+  Stage<DK, NW> nxQ[PARTS], nxG[PARTS];
+#pragma unroll
+  for (int pt = 0; pt < PARTS; ++pt) {
+    const int first = pt * ntiles * TR;
+    rows_q[pt].init(D3, L, tid, first);
+    rows_g[pt].init(D, L, tid, first);
+    stQ[pt].load(base, rows_q[pt].next());
+    stG[pt].load(gbase, rows_g[pt].next());
+    stQ[pt].store(tile(0, pt), sInvQ[0][pt], first, L, tid);
+    stG[pt].store(tile(0, pt) + Tile2::ELEMS, sInvG[0][pt], first, L, tid);
+    r_lse[pt] = r_del[pt] = 0.f;
+    if (tid < TR) {
+      sLse[0][pt][tid] = first + tid < L ? lse_b[first + tid] * LOG2E : INFINITY;
+      sDel[0][pt][tid] = first + tid < L ? del_b[first + tid] : 0.f;
+    }
+    stQ[pt].load(base, rows_q[pt].next());
+    stG[pt].load(gbase, rows_g[pt].next());
   }
-  Stage<DK, NW> nxQ, nxG;
-  stQ.load(base, rows_q.next());
-  stG.load(gbase, rows_g.next());
   __syncthreads();
 
   for (int qt = 0; qt < ntiles; ++qt) {
-    const int qq0 = qt * TR, cur = qt & 1;
+    const int qq0 = (part * ntiles + qt) * TR, cur = qt & 1;
     const bool more = qt + 1 < ntiles;
-    const unsigned short *sQ = smem + cur * BUF, *sG = sQ + Tile2::ELEMS;
-    nxQ.load(base, rows_q.next());
-    nxG.load(gbase, rows_g.next());
-    if (more) {
-      if (tid < TR) {
-        const int qn = qq0 + TR + tid;
-        r_lse = qn < L ? lse_b[qn] * LOG2E : INFINITY;
-        r_del = qn < L ? del_b[qn] : 0.f;
+    const unsigned short *sQ = tile(cur, part), *sG = sQ + Tile2::ELEMS;
+#pragma unroll
+    for (int pt = 0; pt < PARTS; ++pt) {
+      nxQ[pt].load(base, rows_q[pt].next());
+      nxG[pt].load(gbase, rows_g[pt].next());
+      if (more && tid < TR) {
+        const int qn = (pt * ntiles + qt + 1) * TR + tid;
+        r_lse[pt] = qn < L ? lse_b[qn] * LOG2E : INFINITY;
+        r_del[pt] = qn < L ? del_b[qn] : 0.f;
       }
     }
-    const float4 iq4 = *reinterpret_cast<const float4 *>(&sInvQ[cur][4 * lh]);
-    const float4 iga = *reinterpret_cast<const float4 *>(&sInvG[cur][0]), igb = *reinterpret_cast<const float4 *>(&sInvG[cur][4]);
+    const float4 iq4 = *reinterpret_cast<const float4 *>(&sInvQ[cur][part][4 * lh]);
+    const float4 iga = *reinterpret_cast<const float4 *>(&sInvG[cur][part][0]), igb = *reinterpret_cast<const float4 *>(&sInvG[cur][part][4]);
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
@@ -667,12 +761,15 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2
       dp = mfma3(ga, vf[st], dp);   // dP[q][key] = dO V^T
     }
     if (more) {
-      unsigned short *nQ = smem + (cur ^ 1) * BUF;
-      stQ.store(nQ, sInvQ[cur ^ 1], qq0 + TR, L, tid);
-      stG.store(nQ + Tile2::ELEMS, sInvG[cur ^ 1], qq0 + TR, L, tid);
-      if (tid < TR) {
-        sLse[cur ^ 1][tid] = r_lse;
-        sDel[cur ^ 1][tid] = r_del;
+#pragma unroll
+      for (int pt = 0; pt < PARTS; ++pt) {
+        const int qn = (pt * ntiles + qt + 1) * TR;
+        stQ[pt].store(tile(cur ^ 1, pt), sInvQ[cur ^ 1][pt], qn, L, tid);
+        stG[pt].store(tile(cur ^ 1, pt) + Tile2::ELEMS, sInvG[cur ^ 1][pt], qn, L, tid);
+        if (tid < TR) {
+          sLse[cur ^ 1][pt][tid] = r_lse[pt];
+          sDel[cur ^ 1][pt][tid] = r_del[pt];
+        }
       }
     }
     // common scale of the dO groups: dV accumulates (2^14 / g_run) sum Pd dO
@@ -708,8 +805,8 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2
       const int j = r >> 2;
       // (LDS broadcast reads, one float4 per register quadruple: registers are the scarce resource here; query rows beyond
       // L carry lse = +inf, so the row mask costs nothing per element and the key mask is a loop-invariant select)
-      const float4 l4 = *reinterpret_cast<const float4 *>(&sLse[cur][8 * j + 4 * lh]);
-      const float4 d4 = *reinterpret_cast<const float4 *>(&sDel[cur][8 * j + 4 * lh]);
+      const float4 l4 = *reinterpret_cast<const float4 *>(&sLse[cur][part][8 * j + 4 * lh]);
+      const float4 d4 = *reinterpret_cast<const float4 *>(&sDel[cur][part][8 * j + 4 * lh]);
       const float my_l = (r & 3) == 0 ? l4.x : (r & 3) == 1 ? l4.y : (r & 3) == 2 ? l4.z : l4.w;
       const float my_d = (r & 3) == 0 ? d4.x : (r & 3) == 1 ? d4.y : (r & 3) == 2 ? d4.z : d4.w;
       const float p = __builtin_amdgcn_exp2f(k_valid ? fmaf(s[r], cu[j], -my_l) : -INFINITY);
@@ -750,11 +847,38 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2
         dv[t] = mfma3(gt_, pdf, dv[t]);   // dV^T[d][key] += dO^T Pd
       }
     }
-    stQ = nxQ;
-    stG = nxG;
+#pragma unroll
+    for (int pt = 0; pt < PARTS; ++pt) {
+      stQ[pt] = nxQ[pt];
+      stG[pt] = nxG[pt];
+    }
     __syncthreads();
   }
-  const float uk = inv_pow2(bscale), uv = ks * g_run * INV_TWO14;
+  float uk = inv_pow2(bscale), uv = ks * g_run * INV_TWO14;
+  if (PARTS == 2) {  // dK, dV of the second query half, brought to their true scales, are added to the first half's
+    float *xch = reinterpret_cast<float *>(smem) + grp * (2 * NT * 16) * 64 + lane;
+    if (part == 1) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          xch[(t * 16 + r) * 64] = dk[t][r] * uk;
+          xch[(NT * 16 + t * 16 + r) * 64] = dv[t][r] * uv;
+        }
+    }
+    __syncthreads();
+    if (part == 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          dk[t][r] = dk[t][r] * uk + xch[(t * 16 + r) * 64];
+          dv[t][r] = dv[t][r] * uv + xch[(NT * 16 + t * 16 + r) * 64];
+        }
+      uk = uv = 1.f;
+    }
+  }
+  const bool writer = part == 0;
   if (row_scale) {
     float ak = 0.f, av = 0.f;
 #pragma unroll
@@ -764,9 +888,9 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2
         ak = fmaxf(ak, fabsf(dk[t][r]));
         av = fmaxf(av, fabsf(dv[t][r]));
       }
-    publish_row_scale(fmaxf(ak * uk, av * uv), k_ok, b * L + key, tid, row_scale, row_min, &sMin);
+    publish_row_scale(fmaxf(ak * uk, av * uv), k_ok && writer, b * L + key, tid, row_scale, row_min, &sMin);
   }
-  if (k_ok) {
+  if (k_ok && writer) {
     float *okp = dqkv + (size_t)(b * L + key) * D3 + D + h * DK, *ovp = okp + D;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -782,9 +906,9 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2
 }
 
 template <typename K>
-static int set_lds(K kernel) {
+static int set_lds(K kernel, int parts) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)ATTN_LDS);
+                                     (int)(parts * ATTN_LDS));
   if (e != hipSuccess) {
     g_pt_last_hip_error = e;
     return PTAMD_ERR_HIP;
@@ -798,30 +922,54 @@ int persistent_grid(int reserved_cus);  // CUs of the current device (gemm.hip: 
 }
 namespace ptattn16 {
 namespace {
-// 4-wavefront workgroups when the 8-wavefront ones would cover at most half of the CUs
-inline bool small_launch(int B, int L, int H) { return (size_t)((L + 255) / 256) * H * B * 2 <= (size_t)ptgemm::persistent_grid(0); }
+// workgroup shape by the number of workgroups: 8 wavefronts; 4 when those would cover at most half of the CUs; 4 wavefronts
+// on two halves of the streamed dimension (2 x 32 queries or keys per workgroup) when even those would
+enum Shape { W8 = 0, W4 = 1, W4_HALVES = 2 };
+inline Shape launch_shape(int B, int L, int H) {
+  const size_t cus = (size_t)ptgemm::persistent_grid(0), bh = (size_t)H * B;
+  if ((size_t)((L + 255) / 256) * bh * 2 > cus) return W8;
+  return (size_t)((L + 127) / 128) * bh * 2 > cus ? W4 : W4_HALVES;
+}
 
-template <int DK, int NW>
+template <int DK, int NW, int PARTS>
 int launch_fwd(const float *qkv, const int64_t *seq, int B, int L, int H, float p, uint64_t seed, uint32_t sid, float *out,
                float *lse, hipStream_t st) {
-  const dim3 grid((L + 32 * NW - 1) / (32 * NW), H, B);
-  if (int rc = set_lds(attn_fwd_f16x2_kernel<DK, NW>)) return rc;  // idempotent, host-only: no state kept between calls
-  hipLaunchKernelGGL((attn_fwd_f16x2_kernel<DK, NW>), grid, dim3(64 * NW), ATTN_LDS, st, qkv, seq, L, H, p, seed, sid, out, lse);
+  constexpr int QB = 32 * NW / PARTS;
+  const dim3 grid((L + QB - 1) / QB, H, B);
+  if (int rc = set_lds(attn_fwd_f16x2_kernel<DK, NW, PARTS>, PARTS)) return rc;  // idempotent, host-only: no state kept between calls
+  hipLaunchKernelGGL((attn_fwd_f16x2_kernel<DK, NW, PARTS>), grid, dim3(64 * NW), PARTS * ATTN_LDS, st, qkv, seq, L, H, p, seed, sid,
+                     out, lse);
   return pt_check_launch();
 }
-template <int DK, int NW>
+template <int DK, int NW, int PARTS>
 int launch_bwd(const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse, float *delta,
                int B, int L, int H, float p, uint64_t seed, uint32_t sid, float *dqkv, uint32_t *row_scale, uint32_t *row_min,
                hipStream_t st) {
-  const dim3 grid((L + 32 * NW - 1) / (32 * NW), H, B);
-  if (int rc = set_lds(attn_bwd_dq_f16x2_kernel<DK, NW>)) return rc;
-  if (int rc = set_lds(attn_bwd_dkv_f16x2_kernel<DK, NW>)) return rc;
-  hipLaunchKernelGGL((attn_bwd_dq_f16x2_kernel<DK, NW>), grid, dim3(64 * NW), ATTN_LDS, st, qkv, seq, o_fwd, d_o, lse, delta, L, H,
-                     p, seed, sid, dqkv, row_scale, row_min);
+  constexpr int QB = 32 * NW / PARTS;
+  const dim3 grid((L + QB - 1) / QB, H, B);
+  if (int rc = set_lds(attn_bwd_dq_f16x2_kernel<DK, NW, PARTS>, PARTS)) return rc;
+  if (int rc = set_lds(attn_bwd_dkv_f16x2_kernel<DK, NW, PARTS>, PARTS)) return rc;
+  hipLaunchKernelGGL((attn_bwd_dq_f16x2_kernel<DK, NW, PARTS>), grid, dim3(64 * NW), PARTS * ATTN_LDS, st, qkv, seq, o_fwd, d_o, lse,
+                     delta, L, H, p, seed, sid, dqkv, row_scale, row_min);
   if (int rc = pt_check_launch()) return rc;
-  hipLaunchKernelGGL((attn_bwd_dkv_f16x2_kernel<DK, NW>), grid, dim3(64 * NW), ATTN_LDS, st, qkv, seq, d_o, lse, delta, L, H, p,
-                     seed, sid, dqkv, row_scale, row_min);
+  hipLaunchKernelGGL((attn_bwd_dkv_f16x2_kernel<DK, NW, PARTS>), grid, dim3(64 * NW), PARTS * ATTN_LDS, st, qkv, seq, d_o, lse, delta,
+                     L, H, p, seed, sid, dqkv, row_scale, row_min);
   return pt_check_launch();
+}
+template <int DK>
+int fwd_by_shape(Shape sh, const float *qkv, const int64_t *seq, int B, int L, int H, float p, uint64_t seed, uint32_t sid,
+                 float *out, float *lse, hipStream_t st) {
+  if (sh == W8) return launch_fwd<DK, 8, 1>(qkv, seq, B, L, H, p, seed, sid, out, lse, st);
+  if (sh == W4) return launch_fwd<DK, 4, 1>(qkv, seq, B, L, H, p, seed, sid, out, lse, st);
+  return launch_fwd<DK, 4, 2>(qkv, seq, B, L, H, p, seed, sid, out, lse, st);
+}
+template <int DK>
+int bwd_by_shape(Shape sh, const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse,
+                 float *delta, int B, int L, int H, float p, uint64_t seed, uint32_t sid, float *dqkv, uint32_t *row_scale,
+                 uint32_t *row_min, hipStream_t st) {
+  if (sh == W8) return launch_bwd<DK, 8, 1>(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
+  if (sh == W4) return launch_bwd<DK, 4, 1>(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
+  return launch_bwd<DK, 4, 2>(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
 }
 }  // namespace
 }  // namespace ptattn16
@@ -829,21 +977,16 @@ int launch_bwd(const float *qkv, const int64_t *seq, const float *o_fwd, const f
 int pt_attention_fwd_f16x2(const float *qkv, const int64_t *seq, int B, int L, int H, int dk, float p, uint64_t seed,
                            uint32_t sid, float *out, float *lse, hipStream_t st) {
   using namespace ptattn16;
-  const bool small = small_launch(B, L, H);
-  if (dk == 64) return small ? launch_fwd<64, 4>(qkv, seq, B, L, H, p, seed, sid, out, lse, st)
-                             : launch_fwd<64, 8>(qkv, seq, B, L, H, p, seed, sid, out, lse, st);
-  return small ? launch_fwd<32, 4>(qkv, seq, B, L, H, p, seed, sid, out, lse, st)
-               : launch_fwd<32, 8>(qkv, seq, B, L, H, p, seed, sid, out, lse, st);
+  const Shape sh = launch_shape(B, L, H);
+  return dk == 64 ? fwd_by_shape<64>(sh, qkv, seq, B, L, H, p, seed, sid, out, lse, st)
+                  : fwd_by_shape<32>(sh, qkv, seq, B, L, H, p, seed, sid, out, lse, st);
 }
 
 int pt_attention_bwd_f16x2(const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse,
                            float *delta, int B, int L, int H, int dk, float p, uint64_t seed, uint32_t sid, float *dqkv,
                            uint32_t *row_scale, uint32_t *row_min, hipStream_t st) {
   using namespace ptattn16;
-  const bool small = small_launch(B, L, H);
-  if (dk == 64)
-    return small ? launch_bwd<64, 4>(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st)
-                 : launch_bwd<64, 8>(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
-  return small ? launch_bwd<32, 4>(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st)
-               : launch_bwd<32, 8>(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
+  const Shape sh = launch_shape(B, L, H);
+  return dk == 64 ? bwd_by_shape<64>(sh, qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st)
+                  : bwd_by_shape<32>(sh, qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
 }

@@ -468,12 +468,14 @@ def test_attention_f16x2_wide_row_ranges(dev, B, L, H, dk):
 
 
 @pytest.mark.parametrize("dk", [64, 32])
-def test_attention_f16x2_workgroup_sizes_agree(dev, dk):
-    """Launches that would cover at most half of the CUs with 8-wavefront workgroups use 4-wavefront ones
-    (attention_f16x2.hip, small_launch).  A wavefront does the same arithmetic in the same order in both, so a big batch
-    (8 wavefronts) and its first proteins alone (4) must agree BIT FOR BIT - forward, dropout masks and all gradients."""
+def test_attention_f16x2_workgroup_shapes_agree(dev, dk):
+    """The launch picks the workgroup shape by the number of workgroups (attention_f16x2.hip, launch_shape): 8 wavefronts;
+    4 when those would cover at most half of the CUs; 4 wavefronts on two halves of the streamed dimension when even those
+    would.  A wavefront does the same arithmetic in the same order with 8 or 4, so a big batch and its first 6 proteins
+    alone must agree BIT FOR BIT - forward, dropout masks and all gradients; the first 3 alone run on halves, whose
+    partial results are combined at the end: same masks, equal to rounding."""
     from protein_transformer_amd import kernels as K_
-    B, Bs, L, H, p, seed, sid = 17, 3, 300, 8, 0.1, 99, 7
+    B, L, H, p, seed, sid = 17, 300, 8, 0.1, 99, 7
     D = H * dk
     g = torch.Generator().manual_seed(41)
     seq = torch.randint(0, 20, (B, L), generator=g)
@@ -482,14 +484,23 @@ def test_attention_f16x2_workgroup_sizes_agree(dev, dk):
     qkv = torch.randn(B * L, 3 * D, generator=g).to(dev)
     dout = torch.randn(B * L, D, generator=g).to(dev)
     seq = seq.to(dev)
-    o, lse = K_.attention_fwd(qkv, seq, H, p, seed, sid, arith=K_.GEMM_F16X2)
-    dq = K_.attention_bwd(qkv, seq, o, dout, lse, H, p, seed, sid, arith=K_.GEMM_F16X2)
-    n = Bs * L
-    o2, lse2 = K_.attention_fwd(qkv[:n].contiguous(), seq[:Bs].contiguous(), H, p, seed, sid, arith=K_.GEMM_F16X2)
-    dq2 = K_.attention_bwd(qkv[:n].contiguous(), seq[:Bs].contiguous(), o2, dout[:n].contiguous(), lse2, H, p, seed, sid,
-                           arith=K_.GEMM_F16X2)
-    assert torch.equal(o[:n], o2) and torch.equal(lse.view(B, -1)[:Bs], lse2.view(Bs, -1))
-    assert torch.equal(dq[:n], dq2)
+
+    def run(nb):
+        n = nb * L
+        o, lse = K_.attention_fwd(qkv[:n].contiguous(), seq[:nb].contiguous(), H, p, seed, sid, arith=K_.GEMM_F16X2)
+        dq = K_.attention_bwd(qkv[:n].contiguous(), seq[:nb].contiguous(), o, dout[:n].contiguous(), lse, H, p, seed, sid,
+                              arith=K_.GEMM_F16X2)
+        return o, lse.view(nb, -1), dq
+    o, lse, dq = run(B)                 # 2 * 17 * 8 = 272 workgroups of 8 wavefronts: more than the 256 CUs
+    o6, lse6, dq6 = run(6)              # 96 of 8 would cover less than half: 3 * 6 * 8 = 144 of 4 wavefronts
+    assert torch.equal(o[:6 * L], o6) and torch.equal(lse[:6], lse6) and torch.equal(dq[:6 * L], dq6)
+    o3, lse3, dq3 = run(3)              # 72 of 4 still would: 5 * 3 * 8 = 120 workgroups of 2 x 2 wavefronts on key / query halves
+    n = 3 * L
+    assert torch.equal(o3 == 0, o[:n] == 0)       # (the dropped probabilities of a whole row can only vanish together)
+    assert torch.allclose(o3, o[:n], rtol=2e-6, atol=2e-6 * o.abs().max().item())
+    assert torch.allclose(lse3, lse[:3], rtol=1e-6, atol=1e-6)
+    assert ((dq3 - dq[:n]).norm() / dq[:n].norm()).item() < 1e-6
+    assert torch.allclose(dq3, dq[:n], rtol=1e-4, atol=2e-6 * dq.abs().max().item())
     assert torch.isfinite(dq).all() and dq.abs().max() > 0
 
 
