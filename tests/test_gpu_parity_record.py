@@ -141,6 +141,7 @@ def test_parity_record(case):
     pred64 = oenc.encoder_forward({**leaf, **{k: params[k] for k in pe_keys}}, seq.cpu(), nh)
     cs = pred64.view(B, L, 12, 2)
     rad64 = torch.atan2(cs[..., 1], cs[..., 0])
+    radius64 = torch.sqrt(cs[..., 1] ** 2 + cs[..., 0] ** 2).detach().numpy()     # length of the predicted (cos, sin) pair
     stats64, crd64, dang64 = obat.batch_loss_and_grads(rad64, seq.cpu(), crd.cpu(), dtype=torch.float64)
     rad64.backward(dang64)
     ref = {n: v.grad for n, v in leaf.items()}
@@ -208,6 +209,9 @@ def test_parity_record(case):
             m = {
                 "pred_max_abs": float(np.abs(p_np - pred64.detach().numpy())[mask].max()),
                 "angle_max_abs_rad_end_to_end": float(_angle_delta(rad_np, rad64.detach().numpy())[mask].max()),
+                "angle_max_abs_rad_end_to_end_where_radius_ge_0.1": float(
+                    np.where(radius64 >= 0.1, _angle_delta(rad_np, rad64.detach().numpy()), 0.0)[mask].max()),
+                "angle_error_times_radius_max": float((_angle_delta(rad_np, rad64.detach().numpy()) * radius64)[mask].max()),
                 "angle_max_abs_rad_given_identical_encoder_output": float(_angle_delta(rad_np, rad_same)[mask].max()),
                 "coord_max_abs_A_given_identical_angles": [float(x) for x in dcrd],
                 "coord_over_1e-3A_times_max(1,L/128)": [float(x) for x in dcrd / coord_unit],
@@ -241,7 +245,12 @@ def test_parity_record(case):
     for mode, m in rec["modes"].items():
         assert m["pred_max_abs"] < 1e-5, (mode, m["pred_max_abs"])
         assert m["angle_max_abs_rad_given_identical_encoder_output"] < 1e-6, mode
-        assert m["angle_max_abs_rad_end_to_end"] < 1e-4, mode
+        # An angle is atan2 of a predicted (cos, sin) pair of length r: a prediction error e (tolerance 1e-5) turns the angle
+        # by e / r.  1e-4 rad is asserted where r >= 0.1 (where the prediction tolerance implies it); a random-init model also
+        # predicts pairs of length 0.02 - 0.03, whose angle moves by 1e-4 under the fp32 rounding of ANY chain (recorded:
+        # `angle_max_abs_rad_end_to_end`) - for those the bound is the prediction tolerance itself, error x r < 1.5e-5.
+        assert m["angle_max_abs_rad_end_to_end_where_radius_ge_0.1"] < 1e-4, mode
+        assert m["angle_error_times_radius_max"] < 1.5e-5, mode
         # Coordinates given identical angles, against the fp64 build of the same angles.  SURVEY 8(d) quotes 1e-3 A * L / 128
         # as the drift it MEASURED between two fp32 chains on realistic angles; on the arbitrary angles of a freshly
         # initialised model the oracle's own fp32 chain (pinned bit-exact to the reference) is 0.3 - 5 such units from
