@@ -533,11 +533,17 @@ class _EncoderFn(torch.autograd.Function):
 
         def done(first, last):
             if m.grad_hook is not None:
-                join()
                 K.layernorm_bwd_flush(ln_pending)     # a slice handed to the all-reduce must be final
                 o0, _ = m._layout[first]
                 o1, s1 = m._layout[last]
-                m.grad_hook(o0, o1 + int(np.prod(s1)) - o0)
+                if side is None:
+                    m.grad_hook(o0, o1 + int(np.prod(s1)) - o0)
+                else:
+                    # the slice is final once BOTH streams are here: the collective is issued from the side stream behind a
+                    # wait for the main one, so the dX chain on the main stream does not stop for the weight-gradient products
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        m.grad_hook(o0, o1 + int(np.prod(s1)) - o0)
 
         dpred = dpred.contiguous().view(-1, NUM_PREDICTED_ANGLES * 2)
         dpre = K.tanh_bwd(dpred, ctx.pred) if m.use_tanh_out else dpred
