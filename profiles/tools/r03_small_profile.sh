@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 B=${1:-4}
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_b$B -o b$B -- python $R/bench.py --batch $B --steps 10 --warmup 3 --no-cpu-baseline --no-mode-sweep --no-kernel-timing --no-side-stream > $R/gpurun_out/prof_b$B.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_b$B -o b$B -- python $R/bench.py ${PT_BENCH_ARGS:---batch $B} --steps 10 --warmup 3 --no-cpu-baseline --no-mode-sweep --no-kernel-timing --no-side-stream > $R/gpurun_out/prof_b$B.log 2>&1
 f=$(find $R/gpurun_out/prof_b$B -name "*kernel_stats.csv" | head -n 1)
 python - "$f" <<'PY'
 import csv, sys

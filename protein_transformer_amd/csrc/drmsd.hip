@@ -44,13 +44,20 @@ __device__ int protein_len_block(const int64_t *seq, int L, int *s_tmp) {
   return tot;
 }
 
-__global__ __launch_bounds__(CB) void drmsd_compact_kernel(const float *__restrict__ pred,
+// Compaction of one protein's atom slots (14 per residue, NaN = absent) into dense arrays, backbone atoms first: one
+// workgroup per protein, each of its 16 wavefronts owns a contiguous share of the slots and walks it 64 slots at a time
+// (coalesced loads, position of a present atom = running count + rank among the lanes before it: v_mbcnt of the ballot) -
+// no workgroup barrier inside the loops, so the loads of consecutive rows overlap (the old per-thread runs of 28 slots
+// were 2 x 28 dependent strided loads: 46 us whatever the batch).  Order inside the two classes: slot order.
+constexpr int COMPACT_THREADS = 1024;  // 16 wavefronts: 7 rows of 64 slots each at L = 512
+__global__ __launch_bounds__(COMPACT_THREADS) void drmsd_compact_kernel(const float *__restrict__ pred,
                                                            const float *__restrict__ truth,
                                                            const int64_t *__restrict__ seq, int L,
                                                            float4 *__restrict__ pred4, float4 *__restrict__ true4,
                                                            int *__restrict__ idx, Counts *__restrict__ counts) {
-  __shared__ int s_bb[CB], s_ot[CB], s_tmp[CB / 64];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  constexpr int NWAVE = COMPACT_THREADS / 64;
+  __shared__ int s_bb[NWAVE], s_ot[NWAVE], s_tmp[NWAVE];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const size_t nmax = (size_t)L * 14;
   pred += (size_t)b * nmax * 3;
   truth += (size_t)b * nmax * 3;
@@ -59,40 +66,51 @@ __global__ __launch_bounds__(CB) void drmsd_compact_kernel(const float *__restri
   idx += (size_t)b * nmax;
   const int len = protein_len_block(seq + (size_t)b * L, L, s_tmp);
   const int nslot = len * 14;
-  const int per = (nslot + CB - 1) / CB;
-  const int s0 = tid * per, s1 = min(s0 + per, nslot);
-  int nbb = 0, not_ = 0;
-  for (int s = s0; s < s1; ++s) {
-    float tx = truth[s * 3], ty = truth[s * 3 + 1], tz = truth[s * 3 + 2];
-    bool ok = !(isnan(tx) || isnan(ty) || isnan(tz));
-    bool bb = (s % 14) < 3;
-    nbb += ok && bb;
-    not_ += ok && !bb;
+  const int per = ((nslot + NWAVE - 1) / NWAVE + 63) / 64 * 64;   // slots of a wavefront: whole rows of 64
+  const int s0 = min(w * per, nslot), s1 = min(s0 + per, nslot);
+  auto present = [&](int s, float &tx, float &ty, float &tz) __attribute__((always_inline)) {
+    const int sc = min(s, max(nslot - 1, 0));
+    tx = truth[sc * 3]; ty = truth[sc * 3 + 1]; tz = truth[sc * 3 + 2];
+    return s < s1 && !(isnan(tx) || isnan(ty) || isnan(tz));
+  };
+  int nbb = 0, not_ = 0;   // (wavefront-uniform)
+  for (int r = s0; r < s1; r += 64) {
+    float tx, ty, tz;
+    const int s = r + lane;
+    const bool ok = present(s, tx, ty, tz), bb = (s % 14) < 3;
+    nbb += __popcll(__ballot(ok && bb));
+    not_ += __popcll(__ballot(ok && !bb));
   }
-  s_bb[tid] = nbb;
-  s_ot[tid] = not_;
+  if (lane == 0) {
+    s_bb[w] = nbb;
+    s_ot[w] = not_;
+  }
   __syncthreads();
-  // exclusive scan over 256 entries; small enough that every thread just sums its prefix
-  int off_bb = 0, off_ot = 0, tot_bb = 0, tot_ot = 0;
-  for (int t = 0; t < CB; ++t) {
-    int vb = s_bb[t], vo = s_ot[t];
-    if (t < tid) {
-      off_bb += vb;
-      off_ot += vo;
+  int pb = 0, po = 0, tot_bb = 0, tot_ot = 0;
+#pragma unroll
+  for (int t = 0; t < NWAVE; ++t) {
+    if (t < w) {
+      pb += s_bb[t];
+      po += s_ot[t];
     }
-    tot_bb += vb;
-    tot_ot += vo;
+    tot_bb += s_bb[t];
+    tot_ot += s_ot[t];
   }
-  int pb = off_bb, po = tot_bb + off_ot;
-  for (int s = s0; s < s1; ++s) {
-    float tx = truth[s * 3], ty = truth[s * 3 + 1], tz = truth[s * 3 + 2];
-    bool ok = !(isnan(tx) || isnan(ty) || isnan(tz));
-    if (!ok) continue;
-    bool bb = (s % 14) < 3;
-    int pos = bb ? pb++ : po++;
-    pred4[pos] = make_float4(pred[s * 3], pred[s * 3 + 1], pred[s * 3 + 2], 0.f);
-    true4[pos] = make_float4(tx, ty, tz, 0.f);
-    idx[pos] = s;
+  po += tot_bb;
+  for (int r = s0; r < s1; r += 64) {
+    float tx, ty, tz;
+    const int s = r + lane;
+    const bool ok = present(s, tx, ty, tz), bb = (s % 14) < 3;
+    const unsigned long long mb = __ballot(ok && bb), mo = __ballot(ok && !bb);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (ok) {
+      const int pos = bb ? pb + __popcll(mb & below) : po + __popcll(mo & below);
+      pred4[pos] = make_float4(pred[s * 3], pred[s * 3 + 1], pred[s * 3 + 2], 0.f);
+      true4[pos] = make_float4(tx, ty, tz, 0.f);
+      idx[pos] = s;
+    }
+    pb += __popcll(mb);
+    po += __popcll(mo);
   }
   if (tid == 0) counts[b] = Counts{tot_bb + tot_ot, tot_bb, len, 0};
 }
@@ -115,17 +133,26 @@ __global__ __launch_bounds__(CB) void drmsd_compact_kernel(const float *__restri
 // column tile) slot; the finalize kernel adds, per atom and in a fixed order, the row partials of its strip's chunks and
 // the column partials of all strips at or above it: no atomics anywhere, bit-reproducible.  The diagonal tile (I == J) is
 // still swept from both sides inside the tile (its loss terms count half).
-constexpr int TS = 64, STRIP_TILES = 4, RS = TS * STRIP_TILES, CHUNK_TILES = 16;
+constexpr int TS = 64, STRIP_TILES = 4, RS = TS * STRIP_TILES;
+// column tiles per work item: 16, or fewer (8, 4) when the batch would otherwise leave most of the 5 x 256 workgroup slots
+// empty (few or short proteins) - a function of (B, L) only, so a given batch is always cut the same way
+constexpr int MAX_CHUNK_TILES = 16, MIN_CHUNK_TILES = 4, TARGET_ITEMS = 2560;
 constexpr int SUB = 16, CF_LD = SUB + 1;   // the coefficient tile is kept for 16 columns at a time: 4.3 KB per wavefront, 5 workgroups per CU
 
 struct TriLayout {  // per protein: strips x chunks work items, column tiles
-  int strips, chunks, tiles;
+  int strips, chunks, tiles, chunk_tiles;
 };
-__host__ __device__ inline TriLayout tri_layout(int nmax) {
+__host__ __device__ inline TriLayout tri_layout(int nmax, int B) {
   TriLayout t;
   t.tiles = (nmax + TS - 1) / TS;
   t.strips = (t.tiles + STRIP_TILES - 1) / STRIP_TILES;
-  t.chunks = (t.tiles + CHUNK_TILES - 1) / CHUNK_TILES;
+  t.chunk_tiles = MAX_CHUNK_TILES;
+  for (;;) {
+    t.chunks = (t.tiles + t.chunk_tiles - 1) / t.chunk_tiles;
+    const long items = (long)t.strips * (t.chunks + 1) / 2 * B;   // (strip, chunk) pairs of the upper triangle, about
+    if (items >= TARGET_ITEMS || t.chunk_tiles <= MIN_CHUNK_TILES) break;
+    t.chunk_tiles >>= 1;
+  }
   return t;
 }
 
@@ -142,13 +169,13 @@ __global__ __launch_bounds__(RS) void drmsd_tri_kernel(const float4 *__restrict_
   float4 *const s_cs = s_row + RS;                                            // [4][64] (S, Vx, Vy, Vz) per wavefront
   __shared__ double s_red[2 * STRIP_TILES];
   const size_t nmax = (size_t)L * 14;
-  const TriLayout tl = tri_layout((int)nmax);
+  const TriLayout tl = tri_layout((int)nmax, (int)gridDim.y);
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int strip = blockIdx.x / tl.chunks, chunk = blockIdx.x % tl.chunks;
   const Counts cn = counts[b];
   const int n = cn.n, nbb = cn.n_bb, nT = (n + TS - 1) / TS;
   double *part = partials + ((size_t)b * tl.strips * tl.chunks + blockIdx.x) * 2;
-  const int J0 = max(STRIP_TILES * strip, CHUNK_TILES * chunk), J1 = min(nT, CHUNK_TILES * (chunk + 1));
+  const int J0 = max(STRIP_TILES * strip, tl.chunk_tiles * chunk), J1 = min(nT, tl.chunk_tiles * (chunk + 1));
   if (STRIP_TILES * strip >= nT || J0 >= J1) {  // block-uniform: nothing to do (the finalize kernel skips these items too)
     if (tid == 0) part[0] = part[1] = 0.0;
     return;
@@ -298,15 +325,32 @@ __global__ __launch_bounds__(CB) void drmsd_finalize_kernel(const Counts *__rest
   const int b = blockIdx.y, tid = threadIdx.x;
   const Counts cn = counts[b];
   const size_t nmax = (size_t)L * 14;
-  const TriLayout tl = tri_layout((int)nmax);
+  const TriLayout tl = tri_layout((int)nmax, (int)gridDim.y);
   if ((int)blockIdx.x * CB >= max(cn.n, 1)) return;
-  if (tid == 0) {
-    double all = 0, bbp = 0;
+  // the work items' loss partials: every thread adds its share in item order, then a fixed tree over the threads (every
+  // block of the protein needs the total for the gradient scale: one thread walking strips x chunks items was the
+  // kernel's time when small chunks make that 784 items)
+  __shared__ double s_sum[2][CB];
+  {
+    double a = 0, c = 0;
     const int items = tl.strips * tl.chunks;
-    for (int r = 0; r < items; ++r) {
-      all += partials[((size_t)b * items + r) * 2];
-      bbp += partials[((size_t)b * items + r) * 2 + 1];
+    for (int r = tid; r < items; r += CB) {
+      a += partials[((size_t)b * items + r) * 2];
+      c += partials[((size_t)b * items + r) * 2 + 1];
     }
+    s_sum[0][tid] = a;
+    s_sum[1][tid] = c;
+    __syncthreads();
+    for (int o = CB / 2; o > 0; o >>= 1) {
+      if (tid < o) {
+        s_sum[0][tid] += s_sum[0][tid + o];
+        s_sum[1][tid] += s_sum[1][tid + o];
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) {
+    const double all = s_sum[0][0], bbp = s_sum[1][0];
     const double n = cn.n, nb = cn.n_bb;
     const double P = n * (n - 1) * 0.5, Pb = nb * (nb - 1) * 0.5;
     // mse_loss over an empty pair set is NaN in the reference as well
@@ -332,20 +376,40 @@ __global__ __launch_bounds__(CB) void drmsd_finalize_kernel(const Counts *__rest
   const float scale = s_scale;
   const int nT = (cn.n + TS - 1) / TS, J = j / TS, sJ = J / STRIP_TILES;
   float gx = 0.f, gy = 0.f, gz = 0.f;
-  // row side: the chunks of this atom's strip that had work, in order
-  for (int c = 0; c < tl.chunks; ++c) {
-    const int J0 = max(STRIP_TILES * sJ, CHUNK_TILES * c), J1 = min(nT, CHUNK_TILES * (c + 1));
-    if (J0 >= J1) continue;
-    const float4 r = rowpart[(((size_t)b * tl.strips + sJ) * tl.chunks + c) * RS + (j - sJ * RS)];
-    gx += r.x; gy += r.y; gz += r.z;
+  // row side: the chunks of this atom's strip that had work - a contiguous range - added in order; the loads go out four
+  // at a time (a step of few proteins runs this kernel on a fraction of the CUs: dependent-looking loads were its time)
+  {
+    const int c0 = (STRIP_TILES * sJ) / tl.chunk_tiles, c1 = min(tl.chunks, (nT + tl.chunk_tiles - 1) / tl.chunk_tiles);
+    const float4 *rp = rowpart + (((size_t)b * tl.strips + sJ) * tl.chunks) * RS + (j - sJ * RS);
+    int c = c0;
+    for (; c + 4 <= c1; c += 4) {
+      const float4 r0 = rp[(size_t)c * RS], r1 = rp[(size_t)(c + 1) * RS], r2 = rp[(size_t)(c + 2) * RS], r3 = rp[(size_t)(c + 3) * RS];
+      gx += r0.x; gy += r0.y; gz += r0.z;
+      gx += r1.x; gy += r1.y; gz += r1.z;
+      gx += r2.x; gy += r2.y; gz += r2.z;
+      gx += r3.x; gy += r3.y; gz += r3.z;
+    }
+    for (; c < c1; ++c) {
+      const float4 r = rp[(size_t)c * RS];
+      gx += r.x; gy += r.y; gz += r.z;
+    }
   }
   // column side: every strip at or above this atom's tile, in order: g_j += x_j S - V
   const float4 xj = pred4[(size_t)b * nmax + j];
-  for (int s = 0; s <= sJ; ++s) {
-    const float4 cp = colpart[(((size_t)b * tl.strips + s) * tl.tiles + J) * TS + (j & (TS - 1))];
-    gx += fmaf(xj.x, cp.x, -cp.y);
-    gy += fmaf(xj.y, cp.x, -cp.z);
-    gz += fmaf(xj.z, cp.x, -cp.w);
+  {
+    const float4 *cp_ = colpart + ((size_t)b * tl.strips * tl.tiles + J) * TS + (j & (TS - 1));
+    const size_t step = (size_t)tl.tiles * TS;
+    auto add = [&](const float4 &cp) __attribute__((always_inline)) {
+      gx += fmaf(xj.x, cp.x, -cp.y);
+      gy += fmaf(xj.y, cp.x, -cp.z);
+      gz += fmaf(xj.z, cp.x, -cp.w);
+    };
+    int sidx = 0;
+    for (; sidx + 4 <= sJ + 1; sidx += 4) {
+      const float4 q0 = cp_[sidx * step], q1 = cp_[(sidx + 1) * step], q2 = cp_[(sidx + 2) * step], q3 = cp_[(sidx + 3) * step];
+      add(q0); add(q1); add(q2); add(q3);
+    }
+    for (; sidx <= sJ; ++sidx) add(cp_[sidx * step]);
   }
   const int sl = idx[(size_t)b * nmax + j];
   float *out = dcrd + (size_t)b * nmax * 3;
@@ -361,7 +425,7 @@ struct Layout {
 Layout layout(int B, int L) {
   Layout l;
   const size_t nmax = (size_t)L * 14, BN = (size_t)B * nmax;
-  l.tl = tri_layout((int)nmax);
+  l.tl = tri_layout((int)nmax, B);
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o = off;
@@ -401,7 +465,7 @@ int ptamd_drmsd_fwd_bwd(const float *pred_crd, const float *true_crd, const int6
   Counts *counts = reinterpret_cast<Counts *>(ws + l.counts);
   double *partials = reinterpret_cast<double *>(ws + l.partials);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(drmsd_compact_kernel, dim3(B), dim3(CB), 0, st, pred_crd, true_crd, seq, L, pred4, true4, idx,
+  hipLaunchKernelGGL(drmsd_compact_kernel, dim3(B), dim3(COMPACT_THREADS), 0, st, pred_crd, true_crd, seq, L, pred4, true4, idx,
                      counts);
   int rc = pt_check_launch();
   if (rc) return rc;
