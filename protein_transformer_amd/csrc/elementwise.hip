@@ -8,6 +8,7 @@
 //   torch.nn.LayerNorm(D)         .../Sublayers.py:13,17   (eps 1e-5, biased variance, affine)
 //   Dropout / ReLU / tanh backward: autograd of Sublayers.py:17,34 and encoder_only.py:41
 #include "common.h"
+#include <type_traits>
 #include "hp_format.h"
 
 namespace {
@@ -246,7 +247,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
 //                    dropped W that the next GEMM writes (Cauchy-Schwarz with the largest column norm of W)
 // One generator call serves the 8 rows {r0, r0+1, r0+2, r0+3, r0+8, .., r0+11} of a column, so a wavefront takes such a
 // GROUP of rows, draws its words once (4 NV calls per lane) and walks the 8 rows with them.
-template <int NV>
+// HALVES = 2 or 4 (few tokens: fewer 8-row groups than wavefronts): a group is shared by two (four) wavefronts - 4 (2)
+// consecutive rows of the group's row order each - which all draw the group's words: a half (quarter) of the serial row
+// chain per wavefront, which is what a launch with idle wavefronts is bound by (2048 tokens: 21.6 us with one wavefront
+// per group, 16.3 with two).
+template <int NV, int HALVES>
 __global__ __launch_bounds__(256) void layernorm_bwd_dropout_kernel(
     const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ mean,
     const float *__restrict__ rstd, const float *__restrict__ dres, int64_t T, int D, float *__restrict__ dx,
@@ -268,7 +273,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dropout_kernel(
   const float *__restrict__ rsrc = dres ? dres : dy;   // no residual gradient: the loads stay (unconditional), their weight is 0
   const float rflag = dres ? 1.f : 0.f;
   const int64_t ngroups = ((T + 31) / 32) * 4;
-  for (int64_t cr = wid; cr < ngroups; cr += LN_BWD_BLOCKS * 4) {  // cr = call row (4 I + 2 h + gp)
+  for (int64_t item = wid; item < ngroups * HALVES; item += LN_BWD_BLOCKS * 4) {
+    const int64_t cr = item / HALVES;  // cr = call row (4 I + 2 h + gp)
+    const int half = (int)(item % HALVES);  // (wavefront-uniform)
     const int64_t r0 = ((cr >> 2) << 5) + 16 * (cr & 1) + 4 * ((cr >> 1) & 1);
     uint4 rnd[NV][4];
     if (p > 0.f) {
@@ -298,11 +305,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dropout_kernel(
         ra[set][j] = *reinterpret_cast<const float4 *>(rsrc + row * D + c);
       }
     };
-    fetch(0, 0);
+    auto rows_from = [&](auto first) __attribute__((always_inline)) {
+    constexpr int F0 = decltype(first)::value, F1 = F0 + 8 / HALVES;
+    fetch(F0, F0 & 1);
 #pragma unroll
-    for (int f = 0; f < 8; ++f) {
+    for (int f = F0; f < F1; ++f) {
       const int64_t row = r0 + 8 * (f >> 2) + (f & 3);
-      if (f < 7) fetch(f + 1, (f + 1) & 1);
+      if (f < F1 - 1) fetch(f + 1, (f + 1) & 1);
       if (row >= T) continue;  // wavefront-uniform (no loads behind it)
       const float mu = mua[f & 1], rs = rsa[f & 1];
       float4 xh[NV], gy[NV];
@@ -353,6 +362,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dropout_kernel(
         if (bound_scale) bound_scale[row] = bs_bits;
       }
     }
+    };
+    if (HALVES == 1 || half == 0) rows_from(std::integral_constant<int, 0>{});
+    else if (half == 1) rows_from(std::integral_constant<int, 8 / HALVES>{});
+    else if (half == 2) rows_from(std::integral_constant<int, 4>{});
+    else rows_from(std::integral_constant<int, 6>{});
   }
   __shared__ float4 s_dg[3][NV * 64], s_db[3][NV * 64];
   __shared__ uint32_t s_min[2][4];
@@ -571,12 +585,17 @@ int ptamd_layernorm_bwd_dropout(const float *dy, const float *x, const float *ga
   float *part = static_cast<float *>(workspace);
   const dim3 grid(LN_BWD_BLOCKS), block(256);
   hipStream_t st = (hipStream_t)stream;
-#define PT_LN_FUSED(NV)                                                                                                   \
-  hipLaunchKernelGGL(layernorm_bwd_dropout_kernel<NV>, grid, block, 0, st, dy, x, gamma, mean, rstd, dres, T, D, dx, part, \
+  // two or four wavefronts per 8-row group while that still leaves every part of a group a wavefront of its own
+  const int64_t ngroups = ((T + 31) / 32) * 4, nwaves = (int64_t)LN_BWD_BLOCKS * 4;
+  const int halves = ngroups * 4 <= nwaves ? 4 : ngroups * 2 <= nwaves ? 2 : 1;
+#define PT_LN_FUSED(NV, HV)                                                                                                   \
+  hipLaunchKernelGGL((layernorm_bwd_dropout_kernel<NV, HV>), grid, block, 0, st, dy, x, gamma, mean, rstd, dres, T, D, dx, part, \
                      dropout_p, seed, stream_id, dropped, row_scale, bound_factor, bound_scale, row_scale_min, bound_scale_min)
-  if (D <= 256) PT_LN_FUSED(1);
-  else if (D <= 512) PT_LN_FUSED(2);
-  else PT_LN_FUSED(4);
+#define PT_LN_FUSED_BY_T(NV) do { if (halves == 4) PT_LN_FUSED(NV, 4); else if (halves == 2) PT_LN_FUSED(NV, 2); else PT_LN_FUSED(NV, 1); } while (0)
+  if (D <= 256) PT_LN_FUSED_BY_T(1);
+  else if (D <= 512) PT_LN_FUSED_BY_T(2);
+  else PT_LN_FUSED_BY_T(4);
+#undef PT_LN_FUSED_BY_T
 #undef PT_LN_FUSED
   int rc = pt_check_launch();
   if (rc || (!dgamma && !dbeta)) return rc;
