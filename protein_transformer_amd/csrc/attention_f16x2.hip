@@ -922,14 +922,20 @@ int persistent_grid(int reserved_cus);  // CUs of the current device (gemm.hip: 
 }
 namespace ptattn16 {
 namespace {
-// workgroup shape by the number of workgroups: 8 wavefronts; 4 when those would cover at most half of the CUs; 4 wavefronts
-// on two halves of the streamed dimension (2 x 32 queries or keys per workgroup) when even those would
-enum Shape { W8 = 0, W4 = 1, W4_HALVES = 2 };
+// workgroup shape by the number of workgroups: 8 wavefronts (256 queries / keys); when those would cover at most half of
+// the CUs, 8 wavefronts as 4 groups x 2 halves of the streamed dimension (128 per workgroup; W4 = 4 plain wavefronts for
+// the dK/dV kernel, below); when even 128 per workgroup would, 4 wavefronts as 2 groups x 2 halves (64 per workgroup)
+enum Shape { W8 = 0, W4 = 1, W4_HALVES = 2, W8_HALVES = 3 };
 inline Shape launch_shape(int B, int L, int H) {
   const size_t cus = (size_t)ptgemm::persistent_grid(0), bh = (size_t)H * B;
   if ((size_t)((L + 255) / 256) * bh * 2 > cus) return W8;
-  return (size_t)((L + 127) / 128) * bh * 2 > cus ? W4 : W4_HALVES;
+  return (size_t)((L + 127) / 128) * bh * 2 > cus ? W8_HALVES : W4_HALVES;
 }
+// In between (as many 128-query workgroups as CUs, or up to twice as many CUs): 8 wavefronts as 4 query groups x 2 halves
+// for the forward and dQ kernels - the same number of workgroups as with 4 wavefronts, half the tile loop, two
+// wavefronts per SIMD; the dK/dV kernel keeps 4 wavefronts there (it has no registers left for a second staged tile
+// pair at 8: 256 VGPRs already; built with 11 spilled registers it measured 0.5 % of a step).
+inline Shape dkv_shape(Shape sh) { return sh == W8_HALVES ? W4 : sh; }
 
 template <int DK, int NW, int PARTS>
 int launch_fwd(const float *qkv, const int64_t *seq, int B, int L, int H, float p, uint64_t seed, uint32_t sid, float *out,
@@ -942,16 +948,22 @@ int launch_fwd(const float *qkv, const int64_t *seq, int B, int L, int H, float 
   return pt_check_launch();
 }
 template <int DK, int NW, int PARTS>
-int launch_bwd(const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse, float *delta,
-               int B, int L, int H, float p, uint64_t seed, uint32_t sid, float *dqkv, uint32_t *row_scale, uint32_t *row_min,
-               hipStream_t st) {
+int launch_dq(const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse, float *delta,
+              int B, int L, int H, float p, uint64_t seed, uint32_t sid, float *dqkv, uint32_t *row_scale, uint32_t *row_min,
+              hipStream_t st) {
   constexpr int QB = 32 * NW / PARTS;
   const dim3 grid((L + QB - 1) / QB, H, B);
   if (int rc = set_lds(attn_bwd_dq_f16x2_kernel<DK, NW, PARTS>, PARTS)) return rc;
-  if (int rc = set_lds(attn_bwd_dkv_f16x2_kernel<DK, NW, PARTS>, PARTS)) return rc;
   hipLaunchKernelGGL((attn_bwd_dq_f16x2_kernel<DK, NW, PARTS>), grid, dim3(64 * NW), PARTS * ATTN_LDS, st, qkv, seq, o_fwd, d_o, lse,
                      delta, L, H, p, seed, sid, dqkv, row_scale, row_min);
-  if (int rc = pt_check_launch()) return rc;
+  return pt_check_launch();
+}
+template <int DK, int NW, int PARTS>
+int launch_dkv(const float *qkv, const int64_t *seq, const float *d_o, const float *lse, const float *delta, int B, int L, int H,
+               float p, uint64_t seed, uint32_t sid, float *dqkv, uint32_t *row_scale, uint32_t *row_min, hipStream_t st) {
+  constexpr int QB = 32 * NW / PARTS;
+  const dim3 grid((L + QB - 1) / QB, H, B);
+  if (int rc = set_lds(attn_bwd_dkv_f16x2_kernel<DK, NW, PARTS>, PARTS)) return rc;
   hipLaunchKernelGGL((attn_bwd_dkv_f16x2_kernel<DK, NW, PARTS>), grid, dim3(64 * NW), PARTS * ATTN_LDS, st, qkv, seq, d_o, lse, delta,
                      L, H, p, seed, sid, dqkv, row_scale, row_min);
   return pt_check_launch();
@@ -960,16 +972,22 @@ template <int DK>
 int fwd_by_shape(Shape sh, const float *qkv, const int64_t *seq, int B, int L, int H, float p, uint64_t seed, uint32_t sid,
                  float *out, float *lse, hipStream_t st) {
   if (sh == W8) return launch_fwd<DK, 8, 1>(qkv, seq, B, L, H, p, seed, sid, out, lse, st);
-  if (sh == W4) return launch_fwd<DK, 4, 1>(qkv, seq, B, L, H, p, seed, sid, out, lse, st);
+  if (sh == W8_HALVES) return launch_fwd<DK, 8, 2>(qkv, seq, B, L, H, p, seed, sid, out, lse, st);
   return launch_fwd<DK, 4, 2>(qkv, seq, B, L, H, p, seed, sid, out, lse, st);
 }
 template <int DK>
 int bwd_by_shape(Shape sh, const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse,
                  float *delta, int B, int L, int H, float p, uint64_t seed, uint32_t sid, float *dqkv, uint32_t *row_scale,
                  uint32_t *row_min, hipStream_t st) {
-  if (sh == W8) return launch_bwd<DK, 8, 1>(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
-  if (sh == W4) return launch_bwd<DK, 4, 1>(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
-  return launch_bwd<DK, 4, 2>(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
+  int rc;
+  if (sh == W8) rc = launch_dq<DK, 8, 1>(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
+  else if (sh == W8_HALVES) rc = launch_dq<DK, 8, 2>(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
+  else rc = launch_dq<DK, 4, 2>(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
+  if (rc) return rc;
+  const Shape kv = dkv_shape(sh);
+  if (kv == W8) return launch_dkv<DK, 8, 1>(qkv, seq, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
+  if (kv == W4) return launch_dkv<DK, 4, 1>(qkv, seq, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
+  return launch_dkv<DK, 4, 2>(qkv, seq, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
 }
 }  // namespace
 }  // namespace ptattn16

@@ -469,11 +469,10 @@ def test_attention_f16x2_wide_row_ranges(dev, B, L, H, dk):
 
 @pytest.mark.parametrize("dk", [64, 32])
 def test_attention_f16x2_workgroup_shapes_agree(dev, dk):
-    """The launch picks the workgroup shape by the number of workgroups (attention_f16x2.hip, launch_shape): 8 wavefronts;
-    4 when those would cover at most half of the CUs; 4 wavefronts on two halves of the streamed dimension when even those
-    would.  A wavefront does the same arithmetic in the same order with 8 or 4, so a big batch and its first 6 proteins
-    alone must agree BIT FOR BIT - forward, dropout masks and all gradients; the first 3 alone run on halves, whose
-    partial results are combined at the end: same masks, equal to rounding."""
+    """The launch picks the workgroup shape by the number of workgroups (attention_f16x2.hip, launch_shape): 8 wavefronts on
+    256 queries / keys; when those would cover at most half of the CUs, 4 query groups x 2 halves of the key range (the
+    dK/dV kernel: 4 plain wavefronts); when even 128 per workgroup would, 2 groups x 2 halves.  The halves combine partial
+    soft-max states / gradient sums at the end: same dropout masks, results equal to rounding."""
     from protein_transformer_amd import kernels as K_
     B, L, H, p, seed, sid = 17, 300, 8, 0.1, 99, 7
     D = H * dk
@@ -492,15 +491,14 @@ def test_attention_f16x2_workgroup_shapes_agree(dev, dk):
                               arith=K_.GEMM_F16X2)
         return o, lse.view(nb, -1), dq
     o, lse, dq = run(B)                 # 2 * 17 * 8 = 272 workgroups of 8 wavefronts: more than the 256 CUs
-    o6, lse6, dq6 = run(6)              # 96 of 8 would cover less than half: 3 * 6 * 8 = 144 of 4 wavefronts
-    assert torch.equal(o[:6 * L], o6) and torch.equal(lse[:6], lse6) and torch.equal(dq[:6 * L], dq6)
-    o3, lse3, dq3 = run(3)              # 72 of 4 still would: 5 * 3 * 8 = 120 workgroups of 2 x 2 wavefronts on key / query halves
-    n = 3 * L
-    assert torch.equal(o3 == 0, o[:n] == 0)       # (the dropped probabilities of a whole row can only vanish together)
-    assert torch.allclose(o3, o[:n], rtol=2e-6, atol=2e-6 * o.abs().max().item())
-    assert torch.allclose(lse3, lse[:3], rtol=1e-6, atol=1e-6)
-    assert ((dq3 - dq[:n]).norm() / dq[:n].norm()).item() < 1e-6
-    assert torch.allclose(dq3, dq[:n], rtol=1e-4, atol=2e-6 * dq.abs().max().item())
+    for nb in (6, 3):                   # 6: 3 * 6 * 8 = 144 workgroups of 4 x 2 (dK/dV: 4 x 1);  3: 5 * 3 * 8 = 120 of 2 x 2
+        o2, lse2, dq2 = run(nb)
+        n = nb * L
+        assert torch.equal(o2 == 0, o[:n] == 0)       # (the dropped probabilities of a whole row can only vanish together)
+        assert torch.allclose(o2, o[:n], rtol=2e-6, atol=2e-6 * o.abs().max().item()), nb
+        assert torch.allclose(lse2, lse[:nb], rtol=1e-6, atol=1e-6), nb
+        assert ((dq2 - dq[:n]).norm() / dq[:n].norm()).item() < 1e-6, nb
+        assert torch.allclose(dq2, dq[:n], rtol=1e-4, atol=2e-6 * dq.abs().max().item()), nb
     assert torch.isfinite(dq).all() and dq.abs().max() > 0
 
 
