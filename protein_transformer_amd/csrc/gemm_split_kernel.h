@@ -321,7 +321,12 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
       kskip = ld.k0 - ks;
       load_raw(p.A + (A_KMAJOR ? (size_t)ks * p.lda : (size_t)ks), voa, a);
       load_raw(p.B + (B_KMAJOR ? (size_t)ks * p.ldb : (size_t)ks), vob, b);
-      if (F16) {
+      // The row scales of a register set change with the ITEM only: they are loaded with the first stage that each of the
+      // NSETS sets receives from an item and stay in its registers (a stage of K-contiguous operands was 12 operand + 12
+      // scale loads per thread, and the producers' load ISSUE - ~35 cycles per instruction with four wavefronts at it -
+      // is on the critical path of a stage: profiles/r03/r03_gemm_stage_trace.txt).  Uniform branch; the scale loads go
+      // out behind the operand loads, so the in-order count of a later wait for the operands is the same on both paths.
+      if (F16 && ld.k0 - ld.it.kbeg < NSETS * SBK) {
         load_scales<G, A_KMAJOR, TBM>(p.scale_a, soa, sa_);
         load_scales<G, B_KMAJOR, TBN>(p.scale_b, sob, sb_);
       }

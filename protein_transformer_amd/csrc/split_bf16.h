@@ -42,8 +42,9 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t &t1, uin
 // overflow and the residual x s - h1 (one fma, exact) stays a normal f16 for values down to 2^-18 of the row maximum.
 // Scalar operations for the reason given above (v_pk_mul_f32 / v_pk_fma_f32 beside MFMAs).
 __device__ __forceinline__ void split_pair_f16(float x0, float x1, float s0, float s1, uint32_t &t1, uint32_t &t2) {
-  float a0 = x0 * s0, a1 = x1 * s1;
-  asm volatile("" : "+v"(a0));
+  float a0 = x0 * s0;
+  asm volatile("" : "+v"(a0));  // (between the two products: with two DIFFERENT scales the compiler pairs them into a v_pk_mul_f32 otherwise)
+  float a1 = x1 * s1;
   asm volatile("" : "+v"(a1));
   const f16x2 h = __builtin_convertvector((f32x2){a0, a1}, f16x2);  // v_cvt_pk_f16_f32, round to nearest even
   float r0 = fmaf(x0, s0, -(float)h[0]), r1 = fmaf(x1, s1, -(float)h[1]);  // v_fma_mix_f32
@@ -62,8 +63,27 @@ __device__ __forceinline__ void split_pair_f16(float x0, float x1, float s0, flo
 __device__ __forceinline__ void split_quad_f16(float x0, float x1, float x2, float x3, float s0, float s1, float s2,
                                                float s3, uint2 &t1, uint2 &t2) {
 #ifndef PT_MIX_SPLIT
-  split_pair_f16(x0, x1, s0, s1, t1.x, t2.x);
-  split_pair_f16(x2, x3, s2, s3, t1.y, t2.y);
+  // The four products one by one, each behind the one before it: with four DIFFERENT scales (row-contiguous operands: a
+  // float4 is four rows) the compiler otherwise pairs them into v_pk_mul_f32 - 24 per stage in the producers of the
+  // weight-gradient products, each contending with the consumers' MFMAs for the pipe (profiles/r03/r03_gemm_stage_trace.txt).
+  float a0 = x0 * s0;
+  asm volatile("" : "+v"(a0), "+v"(x1));
+  float a1 = x1 * s1;
+  asm volatile("" : "+v"(a1), "+v"(x2));
+  float a2 = x2 * s2;
+  asm volatile("" : "+v"(a2), "+v"(x3));
+  float a3 = x3 * s3;
+  asm volatile("" : "+v"(a3));
+  const f16x2 h01 = __builtin_convertvector((f32x2){a0, a1}, f16x2), h23 = __builtin_convertvector((f32x2){a2, a3}, f16x2);
+  float r0 = fmaf(x0, s0, -(float)h01[0]), r1 = fmaf(x1, s1, -(float)h01[1]);  // v_fma_mix_f32
+  float r2 = fmaf(x2, s2, -(float)h23[0]), r3 = fmaf(x3, s3, -(float)h23[1]);
+  asm volatile("" : "+v"(r0));
+  asm volatile("" : "+v"(r1));
+  asm volatile("" : "+v"(r2));
+  asm volatile("" : "+v"(r3));
+  const f16x2 g01 = __builtin_convertvector((f32x2){r0, r1}, f16x2), g23 = __builtin_convertvector((f32x2){r2, r3}, f16x2);
+  t1 = make_uint2(__builtin_bit_cast(uint32_t, h01), __builtin_bit_cast(uint32_t, h23));
+  t2 = make_uint2(__builtin_bit_cast(uint32_t, g01), __builtin_bit_cast(uint32_t, g23));
 #else
   uint32_t ha, hb, ga, gb;
   asm("v_fma_mixlo_f16 %0, %4, %8, 0\n\t"
