@@ -182,20 +182,23 @@ __device__ __forceinline__ void load_scales(const uint32_t *__restrict__ scale, 
     sc[0] = v.x; sc[1] = v.y; sc[2] = v.z; sc[3] = v.w;
   }
 }
+// float4 number i of the stage (i is a constant after unrolling)
+template <typename G, bool KMAJOR, int ROWS>
+__device__ __forceinline__ void store_split_f16_one(unsigned short *__restrict__ s, int pt, const float4 &v, const float (&sc)[MAX_NV], int i) {
+  constexpr int LPK = ROWS / 4, PLANE = G::template plane<ROWS>(), LD_KR = ROWS + KR_PAD;
+  const int kl = KMAJOR ? pt / LPK + (NPRODUCER / LPK) * i : 4 * (pt % G::QK);
+  uint2 t1, t2;
+  split_quad_f16(v.x, v.y, v.z, v.w, KMAJOR ? sc[0] : sc[i], KMAJOR ? sc[1] : sc[i], KMAJOR ? sc[2] : sc[i], KMAJOR ? sc[3] : sc[i], t1, t2);
+  const int off = KMAJOR ? kl * LD_KR + 4 * (pt % LPK) : G::rk_offset(pt / G::QK + (NPRODUCER / G::QK) * i, kl);
+  *reinterpret_cast<uint2 *>(s + off) = t1;
+  *reinterpret_cast<uint2 *>(s + PLANE + off) = t2;
+}
 template <typename G, bool KMAJOR, int ROWS>
 __device__ __forceinline__ void store_split_f16(unsigned short *__restrict__ s, int pt, const float4 (&v)[G::template nv<ROWS>()],
                                                 const float (&sc)[MAX_NV]) {
-  constexpr int LPK = ROWS / 4, PLANE = G::template plane<ROWS>(), LD_KR = ROWS + KR_PAD, NV = G::template nv<ROWS>();
+  constexpr int NV = G::template nv<ROWS>();
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int kl = KMAJOR ? pt / LPK + (NPRODUCER / LPK) * i : 4 * (pt % G::QK);
-    uint2 t1, t2;
-    split_quad_f16(v[i].x, v[i].y, v[i].z, v[i].w, KMAJOR ? sc[0] : sc[i], KMAJOR ? sc[1] : sc[i], KMAJOR ? sc[2] : sc[i],
-                   KMAJOR ? sc[3] : sc[i], t1, t2);
-    const int off = KMAJOR ? kl * LD_KR + 4 * (pt % LPK) : G::rk_offset(pt / G::QK + (NPRODUCER / G::QK) * i, kl);
-    *reinterpret_cast<uint2 *>(s + off) = t1;
-    *reinterpret_cast<uint2 *>(s + PLANE + off) = t2;
-  }
+  for (int i = 0; i < NV; ++i) store_split_f16_one<G, KMAJOR, ROWS>(s, pt, v[i], sc, i);
 }
 // scale (bits of a power of two) of a row whose largest |x| has the bits `amax`: max |x| * scale in [2^14, 2^15);
 // rows of zeros / subnormals get the largest finite power.  A larger maximum gives a SMALLER scale (atomicMin).
@@ -315,12 +318,8 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
       scale_offsets<G, B_KMAJOR, TBN>(p.N, ld.it.bn0, pt, sob, p.scale_b_stride);
     }
     int rskip[NSETS];
-    auto fetch = [&](float4 (&a)[NVA], float4 (&b)[NVB], int &kskip, float (&sa_)[MAX_NV], float (&sb_)[MAX_NV]) __attribute__((always_inline)) {
-      const int klim = ld.it.kend - ld.k0;
-      const int ks = klim >= SBK ? ld.k0 : ld.it.kend - SBK;  // the last stage of an item may start early
-      kskip = ld.k0 - ks;
-      load_raw(p.A + (A_KMAJOR ? (size_t)ks * p.lda : (size_t)ks), voa, a);
-      load_raw(p.B + (B_KMAJOR ? (size_t)ks * p.ldb : (size_t)ks), vob, b);
+    // what follows the operand loads of a stage: the row scales (see below), the cursor, the offsets of a new item
+    auto fetch_tail = [&](float (&sa_)[MAX_NV], float (&sb_)[MAX_NV]) __attribute__((always_inline)) {
       // The row scales of a register set change with the ITEM only: they are loaded with the first stage that each of the
       // NSETS sets receives from an item and stay in its registers (a stage of K-contiguous operands was 12 operand + 12
       // scale loads per thread, and the producers' load ISSUE - ~35 cycles per instruction with four wavefronts at it -
@@ -341,6 +340,14 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
         }
       }
     };
+    auto fetch = [&](float4 (&a)[NVA], float4 (&b)[NVB], int &kskip, float (&sa_)[MAX_NV], float (&sb_)[MAX_NV]) __attribute__((always_inline)) {
+      const int klim = ld.it.kend - ld.k0;
+      const int ks = klim >= SBK ? ld.k0 : ld.it.kend - SBK;  // the last stage of an item may start early
+      kskip = ld.k0 - ks;
+      load_raw(p.A + (A_KMAJOR ? (size_t)ks * p.lda : (size_t)ks), voa, a);
+      load_raw(p.B + (B_KMAJOR ? (size_t)ks * p.ldb : (size_t)ks), vob, b);
+      fetch_tail(sa_, sb_);
+    };
     // convert + store the stage under `st` into LDS buffer `buf`, then refill the registers two stages ahead
     auto produce = [&](float4 (&a)[NVA], float4 (&b)[NVB], int &kskip, float (&sa_)[MAX_NV], float (&sb_)[MAX_NV], int buf) __attribute__((always_inline)) {
       unsigned short *sa = smem + buf * STAGE, *sb = sa + G::NPLANES * PLANE_A;
@@ -356,8 +363,37 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
         }
       }
       if (F16) {
-        store_split_f16<G, A_KMAJOR, TBM>(sa, pt, a, sa_);
-        store_split_f16<G, B_KMAJOR, TBN>(sb, pt, b, sb_);
+        // f16x2: a register is REFILLED (stage + NSETS) right behind its conversion, two float4 at a time, instead of all
+        // loads behind all conversions: the load unit takes 16 cycles per 1 KB instruction and four wavefronts feed it, so
+        // 12 loads issued back to back held a producer for 600 cycles with nothing to do (profiles/r03/r03_gemm_stage_trace.txt);
+        // spread over the conversion they go out while the wavefront computes.  The registers keep their places (a float4
+        // is loaded into the slot that was just converted), the in-order load count is the same on every path.
+        const int klim = ld.it.kend - ld.k0;
+        const int ks_next = klim >= SBK ? ld.k0 : ld.it.kend - SBK;  // the last stage of an item may start early
+        const float *na = p.A + (A_KMAJOR ? (size_t)ks_next * p.lda : (size_t)ks_next);
+        const float *nb = p.B + (B_KMAJOR ? (size_t)ks_next * p.ldb : (size_t)ks_next);
+        constexpr int GRP = 2;
+#pragma unroll
+        for (int i0 = 0; i0 < NVA; i0 += GRP) {
+#pragma unroll
+          for (int i = i0; i < i0 + GRP && i < NVA; ++i) store_split_f16_one<G, A_KMAJOR, TBM>(sa, pt, a[i], sa_, i);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = i0; i < i0 + GRP && i < NVA; ++i)
+            a[i] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(na) + voa[i]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i0 = 0; i0 < NVB; i0 += GRP) {
+#pragma unroll
+          for (int i = i0; i < i0 + GRP && i < NVB; ++i) store_split_f16_one<G, B_KMAJOR, TBN>(sb, pt, b[i], sb_, i);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = i0; i < i0 + GRP && i < NVB; ++i)
+            b[i] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(nb) + vob[i]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        kskip = ld.k0 - ks_next;
       } else {
         store_split<G, A_KMAJOR, TBM>(sa, pt, a);
         store_split<G, B_KMAJOR, TBN>(sb, pt, b);
@@ -386,7 +422,8 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
       // the set could not stay in place across the loop and the copies (each waiting for its load) would drain the
       // prefetch queue every iteration
       __builtin_amdgcn_sched_barrier(0);
-      fetch(a, b, kskip, sa_, sb_);
+      if (F16) fetch_tail(sa_, sb_);
+      else fetch(a, b, kskip, sa_, sb_);
     };
     // (the scheduling fences keep the ISSUE ORDER of the prologue loads: the scheduler would otherwise sink the later
     // fetches below the refill to shorten live ranges, and since vmcnt counts in order every later wait for an older
