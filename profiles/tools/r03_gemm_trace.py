@@ -47,8 +47,8 @@ for wg in range(2):
         d = lambda a, b: ((x[8:56, a] - x[8:56, b]) & 0xFFFFFFFF)   # noqa: E731
         stage = ((x[9:57, 0] - x[8:56, 0]) & 0xFFFFFFFF)
         if w >= 4:   # producer: 0 = top, 1 = loads of the set arrived, 2 = converted and stored to LDS (issue), 3 = refill issued
-            print(f"producer {w}: stage {stage.mean():7.0f} [{stage.min():5d}..{stage.max():5d}] | wait loads {d(1, 0).mean():6.0f}  convert+store {d(2, 1).mean():6.0f}"
-                  f"  refill issue {d(3, 2).mean():6.0f}  barrier wait {(stage - d(3, 0)).mean():6.0f}")
+            print(f"producer {w}: stage {stage.mean():7.0f} [{stage.min():5d}..{stage.max():5d}] | (stamp) {d(1, 0).mean():6.0f}  convert+store+refill {d(2, 1).mean():6.0f}"
+                  f"  tail {d(3, 2).mean():6.0f}  barrier wait {(stage - d(3, 0)).mean():6.0f}")
         else:        # consumer: 0 = stage start, 1 = MFMAs issued, 2 = barrier passed
             print(f"consumer {w}: stage {stage.mean():7.0f} [{stage.min():5d}..{stage.max():5d}] | reads+MFMA issue {d(1, 0).mean():6.0f}  barrier wait {d(2, 1).mean():6.0f}"
                   f"  rest {(stage - d(2, 0)).mean():6.0f}")
