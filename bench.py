@@ -389,7 +389,7 @@ def main():
              "auto": "f32 (GEMM and attention operands scaled by powers of two and split into 2 f16 terms [activation x weight "
                      "products, weight-gradient products whose operands come with a uniform scale, attention with head size "
                      "64 / 32] or exactly into 3 bf16 terms [the other weight-gradient products; everything when tokens x "
-                     "d_model < 2^21] on the f16 / bf16 MFMA pipe, f32 accumulate; the rest f32)"}.get(
+                     "d_model < 2^20] on the f16 / bf16 MFMA pipe, f32 accumulate; the rest f32)"}.get(
         a.gemm_mode, "f32 (GEMM operands split exactly into 3 bf16 terms on the bf16 MFMA pipe, f32 accumulate; the rest f32)")
     if rank == 0:
         shape = (f"{a.batch} proteins x L={a.length} per GPU" if not a.ragged else

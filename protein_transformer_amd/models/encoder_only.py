@@ -426,7 +426,7 @@ class _EncoderFn(torch.autograd.Function):
         W = lambda name: m._slice(flat, name)                                      # noqa: E731
         ar = K.get_gemm_mode() if m.gemm_mode is None else int(m.gemm_mode)        # every launch below carries it
         attn_default = ar                 # the attention kernels find their f16x2 scales themselves: AUTO stays AUTO for them
-        if ar == K.GEMM_AUTO and B * L * D < (AUTO_F16X2_MIN_WORK >> 1 if D >= 512 else AUTO_F16X2_MIN_WORK):
+        if ar == K.GEMM_AUTO and B * L * D < AUTO_F16X2_MIN_WORK:
             ar = K.GEMM_BF16X3         # launch-bound step: the scale bookkeeping of f16x2 costs more than its products save
         pe = m.encoder.positional_enc.pe[0]
         # ---- front end: embedding (+ doubled positional add) or one-hot, then the optional Conv1d stack
@@ -653,10 +653,11 @@ class _EncoderFn(torch.autograd.Function):
         return None, None, None, None
 
 
-# tokens x d_model below which AUTO runs the whole step in bf16x3 (measured: 2.9 against 3.2 ms/step at 4096 x 256,
-# 10.2 against 9.8 at 16384 x 256 - profiles/r02/r02_v2_bench_cfg2.json, cfg3); half of it for d_model >= 512, where the
-# f16x2 path (with the LDS-DMA forward products) wins from 2048 tokens on (4.92 against 5.34 ms at 2048 x 512, round 3)
-AUTO_F16X2_MIN_WORK = 1 << 21
+# tokens x d_model below which AUTO runs the whole step in bf16x3: the scale bookkeeping of f16x2 costs more than its products
+# save on a launch-bound step (config 1: 1.04 against 1.39 ms).  From 2^20 on f16x2 wins: 4.92 against 5.34 ms at 2048 x 512
+# (with the LDS-DMA forward products), and since the producers of the staging GEMM were trimmed (end of round 3) also at
+# 4096 x 256: 2.23 against 2.28 ms (config 2; it was 3.2 against 2.9 in round 2).
+AUTO_F16X2_MIN_WORK = 1 << 20
 # tokens x d_model below which the weight-gradient products of the backward pass run on a SIDE stream next to the dX chain
 # (few output tiles per product: the persistent kernels leave CUs idle that the other stream's kernel can take).  Only for
 # d_model >= 512 and >= 4096 tokens: measured -5 % at 8, -3 % at 16, -1.2 % at 32 proteins x 512, +-3 % at 4
