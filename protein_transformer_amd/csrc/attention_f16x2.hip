@@ -387,9 +387,7 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2
     const float4 ivh = lh ? ivb : iva;
     const float fv[4] = {ivh.x * TWO14 * vn, ivh.y * TWO14 * vn, ivh.z * TWO14 * vn, ivh.w * TWO14 * vn};  // <= 2^14
     if (p_drop > 0.f) {
-      const uint32_t keep = attn_keep_bits_keys_in_rows(dk_, q_part, k0, lh);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = keep_or_zero(s[r], keep, r);  // the 1 / (1 - p) is applied to O at the end
+      attn_drop_keys_in_rows(dk_, q_part, k0, lh, s);  // the 1 / (1 - p) is applied to O at the end
     }
     // O^T[d][q] += V^T[d][key] P^T[key][q]: the accumulator rows of s are already in the k order of frag_cols
 #pragma unroll
@@ -581,7 +579,7 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2
       ug[j] = gq * iv[j];      // accumulator -> dP (with the dropout scale)
       wk[j] = scale * ik[j];   // dS -> dS / (K group scale): the operand of the product with the SCALED K^T
     }
-    const uint32_t keep = p_drop > 0.f ? attn_keep_bits_keys_in_rows(dk_, q_part, k0, lh) : 0xffffu;
+    if (p_drop > 0.f) attn_drop_keys_in_rows(dk_, q_part, k0, lh, dp);  // dropped probabilities carry no gradient: dP = 0 there
     float wmax = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -590,8 +588,7 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2
       const float4 b4 = *reinterpret_cast<const float4 *>(&sBias[cur][part][8 * j + 4 * lh]);
       const float nb = ((r & 3) == 0 ? b4.x : (r & 3) == 1 ? b4.y : (r & 3) == 2 ? b4.z : b4.w) - my_lse2;
       const float p = __builtin_amdgcn_exp2f(fmaf(s[r], cu[j], nb));
-      float g = dp[r] * ug[j];
-      if (p_drop > 0.f) g = keep_or_zero(g, keep, r);
+      const float g = dp[r] * ug[j];
       s[r] = p * (g - my_delta) * wk[j];
       wmax = fmaxf(wmax, fabsf(s[r]));
     }

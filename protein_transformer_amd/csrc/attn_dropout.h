@@ -47,6 +47,20 @@ __device__ __forceinline__ uint32_t attn_keep_bits_keys_in_rows(const AttnDrop &
   }
   return bits;
 }
+// The same decisions APPLIED to the 16 accumulator values of a lane instead of collected as bits: one 16-bit compare on a
+// half of the word and one select per element (the bit mask costs a compare, a select, a shift and an or per element to
+// build and two more to apply).  x[2j], x[2j + 1] belong to the word of pair j as above.
+template <typename V>
+__device__ __forceinline__ void attn_drop_keys_in_rows(const AttnDrop &d, uint32_t q_part, int k0, int lh, V &x) {
+  const uint32_t base = attn_kp_part(d, (uint32_t)((k0 >> 1) + 2 * lh));
+  const uint16_t t16 = (uint16_t)d.thr16;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t w = attn_word(q_part, base + (uint32_t)((j & 1) + 4 * (j >> 1)) * ATTN_C_K);
+    x[2 * j] = (uint16_t)w >= t16 ? x[2 * j] : 0.f;
+    x[2 * j + 1] = (uint16_t)(w >> 16) >= t16 ? x[2 * j + 1] : 0.f;
+  }
+}
 // Keys in lanes, queries in rows (dK/dV kernel), q0 = first query of the 32-query block: register r holds query
 // q0 + 4 lh + (r & 3) + 8 (r >> 2); the lane's key selects the half of every word.  Returns bit r = keep.
 __device__ __forceinline__ uint32_t attn_keep_bits_queries_in_rows(const AttnDrop &d, uint32_t key, int q0, int lh) {
