@@ -173,6 +173,33 @@ def test_drmsd_gradient_vs_autograd(dev):
     assert rel_l2(ag.grad.cpu().numpy(), a64.grad.numpy()) < 1e-4
 
 
+def test_drmsd_does_not_depend_on_the_batch_it_is_cut_for(dev):
+    """The pair kernel cuts a protein's triangle into work items of 16, 8 or 4 column tiles by the occupancy of the WHOLE
+    batch (drmsd.hip, tri_layout: 32 / 16 / 4 proteins x 512 residues take 16 / 8 / 4), and the finalize kernel adds the items'
+    partials in a fixed order: per-protein losses and gradients of the same proteins must agree to rounding whatever
+    batch they are computed in, and be identical from run to run."""
+    from protein_transformer_amd.losses import drmsd_forward_backward
+    B, L = 32, 512
+    g = torch.Generator().manual_seed(17)
+    pred = (torch.randn(B, L * 14, 3, generator=g) * 12).to(dev)
+    true = (torch.randn(B, L * 14, 3, generator=g) * 12)
+    true[torch.rand(B, L * 14, generator=g) < 0.3] = float("nan")          # absent atoms
+    true = true.to(dev)
+    seq = torch.randint(0, 20, (B, L), generator=g)
+    seq[1, 400:] = 20
+    seq[2, 77:] = 20
+    seq = seq.to(dev)
+    ref_s, ref_g = drmsd_forward_backward(pred, true, seq)
+    ref_s, ref_g = ref_s.clone(), ref_g.clone()
+    again_s, again_g = drmsd_forward_backward(pred, true, seq)
+    assert torch.equal(again_s, ref_s) and torch.equal(again_g, ref_g)
+    for nb in (16, 4):
+        s_, g_ = drmsd_forward_backward(pred[:nb].contiguous(), true[:nb].contiguous(), seq[:nb].contiguous())
+        assert torch.allclose(s_, ref_s[:nb], rtol=2e-6, atol=0), nb
+        scale = ref_g[:nb].abs().max().item()
+        assert torch.allclose(g_, ref_g[:nb], rtol=1e-4, atol=2e-6 * scale), nb
+
+
 def test_drmsd_work_golden(golden, dev):
     from protein_transformer_amd.losses import drmsd_work
     g = golden("g4_drmsd_work")
