@@ -195,6 +195,28 @@ def test_gemm_randomised(dev, seed):
         K_.set_gemm_mode(old)
 
 
+@pytest.mark.parametrize("mode", [1, 3])
+def test_gemm_tile_heights_agree(dev, mode):
+    """The staging GEMM takes 128-row tiles where 256-row tiles would leave most CUs idle (gemm_split_kernel.h, launch): the
+    same rows computed as part of a product that fills the chip with 256-row tiles and as a small product of their own
+    (128-row tiles) must be the same bits - epilogue and dropout masks included: an element's k order does not change."""
+    from protein_transformer_amd import kernels as K_
+    g = torch.Generator().manual_seed(5 + mode)
+    T, Ts, N, Kd = 16384, 1024, 512, 512
+    a = torch.randn(T, Kd, generator=g).to(dev)
+    w, bias = (torch.randn(N, Kd, generator=g) * 0.05).to(dev), torch.randn(N, generator=g).to(dev)
+    res = torch.randn(T, N, generator=g).to(dev)
+
+    def run(rows):
+        c = torch.empty(rows, N, device=dev)
+        K_.gemm(a[:rows], w, c, M=rows, N=N, K=Kd, lda=Kd, ldb=Kd, ldc=N, bias=bias, residual=res[:rows], ldr=N, dropout_p=0.1,
+                seed=11, stream_id=4, arith=mode)
+        return c
+    big, small = run(T), run(Ts)
+    assert torch.equal(big[:Ts], small)
+    assert (small == res[:Ts]).float().mean().item() > 0.05          # (dropped elements: the residual alone)
+
+
 def test_gemm_split_bf16_is_fp32_grade(dev):
     """The default arithmetic (three-term bf16 split, six MFMA products) against fp64, next to the exact-f32 MFMA.
 
