@@ -342,15 +342,17 @@ class _TransformerBase(nn.Module):
                 L["dqkv_stats"] = dq_stats[i]
                 L["minbuf"] = minbuf
             cache = caches[key] = dict(layers=layers, wjobs=wjobs, bjobs=bjobs, keep=(ints, stats, factor, ones, dq_stats, minbuf))
-            # the two weight matrices that sit behind a LayerNorm, pre-split once per forward pass for ptamd_gemm_hp
+            # the FFN-layer-1 weights (behind the second LayerNorm), pre-split once per forward pass for ptamd_gemm_hp.  (The QKV
+            # weights were too until the producers of the staging GEMM were trimmed at the end of round 3: QKV now runs
+            # 34.7 / 58.5 / 106.8 us on it at 4096 / 8192 / 16384 tokens against 35.4 / 70.5 / 110.3 on ptamd_gemm_hp, and the
+            # first LayerNorm no longer writes planes; FFN-1, with its ReLU + dropout epilogue, stays: 142 against 167 us.)
             cache["hp_mats"], cache["hp_outs"] = [], []
             if self.hp_forward and D % 32 == 0 and D <= 2048:
                 for i, L in enumerate(layers):
-                    wqkv, _ = self._qkv(flat, i)
                     w1 = W(f"encoder.enc_layers.{i}.pwff.layer1.weight")
-                    L["hp_qkv"], L["hp_1"] = K.HpOperand(3 * D, D, dev), K.HpOperand(F, D, dev)
-                    cache["hp_mats"] += [wqkv, w1]
-                    cache["hp_outs"] += [L["hp_qkv"], L["hp_1"]]
+                    L["hp_1"] = K.HpOperand(F, D, dev)
+                    cache["hp_mats"] += [w1]
+                    cache["hp_outs"] += [L["hp_1"]]
         K.weight_scales(cache["wjobs"])
         K.bound_scales(cache["bjobs"])
         if cache["hp_mats"] and hp:
@@ -453,7 +455,7 @@ class _EncoderFn(torch.autograd.Function):
         scales = m._step_scales(flat, ar, p, pa, hp=want_hp)
         # The products right behind a LayerNorm (QKV, FFN layer 1) run on ptamd_gemm_hp: the LayerNorm kernel writes its
         # output a second time as pre-split planes (one buffer, consumed at once), the weights were split above.
-        use_hp = want_hp and scales is not None and "hp_qkv" in scales[0]
+        use_hp = want_hp and scales is not None and "hp_1" in scales[0]
         hplanes = torch.empty(K.lib().ptamd_hp_bytes(Tn, D), dtype=torch.uint8, device=x.device) if use_hp else None
         for i in range(m.nlayers):
             b = f"encoder.enc_layers.{i}."
@@ -462,12 +464,8 @@ class _EncoderFn(torch.autograd.Function):
             wqkv, bqkv = m._qkv(flat, i)
             s_h1 = torch.empty(Tn, dtype=torch.int32, device=x.device) if sc else None
             h1, mean1, rstd1 = K.layernorm_fwd(x, W(b + "sublayer_connections.0.norm.weight"),
-                                               W(b + "sublayer_connections.0.norm.bias"), row_scale=s_h1, planes=hplanes)
-            if use_hp:
-                qkv = K.gemm_hp(K.hp_view(hplanes, s_h1, Tn, D), sc["hp_qkv"],
-                                torch.empty(Tn, 3 * D, dtype=torch.float32, device=x.device), bias=bqkv)
-            else:
-                qkv = K.linear_fwd(h1, wqkv, bqkv, arith=ar, a_scale=s_h1, b_scale=sc and sc["rs_qkv"])
+                                               W(b + "sublayer_connections.0.norm.bias"), row_scale=s_h1)
+            qkv = K.linear_fwd(h1, wqkv, bqkv, arith=ar, a_scale=s_h1, b_scale=sc and sc["rs_qkv"])
             att, lse = K.attention_fwd(qkv, seq, H, pa, seed, sid + _SITE_ATTN,
                                         arith=attn_default if m.attn_mode is None else m.attn_mode)
             x2 = K.linear_fwd(att, W(b + "self_attn.wo.weight"), W(b + "self_attn.wo.bias"), residual=x, ldr=D,
