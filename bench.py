@@ -40,9 +40,11 @@ sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0        # same table: dense bf16 / f16 matrix peak (the marketing figure includes 2:1 sparsity)
+TRAFFIC_RECORD = "r04/r04_gemm_hbm_traffic.json"     # under profiles/: PMC traffic of the GEMM launches of the default command
 
 CONFIGS = {   # BASELINE.json configs[i-1]
-    1: dict(model="enc-only", d_model=64, n_layers=2, n_head=8, d_ff=128, batch=4, length=64, loss="drmsd", ragged="short"),
+    # (-dih is not named by BASELINE configs[0]: the reference's default 2048, train.py:479 - 565,272 parameters)
+    1: dict(model="enc-only", d_model=64, n_layers=2, n_head=8, d_ff=2048, batch=4, length=64, loss="drmsd", ragged="short"),
     2: dict(model="enc-only", d_model=256, n_layers=4, n_head=8, d_ff=2048, batch=16, length=256, loss="drmsd"),
     3: dict(model="conv-enc|3,7,11|2,2,2", d_model=256, n_layers=6, n_head=8, d_ff=2048, batch=32, length=512, loss="combined"),
     4: dict(model="enc-only", d_model=512, n_layers=6, n_head=8, d_ff=2048, batch=32, length=512, loss="drmsd"),
@@ -69,10 +71,13 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-proteins", type=int, default=None, help="proteins in the bounded CPU-baseline sample (pool leg)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--verify-dp", action="store_true",
+                    help="pre-pass: the SUM over the ranks of the all-reduced gradient against the gradient of the whole global "
+                         "batch computed by rank 0 alone (dropout 0); reported as communication.verify_dp")
     ap.add_argument("--no-mode-sweep", action="store_true", help="skip the bf16x3 / f32 re-runs of the timed loop")
     ap.add_argument("--no-attn-row-scales", action="store_true", help="ablation: dqkv row scales by a pass over dqkv")
     ap.add_argument("--no-side-stream", action="store_true", help="ablation: weight-gradient products of small batches on the main stream")
-    ap.add_argument("--no-hp-forward", action="store_true", help="ablation: QKV / FFN-layer-1 forward products on ptamd_gemm instead of ptamd_gemm_hp")
+    ap.add_argument("--no-hp-forward", action="store_true", help="ablation: the FFN-layer-1 forward product on ptamd_gemm instead of ptamd_gemm_hp")
     ap.add_argument("--attn-mode", default=None, choices=["f32", "bf16x3", "f16x2"],
                     help="arithmetic of the attention kernels alone (ablation; default: that of --gemm-mode)")
     ap.add_argument("--gemm-mode", default="auto", choices=["f32", "bf16x3", "bf16x3full", "f16x2", "auto"],
@@ -117,7 +122,10 @@ def cpu_baseline(a, batch_cpu, params):
     host_cores = os.cpu_count() or 1
     avail, L = batch_cpu["seq"].shape
     heavy = L * L * a.d_model >= 200 * 200 * 512
-    n_pool = a.cpu_proteins or (min(8, avail) if heavy else min(avail, 16))
+    # The pool leg takes the WHOLE batch when the host has a core per protein (the reference's pool maps all of them at
+    # once: one protein per worker, ~12 s at L = 512); on a host with fewer cores a bounded sample of max(8, cores) proteins
+    # keeps the leg at 10-30 s
+    n_pool = a.cpu_proteins or (min(avail, max(8, min(32, host_cores))) if heavy else min(avail, 32))
     workers = max(1, min(host_cores, n_pool))           # the reference asks for cpu_count() workers; only n_pool get work
     t0 = time.perf_counter()
     # (workers pinned to one torch thread each: left at the default every worker starts cpu_count() intra-op threads and
@@ -185,6 +193,53 @@ def make_batches(a, rank, dev, n_batches):
         first = first or b
         out.append(tuple(b[k].pin_memory() for k in ("seq", "true_ang", "true_crd")))
     return out, synthetic.angle_means(first["true_ang"]), first
+
+
+def verify_dp(a, model, args, dev):
+    """`--verify-dp`: does the data-parallel step compute what one process computes on the global batch?  Every rank runs
+    forward + loss + backward on ITS batch with dropout 0 and the gradients are SUM-all-reduced the way a step does it
+    (per-layer hooks from the backward pass); rank 0 then regenerates every rank's batch, runs the concatenated global batch
+    alone (no collective: dp.single_process) and reports || sum_ranks g - g_full || / || g_full ||.  Reference semantics:
+    the gradient is the SUM over proteins (losses.py:166-167)."""
+    from protein_transformer_amd import dp
+    from protein_transformer_amd.train import get_losses
+    world, rank = dp.world_size(), dp.rank()
+    p, pa = model.dropout, model.attn_dropout
+    model.set_dropout(0.0)
+
+    def grad_of(batch):
+        seq, ang, crd = (t.to(dev) for t in batch)
+        model.zero_grad()
+        pred = model(seq, ang)
+        get_losses(args, pred, ang, crd, seq, n_res=int((seq != 20).sum()))
+        dp.all_reduce_gradients(model)
+        torch.cuda.synchronize()
+        return model.flat_parameters()[1].clone()
+
+    g_sum = grad_of(make_batches(a, rank, dev, 1)[0][0])
+    out = None
+    if rank == 0:
+        parts = [make_batches(a, r, dev, 1)[0][0] for r in range(world)]
+        Lmax = max(b[0].shape[1] for b in parts)
+
+        def pad(t, n, value):                                          # [B, n_i, ...] -> [B, n, ...]
+            if t.shape[1] == n:
+                return t
+            fill = torch.full((t.shape[0], n - t.shape[1]) + tuple(t.shape[2:]), value, dtype=t.dtype)
+            return torch.cat([t, fill], 1)
+        full = (torch.cat([pad(b[0], Lmax, 20) for b in parts]), torch.cat([pad(b[1], Lmax, 0.0) for b in parts]),
+                torch.cat([pad(b[2], Lmax * 14, 0.0) for b in parts]))
+        with dp.single_process(model):
+            g_full = grad_of(full)
+        num, den = float((g_sum.double() - g_full.double()).norm()), float(g_full.double().norm())
+        out = {"rel_l2": num / max(den, 1e-300), "grad_norm_full_batch": den, "global_batch": int(full[0].shape[0]),
+               "tolerance": 1e-4, "ok": bool(num <= 1e-4 * den),
+               "what": "|| SUM over ranks of the all-reduced gradient - gradient of the whole global batch computed by rank 0 "
+                       "alone || / || the latter ||, dropout 0, same model"}
+    dp.barrier()
+    model.set_dropout(p, pa)
+    model.zero_grad()
+    return out
 
 
 def make_model(a, angle_means, dev):
@@ -262,6 +317,8 @@ def main():
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         return float(t.item()), out
 
+    who = dp.describe()                                              # backend, RCCL version, every rank's device identity
+    verified = verify_dp(a, model, args, dev) if a.verify_dp else None
     for i in range(a.warmup):
         losses = step(i)
     timing = None if a.no_kernel_timing else []
@@ -278,7 +335,7 @@ def main():
     gc.disable()                # a generation-2 collection over the event pool costs ~60 ms when it lands in the timed steps
     dt, losses = timed(step, a.warmup)                               # THE timed region: K steps, nothing else on the host
     n_res_timed = sum(res_of[(a.warmup + i) % nb] for i in range(a.steps))
-    comm = None
+    comm = {k: who[k] for k in ("backend", "rccl_version", "world_size", "ranks_ok", "distinct_devices", "ranks_seen") if k in who}
     if world > 1:
         # the same K steps with two events per step around the tail wait of the gradient all-reduce: how much of the
         # reduction the overlap with backward did NOT hide (a pass of its own, like the GEMM events below)
@@ -288,12 +345,12 @@ def main():
         wt = torch.tensor([wait_ms], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(wt, op=torch.distributed.ReduceOp.MAX)     # the slowest rank's wait
         wait_ms = float(wt.item())
-        comm = {"allreduce_wait_ms": round(wait_ms, 4), "comm_bytes": nbytes,
+        comm.update({"allreduce_wait_ms": round(wait_ms, 4), "comm_bytes": nbytes,
                 "ms_per_step_in_this_pass": round(1e3 * dt_comm / a.steps, 3),
                 "what": "per step and rank: time the compute stream waited for the SUM all-reduce of the flat gradient (issued per "
                         "encoder layer from the backward pass, RCCL stream) after backward had been enqueued; bytes all-reduced "
                         "(+ one 19-entry fp64 vector of loss statistics)",
-                "reserved_cus": int(kernels.GEMM_RESERVED_CUS)}
+                "reserved_cus": int(kernels.GEMM_RESERVED_CUS)})
     dt_h2d, _ = timed(step_h2d, a.warmup)
     dt_inst = None
     if timing is not None:
@@ -328,12 +385,32 @@ def main():
     flat_p, flat_g = model.flat_parameters()
     if not (bool(torch.isfinite(flat_p).all()) and bool(torch.isfinite(flat_g).all())):
         sys.exit("bench.py: non-finite parameters / gradients after the timed steps - the measurement is invalid")
+    # ... and after all those steps every rank must hold the SAME parameters, bit for bit (same SUM-reduced gradient, same
+    # update): max - min over the ranks of sum |p| and of a hash of the flat buffer's bit patterns, both 0 or the line says so
+    comm["param_checksum_spread"] = dp.param_checksum_spread(model)
+    if verified is not None or a.verify_dp:
+        comm["verify_dp"] = verified
 
-    traffic = None          # HBM bytes per GEMM launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-    tpath = os.path.join(ROOT, "profiles", "r03", "r03_gemm_hbm_traffic.json")
-    if os.path.exists(tpath) and a.config == 4 and a.batch == 32 and a.gemm_mode == "auto":
-        with open(tpath) as f:
-            traffic = round(json.load(f)["hbm_bytes_per_launch"])
+    # HBM bytes per GEMM launch: NOT measured in this run (PMC counters need rocprofv3 around the process) but read from the
+    # record of separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this command (profiles/tools/r04_collect.sh ->
+    # profiles/summarize.py traffic); the record names the GEMM sources it was measured on and is refused when they differ
+    traffic, traffic_note = None, None
+    tpath = os.path.join(ROOT, "profiles", TRAFFIC_RECORD)
+    if a.config == 4 and a.batch == 32 and a.gemm_mode == "auto":
+        from protein_transformer_amd.build import gemm_source_digest
+        if not os.path.exists(tpath):
+            traffic_note = f"no record profiles/{TRAFFIC_RECORD}"
+        else:
+            with open(tpath) as f:
+                rec = json.load(f)
+            if rec.get("gemm_source_digest") != gemm_source_digest():
+                traffic_note = (f"profiles/{TRAFFIC_RECORD} was measured on other GEMM sources (digest "
+                                f"{str(rec.get('gemm_source_digest'))[:12]} != {gemm_source_digest()[:12]}): stale, not reported")
+            else:
+                traffic = round(rec["hbm_bytes_per_launch"])
+                traffic_note = (f"read from profiles/{TRAFFIC_RECORD} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                f"command on the same GEMM sources, digest {gemm_source_digest()[:12]}; FETCH x 2 per the gfx950 "
+                                f"correction of the guide); not measured in this run")
     roofline = None
     if timing:
         flops = sum(t[0] for t in timing)
@@ -363,7 +440,9 @@ def main():
         pipe_peak = BF16_MFMA_PEAK_TFLOPS if products > 1 else F32_MFMA_PEAK_TFLOPS
         roofline = {"bound": "mfma", "kernel": kern,
                     "achieved": round(issued, 1), "peak": pipe_peak, "unit": "TFLOP/s",
-                    "frac": round(issued / pipe_peak, 4), "traffic": traffic,
+                    "frac": round(issued / pipe_peak, 4), "traffic": traffic, "traffic_source": traffic_note,
+                    "mfma_issue_frac": round(issued / pipe_peak, 4),
+                    "algorithmic_frac_of_f32_mfma_peak": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
                     "achieved_is": "matrix-pipe FLOP ISSUED per second of GEMM kernel time: algorithmic 2*M*N*K of every launch x the "
                                    "matrix-pipe products its arithmetic spends per fp32 product (3: two f16 terms, 6 / 9: three bf16 "
                                    "terms, 1: f32 MFMA), HIP events around every ptamd_gemm / ptamd_gemm_hp call",
@@ -373,8 +452,10 @@ def main():
                                        "what": "algorithmic fp32 FLOP per second, and the rate at which the launch mix would run with "
                                                "the matrix pipe at its dense peak throughout: sum(flop) / sum(flop_i * products_i / peak)"},
                     "launch_mix": mix,
-                    "traffic_unit": "HBM bytes per launch (PMC, profiles/r03/r03_gemm_hbm_traffic.json: separate --pmc FETCH_SIZE / "
-                                    "WRITE_SIZE passes, FETCH x 2 per the gfx950 correction of the guide)",
+                    "traffic_unit": "HBM bytes per launch",
+                    "frac_is": "mfma_issue_frac = achieved / peak (the definition of rounds 3-4); rounds 1-2 printed the algorithmic fp32 "
+                               "rate, kept in f32_equivalent (and against the f32 MFMA peak in algorithmic_frac_of_f32_mfma_peak) so "
+                               "that the series stays comparable",
                     "algorithmic_bytes_per_launch": round(sum(b for b in gemm_bytes) / max(len(gemm_bytes), 1)),
                     "launches_per_step": round(len(timing) / a.steps, 1), "avg_launch_us": round(1e3 * ms / len(timing), 2),
                     "gflop_per_step": round(flops / a.steps / 1e9, 1),
@@ -411,8 +492,12 @@ def main():
             "arithmetic_modes": {a.gemm_mode: {"ms_per_step": round(1e3 * dt / a.steps, 3)}, **sweep},
             "roofline": roofline,
         }
-        if comm is not None:
-            out["communication"] = comm
+        # the guard of AUTO's bound-derived f16x2 scales (models/encoder_only.py AutoGuard): products per step that left their
+        # bound for exact scales / bf16x3 because the measured slack of the bound exceeded 8 binades, and what was measured
+        guard = model.auto_guard.report()
+        out["auto_fallbacks_per_step"] = round(guard["fallbacks_per_step"], 3)
+        out["auto_guard"] = guard
+        out["communication"] = comm
         if world == 1 and not a.no_cpu_baseline:
             keys = ("seq", "true_ang", "true_crd")
             pick = min(range(nb), key=lambda i: abs(host_batches[i][0].shape[1] - 200)) if a.ragged == "binned" else 0

@@ -50,6 +50,19 @@ def _digest(path, extra):
     return h.hexdigest()
 
 
+def gemm_source_digest():
+    """SHA-1 over the sources of the GEMM kernels: what a stored PMC traffic record (profiles/rNN/*_gemm_hbm_traffic.json)
+    names as the code it was measured on; bench.py reports a record only while the digest matches the tree."""
+    h = hashlib.sha1()
+    names = sorted(glob.glob(os.path.join(CSRC, "gemm*")) + [os.path.join(CSRC, n) for n in ("hp_format.h", "split_bf16.h", "common.h")])
+    for n in names:
+        if os.path.isfile(n):
+            h.update(os.path.basename(n).encode())
+            with open(n, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ_DIR, exist_ok=True)
     headers = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h")))

@@ -335,8 +335,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dropout_kernel(
       for (int j = 0; j < NV; ++j) {
         const int c = (j * 64 + lane) * 4;
         if (c < D) {
-          // rs * (..) + r as ONE fma each, like the compiler contracts `o += r` in layernorm_bwd_kernel (the two kernels are
-          // compared bit for bit); r * rflag is exact (rflag is 0 or 1: no residual gradient -> + 0)
+          // rs * (..) + r as ONE fma each (r * rflag is exact: rflag is 0 or 1, no residual gradient -> + 0).  The unfused
+          // layernorm_bwd_kernel contracts differently, so the two agree to rounding, not bit for bit
+          // (tests/test_gpu_scales.py compares them at 2e-6 relative)
           const float4 r = ra[f & 1][j];
           float4 o = make_float4(fmaf(rs, gy[j].x - m1 - xh[j].x * m2, r.x * rflag), fmaf(rs, gy[j].y - m1 - xh[j].y * m2, r.y * rflag),
                                  fmaf(rs, gy[j].z - m1 - xh[j].z * m2, r.z * rflag), fmaf(rs, gy[j].w - m1 - xh[j].w * m2, r.w * rflag));

@@ -28,12 +28,38 @@ def is_initialized():
     return dist.is_available() and dist.is_initialized()
 
 
+_SINGLE = 0          # > 0 inside `single_process()`: this process acts as a world of one (no collectives)
+
+
 def world_size():
-    return dist.get_world_size() if is_initialized() else 1
+    return dist.get_world_size() if is_initialized() and not _SINGLE else 1
 
 
 def rank():
-    return dist.get_rank() if is_initialized() else 0
+    return dist.get_rank() if is_initialized() and not _SINGLE else 0
+
+
+class single_process:
+    """Context: inside it THIS process runs as a world of one - `world_size()` is 1, no collective is issued, a model's
+    gradient hook is detached - while the process group stays up.  For self-checks that compare the data-parallel result
+    with the same work done by one rank (`bench.py --verify-dp`); the other ranks must not enter a collective meanwhile."""
+
+    def __init__(self, model=None):
+        self.model, self.hook = model, None
+
+    def __enter__(self):
+        global _SINGLE
+        _SINGLE += 1
+        if self.model is not None:
+            self.hook, self.model.grad_hook = self.model.grad_hook, None
+        return self
+
+    def __exit__(self, *exc):
+        global _SINGLE
+        _SINGLE -= 1
+        if self.model is not None:
+            self.model.grad_hook = self.hook
+        return False
 
 
 def local_rank():
@@ -178,6 +204,54 @@ def all_reduce_gradients(model, empty=False):
     if meter:
         e1.record()
         COMM_METER.append((e0, e1, nbytes))
+
+
+def describe():
+    """Who is in the job, as the job itself sees it (the self-check block of the bench line): backend, collective library
+    version, and for every rank its device identity - gathered over the process group, so a rank that is missing, doubled
+    or sitting on the same GPU as another one shows up here and not only in the scaling curve."""
+    me = {"rank": rank(), "local_rank": local_rank(), "host": os.uname().nodename, "pid": os.getpid()}
+    if torch.cuda.is_available():
+        i = torch.cuda.current_device()
+        pr = torch.cuda.get_device_properties(i)
+        me.update(device=i, name=pr.name, uuid=str(getattr(pr, "uuid", "")), cus=int(pr.multi_processor_count),
+                  pci=str(getattr(pr, "pci_bus_id", "")) + ":" + str(getattr(pr, "pci_device_id", "")))
+    out = {"backend": dist.get_backend() if is_initialized() else "none (single process)", "world_size": world_size()}
+    if out["backend"] == "nccl":
+        try:
+            out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:                                    # noqa: BLE001 - a version string is not worth a failed run
+            out["rccl_version"] = f"unknown ({type(e).__name__})"
+    if world_size() > 1:
+        seen = [None] * world_size()
+        dist.all_gather_object(seen, me)
+    else:
+        seen = [me]
+    out["ranks_seen"] = seen
+    ids = [(r.get("host"), r.get("uuid") or r.get("pci") or r.get("device")) for r in seen]
+    out["distinct_devices"] = len(set(ids))
+    out["ranks_ok"] = sorted(r["rank"] for r in seen) == list(range(world_size()))
+    return out
+
+
+def param_checksums(model):
+    """(sum |p| in fp64, wrap-around int64 sum of the parameters' BIT PATTERNS) of the flat parameter buffer: two numbers
+    that are equal on every rank iff the ranks hold the same parameters (the second one bit for bit, order-independent)."""
+    flat, _ = model.flat_parameters()
+    return float(flat.double().abs().sum().item()), int(flat.view(torch.int32).to(torch.int64).sum().item())
+
+
+def param_checksum_spread(model):
+    """max - min over the ranks of the two `param_checksums` (must both be 0: after the SUM all-reduce every rank applies
+    the same update to the same parameters) + rank 0's values."""
+    a, h = param_checksums(model)
+    if world_size() == 1:
+        return {"abs_sum_spread": 0.0, "bit_hash_spread": 0, "abs_sum": a, "bit_hash": h, "ranks": 1}
+    every = [None] * world_size()
+    dist.all_gather_object(every, (a, h))
+    return {"abs_sum_spread": max(x[0] for x in every) - min(x[0] for x in every),
+            "bit_hash_spread": max(x[1] for x in every) - min(x[1] for x in every),
+            "abs_sum": every[0][0], "bit_hash": every[0][1], "ranks": len(every)}
 
 
 def all_reduce_sum_(t):

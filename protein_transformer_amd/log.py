@@ -107,6 +107,9 @@ def update_loss_trackers(args, epoch_i, metrics):
     return metrics
 
 
+REFERENCE_CSV = False     # True: the granularity column carries upstream's literal "epoch" on every row (log.py:130)
+
+
 def prepare_log_header(args):
     if args.loss == "combined":
         return 'drmsd,ln_drmsd,rmse,rmsd,combined,lr,mode,granularity,time,speed'
@@ -117,13 +120,15 @@ def log_batch(log_writer, metrics, start_time, mode="valid", end_of_epoch=False,
     """One CSV row (log.py:115-130): ten values - drmsd, ln_drmsd, rmse, rmsd, combined, lr, mode, granularity, time,
     speed; like upstream the `combined` value is written whatever the header of `prepare_log_header` lists.  One
     deliberate difference: the granularity column says "batch" for per-batch rows (upstream writes the literal "epoch"
-    in both cases, log.py:130)."""
+    in both cases, log.py:130) - unless `REFERENCE_CSV` is set (`train.py --reference-csv`), which reproduces the
+    upstream column byte for byte for consumers of the reference's `.train` files."""
     t = t or time.time()
     m = metrics[mode]
     be = "epoch" if end_of_epoch else "batch"
+    label = "epoch" if REFERENCE_CSV else be
     lr = metrics["history-lr"][-1] if metrics["history-lr"] else 0
     log_writer.writerow([m[f"{be}-drmsd-full"], m[f"{be}-lndrmsd-full"], np.sqrt(m[f"{be}-mse-full"]),
-                         m[f"{be}-rmsd-full"], m[f"{be}-combined-full"], lr, mode, be, round(t - start_time, 4),
+                         m[f"{be}-rmsd-full"], m[f"{be}-combined-full"], lr, mode, label, round(t - start_time, 4),
                          m.get("speed", 0)])
 
 

@@ -99,6 +99,100 @@ class _EncoderHolder(nn.Module):
         self.enc_layers = nn.ModuleList([_LayerHolder(dlayer, dff) for _ in range(n_layers)])
 
 
+class AutoGuard:
+    """Run-time guard of the BOUND-derived f16x2 scales of the AUTO arithmetic (csrc/scales.hip).
+
+    Five operands per encoder layer are scaled by a bound that follows from the weights alone instead of their measured
+    maximum: the attention output `att` and the FFN hidden layer `f1` (A of the two products behind them and one operand of
+    their weight-gradient products), the hidden gradient `dz1` (bound from the row norms of `dy2`), and the LayerNorm
+    outputs `h1`, `h2` as operands of weight-gradient products.  A bound 2^k above the true maximum costs k of the 18
+    binades in which an element keeps its 22 bits - nothing a step can see while k is small, but nothing in the step
+    measures k either.  The guard does, off the hot path: every `interval`-th training step (and the first one) the
+    backward pass measures the true max |x| of the five operands of every layer with one small launch per layer
+    (ptamd_weight_scales' statistics: a streaming pass, ~0.35 ms per measured step at config 4), copies them and the bound
+    scales to pinned host memory behind an event, and the next forward pass that finds the event complete turns them into
+    `slack[layer][site]` binades - no host synchronisation anywhere.  Where slack > `max_slack` (or the bound was
+    VIOLATED, slack < 0) the operand stops using its bound: the activation x weight products take the exact row scales of
+    a pass over the operand (ptamd_gemm finds them itself when `a_scale` is NULL - still f16x2, exact scales), the
+    weight-gradient products run in bf16x3 (exact three-term split, no scales).  The first step of a model runs on the
+    bounds (nothing is measured yet); `fallbacks` counts the products switched, per step."""
+    SITES = ("att", "f1", "dz1", "h1", "h2")
+    # products a site switches when it falls back: (activation x weight products, weight-gradient products)
+    PRODUCTS = {"att": 2, "f1": 2, "dz1": 2, "h1": 1, "h2": 1}
+
+    def __init__(self, nlayers, interval=16, max_slack=8):
+        self.nlayers, self.interval, self.max_slack = nlayers, int(interval), int(max_slack)
+        self.enabled = True
+        self.off = np.zeros((nlayers, len(self.SITES)), dtype=bool)      # True: the site does not use its bound
+        self.slack = None                                               # last measured binades [nlayers, 5]
+        self.max_slack_seen = np.full(len(self.SITES), -np.inf)
+        self.violations = 0                                             # bounds found BELOW the measured maximum
+        self.train_steps = self.measured_steps = self.fallback_products = 0
+        self._pending = None
+
+    def want_measure(self):
+        return self.enabled and self._pending is None and self.train_steps % max(self.interval, 1) == 0
+
+    def submit(self, stats, ints, minbuf, layers):
+        """Called at the end of a measuring backward pass: asynchronous copies of the measured maxima and of the bound
+        scales into pinned memory, one event behind them."""
+        host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (stats, ints, minbuf)]
+        for h, t in zip(host, (stats, ints, minbuf)):
+            h.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        # element offsets of the uniform bound scales inside `ints` / `minbuf` (views of them, see _step_scales)
+        where = [{k: (L[k].storage_offset() - ints.storage_offset()) for k in ("att_scale", "f1_scale", "h1_scale", "h2_scale")}
+                 for L in layers]
+        self._pending = (ev, host, where)
+
+    def poll(self):
+        """Called at the start of every forward pass: if a measurement has landed, update the slack table and the sites."""
+        if self._pending is None or not self._pending[0].query():
+            return
+        _, (stats, ints, minbuf), where = self._pending
+        self._pending = None
+        mx = stats.numpy()[:, :, 2].astype(np.float64)                  # [nlayers, 5]: max |x| of att, f1, dz1, h1, h2
+        bits = ints.numpy().view(np.uint32)
+        mb = minbuf.numpy().view(np.uint32)
+        sb = np.array([[bits[where[i]["att_scale"]], bits[where[i]["f1_scale"]], mb[i, 4], bits[where[i]["h1_scale"]],
+                        bits[where[i]["h2_scale"]]] for i in range(self.nlayers)], dtype=np.uint32)
+        slack = self.slack_binades(mx, sb)
+        self.slack = slack
+        self.measured_steps += 1
+        self.max_slack_seen = np.maximum(self.max_slack_seen, slack.max(0))
+        self.violations += int((slack < 0).sum())
+        self.off = (slack > self.max_slack) | (slack < 0)
+
+    @staticmethod
+    def slack_binades(max_abs, scale_bits):
+        """Binades by which a bound exceeds what it bounds.  `scale_bits`: the f16x2 scale derived from the bound - the
+        power of two that takes the BOUND into [2^14, 2^15) - as uint32 bit patterns; `max_abs`: the measured max |x|.
+        max_abs * scale lies in [2^(14-k), 2^(15-k)): k = 0 when the bound is as good as the maximum, k < 0 when the bound
+        was too small (the f16 split would overflow from k <= -1).  Slots whose scale is the atomicMin preset 0x7F000000
+        (no bound-derived scale in this pass) and all-zero operands count as k = 0."""
+        max_abs = np.asarray(max_abs, dtype=np.float64)
+        scale_bits = np.asarray(scale_bits, dtype=np.uint32)
+        s = scale_bits.view(np.float32).astype(np.float64)
+        m = max_abs * s
+        ok = (scale_bits != 0x7F000000) & np.isfinite(m) & (m > 0)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            k = 14.0 - np.floor(np.log2(np.where(ok, m, 2.0 ** 14)))
+        return np.where(ok, k, 0.0)
+
+    def count_step(self):
+        self.train_steps += 1
+        self.fallback_products += int(sum(self.PRODUCTS[s] * int(self.off[:, j].sum()) for j, s in enumerate(self.SITES)))
+
+    def report(self):
+        return {"fallbacks_per_step": self.fallback_products / max(self.train_steps, 1), "measured_steps": self.measured_steps,
+                "steps": self.train_steps, "interval": self.interval, "max_slack_binades_allowed": self.max_slack,
+                "bound_violations": self.violations,
+                "max_slack_binades_seen": {s: (None if not np.isfinite(v) else float(v))
+                                           for s, v in zip(self.SITES, self.max_slack_seen)},
+                "sites_off_bounds_now": int(self.off.sum())}
+
+
 class _TransformerBase(nn.Module):
     """Shared implementation of `enc-only` and `conv-enc`: parameter flattening, forward/backward driver."""
 
@@ -148,8 +242,9 @@ class _TransformerBase(nn.Module):
         self.attn_row_scales = True                  # dqkv row scales from the attention backward kernels (False: a pass; ablation)
         self.attn_mode = None                        # arithmetic of the attention kernels alone (ablations); None = gemm_mode
         self.gemm_mode = None                        # kernels.GEMM_* arithmetic of THIS model; None = kernels.get_gemm_mode()
-        self.hp_forward = True                       # QKV / FFN-layer-1 products on ptamd_gemm_hp from LayerNorm-written planes
+        self.hp_forward = True                       # FFN-layer-1 forward product on ptamd_gemm_hp from LayerNorm-written planes (read every pass)
         self.side_stream_dw = True                   # small batches: weight-gradient products on a side stream
+        self.auto_guard = AutoGuard(nlayers)         # measures the slack of the bound-derived f16x2 scales, falls back per site
         self._init_parameters()
 
     # ------------------------------------------------------------------ parameters
@@ -338,16 +433,19 @@ class _TransformerBase(nn.Module):
                 layers.append(L)
             assert o == n_i
             dq_stats = torch.zeros(self.nlayers, 4, dtype=torch.float32, device=dev)
+            gstats = torch.zeros(self.nlayers, len(AutoGuard.SITES), 4, dtype=torch.float32, device=dev)   # AutoGuard measurements
             for i, L in enumerate(layers):
                 L["dqkv_stats"] = dq_stats[i]
                 L["minbuf"] = minbuf
-            cache = caches[key] = dict(layers=layers, wjobs=wjobs, bjobs=bjobs, keep=(ints, stats, factor, ones, dq_stats, minbuf))
+                L["guard_stats"], L["ints"] = gstats, ints
+            cache = caches[key] = dict(layers=layers, wjobs=wjobs, bjobs=bjobs,
+                                       keep=(ints, stats, factor, ones, dq_stats, minbuf, gstats))
             # the FFN-layer-1 weights (behind the second LayerNorm), pre-split once per forward pass for ptamd_gemm_hp.  (The QKV
             # weights were too until the producers of the staging GEMM were trimmed at the end of round 3: QKV now runs
             # 34.7 / 58.5 / 106.8 us on it at 4096 / 8192 / 16384 tokens against 35.4 / 70.5 / 110.3 on ptamd_gemm_hp, and the
             # first LayerNorm no longer writes planes; FFN-1, with its ReLU + dropout epilogue, stays: 142 against 167 us.)
             cache["hp_mats"], cache["hp_outs"] = [], []
-            if self.hp_forward and D % 32 == 0 and D <= 2048:
+            if D % 32 == 0 and D <= 2048:         # (built whatever `hp_forward` says now: the flag is read at use time)
                 for i, L in enumerate(layers):
                     w1 = W(f"encoder.enc_layers.{i}.pwff.layer1.weight")
                     L["hp_1"] = K.HpOperand(F, D, dev)
@@ -451,12 +549,23 @@ class _EncoderFn(torch.autograd.Function):
         # outputs from the LayerNorm kernel itself (None: the arithmetic of this pass does not use them)
         Tn = B * L
         # (below HP_MIN_TOKENS the staging GEMM with 128-row tiles is the faster of the two: profiles/r03/r03_tile_height.txt)
-        want_hp = Tn >= HP_MIN_TOKENS
+        want_hp = Tn >= HP_MIN_TOKENS and bool(m.hp_forward)
         scales = m._step_scales(flat, ar, p, pa, hp=want_hp)
-        # The products right behind a LayerNorm (QKV, FFN layer 1) run on ptamd_gemm_hp: the LayerNorm kernel writes its
-        # output a second time as pre-split planes (one buffer, consumed at once), the weights were split above.
+        # FFN layer 1 (the product behind the second LayerNorm) runs on ptamd_gemm_hp: the LayerNorm kernel writes its
+        # output a second time as pre-split planes (one buffer, consumed at once), the weights were split above.  (QKV, the
+        # product behind the first LayerNorm, is as fast on the staging GEMM since the end of round 3 and stays there.)
         use_hp = want_hp and scales is not None and "hp_1" in scales[0]
         hplanes = torch.empty(K.lib().ptamd_hp_bytes(Tn, D), dtype=torch.uint8, device=x.device) if use_hp else None
+        # the guard of the bound-derived scales: sites whose measured slack is too large do not use their bound (AutoGuard)
+        guard = m.auto_guard if (scales is not None and m.auto_guard.enabled) else None
+        measure = False
+        if guard is not None:
+            guard.poll()
+            if train and torch.is_grad_enabled():
+                measure = guard.want_measure()
+                guard.count_step()
+        off = guard.off if guard is not None else None
+        ctx_off = None if off is None else off.copy()
         for i in range(m.nlayers):
             b = f"encoder.enc_layers.{i}."
             sid = i * 8
@@ -468,9 +577,11 @@ class _EncoderFn(torch.autograd.Function):
             qkv = K.linear_fwd(h1, wqkv, bqkv, arith=ar, a_scale=s_h1, b_scale=sc and sc["rs_qkv"])
             att, lse = K.attention_fwd(qkv, seq, H, pa, seed, sid + _SITE_ATTN,
                                         arith=attn_default if m.attn_mode is None else m.attn_mode)
+            use_b = sc is not None and not (off is not None and off[i, 0])          # att on its bound (else: exact row scales)
             x2 = K.linear_fwd(att, W(b + "self_attn.wo.weight"), W(b + "self_attn.wo.bias"), residual=x, ldr=D,
                               dropout_p=p, seed=seed, stream_id=sid + _SITE_ATTN_OUT, arith=ar,
-                              a_scale=sc and sc["att_scale"], a_scale_stride=0, b_scale=sc and sc["rs_o"])
+                              a_scale=sc["att_scale"] if use_b else None, a_scale_stride=0 if use_b else 1,
+                              b_scale=sc and sc["rs_o"])
             s_h2 = torch.empty(Tn, dtype=torch.int32, device=x.device) if sc else None
             h2, mean2, rstd2 = K.layernorm_fwd(x2, W(b + "sublayer_connections.1.norm.weight"),
                                                W(b + "sublayer_connections.1.norm.bias"), row_scale=s_h2, planes=hplanes)
@@ -482,15 +593,18 @@ class _EncoderFn(torch.autograd.Function):
                 f1 = K.linear_fwd(h2, W(b + "pwff.layer1.weight"), W(b + "pwff.layer1.bias"), flags=K.EPI_RELU,
                                   dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_HID, arith=ar,
                                   a_scale=s_h2, b_scale=sc and sc["rs_1"])
+            use_b = sc is not None and not (off is not None and off[i, 1])          # f1 on its bound
             x3 = K.linear_fwd(f1, W(b + "pwff.layer2.weight"), W(b + "pwff.layer2.bias"), residual=x2, ldr=D,
                               dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_OUT, arith=ar,
-                              a_scale=sc and sc["f1_scale"], a_scale_stride=0, b_scale=sc and sc["rs_2"])
+                              a_scale=sc["f1_scale"] if use_b else None, a_scale_stride=0 if use_b else 1,
+                              b_scale=sc and sc["rs_2"])
             saved.append((x, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, f1))
             x = x3
         pred = K.linear_fwd(x, W("output_projection.weight"), W("output_projection.bias"),
                             flags=K.EPI_TANH if m.use_tanh_out else 0, arith=ar)
         ctx.model, ctx.seed, ctx.seq, ctx.flat, ctx.arith, ctx.attn_arith = m, seed, seq, flat, ar, attn_default
         ctx.p, ctx.pa = p, pa
+        ctx.guard, ctx.measure, ctx.off = guard, measure, ctx_off
         ctx.saved, ctx.conv_saved, ctx.scales = saved, conv_saved, scales
         ctx.x_last, ctx.pred = x, pred
         return pred
@@ -543,6 +657,7 @@ class _EncoderFn(torch.autograd.Function):
                     with torch.cuda.stream(side):
                         m.grad_hook(o0, o1 + int(np.prod(s1)) - o0)
 
+        off = ctx.off
         dpred = dpred.contiguous().view(-1, NUM_PREDICTED_ANGLES * 2)
         dpre = K.tanh_bwd(dpred, ctx.pred) if m.use_tanh_out else dpred
         K.linear_bwd_weight(dpre, ctx.x_last, G("output_projection.weight"), G("output_projection.bias"),
@@ -567,15 +682,20 @@ class _EncoderFn(torch.autograd.Function):
             if dy2 is None:
                 dy2 = K.dropout_bwd(dx, p, seed, sid + _SITE_FFN_OUT) if p > 0 else dx
             uni = sc is not None and have_min              # uniform scales of both operands: the dW product runs in f16x2
+            o_att, o_f1, o_dz1, o_h1, o_h2 = (bool(v) for v in off[i]) if off is not None else (False,) * 5   # AutoGuard
             dw(dy2, f1, G(b + "pwff.layer2.weight"), G(b + "pwff.layer2.bias"), arith=ar,
-                                dy_scale=sc["dy2_min"] if uni else None, x_scale=sc["f1_scale"] if uni else None)
+                                dy_scale=sc["dy2_min"] if uni and not o_f1 else None, x_scale=sc["f1_scale"] if uni and not o_f1 else None)
             # backward of layer2 and, in its epilogue, of the ReLU + dropout in front of it (gate = saved f1)
             dz1 = K.linear_bwd_input(dy2, W(b + "pwff.layer2.weight"), gate=f1, gate_dropout_p=p, arith=ar,
                                      a_scale=s_dy2 if sc else None, b_scale=sc and sc["cs_2"])
+            if ctx.measure:     # the true maxima of the five bound-scaled operands of this layer (AutoGuard; every 16th step)
+                gs = sc["guard_stats"][i]
+                K.weight_scales([dict(w=t, stats=gs[j], rows_only=True) for j, t in enumerate((att, f1, dz1, h1, h2))])
+            uni1 = uni and not (o_dz1 or o_h2)
             dw(dz1, h2, G(b + "pwff.layer1.weight"), G(b + "pwff.layer1.bias"), arith=ar,
-                                dy_scale=sc["dz1_min"] if uni else None, x_scale=sc["h2_scale"] if uni else None)
+                                dy_scale=sc["dz1_min"] if uni1 else None, x_scale=sc["h2_scale"] if uni1 else None)
             dh2 = K.linear_bwd_input(dz1, W(b + "pwff.layer1.weight"), arith=ar,
-                                     a_scale=bs_dz1 if sc else None, b_scale=sc and sc["cs_1"])
+                                     a_scale=bs_dz1 if sc and not o_dz1 else None, b_scale=sc and sc["cs_1"])
             # x2 = x + drop(att Wo^T + bo)
             g2w, g2b = G(b + "sublayer_connections.1.norm.weight"), G(b + "sublayer_connections.1.norm.bias")
             if fuse:
@@ -588,7 +708,7 @@ class _EncoderFn(torch.autograd.Function):
                 dx2 = K.layernorm_bwd(dh2, x2, W(b + "sublayer_connections.1.norm.weight"), mean2, rstd2, g2w, g2b, dres=dx,
                                       pending=ln_pending)
                 dyo = K.dropout_bwd(dx2, p, seed, sid + _SITE_ATTN_OUT) if p > 0 else dx2
-            uni_o = sc is not None and fuse
+            uni_o = sc is not None and fuse and not o_att
             dw(dyo, att, G(b + "self_attn.wo.weight"), G(b + "self_attn.wo.bias"), arith=ar,
                                 dy_scale=sc["dyo_min"] if uni_o else None, x_scale=sc["att_scale"] if uni_o else None)
             datt = K.linear_bwd_input(dyo, W(b + "self_attn.wo.weight"), arith=ar, a_scale=s_dyo, b_scale=sc and sc["cs_o"])
@@ -608,7 +728,7 @@ class _EncoderFn(torch.autograd.Function):
                     s_dqkv, dq_uni = i32(), sc["dqkv_scale"]
                     K.weight_scales([dict(w=dqkv, row_scale=s_dqkv, stats=sc["dqkv_stats"], rows_only=True)])
                     K.bound_scales([dict(w=sc["dqkv_stats"], w_index=2, out_scale=sc["dqkv_scale"])])
-                dw(dqkv, h1, gw, gb, arith=ar, dy_scale=dq_uni, x_scale=sc["h1_scale"])
+                dw(dqkv, h1, gw, gb, arith=ar, dy_scale=None if o_h1 else dq_uni, x_scale=None if o_h1 else sc["h1_scale"])
                 dh1 = K.linear_bwd_input(dqkv, wqkv, arith=ar, a_scale=s_dqkv, b_scale=sc["cs_qkv"])
             else:
                 dw(dqkv, h1, gw, gb, arith=ar)
@@ -632,6 +752,8 @@ class _EncoderFn(torch.autograd.Function):
             ctx.saved[i] = None
         K.layernorm_bwd_flush(ln_pending)
         join()
+        if ctx.measure:
+            ctx.guard.submit(scales[0]["guard_stats"], scales[0]["ints"], scales[0]["minbuf"], scales)
         # ---- front end
         if not m.use_embedding:
             dx = K.posenc_add_bwd(dx, p, seed)

@@ -404,6 +404,9 @@ def create_parser():
                      help="'B,L[,n_batches]': train on generated fixed-length batches instead of --data.")
     new.add_argument("--log_dir", type=str, default="../data/logs")
     new.add_argument("--chkpt_dir", type=str, default="../data/checkpoints")
+    new.add_argument("--reference-csv", dest="reference_csv", action="store_true",
+                     help="Write the granularity column of the .train log exactly like the reference (the literal 'epoch' "
+                          "on per-batch rows too, log.py:130) instead of 'batch' / 'epoch'.")
     return parser
 
 
@@ -444,6 +447,8 @@ def main():
     os.makedirs(args.log_dir, exist_ok=True)
     os.makedirs(args.chkpt_dir, exist_ok=True)
     args.log_file = os.path.join(args.log_dir, args.name + '.train')
+    from . import log as _log
+    _log.REFERENCE_CSV = bool(args.reference_csv)
     args.chkpt_path = os.path.join(args.chkpt_dir, args.name)
     START_TIME = time.time()                      # load_model moves it back by the checkpoint's elapsed time
     model, optimizer, scheduler, resumed, metrics = load_model(model, optimizer, scheduler, args)

@@ -110,6 +110,23 @@ def _worker(rank, world, port, out_dir):
     assert len(out[0][0]) == len(out[1][0]) > 0
     flat_eval = sorted(x for r in (0, 1) for b in out[r][1] for x in b)
     assert flat_eval == sorted(lens2)                                               # evaluation covers every protein once
+    # the self-check block of the bench line: who is in the job, and do the ranks hold the same parameters
+    who = dp.describe()
+    assert who["backend"] == "gloo" and who["world_size"] == world and who["ranks_ok"]
+    assert sorted(r["rank"] for r in who["ranks_seen"]) == [0, 1] and len({r["pid"] for r in who["ranks_seen"]}) == 2
+    same = types.SimpleNamespace(flat_parameters=lambda: (torch.arange(8, dtype=torch.float32) - 3.5, None))
+    sp = dp.param_checksum_spread(same)
+    assert sp["abs_sum_spread"] == 0.0 and sp["bit_hash_spread"] == 0 and sp["ranks"] == 2 and sp["abs_sum"] == 16.0
+    differ = types.SimpleNamespace(flat_parameters=lambda: (torch.arange(8, dtype=torch.float32) + 1e-3 * rank, None))
+    sp = dp.param_checksum_spread(differ)
+    assert sp["abs_sum_spread"] > 0 and sp["bit_hash_spread"] != 0                  # one ulp on one rank is seen
+    # single_process(): this rank acts as a world of one (no collective, hook detached) while the group stays up
+    hooked = types.SimpleNamespace(grad_hook=lambda *a: 1 / 0)
+    with dp.single_process(hooked):
+        assert dp.world_size() == 1 and dp.rank() == 0 and hooked.grad_hook is None
+        t1 = dp.all_reduce_sum_(torch.tensor([5.0]))
+        assert float(t1) == 5.0
+    assert dp.world_size() == world and dp.rank() == rank and hooked.grad_hook is not None
     dp.barrier()
     dp.shutdown()
 

@@ -9,9 +9,15 @@ and inputs through the HIP path and through the fp64 evaluation of the oracle's 
     per-protein drmsd (relative) and lndrmsd (absolute) deltas,
     relative L2 error of the parameter gradient - whole vector, per parameter group, and the worst single tensor.
 
-The record is written to gpurun_out/parity/r03_parity.json (copied to profiles/r03_parity.json for the judge); the test
+The record is written to gpurun_out/parity/r04_parity.json (copied to profiles/r04/r04_parity.json for the judge); the test
 asserts the section 8(d) tolerances on what it measured, per parameter GROUP for the gradients (a whole-vector norm cannot
 see a wrong gradient in a small group: LayerNorm gains, biases).
+
+Round 4: every configuration is run on `PTAMD_PARITY_SEEDS` independent draws (model initialisation AND batch; default 2
+in the test suite, 8 in the committed record: profiles/tools/r04_parity_seeds.sh) and the record carries, per config and
+arithmetic, the median and the maximum of every quantity over the draws, the per-group gradient errors, the number of
+draws in which two arithmetics took different sides of a ReLU, and the SKIP RATE of ill-conditioned draws - "which
+arithmetic is closest varies by draw" as a table instead of a sentence.
 
 Configs 3-5 are run on a 4-protein slice of their batch at full model size and full length: every quantity here is a
 per-protein quantity (losses, coordinates) or a sum over proteins (gradient), and the fp64 oracle step on the CPU is what
@@ -28,11 +34,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.environ.get("PTAMD_PARITY_OUT", os.path.join(ROOT, "gpurun_out", "parity", "r03_parity.json"))
+OUT = os.environ.get("PTAMD_PARITY_OUT", os.path.join(ROOT, "gpurun_out", "parity", "r04_parity.json"))
+N_DRAWS = int(os.environ.get("PTAMD_PARITY_SEEDS", "2"))
 
 # (BASELINE config number, model string, d_model, layers, heads, d_ff, lengths of the proteins run here, loss)
 CASES = [
-    (1, "enc-only", 64, 2, 8, 128, [64, 31, 17, 48], "drmsd"),
+    (1, "enc-only", 64, 2, 8, 2048, [64, 31, 17, 48], "drmsd"),       # (-dih at the reference's default, train.py:479)
     (2, "enc-only", 256, 4, 8, 2048, [256, 256, 201, 97], "drmsd"),
     (3, "conv-enc|3,7,11|2,2,2", 256, 6, 8, 2048, [512, 512, 300, 129], "combined"),
     (4, "enc-only", 512, 6, 8, 2048, [512, 512, 411, 77], "drmsd"),
@@ -84,8 +91,8 @@ def _angle_delta(a, b):
     return np.minimum(d, 2 * np.pi - d)
 
 
-@pytest.mark.parametrize("case", CASES, ids=[f"config{c[0]}" for c in CASES])
-def test_parity_record(case):
+def _run_draw(case, draw):
+    """One independent draw (model initialisation + batch) of one configuration -> its record (dict)."""
     from oracle import batched as obat
     from oracle import encoder as oenc
     from protein_transformer_amd import kernels as K_
@@ -113,12 +120,13 @@ def test_parity_record(case):
     # device - backbone within 2e-5 A of fp64 - but the one side-chain atom built on the collinear triple was 8.9e-3 A off,
     # and the oracle's fp32 chain 1 - 4e-3 A off from there to the end of the chain.)
     skipped = []
-    gen = torch.Generator().manual_seed(1234 + cfg)
+    gen = torch.Generator().manual_seed(1234 + cfg + 7919 * draw)
     for attempt in range(8):
-        seed = 100 + cfg + 1000 * attempt
+        seed = 100 + cfg + 1000 * attempt + 100000 * draw
         batch = synthetic.make_batch(lens, L_pad=L, seed=seed, build_coords=build, frac_missing=0.02)
         seq, ang, crd = (batch[k].to(dev) for k in ("seq", "true_ang", "true_crd"))
-        model = _make_model(dev, model_s, dm, nl, nh, dff, L, synthetic.angle_means(batch["true_ang"]), seed=7 + cfg + attempt)
+        model = _make_model(dev, model_s, dm, nl, nh, dff, L, synthetic.angle_means(batch["true_ang"]),
+                            seed=7 + cfg + attempt + 131 * draw)
         rad_probe = angles_forward(model(seq, ang).detach()).cpu().double()
         c64 = obat.generate_coords_batched(rad_probe, seq.cpu(), torch.float64).numpy()
         sign = torch.randint(0, 2, rad_probe.shape, generator=gen).double() * 2 - 1
@@ -149,7 +157,7 @@ def test_parity_record(case):
 
     rec = {"config": cfg, "model": f"{model_s} d_model={dm} n_layers={nl} n_head={nh} d_ff={dff}", "lengths": lens,
            "loss": loss, "dropout": 0.0, "reference": "fp64 evaluation of the oracle (oracle.encoder + oracle.batched)",
-           "seed": seed, "skipped_draws": skipped, "modes": {}}
+           "seed": seed, "draw": draw, "skipped_draws": skipped, "modes": {}}
     old = K_.get_gemm_mode()
     # The ReLU of the FFN is not differentiable at 0: an element of the hidden layer within rounding of 0 is "on" in one
     # arithmetic and "off" in another (or in fp64), and its whole back-propagated term then differs - with per-token
@@ -231,6 +239,47 @@ def test_parity_record(case):
     flips = {f"{a}_vs_{b}": [int((x != y).sum().item()) for x, y in zip(gates[a], gates[b])][::-1]
              for a, b in (("auto", "bf16x3"), ("auto", "f32"), ("bf16x3", "f32"))}
     rec["relu_gate_differences_per_layer"] = flips
+    return rec
+
+
+def _aggregate(draws):
+    """median / max over the draws of every scalar of the per-mode records (lists: their maximum per draw first)."""
+    out = {}
+    for mode in MODES:
+        ms = [d["modes"][mode] for d in draws]
+        agg = {}
+        for k, v in ms[0].items():
+            if isinstance(v, dict) and "value" in v:
+                vals = [m[k]["value"] for m in ms]
+            elif isinstance(v, dict):
+                agg[k] = {g: {"median": float(np.median([m[k][g] for m in ms if g in m[k]])),
+                              "max": float(np.max([m[k][g] for m in ms if g in m[k]]))} for g in v}
+                continue
+            elif isinstance(v, list):
+                vals = [max(m[k]) for m in ms]
+            else:
+                vals = [m[k] for m in ms]
+            agg[k] = {"median": float(np.median(vals)), "max": float(np.max(vals))}
+        out[mode] = agg
+    return out
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"config{c[0]}" for c in CASES])
+def test_parity_record(case):
+    cfg = case[0]
+    draws = [_run_draw(case, d) for d in range(N_DRAWS)]
+    n_skipped = sum(len(d["skipped_draws"]) for d in draws)
+    flip_draws = {k: sum(1 for d in draws if sum(d["relu_gate_differences_per_layer"][k]) > 0)
+                  for k in draws[0]["relu_gate_differences_per_layer"]}
+    # which arithmetic is closest to fp64 in the whole-vector gradient, draw by draw
+    closest = {m: 0 for m in MODES}
+    for d in draws:
+        closest[min(MODES, key=lambda m: d["modes"][m]["grad_rel_l2"])] += 1
+    rec = {"config": cfg, "model": draws[0]["model"], "lengths": draws[0]["lengths"], "loss": draws[0]["loss"], "dropout": 0.0,
+           "reference": draws[0]["reference"], "draws": len(draws),
+           "ill_conditioned_draws_skipped": n_skipped, "skip_rate": n_skipped / (n_skipped + len(draws)),
+           "summary_over_draws": _aggregate(draws), "draws_with_relu_gate_differences": flip_draws,
+           "draws_in_which_the_arithmetic_is_closest_to_fp64_in_grad_rel_l2": closest, "per_draw": draws}
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     allrec = {}
     if os.path.exists(OUT):
@@ -239,8 +288,13 @@ def test_parity_record(case):
     allrec[f"config{cfg}"] = rec
     with open(OUT, "w") as f:
         json.dump(allrec, f, indent=1, sort_keys=True)
-    print(json.dumps(rec["modes"]["auto"], indent=1))
+    print(json.dumps(rec["summary_over_draws"]["auto"], indent=1))
+    for d in draws:
+        _assert_draw(d)
 
+
+def _assert_draw(rec):
+    flips = rec["relu_gate_differences_per_layer"]
     # ---- SURVEY 8(d) tolerances on the measured numbers, every arithmetic
     for mode, m in rec["modes"].items():
         assert m["pred_max_abs"] < 1e-5, (mode, m["pred_max_abs"])

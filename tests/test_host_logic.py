@@ -74,6 +74,20 @@ def test_metrics_and_speed():
     m = log.update_loss_trackers(args, 0, m)
     assert m["best_valid_loss_so_far"] == 2.0 and m["epoch_last_improved"] == 0
     assert log.prepare_log_header(args).split(",")[:4] == ["drmsd", "ln_drmsd", "rmse", "rmsd"]
+    # the granularity column: "batch" / "epoch" by default, upstream's literal "epoch" on every row with --reference-csv
+    import csv
+    import io
+    for ref_csv, want in ((False, ["batch", "epoch"]), (True, ["epoch", "epoch"])):
+        buf = io.StringIO()
+        log.REFERENCE_CSV = ref_csv
+        try:
+            w = csv.writer(buf)
+            log.log_batch(w, m, 0.0, mode="train", end_of_epoch=False, t=1.0)
+            log.log_batch(w, m, 0.0, mode="train", end_of_epoch=True, t=2.0)
+        finally:
+            log.REFERENCE_CSV = False
+        rows = list(csv.reader(io.StringIO(buf.getvalue())))
+        assert [r[7] for r in rows] == want and all(len(r) == 10 and r[6] == "train" for r in rows)
 
 
 def test_synthetic_batch():
@@ -154,3 +168,26 @@ def test_dropout_generator_statistics():
         hist = np.bincount((w >> np.uint32(24)), minlength=256)
         e = w.size / 256
         assert ((hist - e) ** 2 / e).sum() / 255 < 1.3
+
+
+def test_auto_guard_slack_arithmetic():
+    """AutoGuard.slack_binades (models/encoder_only.py): binades between a bound-derived f16x2 scale and the scale the
+    measured maximum would have got - the number the guard compares with its threshold."""
+    from protein_transformer_amd.models.encoder_only import AutoGuard
+
+    def scale_bits(amax):                       # common.h pt_row_scale_bits: amax * scale in [2^14, 2^15)
+        e = int(np.float32(amax).view(np.uint32)) >> 23
+        return np.uint32(min(268 - e, 254) << 23)
+    bound = 3.7
+    sb = scale_bits(bound)
+    got = AutoGuard.slack_binades([bound, bound / 2, bound / 300.0, bound * 2.1, 0.0, 1.0], [sb, sb, sb, sb, sb, 0x7F000000])
+    #      exact bound: 0; half: 1; 1/300 (2^-8.2, mantissa of 3.7 is 1.85): 9; bound exceeded by 2.1x: -1 (or -2);
+    #      all-zero operand: 0; unused atomicMin slot: 0
+    assert got[0] == 0 and got[1] == 1 and got[2] in (8, 9) and got[3] < 0 and got[4] == 0 and got[5] == 0
+    g = AutoGuard(2, interval=4, max_slack=8)
+    assert g.want_measure() and not g.off.any()
+    g.count_step()
+    assert not g.want_measure() and g.report()["fallbacks_per_step"] == 0.0
+    g.off[1, 1] = True                          # f1 of layer 1 off its bound: the FFN-2 forward and weight-gradient products
+    g.count_step()
+    assert g.report()["fallbacks_per_step"] == 1.0 and g.report()["sites_off_bounds_now"] == 1
