@@ -902,6 +902,337 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2
   }
 }
 
+// =================================================================================================== fused backward
+// dQ, dK and dV in ONE sweep (round 4; dk = 64, 8 wavefronts; launched when protein x head workgroups fill the chip).
+// The reference's backward of softmax(QK^T / sqrt(dk)) V (Attention.py:14-22) is one pass over the score matrix; the two
+// kernels above walk it twice (exp2 / dropout hash / two-term splitting in both).  This kernel is the dK/dV kernel - one
+// workgroup per (protein, head), a wavefront per 32 keys, query tiles streaming through LDS - with two additions:
+//   * an OUTER loop over the 256-key blocks of the protein, so that every contribution to a query's dQ comes from this
+//     workgroup, in a fixed order (first block: store, later blocks: read - add - store by the same lane; no atomics, no
+//     slabs, bit-reproducible);
+//   * dQ^T[d][q] += K^T[d][key] dS^T[key][q] for a query tile over the 256 keys of the block: every wavefront leaves its dS
+//     tile (keys in lanes) in LDS as two f16 planes [key][q], scaled by the lane's inverse K row scale and ONE power of two
+//     per wavefront and tile (published beside it); the block's scaled K rows sit in LDS as planes [key][d] for the whole
+//     block; behind a barrier wavefront w computes the 16 (d) x 16 (q) piece (w & 3, w >> 2) of dQ^T with
+//     v_mfma_f32_16x16x32_f16 over the eight 32-key steps - both operands by transposing reads (ds_read_b64_tr_b16), each
+//     step's three products into a fresh accumulator that is added with the step's inverse scale - so no partial dQ is
+//     ever exchanged between wavefronts.
+// LDS: 48 KB staging (as above) + 64 KB K planes + 32 KB dS planes = 144 KB.  delta comes from attn_delta_kernel.
+constexpr int FK = 256;                              // keys of a block = 8 wavefronts x 32
+constexpr int KP_PLANE = FK * 64, DS_PLANE = FK * 32;  // f16 elements of a K plane / a dS plane
+constexpr size_t FUSED_LDS = ATTN_LDS + (size_t)(2 * KP_PLANE + 2 * DS_PLANE) * sizeof(unsigned short);
+// K planes [key][64]: 16-byte chunk c of row r at c ^ (2 ((r >> 1) & 3)) - the transposing reads of a 16 x 16 piece
+// (4 rows x 32 bytes per 16 lanes, rows 4 g .. 4 g + 3 of lane group g) then touch every bank once per 32 lanes
+__device__ __forceinline__ int kp_off(int row, int d) { return row * 64 + ((((d >> 3) ^ (2 * ((row >> 1) & 3))) & 7) << 3) + (d & 7); }
+// dS planes [key][32]: the 32-byte half (q >> 4) of row r at half ^ ((r >> 2) & 1)
+__device__ __forceinline__ int ds_off(int row, int q) { return row * 32 + ((((q >> 4) ^ (row >> 2)) & 1) << 4) + (q & 15); }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float *__restrict__ o_fwd, const float *__restrict__ d_o,
+                                                        int rows, int L, int H, int dk, float *__restrict__ delta) {
+  // delta[b, h, q] = sum_d dO[b q, h dk + d] O[b q, h dk + d]: dk / 4 lanes per (row, head), one float4 each
+  const int lp = dk >> 2, per_row = H * lp;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t row = i / per_row;
+  const int c = (int)(i % per_row), h = c / lp;
+  float acc = 0.f;
+  if (row < (size_t)rows) {
+    const float4 g = *reinterpret_cast<const float4 *>(d_o + row * (size_t)(H * dk) + 4 * c);
+    const float4 o = *reinterpret_cast<const float4 *>(o_fwd + row * (size_t)(H * dk) + 4 * c);
+    acc = (g.x * o.x + g.y * o.y) + (g.z * o.z + g.w * o.w);
+  }
+  for (int off = lp >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);   // (lp lanes of a head are adjacent, lp <= 16)
+  if (row < (size_t)rows && (c % lp) == 0) {
+    const size_t b = row / L, q = row % L;
+    delta[(b * H + h) * L + q] = acc;
+  }
+}
+
+__global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_fused_f16x2_kernel(
+    const float *__restrict__ qkv, const int64_t *__restrict__ seq, const float *__restrict__ d_o,
+    const float *__restrict__ lse, const float *__restrict__ delta, int L, int H, float p_drop, uint64_t seed,
+    uint32_t stream_id, float *__restrict__ dqkv, uint32_t *__restrict__ row_scale, uint32_t *__restrict__ row_min) {
+  constexpr int DK = 64, NW = 8, KS = DK / 16, NT = DK / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  __shared__ __attribute__((aligned(16))) float sLse[2][TR], sDel[2][TR];
+  __shared__ __attribute__((aligned(16))) float sInvQ[2][8], sInvG[2][8];
+  __shared__ float sInvC[NW];
+  __shared__ unsigned int sMin;
+  unsigned short *const sKP = smem + 2 * BUF, *const sDS = sKP + 2 * KP_PLANE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int i16 = lane & 15, g16 = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int D = H * DK, D3 = 3 * D;
+  const float *base = qkv + (size_t)b * L * D3 + h * DK;
+  const float *gbase = d_o + (size_t)b * L * D + h * DK;
+  const float *lse_b = lse + ((size_t)b * H + h) * L, *del_b = delta + ((size_t)b * H + h) * L;
+  const float scale = 0.125f;
+  const AttnDrop dk_ = make_attn_drop(seed, stream_id, (uint32_t)(b * H + h), p_drop);
+  const float ks = p_drop > 0.f ? dk_.ks : 1.f;
+  const int ntiles = (L + TR - 1) / TR, nkb = (L + FK - 1) / FK;
+  const int db = 16 * (wave & 3), qb = 16 * (wave >> 2);   // this wavefront's piece of a tile's dQ^T
+  auto tile = [&](int buf) __attribute__((always_inline)) { return smem + buf * BUF; };
+  uint32_t my_min = 0x7F000000u;                          // smallest f16x2 scale of the dQ rows this thread published
+
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int key = kb * FK + wave * 32 + l31;
+    const bool k_ok = key < L;
+    const bool k_valid = k_ok && seq[(size_t)b * L + key] != PTAMD_PAD_ID;
+    f16x8 kf[KS][2], vf[KS][2];
+    const float ikl = load_row_scaled<KS>(base + D, D3, min(key, L - 1), k_ok, lh, kf);
+    const float ivl = load_row_scaled<KS>(base + 2 * D, D3, min(key, L - 1), k_ok, lh, vf);
+    const float ck = scale * LOG2E * ikl, gk = ivl * ks;
+    {  // the scaled K rows of the block as LDS planes (the previous block's readers are behind the last barrier of its loop)
+      const int row = wave * 32 + l31;
+#pragma unroll
+      for (int st = 0; st < KS; ++st)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) *reinterpret_cast<f16x8 *>(sKP + t * KP_PLANE + kp_off(row, 16 * st + 8 * lh)) = kf[st][t];
+    }
+    f32x16 dk[NT], dv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dk[t][r] = dv[t][r] = 0.f;
+    float bscale = BSCALE0, g_run = 0.f;
+
+    Stage<DK, NW> stQ, stG, nxQ, nxG;
+    TileRows<DK, NW> rows_q, rows_g;
+    float r_lse = 0.f, r_del = 0.f;
+    rows_q.init(D3, L, tid, 0);
+    rows_g.init(D, L, tid, 0);
+    stQ.load(base, rows_q.next());
+    stG.load(gbase, rows_g.next());
+    stQ.store(tile(0), sInvQ[0], 0, L, tid);
+    stG.store(tile(0) + Tile2::ELEMS, sInvG[0], 0, L, tid);
+    if (tid < TR) {
+      sLse[0][tid] = tid < L ? lse_b[tid] * LOG2E : INFINITY;
+      sDel[0][tid] = tid < L ? del_b[tid] : 0.f;
+    }
+    stQ.load(base, rows_q.next());
+    stG.load(gbase, rows_g.next());
+    __syncthreads();
+
+    for (int qt = 0; qt < ntiles; ++qt) {
+      const int qq0 = qt * TR, cur = qt & 1;
+      const bool more = qt + 1 < ntiles;
+      const unsigned short *sQ = tile(cur), *sG = sQ + Tile2::ELEMS;
+      nxQ.load(base, rows_q.next());
+      nxG.load(gbase, rows_g.next());
+      if (more && tid < TR) {
+        const int qn = (qt + 1) * TR + tid;
+        r_lse = qn < L ? lse_b[qn] * LOG2E : INFINITY;
+        r_del = qn < L ? del_b[qn] : 0.f;
+      }
+      const float4 iq4 = *reinterpret_cast<const float4 *>(&sInvQ[cur][4 * lh]);
+      const float4 iga = *reinterpret_cast<const float4 *>(&sInvG[cur][0]), igb = *reinterpret_cast<const float4 *>(&sInvG[cur][4]);
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+      for (int st = 0; st < KS; ++st) {
+        f16x8 qa[2], ga[2];
+        Tile2::frag_rows(sQ, st, lane, qa);
+        Tile2::frag_rows(sG, st, lane, ga);
+        s = mfma3(qa, kf[st], s);     // S[q][key]
+        dp = mfma3(ga, vf[st], dp);   // dP[q][key] = dO V^T
+      }
+      if (more) {
+        const int qn = (qt + 1) * TR;
+        stQ.store(tile(cur ^ 1), sInvQ[cur ^ 1], qn, L, tid);
+        stG.store(tile(cur ^ 1) + Tile2::ELEMS, sInvG[cur ^ 1], qn, L, tid);
+        if (tid < TR) {
+          sLse[cur ^ 1][tid] = r_lse;
+          sDel[cur ^ 1][tid] = r_del;
+        }
+      }
+      const float gt = fmaxf(fmaxf(fmaxf(iga.x, iga.y), fmaxf(iga.z, iga.w)), fmaxf(fmaxf(igb.x, igb.y), fmaxf(igb.z, igb.w)));
+      if (gt > g_run) {  // (wavefront-uniform)
+        const float resc = g_run * inv_pow2(gt);
+        g_run = gt;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = dv[t][r] * resc;
+            asm volatile("" : "+v"(v));
+            dv[t][r] = v;
+          }
+      }
+      const float gn = inv_pow2(g_run);
+      const float4 igh = lh ? igb : iga;
+      const float iq[4] = {iq4.x, iq4.y, iq4.z, iq4.w}, ig[4] = {igh.x, igh.y, igh.z, igh.w};
+      float cu[4], ug[4], wq[4], fp[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        cu[j] = ck * iq[j];
+        ug[j] = gk * ig[j];
+        wq[j] = scale * iq[j];
+        fp[j] = ig[j] * TWO14 * gn;
+      }
+      f32x16 pd;   // dropped probabilities (operand of dV)
+      const uint32_t keepbits = p_drop > 0.f ? attn_keep_bits_queries_in_rows_paired(dk_, (uint32_t)key, qq0, lh) : 0xffffu;
+      float wmax = 0.f;
+      float gm[4] = {0.f, 0.f, 0.f, 0.f};   // max |dS / (Q group scale)| per register quadruple (= per Q group)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = r >> 2;
+        const float4 l4 = *reinterpret_cast<const float4 *>(&sLse[cur][8 * j + 4 * lh]);
+        const float4 d4 = *reinterpret_cast<const float4 *>(&sDel[cur][8 * j + 4 * lh]);
+        const float my_l = (r & 3) == 0 ? l4.x : (r & 3) == 1 ? l4.y : (r & 3) == 2 ? l4.z : l4.w;
+        const float my_d = (r & 3) == 0 ? d4.x : (r & 3) == 1 ? d4.y : (r & 3) == 2 ? d4.z : d4.w;
+        const float p = __builtin_amdgcn_exp2f(k_valid ? fmaf(s[r], cu[j], -my_l) : -INFINITY);
+        float g = dp[r] * ug[j], pk = p;
+        if (p_drop > 0.f) {
+          g = keep_or_zero(g, keepbits, r);
+          pk = keep_or_zero(p, keepbits, r);
+        }
+        pd[r] = pk;
+        s[r] = p * (g - my_d) * wq[j];   // dS[q][key] / (Q group scale)
+        gm[j] = fmaxf(gm[j], fabsf(s[r]));
+      }
+      // ---- this wavefront's dS tile into LDS: planes [key][q] of dS scale / (K row scale) = s (Q group scale) / (K row
+      // scale) - powers of two, exact - times one power of two for the whole tile of the wavefront
+      {
+        float fq[4];
+        uint32_t w2 = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          fq[j] = ikl * inv_pow2(iq[j]);
+          w2 = max(w2, abs_bits(gm[j] * fq[j]));
+          wmax = fmaxf(wmax, gm[j]);
+        }
+        const uint32_t sbits = pt_row_scale_bits(group_umax<64>(w2));
+        const float cw = __uint_as_float(sbits);
+        const int row = wave * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          uint2 h1, h2;
+          const float cj = cw * fq[j];
+          split_quad_f16(s[4 * j], s[4 * j + 1], s[4 * j + 2], s[4 * j + 3], cj, cj, cj, cj, h1, h2);
+          const int off = ds_off(row, 8 * j + 4 * lh);
+          *reinterpret_cast<uint2 *>(sDS + off) = h1;
+          *reinterpret_cast<uint2 *>(sDS + DS_PLANE + off) = h2;
+        }
+        if (lane == 0) sInvC[wave] = __uint_as_float((254u << 23) - sbits);
+      }
+      wmax = fmaxf(wmax, __shfl_xor(wmax, 32, 64));
+      const float ratio = online_scale(wmax, bscale);
+      if (__builtin_amdgcn_ballot_w64(ratio != 1.f)) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = dk[t][r] * ratio;
+            asm volatile("" : "+v"(v));
+            dk[t][r] = v;
+          }
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const float xs[8] = {s[8 * m], s[8 * m + 1], s[8 * m + 2], s[8 * m + 3], s[8 * m + 4], s[8 * m + 5], s[8 * m + 6], s[8 * m + 7]};
+        const float xp[8] = {pd[8 * m], pd[8 * m + 1], pd[8 * m + 2], pd[8 * m + 3], pd[8 * m + 4], pd[8 * m + 5], pd[8 * m + 6], pd[8 * m + 7]};
+        f16x8 dsf[2], pdf[2];
+        split8g(xs, bscale, bscale, dsf);
+        split8g(xp, fp[2 * m], fp[2 * m + 1], pdf);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          f16x8 qt_[2], gt_[2];
+          Tile2::frag_cols(sQ, 16 * m, 32 * t, lane, qt_);
+          dk[t] = mfma3(qt_, dsf, dk[t]);   // dK^T[d][key] += Q^T dS
+          Tile2::frag_cols(sG, 16 * m, 32 * t, lane, gt_);
+          dv[t] = mfma3(gt_, pdf, dv[t]);   // dV^T[d][key] += dO^T Pd
+        }
+      }
+      stQ = nxQ;
+      stG = nxG;
+      __syncthreads();  // every wavefront's dS tile (and the next staged tiles) is in LDS; nobody reads the current tiles any more
+      // ---- dQ^T[db .. db + 16][qb .. qb + 16] of this query tile over the 256 keys of the block
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+      for (int st = 0; st < NW; ++st) {
+        const int r1 = st * 32 + 4 * g16 + (i16 >> 2);
+        f16x8 a[2], bq[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const unsigned short *ka = sKP + t * KP_PLANE, *da = sDS + t * DS_PLANE;
+          const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(ka + kp_off(r1, db + 4 * (i16 & 3))));
+          const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(ka + kp_off(r1 + 16, db + 4 * (i16 & 3))));
+          const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(da + ds_off(r1, qb + 4 * (i16 & 3))));
+          const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(da + ds_off(r1 + 16, qb + 4 * (i16 & 3))));
+          a[t] = __builtin_bit_cast(f16x8, (s16x8)__builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+          bq[t] = __builtin_bit_cast(f16x8, (s16x8)__builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], bq[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], bq[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], bq[0], c, 0, 0, 0);
+        const float ic = sInvC[st];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(c[e], ic, acc[e]);
+      }
+      {  // lane (i16, g16): query qq0 + qb + i16, d = db + 4 g16 + 0..3
+        const int q = qq0 + qb + i16;
+        float *op = dqkv + (size_t)(b * L + min(q, L - 1)) * D3 + h * DK + db + 4 * g16;
+        float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (kb > 0 && q < L) {
+          const float4 old = *reinterpret_cast<const float4 *>(op);
+          v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+        }
+        if (q < L) *reinterpret_cast<float4 *>(op) = v;
+        if (row_scale && kb == nkb - 1) {   // the row's f16x2 scale: the four lane groups hold 16 d of the row's 64
+          uint32_t am = q < L ? umax4(v) : 0u;
+          am = max(am, (uint32_t)__shfl_xor((int)am, 16, 64));
+          am = max(am, (uint32_t)__shfl_xor((int)am, 32, 64));
+          const uint32_t sb = pt_row_scale_bits(am);
+          if (q < L && g16 == 0) atomicMin(row_scale + (size_t)b * L + q, sb);
+          if (q < L) my_min = min(my_min, sb);
+        }
+      }
+      __syncthreads();  // the dS planes (and, behind the last tile of a block, the K planes) may be rewritten
+    }
+    // ---- dK, dV of this key block
+    const float uk = inv_pow2(bscale), uv = ks * g_run * INV_TWO14;
+    if (row_scale) {
+      float ak = 0.f, av = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          ak = fmaxf(ak, fabsf(dk[t][r]));
+          av = fmaxf(av, fabsf(dv[t][r]));
+        }
+      float amax = fmaxf(ak * uk, av * uv);
+      amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+      const uint32_t sb = k_ok ? pt_row_scale_bits(__float_as_uint(amax)) : 0x7F000000u;
+      if (k_ok && lane < 32) atomicMin(row_scale + (size_t)b * L + key, sb);
+      my_min = min(my_min, sb);
+    }
+    if (k_ok) {
+      float *okp = dqkv + (size_t)(b * L + key) * D3 + D + h * DK, *ovp = okp + D;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = t * 32 + 8 * g + 4 * lh;
+          *reinterpret_cast<float4 *>(okp + d) =
+              make_float4(dk[t][4 * g] * uk, dk[t][4 * g + 1] * uk, dk[t][4 * g + 2] * uk, dk[t][4 * g + 3] * uk);
+          *reinterpret_cast<float4 *>(ovp + d) =
+              make_float4(dv[t][4 * g] * uv, dv[t][4 * g + 1] * uv, dv[t][4 * g + 2] * uv, dv[t][4 * g + 3] * uv);
+        }
+    }
+  }
+  if (row_scale && row_min) {  // the smallest scale of all rows this workgroup wrote: one global atomic per copy
+    if (tid == 0) sMin = 0x7F000000u;
+    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) my_min = min(my_min, (uint32_t)__shfl_xor((int)my_min, o, 64));
+    if (lane == 0) atomicMin(&sMin, my_min);
+    __syncthreads();
+    if (tid < 4) atomicMin(row_min + tid, sMin);
+  }
+}
+
 template <typename K>
 static int set_lds(K kernel, int parts) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -972,6 +1303,29 @@ int fwd_by_shape(Shape sh, const float *qkv, const int64_t *seq, int B, int L, i
   if (sh == W8_HALVES) return launch_fwd<DK, 8, 2>(qkv, seq, B, L, H, p, seed, sid, out, lse, st);
   return launch_fwd<DK, 4, 2>(qkv, seq, B, L, H, p, seed, sid, out, lse, st);
 }
+// the fused kernel: dk = 64 and enough (protein, head) pairs that one workgroup each fills more than half of the chip
+// (PTAMD_ATTN_FUSED = 0 / 1 in the environment, read at every call: never / whenever dk = 64 - for tests, which run small
+// batches, and for A/B measurements; the choice changes the summation order of dQ, nothing else)
+inline bool use_fused(int B, int L, int H, int dk) {
+  if (dk != 64) return false;
+  if (const char *e = getenv("PTAMD_ATTN_FUSED")) return e[0] == '1';
+  return (size_t)B * H * 2 > (size_t)ptgemm::persistent_grid(0);
+}
+int launch_fused(const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse, float *delta,
+                 int B, int L, int H, float p, uint64_t seed, uint32_t sid, float *dqkv, uint32_t *row_scale,
+                 uint32_t *row_min, hipStream_t st) {
+  const size_t items = (size_t)B * L * H * 16;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, o_fwd, d_o, B * L, L, H, 64, delta);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_fused_f16x2_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS);
+  if (e != hipSuccess) {
+    g_pt_last_hip_error = e;
+    return PTAMD_ERR_HIP;
+  }
+  hipLaunchKernelGGL(attn_bwd_fused_f16x2_kernel, dim3(1, H, B), dim3(512), FUSED_LDS, st, qkv, seq, d_o, lse, delta, L, H, p,
+                     seed, sid, dqkv, row_scale, row_min);
+  return pt_check_launch();
+}
 template <int DK>
 int bwd_by_shape(Shape sh, const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse,
                  float *delta, int B, int L, int H, float p, uint64_t seed, uint32_t sid, float *dqkv, uint32_t *row_scale,
@@ -1001,6 +1355,7 @@ int pt_attention_bwd_f16x2(const float *qkv, const int64_t *seq, const float *o_
                            float *delta, int B, int L, int H, int dk, float p, uint64_t seed, uint32_t sid, float *dqkv,
                            uint32_t *row_scale, uint32_t *row_min, hipStream_t st) {
   using namespace ptattn16;
+  if (use_fused(B, L, H, dk)) return launch_fused(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
   const Shape sh = launch_shape(B, L, H);
   return dk == 64 ? bwd_by_shape<64>(sh, qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st)
                   : bwd_by_shape<32>(sh, qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);

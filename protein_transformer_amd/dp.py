@@ -128,13 +128,26 @@ def shard_indices(lengths, world=None, r=None):
     return sorted(mine)
 
 
+def broadcast_parameters(model, src=0):
+    """Every rank takes rank `src`'s flat parameter buffer: data-parallel replicas must START identical - the SUM-reduced
+    gradient keeps them identical from then on (bench.py's `param_checksum_spread` checks exactly that).  Anything that
+    makes the ranks' initialisations differ (a seed, statistics of a rank's own data such as the angle means that
+    initialise the output bias, encoder_only.py:28-33) is overwritten here."""
+    if world_size() > 1:
+        flat, _ = model.flat_parameters()
+        dist.broadcast(flat, src=src)
+
+
 def attach(model):
     """Overlap the gradient reduction with backward: reduce each slice of the flat gradient buffer as soon
-    as `_EncoderFn.backward` reports it final (model.grad_hook).  The work handles live on the model."""
+    as `_EncoderFn.backward` reports it final (model.grad_hook).  The work handles live on the model.  The replicas are
+    synchronised first (`broadcast_parameters`)."""
     model._dp_pending = []
     if world_size() == 1:
         model.grad_hook = None
         return model
+    if hasattr(model, "flat_parameters") and getattr(model, "_flat_numel", None):
+        broadcast_parameters(model)
 
     def hook(offset, numel):
         g = model._flat_grad

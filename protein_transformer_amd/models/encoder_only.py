@@ -100,32 +100,47 @@ class _EncoderHolder(nn.Module):
 
 
 class AutoGuard:
-    """Run-time guard of the BOUND-derived f16x2 scales of the AUTO arithmetic (csrc/scales.hip).
+    """Run-time guard of the AUTO arithmetic's two assumptions (csrc/scales.hip).
 
-    Five operands per encoder layer are scaled by a bound that follows from the weights alone instead of their measured
-    maximum: the attention output `att` and the FFN hidden layer `f1` (A of the two products behind them and one operand of
-    their weight-gradient products), the hidden gradient `dz1` (bound from the row norms of `dy2`), and the LayerNorm
-    outputs `h1`, `h2` as operands of weight-gradient products.  A bound 2^k above the true maximum costs k of the 18
-    binades in which an element keeps its 22 bits - nothing a step can see while k is small, but nothing in the step
-    measures k either.  The guard does, off the hot path: every `interval`-th training step (and the first one) the
-    backward pass measures the true max |x| of the five operands of every layer with one small launch per layer
-    (ptamd_weight_scales' statistics: a streaming pass, ~0.35 ms per measured step at config 4), copies them and the bound
-    scales to pinned host memory behind an event, and the next forward pass that finds the event complete turns them into
-    `slack[layer][site]` binades - no host synchronisation anywhere.  Where slack > `max_slack` (or the bound was
-    VIOLATED, slack < 0) the operand stops using its bound: the activation x weight products take the exact row scales of
-    a pass over the operand (ptamd_gemm finds them itself when `a_scale` is NULL - still f16x2, exact scales), the
-    weight-gradient products run in bf16x3 (exact three-term split, no scales).  The first step of a model runs on the
-    bounds (nothing is measured yet); `fallbacks` counts the products switched, per step."""
+    (1) BOUND-derived scales.  Five operands per encoder layer are scaled by a bound that follows from the weights alone
+    instead of their measured maximum: the attention output `att` and the FFN hidden layer `f1` (A of the two products
+    behind them and one operand of their weight-gradient products), the hidden gradient `dz1` (bound from the row norms of
+    `dy2`), and the LayerNorm outputs `h1`, `h2` as operands of weight-gradient products.  A bound 2^k above the true
+    maximum costs k of the 18 binades in which an element keeps its 22 bits: harmless while k is small, garbage at k = 18
+    (measured: LayerNorm gains spanning 2^+-8 against compensating weight columns give k = 17 .. 19 and predictions that are
+    0.3 off, tests/test_gpu_auto_guard.py).  Nothing inside a step measures k - the guard does, off the hot path.
+    (2) Moderate dynamic range ALONG THE CONTRACTED INDEX.  A two-term f16 product is accurate relative to the largest
+    element of an operand row; a function-preserving rescaling of hidden units (row n of W1 times 2^c, column n of W2 times
+    2^-c) spreads both operands of the product over c binades along n.  The per-row / per-column scales of every weight
+    matrix are computed every step anyway: their spread (binades between the largest and the smallest) along the
+    contracted index of each activation x weight product is the second thing the guard looks at.
+
+    Mechanics: every `interval`-th training step (and the first one) the backward pass measures the true max |x| of the five
+    operands of every layer (ptamd_weight_scales' statistics: one streaming launch per layer, ~0.35 ms per measured step at
+    config 4) and copies them, the bound scales and the weight scales to pinned host memory behind an event; the next
+    forward pass that finds the event complete turns them into `slack[layer][site]` and `spread[layer][product]` - no host
+    synchronisation anywhere.  A site whose slack exceeds `max_slack` (or whose bound was VIOLATED, slack < 0) stops using
+    its bound: the activation x weight products take the exact row scales of a pass over the operand (ptamd_gemm finds
+    them itself when `a_scale` is NULL - still f16x2, exact scales), the weight-gradient products run in bf16x3 (exact
+    three-term split, no scales).  A product whose weight-scale spread exceeds `max_spread` runs in bf16x3.  UNTIL THE FIRST
+    MEASUREMENT HAS LANDED NOTHING IS TRUSTED: every site is off its bound and every product counts as wide (the first step
+    of a model, or the first steps while the copy is in flight, cost what the bf16x3 arithmetic costs).
+    `fallback_products` counts the products switched, per step."""
     SITES = ("att", "f1", "dz1", "h1", "h2")
     # products a site switches when it falls back: (activation x weight products, weight-gradient products)
     PRODUCTS = {"att": 2, "f1": 2, "dz1": 2, "h1": 1, "h2": 1}
+    # activation x weight products and the weight scales along their contracted index (names of _step_scales)
+    WIDE = (("qkv", "cs_qkv"), ("wo", "cs_o"), ("ff1", "cs_1"), ("ff2", "cs_2"),
+            ("dx_qkv", "rs_qkv"), ("dx_wo", "rs_o"), ("dx_ff1", "rs_1"), ("dx_ff2", "rs_2"))
 
-    def __init__(self, nlayers, interval=16, max_slack=8):
-        self.nlayers, self.interval, self.max_slack = nlayers, int(interval), int(max_slack)
+    def __init__(self, nlayers, interval=16, max_slack=8, max_spread=12):
+        self.nlayers, self.interval, self.max_slack, self.max_spread = nlayers, int(interval), int(max_slack), int(max_spread)
         self.enabled = True
-        self.off = np.zeros((nlayers, len(self.SITES)), dtype=bool)      # True: the site does not use its bound
-        self.slack = None                                               # last measured binades [nlayers, 5]
+        self.off = np.ones((nlayers, len(self.SITES)), dtype=bool)      # True: the site does not use its bound
+        self.wide = np.ones((nlayers, len(self.WIDE)), dtype=bool)      # True: the product runs in bf16x3
+        self.slack = self.spread = None                                 # last measurement [nlayers, 5] / [nlayers, 8]
         self.max_slack_seen = np.full(len(self.SITES), -np.inf)
+        self.max_spread_seen = -np.inf
         self.violations = 0                                             # bounds found BELOW the measured maximum
         self.train_steps = self.measured_steps = self.fallback_products = 0
         self._pending = None
@@ -134,20 +149,20 @@ class AutoGuard:
         return self.enabled and self._pending is None and self.train_steps % max(self.interval, 1) == 0
 
     def submit(self, stats, ints, minbuf, layers):
-        """Called at the end of a measuring backward pass: asynchronous copies of the measured maxima and of the bound
-        scales into pinned memory, one event behind them."""
+        """Called at the end of a measuring backward pass: asynchronous copies of the measured maxima and of the bound /
+        weight scales into pinned memory, one event behind them."""
         host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (stats, ints, minbuf)]
         for h, t in zip(host, (stats, ints, minbuf)):
             h.copy_(t, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        # element offsets of the uniform bound scales inside `ints` / `minbuf` (views of them, see _step_scales)
-        where = [{k: (L[k].storage_offset() - ints.storage_offset()) for k in ("att_scale", "f1_scale", "h1_scale", "h2_scale")}
-                 for L in layers]
+        # element ranges of the scales inside `ints` (views of it, see _step_scales)
+        names = ("att_scale", "f1_scale", "h1_scale", "h2_scale") + tuple(w for _, w in self.WIDE)
+        where = [{k: (L[k].storage_offset() - ints.storage_offset(), L[k].numel()) for k in names} for L in layers]
         self._pending = (ev, host, where)
 
     def poll(self):
-        """Called at the start of every forward pass: if a measurement has landed, update the slack table and the sites."""
+        """Called at the start of every forward pass: if a measurement has landed, update the tables."""
         if self._pending is None or not self._pending[0].query():
             return
         _, (stats, ints, minbuf), where = self._pending
@@ -155,14 +170,26 @@ class AutoGuard:
         mx = stats.numpy()[:, :, 2].astype(np.float64)                  # [nlayers, 5]: max |x| of att, f1, dz1, h1, h2
         bits = ints.numpy().view(np.uint32)
         mb = minbuf.numpy().view(np.uint32)
-        sb = np.array([[bits[where[i]["att_scale"]], bits[where[i]["f1_scale"]], mb[i, 4], bits[where[i]["h1_scale"]],
-                        bits[where[i]["h2_scale"]]] for i in range(self.nlayers)], dtype=np.uint32)
+        sb = np.array([[bits[where[i]["att_scale"][0]], bits[where[i]["f1_scale"][0]], mb[i, 4], bits[where[i]["h1_scale"][0]],
+                        bits[where[i]["h2_scale"][0]]] for i in range(self.nlayers)], dtype=np.uint32)
         slack = self.slack_binades(mx, sb)
-        self.slack = slack
+        spread = np.array([[self.spread_binades(bits[where[i][w][0]:where[i][w][0] + where[i][w][1]]) for _, w in self.WIDE]
+                           for i in range(self.nlayers)])
+        self.slack, self.spread = slack, spread
         self.measured_steps += 1
         self.max_slack_seen = np.maximum(self.max_slack_seen, slack.max(0))
+        self.max_spread_seen = max(self.max_spread_seen, float(spread.max()))
         self.violations += int((slack < 0).sum())
         self.off = (slack > self.max_slack) | (slack < 0)
+        self.wide = spread > self.max_spread
+
+    @staticmethod
+    def spread_binades(scale_bits):
+        """Binades between the largest and the smallest of a weight matrix's row (column) maxima, from their f16x2 scales
+        (powers of two; all-zero rows - the largest finite scale - do not count)."""
+        e = (np.asarray(scale_bits, dtype=np.uint32) >> 23).astype(np.int64)
+        e = e[e < 254]
+        return float(e.max() - e.min()) if e.size else 0.0
 
     @staticmethod
     def slack_binades(max_abs, scale_bits):
@@ -183,14 +210,16 @@ class AutoGuard:
     def count_step(self):
         self.train_steps += 1
         self.fallback_products += int(sum(self.PRODUCTS[s] * int(self.off[:, j].sum()) for j, s in enumerate(self.SITES)))
+        self.fallback_products += int(self.wide.sum())
 
     def report(self):
         return {"fallbacks_per_step": self.fallback_products / max(self.train_steps, 1), "measured_steps": self.measured_steps,
                 "steps": self.train_steps, "interval": self.interval, "max_slack_binades_allowed": self.max_slack,
-                "bound_violations": self.violations,
+                "max_weight_scale_spread_binades_allowed": self.max_spread, "bound_violations": self.violations,
                 "max_slack_binades_seen": {s: (None if not np.isfinite(v) else float(v))
                                            for s, v in zip(self.SITES, self.max_slack_seen)},
-                "sites_off_bounds_now": int(self.off.sum())}
+                "max_weight_scale_spread_binades_seen": None if not np.isfinite(self.max_spread_seen) else self.max_spread_seen,
+                "sites_off_bounds_now": int(self.off.sum()), "products_in_bf16x3_now": int(self.wide.sum())}
 
 
 class _TransformerBase(nn.Module):
@@ -502,6 +531,7 @@ class _TransformerBase(nn.Module):
         # the flat buffer is a leaf of the autograd graph only so that backward() reaches _EncoderFn.backward;
         # gradients are written into the flat gradient buffer directly
         anchor = flat.detach().requires_grad_(torch.is_grad_enabled())
+        self.__dict__["_fwd_grad"] = torch.is_grad_enabled()      # (grad mode is off inside autograd.Function.forward)
         out = _EncoderFn.apply(anchor, seq, self, seed)
         return out.view(seq.shape[0], seq.shape[1], NUM_PREDICTED_ANGLES * 2)
 
@@ -561,11 +591,19 @@ class _EncoderFn(torch.autograd.Function):
         measure = False
         if guard is not None:
             guard.poll()
-            if train and torch.is_grad_enabled():
+            if train and m.__dict__.get("_fwd_grad", False):          # a training step: a backward pass will follow
                 measure = guard.want_measure()
                 guard.count_step()
         off = guard.off if guard is not None else None
-        ctx_off = None if off is None else off.copy()
+        wide = guard.wide if guard is not None else None
+        ctx_off = None if off is None else (off.copy(), wide.copy())
+
+        def prod(i, k, **scale_kw):
+            """arithmetic + scales of activation x weight product k of layer i (AutoGuard.WIDE order): bf16x3 without scales
+            when the weight's scales spread too far along the contracted index, else the pass's arithmetic with `scale_kw`"""
+            if wide is not None and wide[i, k]:
+                return dict(arith=K.GEMM_BF16X3)
+            return dict(arith=ar, **scale_kw)
         for i in range(m.nlayers):
             b = f"encoder.enc_layers.{i}."
             sid = i * 8
@@ -574,30 +612,30 @@ class _EncoderFn(torch.autograd.Function):
             s_h1 = torch.empty(Tn, dtype=torch.int32, device=x.device) if sc else None
             h1, mean1, rstd1 = K.layernorm_fwd(x, W(b + "sublayer_connections.0.norm.weight"),
                                                W(b + "sublayer_connections.0.norm.bias"), row_scale=s_h1)
-            qkv = K.linear_fwd(h1, wqkv, bqkv, arith=ar, a_scale=s_h1, b_scale=sc and sc["rs_qkv"])
+            qkv = K.linear_fwd(h1, wqkv, bqkv, **prod(i, 0, a_scale=s_h1, b_scale=sc and sc["rs_qkv"]))
             att, lse = K.attention_fwd(qkv, seq, H, pa, seed, sid + _SITE_ATTN,
                                         arith=attn_default if m.attn_mode is None else m.attn_mode)
             use_b = sc is not None and not (off is not None and off[i, 0])          # att on its bound (else: exact row scales)
             x2 = K.linear_fwd(att, W(b + "self_attn.wo.weight"), W(b + "self_attn.wo.bias"), residual=x, ldr=D,
-                              dropout_p=p, seed=seed, stream_id=sid + _SITE_ATTN_OUT, arith=ar,
-                              a_scale=sc["att_scale"] if use_b else None, a_scale_stride=0 if use_b else 1,
-                              b_scale=sc and sc["rs_o"])
+                              dropout_p=p, seed=seed, stream_id=sid + _SITE_ATTN_OUT,
+                              **prod(i, 1, a_scale=sc["att_scale"] if use_b else None, a_scale_stride=0 if use_b else 1,
+                                     b_scale=sc and sc["rs_o"]))
             s_h2 = torch.empty(Tn, dtype=torch.int32, device=x.device) if sc else None
             h2, mean2, rstd2 = K.layernorm_fwd(x2, W(b + "sublayer_connections.1.norm.weight"),
                                                W(b + "sublayer_connections.1.norm.bias"), row_scale=s_h2, planes=hplanes)
-            if use_hp:
+            if use_hp and not (wide is not None and wide[i, 2]):
                 f1 = K.gemm_hp(K.hp_view(hplanes, s_h2, Tn, D), sc["hp_1"],
                                torch.empty(Tn, m.dff, dtype=torch.float32, device=x.device), bias=W(b + "pwff.layer1.bias"),
                                flags=K.EPI_RELU, dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_HID)
             else:
                 f1 = K.linear_fwd(h2, W(b + "pwff.layer1.weight"), W(b + "pwff.layer1.bias"), flags=K.EPI_RELU,
-                                  dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_HID, arith=ar,
-                                  a_scale=s_h2, b_scale=sc and sc["rs_1"])
+                                  dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_HID,
+                                  **prod(i, 2, a_scale=s_h2, b_scale=sc and sc["rs_1"]))
             use_b = sc is not None and not (off is not None and off[i, 1])          # f1 on its bound
             x3 = K.linear_fwd(f1, W(b + "pwff.layer2.weight"), W(b + "pwff.layer2.bias"), residual=x2, ldr=D,
-                              dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_OUT, arith=ar,
-                              a_scale=sc["f1_scale"] if use_b else None, a_scale_stride=0 if use_b else 1,
-                              b_scale=sc and sc["rs_2"])
+                              dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_OUT,
+                              **prod(i, 3, a_scale=sc["f1_scale"] if use_b else None, a_scale_stride=0 if use_b else 1,
+                                     b_scale=sc and sc["rs_2"]))
             saved.append((x, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, f1))
             x = x3
         pred = K.linear_fwd(x, W("output_projection.weight"), W("output_projection.bias"),
@@ -657,7 +695,12 @@ class _EncoderFn(torch.autograd.Function):
                     with torch.cuda.stream(side):
                         m.grad_hook(o0, o1 + int(np.prod(s1)) - o0)
 
-        off = ctx.off
+        off, wide = ctx.off if ctx.off is not None else (None, None)
+
+        def prod(i, k, **scale_kw):      # as in forward: dX products 4..7 of AutoGuard.WIDE
+            if wide is not None and wide[i, k]:
+                return dict(arith=K.GEMM_BF16X3)
+            return dict(arith=ar, **scale_kw)
         dpred = dpred.contiguous().view(-1, NUM_PREDICTED_ANGLES * 2)
         dpre = K.tanh_bwd(dpred, ctx.pred) if m.use_tanh_out else dpred
         K.linear_bwd_weight(dpre, ctx.x_last, G("output_projection.weight"), G("output_projection.bias"),
@@ -686,16 +729,16 @@ class _EncoderFn(torch.autograd.Function):
             dw(dy2, f1, G(b + "pwff.layer2.weight"), G(b + "pwff.layer2.bias"), arith=ar,
                                 dy_scale=sc["dy2_min"] if uni and not o_f1 else None, x_scale=sc["f1_scale"] if uni and not o_f1 else None)
             # backward of layer2 and, in its epilogue, of the ReLU + dropout in front of it (gate = saved f1)
-            dz1 = K.linear_bwd_input(dy2, W(b + "pwff.layer2.weight"), gate=f1, gate_dropout_p=p, arith=ar,
-                                     a_scale=s_dy2 if sc else None, b_scale=sc and sc["cs_2"])
+            dz1 = K.linear_bwd_input(dy2, W(b + "pwff.layer2.weight"), gate=f1, gate_dropout_p=p,
+                                     **prod(i, 7, a_scale=s_dy2 if sc else None, b_scale=sc and sc["cs_2"]))
             if ctx.measure:     # the true maxima of the five bound-scaled operands of this layer (AutoGuard; every 16th step)
                 gs = sc["guard_stats"][i]
                 K.weight_scales([dict(w=t, stats=gs[j], rows_only=True) for j, t in enumerate((att, f1, dz1, h1, h2))])
             uni1 = uni and not (o_dz1 or o_h2)
             dw(dz1, h2, G(b + "pwff.layer1.weight"), G(b + "pwff.layer1.bias"), arith=ar,
                                 dy_scale=sc["dz1_min"] if uni1 else None, x_scale=sc["h2_scale"] if uni1 else None)
-            dh2 = K.linear_bwd_input(dz1, W(b + "pwff.layer1.weight"), arith=ar,
-                                     a_scale=bs_dz1 if sc and not o_dz1 else None, b_scale=sc and sc["cs_1"])
+            dh2 = K.linear_bwd_input(dz1, W(b + "pwff.layer1.weight"),
+                                     **prod(i, 6, a_scale=bs_dz1 if sc and not o_dz1 else None, b_scale=sc and sc["cs_1"]))
             # x2 = x + drop(att Wo^T + bo)
             g2w, g2b = G(b + "sublayer_connections.1.norm.weight"), G(b + "sublayer_connections.1.norm.bias")
             if fuse:
@@ -711,7 +754,7 @@ class _EncoderFn(torch.autograd.Function):
             uni_o = sc is not None and fuse and not o_att
             dw(dyo, att, G(b + "self_attn.wo.weight"), G(b + "self_attn.wo.bias"), arith=ar,
                                 dy_scale=sc["dyo_min"] if uni_o else None, x_scale=sc["att_scale"] if uni_o else None)
-            datt = K.linear_bwd_input(dyo, W(b + "self_attn.wo.weight"), arith=ar, a_scale=s_dyo, b_scale=sc and sc["cs_o"])
+            datt = K.linear_bwd_input(dyo, W(b + "self_attn.wo.weight"), **prod(i, 5, a_scale=s_dyo, b_scale=sc and sc["cs_o"]))
             # the f16x2 attention kernels leave the row scales of dqkv (A of the dX product) and the smallest of them (the
             # uniform scale of dqkv as operand of the dW product) behind; other arithmetics: one pass over dqkv
             attn_scales = sc is not None and m.attn_row_scales and K.attention_row_scales_available(D // H, attn_ar)
@@ -729,7 +772,7 @@ class _EncoderFn(torch.autograd.Function):
                     K.weight_scales([dict(w=dqkv, row_scale=s_dqkv, stats=sc["dqkv_stats"], rows_only=True)])
                     K.bound_scales([dict(w=sc["dqkv_stats"], w_index=2, out_scale=sc["dqkv_scale"])])
                 dw(dqkv, h1, gw, gb, arith=ar, dy_scale=None if o_h1 else dq_uni, x_scale=None if o_h1 else sc["h1_scale"])
-                dh1 = K.linear_bwd_input(dqkv, wqkv, arith=ar, a_scale=s_dqkv, b_scale=sc["cs_qkv"])
+                dh1 = K.linear_bwd_input(dqkv, wqkv, **prod(i, 4, a_scale=s_dqkv, b_scale=sc["cs_qkv"]))
             else:
                 dw(dqkv, h1, gw, gb, arith=ar)
                 dh1 = K.linear_bwd_input(dqkv, wqkv, arith=ar)

@@ -1,0 +1,212 @@
+"""The fused attention backward kernel (csrc/attention_f16x2.hip: attn_bwd_fused_f16x2_kernel - dQ, dK and dV in one sweep
+over the score matrix, reference Attention.py:14-22) against dense fp64 attention and against the two-kernel path.
+
+The library picks the fused kernel when (proteins x heads) workgroups fill the chip; `PTAMD_ATTN_FUSED=1 / 0` in the
+environment (read at every call) forces / forbids it for head size 64 - the tests run it on small batches that way, on
+one, two and three 256-key blocks (the outer loop: dQ is stored by the first block and read - add - stored by the others),
+ragged lengths, padding, dropout, wide dynamic ranges, degenerate rows, and check the row scales it leaves behind.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_kernels import assert_close, ref_attention, rnd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+class fused:
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        self.old = os.environ.get("PTAMD_ATTN_FUSED")
+        os.environ["PTAMD_ATTN_FUSED"] = "1" if self.on else "0"
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("PTAMD_ATTN_FUSED", None)
+        else:
+            os.environ["PTAMD_ATTN_FUSED"] = self.old
+
+
+def _seq(B, L, lens, seed=0):
+    seq = torch.full((B, L), 20, dtype=torch.int64)
+    for b, n in enumerate(lens):
+        seq[b, :n] = torch.randint(0, 20, (n,), generator=torch.Generator().manual_seed(seed + b))
+    return seq
+
+
+@pytest.mark.parametrize("B,L,H,lens", [(2, 512, 8, [512, 300]), (1, 130, 2, [130]), (3, 700, 2, [700, 513, 31]),
+                                        (2, 256, 4, [256, 1]), (1, 257, 1, [257]), (2, 33, 2, [33, 7])])
+@pytest.mark.parametrize("arith", ["f16x2", "auto"])
+def test_fused_backward_vs_fp64(dev, B, L, H, lens, arith):
+    from protein_transformer_amd import kernels as K_
+    ar = K_.GEMM_F16X2 if arith == "f16x2" else K_.GEMM_AUTO
+    dk, D = 64, 64 * H
+    seq = _seq(B, L, lens)
+    qkv = rnd((B, L, 3 * D), 20, 1.5).double().requires_grad_()
+    out, _ = ref_attention(qkv, seq != 20, H)
+    dout = rnd((B, L, D), 21).double()
+    out.backward(dout)
+    qd = qkv.detach().float().view(B * L, 3 * D).to(dev)
+    o, lse = K_.attention_fwd(qd, seq.to(dev), H, 0.0, 0, 0, arith=ar)
+    with fused(True):
+        dqkv = K_.attention_bwd(qd, seq.to(dev), o, dout.float().view(B * L, D).to(dev), lse, H, 0.0, 0, 0, arith=ar)
+        again = K_.attention_bwd(qd, seq.to(dev), o, dout.float().view(B * L, D).to(dev), lse, H, 0.0, 0, 0, arith=ar)
+    with fused(False):
+        two = K_.attention_bwd(qd, seq.to(dev), o, dout.float().view(B * L, D).to(dev), lse, H, 0.0, 0, 0, arith=ar)
+    ref = qkv.grad.view(B * L, 3 * D)
+    assert_close(dqkv, ref, 1e-4, 2e-6 * max(1.0, ref.abs().max().item()), "fused attention bwd")
+    assert torch.equal(dqkv, again)                                  # fixed summation order: bit-reproducible
+    # the same dK / dV arithmetic as the two-kernel path, dQ by another route: equal to rounding
+    assert ((dqkv - two).norm() / two.norm()).item() < 1e-6
+    for i, name in enumerate(("dQ", "dK", "dV")):
+        a, r = dqkv.view(B * L, 3, D)[:, i].double().cpu(), ref.view(B * L, 3, D)[:, i]
+        assert ((a - r).norm() / r.norm()).item() < 2e-6, name
+
+
+def test_fused_randomised(dev):
+    from protein_transformer_amd import kernels as K_
+    rng = np.random.default_rng(77)
+    with fused(True):
+        for it in range(16):
+            B, H, L = int(rng.integers(1, 4)), int(rng.choice([1, 2, 4])), int(rng.integers(2, 800))
+            D = H * 64
+            seq = torch.full((B, L), 20, dtype=torch.int64)
+            for b in range(B):
+                n = int(rng.integers(1, L + 1)) if b else L
+                seq[b, :n] = torch.tensor(rng.integers(0, 20, n))
+            qkv = torch.tensor(rng.normal(0, 1.2, (B, L, 3 * D)), dtype=torch.float32).double().requires_grad_()
+            out, _ = ref_attention(qkv, seq != 20, H)
+            dout = torch.tensor(rng.normal(0, 1, (B, L, D)), dtype=torch.float64)
+            out.backward(dout)
+            qd = qkv.detach().float().view(B * L, 3 * D).to(dev)
+            o, lse = K_.attention_fwd(qd, seq.to(dev), H, 0.0, 0, 0, arith=K_.GEMM_F16X2)
+            dqkv = K_.attention_bwd(qd, seq.to(dev), o, dout.float().view(B * L, D).to(dev), lse, H, 0.0, 0, 0, arith=K_.GEMM_F16X2)
+            ref = qkv.grad.view(B * L, 3 * D)
+            what = f"B={B} H={H} L={L} lens={(seq != 20).sum(1).tolist()}"
+            assert_close(dqkv, ref, 1e-4, 2e-6 * max(1.0, ref.abs().max().item()), "fused attention bwd " + what)
+
+
+def test_fused_dropout_masks_match_the_forward_kernel(dev):
+    """Forward with V = I recovers the dropout mask; the fused backward must have drawn the same one (dense fp64 math with
+    that mask), on more than one key block."""
+    from protein_transformer_amd import kernels as K_
+    B, L, H, p, seed, sid, dk = 2, 320, 2, 0.25, 4242, 5, 64
+    D = H * dk
+    seq = _seq(B, L, [L, L - 37], seed=3)
+    qkv = rnd((B, L, 3 * D), 22, 1.2)
+    # the mask of key block j from a forward pass whose V has the identity in rows 64 j .. 64 j + 63
+    keep = torch.zeros(B, H, L, L, dtype=torch.bool)
+    _, pr = ref_attention(qkv.double(), seq != 20, H)
+    for j in range(L // dk):
+        eye = qkv.clone()
+        v = torch.zeros(L, dk)
+        v[dk * j:dk * (j + 1)] = torch.eye(dk)
+        eye[:, :, 2 * D:] = v[None].repeat(B, 1, H)
+        pd, _ = K_.attention_fwd(eye.view(B * L, 3 * D).to(dev), seq.to(dev), H, p, seed, sid, arith=K_.GEMM_F16X2)
+        keep[:, :, :, dk * j:dk * (j + 1)] = pd.view(B, L, H, dk).permute(0, 2, 1, 3).cpu() != 0
+    q64 = qkv.double().requires_grad_()
+    out, _ = ref_attention(q64, seq != 20, H, mask_keep=keep.double(), p=p)
+    dout = rnd((B, L, D), 23).double()
+    out.backward(dout)
+    qd = qkv.view(B * L, 3 * D).to(dev)
+    o, lse = K_.attention_fwd(qd, seq.to(dev), H, p, seed, sid, arith=K_.GEMM_F16X2)
+    assert_close(o.view(B, L, D), out, 1e-5, 5e-6, "attention fwd (dropout)")
+    with fused(True):
+        dqkv = K_.attention_bwd(qd, seq.to(dev), o, dout.float().view(B * L, D).to(dev), lse, H, p, seed, sid, arith=K_.GEMM_F16X2)
+    ref = q64.grad.view(B * L, 3 * D)
+    assert_close(dqkv, ref, 1e-4, 5e-6 * max(1.0, ref.abs().max().item()), "fused attention bwd (dropout)")
+
+
+def test_fused_wide_row_ranges_and_degenerate_rows(dev):
+    from protein_transformer_amd import kernels as K_
+    B, L, H, dk = 2, 512, 8, 64
+    g = torch.Generator().manual_seed(11)
+    D = H * dk
+    qkv = torch.randn(B, L, 3 * D, generator=g, dtype=torch.float64)
+    dout = torch.randn(B, L, D, generator=g, dtype=torch.float64)
+    qkv[:, :, D:2 * D] *= 10 ** (torch.rand(B, L, 1, generator=g, dtype=torch.float64) * 2.5 - 2)
+    qkv[:, :, 2 * D:] *= 10 ** (torch.rand(B, L, 1, generator=g, dtype=torch.float64) * 4 - 3)
+    dout *= 10 ** (torch.rand(B, L, 1, generator=g, dtype=torch.float64) * 4 - 8)
+    qkv = qkv.float().double().requires_grad_()
+    dout = dout.float().double()
+    seq = torch.randint(0, 20, (B, L), generator=g)
+    seq[-1, L - 37:] = 20
+    out, _ = ref_attention(qkv, seq != 20, H)
+    out.backward(dout)
+    qd = qkv.detach().float().view(B * L, 3 * D).to(dev)
+    o, lse = K_.attention_fwd(qd, seq.to(dev), H, 0.0, 0, 0, arith=K_.GEMM_F16X2)
+    with fused(True):
+        dq = K_.attention_bwd(qd, seq.to(dev), o, dout.float().view(B * L, D).to(dev), lse, H, 0.0, 0, 0, arith=K_.GEMM_F16X2)
+    assert torch.isfinite(dq).all()
+    gr = qkv.grad
+    for i, name in enumerate(("dQ", "dK", "dV")):
+        a, r = dq.view(B, L, 3 * D)[:, :, i * D:(i + 1) * D].double().cpu(), gr[:, :, i * D:(i + 1) * D]
+        assert ((a - r).norm() / r.norm()).item() < 2e-6, name
+    # degenerate rows: zero K / V groups and tiles, a fully padded tile, huge and tiny magnitudes, zero gradients
+    B, L, H = 2, 300, 2
+    D = H * dk
+    qkv = torch.randn(B, L, 3 * D, generator=g)
+    qkv[0, 32:72, D:] = 0.0
+    qkv[1, :, 2 * D:] *= 3000.0
+    qkv[1, 5:9, 2 * D:] *= 1e-12
+    seq = torch.randint(0, 20, (B, L), generator=g)
+    seq[1, 96:] = 20
+    dout = torch.randn(B, L, D, generator=g) * 1e-20
+    qd = qkv.view(B * L, 3 * D).to(dev)
+    res = {}
+    for mode, on in ((K_.GEMM_F32, False), (K_.GEMM_F16X2, True)):
+        o, lse = K_.attention_fwd(qd, seq.to(dev), H, 0.0, 0, 0, arith=mode)
+        with fused(on):
+            dq = K_.attention_bwd(qd, seq.to(dev), o, dout.view(B * L, D).to(dev), lse, H, 0.0, 0, 0, arith=mode)
+        assert torch.isfinite(dq).all()
+        res[mode] = dq.double().cpu()
+    assert ((res[K_.GEMM_F32] - res[K_.GEMM_F16X2]).norm() / res[K_.GEMM_F32].norm()).item() < 3e-6
+    with fused(True):
+        for dz in (torch.zeros(B, L, D), torch.cat([torch.zeros(1, L, D), torch.randn(1, L, D, generator=g)])):
+            o, lse = K_.attention_fwd(qd, seq.to(dev), H, 0.1, 3, 1, arith=K_.GEMM_F16X2)
+            dq = K_.attention_bwd(qd, seq.to(dev), o, dz.view(B * L, D).to(dev), lse, H, 0.1, 3, 1, arith=K_.GEMM_F16X2)
+            assert torch.isfinite(dq).all() and (dq.view(B, L, 3 * D)[0] == 0).all()
+
+
+def test_fused_row_scales_and_automatic_choice(dev):
+    """The f16x2 row scales of dqkv the fused kernel leaves behind are those of a pass over what it wrote; with 17 proteins
+    x 8 heads = 136 workgroups (more than half of the 256 CUs) the library takes the fused kernel by itself."""
+    from test_gpu_scales import as_float, scale_of
+    from protein_transformer_amd import kernels as K
+    B, L, H, dk = 17, 300, 8, 64
+    g = torch.Generator().manual_seed(3)
+    D = H * dk
+    qkv = torch.randn(B * L, 3 * D, generator=g).to(dev)
+    dout = (torch.randn(B * L, D, generator=g) * torch.exp(2 * torch.randn(B * L, 1, generator=g))).to(dev) * 1e-3
+    seq = torch.randint(0, 20, (B, L), generator=g)
+    seq[0, L - 40:] = 20
+    seq = seq.to(dev)
+    o, lse = K.attention_fwd(qkv, seq, H, 0.1, 5, 2, arith=K.GEMM_F16X2)
+    out = {}
+    for name, ctx in (("auto", None), ("fused", fused(True)), ("two", fused(False))):
+        rs = torch.full((B * L,), 0x7F000000, dtype=torch.int32, device=dev)
+        mn = torch.full((4,), 0x7F000000, dtype=torch.int32, device=dev)
+        if ctx is None:
+            assert "PTAMD_ATTN_FUSED" not in os.environ
+            dq = K.attention_bwd(qkv, seq, o, dout, lse, H, 0.1, 5, 2, arith=K.GEMM_F16X2, row_scale=rs, row_scale_min=mn)
+        else:
+            with ctx:
+                dq = K.attention_bwd(qkv, seq, o, dout, lse, H, 0.1, 5, 2, arith=K.GEMM_F16X2, row_scale=rs, row_scale_min=mn)
+        want = scale_of(dq.abs().amax(dim=1).cpu().numpy())
+        assert np.array_equal(as_float(rs), want), name
+        assert np.array_equal(as_float(mn), np.full(4, want.min())), name
+        out[name] = dq
+    assert torch.equal(out["auto"], out["fused"])                    # 136 workgroups: the library chose the fused kernel
+    assert not torch.equal(out["fused"], out["two"])                 # (another summation order of dQ)
+    assert ((out["fused"] - out["two"]).norm() / out["two"].norm()).item() < 1e-6

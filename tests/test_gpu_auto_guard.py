@@ -113,9 +113,12 @@ def test_guard_measures_slack(dev):
     finally:
         K.weight_scales = real
     rep = guard.report()
+    per_layer = sum(guard.PRODUCTS.values()) + len(guard.WIDE)
     assert rep["steps"] == 5 and rep["measured_steps"] >= 2 and rep["bound_violations"] == 0
-    assert rep["fallbacks_per_step"] == 0.0 and rep["sites_off_bounds_now"] == 0
+    # the first step trusted nothing (no measurement yet): every site off its bound, every product in bf16x3; then nothing
+    assert rep["fallbacks_per_step"] == 2 * per_layer / 5 and rep["sites_off_bounds_now"] == 0 and rep["products_in_bf16x3_now"] == 0
     assert guard.slack.shape == (2, 5) and (guard.slack >= 0).all() and (guard.slack <= 8).all(), guard.slack
+    assert guard.spread.shape == (2, 8) and (guard.spread >= 0).all() and (guard.spread <= 6).all(), guard.spread
     # steps 0, 2, 4 measured, layers in backward order: the last completed measurement the guard has read is of step 2
     assert len(seen) == 6
     flat, _ = model.flat_parameters()
@@ -126,7 +129,11 @@ def test_guard_measures_slack(dev):
         bits = np.array([int(layers[i][k][0].item()) & 0xFFFFFFFF for k in ("att_scale", "f1_scale")], dtype=np.uint32)
         want = guard.slack_binades(by_hand[:2], bits)
         assert np.array_equal(want, got[i, :2]), (i, want, got[i])
-    update_record(OUT, "guard_on_a_plain_model", {"slack_binades[layer][att,f1,dz1,h1,h2]": guard.slack.tolist(), **rep})
+        w2 = dict(model.named_parameters())[f"encoder.enc_layers.{i}.pwff.layer2.weight"].detach()
+        e = torch.frexp(w2.abs().amax(dim=0))[1]                    # exponents of the column maxima of W2
+        assert guard.spread[i, 3] == float(e.max() - e.min())       # ... whose spread is what FFN-2's product is judged by
+    update_record(OUT, "guard_on_a_plain_model", {"slack_binades[layer][att,f1,dz1,h1,h2]": guard.slack.tolist(),
+                                                  "weight_scale_spread_binades[layer][product]": guard.spread.tolist(), **rep})
 
 
 def _stretch(model, log2_gain=8, log2_unit=10, emb_factor=1e4, seed=0):
@@ -158,96 +165,138 @@ def _stretch(model, log2_gain=8, log2_unit=10, emb_factor=1e4, seed=0):
         sd["encoder.input_embedding.emb.weight"][7].mul_(emb_factor)
 
 
-@pytest.mark.parametrize("what", ["gains", "units", "token", "all"])
+@pytest.mark.parametrize("what", ["gains", "units", "units5", "token", "all"])
 def test_adversarial_ranges(dev, what):
+    """Three passes in AUTO: (1) the first pass of a model - nothing measured yet, nothing trusted; (2) the pass after the
+    measurement has landed - bounds with small slack and products with a small weight-scale spread back on the fast path,
+    the others where the guard put them; (3) for the record only, the round-3 behaviour (guard disabled: every bound
+    trusted).  (1) and (2) must meet the prediction / dRMSD / gradient tolerances against fp64 - or, where the exact-f32
+    MFMA chain itself is beyond them on these weights, be no worse than 3 x that chain."""
     from protein_transformer_amd import kernels as K
     model, batch = _setup(dev, 2, 8, 512, 2048, [256] * 7 + [173], seed=11)
-    _stretch(model, log2_gain=8 if what in ("gains", "all") else 0, log2_unit=10 if what in ("units", "all") else 0,
-             emb_factor=1e4 if what in ("token", "all") else 1.0)
+    _stretch(model, log2_gain=8 if what in ("gains", "all") else 0,
+             log2_unit={"units": 10, "all": 10, "units5": 5}.get(what, 0), emb_factor=1e4 if what in ("token", "all") else 1.0)
     params = {k: v.detach().cpu().double() for k, v in model.state_dict().items()}
     ref = fp64_reference(params, batch[0], batch[2], 8)
     guard = model.auto_guard
     guard.interval = 1
     rec = {"f32": _errors(model, batch, dev, ref, K.GEMM_F32), "bf16x3": _errors(model, batch, dev, ref, K.GEMM_BF16X3)}
-    guard.train_steps = 0
-    rec["auto_first_pass_on_bounds"] = _errors(model, batch, dev, ref, K.GEMM_AUTO)
+    assert guard.train_steps == 0 and guard.off.all() and guard.wide.all()
+    rec["auto_first_pass_nothing_trusted"] = _errors(model, batch, dev, ref, K.GEMM_AUTO)
     torch.cuda.synchronize()
     rec["auto_second_pass_guarded"] = _errors(model, batch, dev, ref, K.GEMM_AUTO)          # its forward reads the measurement
     assert guard.measured_steps >= 1 and guard.report()["bound_violations"] == 0
     rec["slack_binades[layer][att,f1,dz1,h1,h2]"] = guard.slack.tolist()
-    rec["sites_off_bounds"] = int(guard.off.sum())
+    rec["weight_scale_spread_binades[layer][" + ",".join(n for n, _ in guard.WIDE) + "]"] = guard.spread.tolist()
+    rec["sites_off_bounds"], rec["products_in_bf16x3"] = int(guard.off.sum()), int(guard.wide.sum())
+    guard.enabled = False
+    rec["auto_with_the_guard_disabled_every_bound_trusted"] = _errors(model, batch, dev, ref, K.GEMM_AUTO)
+    guard.enabled = True
     update_record(OUT, f"adversarial_{what}", rec)
     strict = rec["f32"]
-    for name in ("auto_first_pass_on_bounds", "auto_second_pass_guarded"):
+    for name in ("auto_first_pass_nothing_trusted", "auto_second_pass_guarded"):
         e = rec[name]
-        fired = name.endswith("guarded") and guard.off.any()
-        # the prediction / dRMSD tolerances of SURVEY 8(d) - or, where the exact-f32 MFMA chain itself is beyond them on these
-        # weights (fp32 rounding of activations 1e4 x the usual size), no worse than 3 x the exact-f32 chain
-        assert e["pred_max_abs"] < max(1e-5, 3 * strict["pred_max_abs"]), (name, fired, e["pred_max_abs"], strict["pred_max_abs"])
-        assert e["drmsd_rel_max"] < max(1e-4, 3 * strict["drmsd_rel_max"]), (name, fired, e["drmsd_rel_max"])
-        assert e["grad_rel_l2"] < max(1e-3, 3 * strict["grad_rel_l2"]), (name, fired, e["grad_rel_l2"], strict["grad_rel_l2"])
-    if what in ("units", "all"):
-        # FFN units spanning 2^20 put the hidden layer's largest element far above the typical one: what the slack measures
-        # is how far the BOUND is above that largest element - it must have been measured, whatever it is
-        assert np.isfinite(guard.slack).all()
+        assert e["pred_max_abs"] < max(1e-5, 3 * strict["pred_max_abs"]), (name, e["pred_max_abs"], strict["pred_max_abs"])
+        assert e["drmsd_rel_max"] < max(1e-4, 3 * strict["drmsd_rel_max"]), (name, e["drmsd_rel_max"])
+        assert e["grad_rel_l2"] < max(1e-3, 3 * strict["grad_rel_l2"]), (name, e["grad_rel_l2"], strict["grad_rel_l2"])
+    if what in ("gains", "all"):      # gains 2^+-8 against compensating columns: the LayerNorm-derived bounds are 2^17 .. 2^19 loose
+        assert guard.off[:, :2].all() and guard.slack[:, :2].min() > 8
+        assert guard.wide[:, [0, 2]].all()                 # ... and the columns of W_qkv / W_1 span 2^16
+    if what in ("units", "all"):      # hidden units over 2^+-10: rows of W1 / columns of W2 span 2^20 - FFN-2 forward, dX-FFN-1
+        assert guard.wide[:, [3, 6]].all() and guard.spread[:, [3, 6]].min() >= 16
+    if what in ("units5", "token"):   # inside the supported range: everything stays on the fast path and meets the tolerances
+        assert not guard.off.any() and not guard.wide.any()
 
 
 @pytest.mark.parametrize("optimizer,lr,default_steps", [("adam", 1e-4, 200), ("sgd", 1e-2, 60)])
 def test_moved_weights_trajectory(dev, optimizer, lr, default_steps):
     """BASELINE config-2 model (d256, 4 layers, 8 heads, dff 2048); 8 proteins x L <= 64 so that the fp64 oracle - a Python
-    loop over the NeRF chain - makes `PTAMD_TRAJ_STEPS` (default 200) steps in minutes.  AUTO resolves to f16x2 here
-    (`AUTO_F16X2_MIN_WORK` lowered for the test: 512 tokens x 256 would otherwise run in bf16x3)."""
+    loop over the NeRF chain - makes `PTAMD_TRAJ_STEPS` (default 200 Adam / 60 SGD) steps in minutes.  AUTO resolves to
+    f16x2 here (`AUTO_F16X2_MIN_WORK` lowered for the test: 512 tokens x 256 would otherwise run in bf16x3).
+
+    What CAN be asserted about N optimizer steps.  Training this model is chaotic: the loss is a dRMSD of NeRF chains built
+    from the predicted angles, Adam turns the SIGN of a gradient component at rounding level into a full-size update, and
+    ReLU gates flip.  The test therefore runs, from the same initialisation and on the same batch,
+      * the device in all three arithmetics (AUTO, bf16x3, exact-f32 MFMA),
+      * the fp64 oracle, and the fp64 oracle once more from weights perturbed by ONE fp32 rounding (relative 6e-8) for the
+        first `control` steps: what an ideal fp32 implementation could at best achieve,
+    and asserts (a) the first steps agree to the single-step tolerances, (b) AUTO's distance from the fp64 trajectory is of
+    the size of the exact-f32 arithmetic's and of the perturbed fp64 run's (not worse than 3 x the larger), (c) every run
+    trains, (d) a single-step parity record AT the last step - the weights have moved by up to 35 % - meets the single-step
+    tolerances in every arithmetic, (e) the guard found every bound within 8 binades all the way."""
     from protein_transformer_amd import kernels as K
     from protein_transformer_amd.models import encoder_only as EO
     from protein_transformer_amd.optim import FusedAdam, FusedSGD
     from protein_transformer_amd.train import train_step
     steps = int(os.environ.get("PTAMD_TRAJ_STEPS", str(default_steps)))
+    control = min(steps, 40)
     lens = [64, 64, 57, 64, 33, 64, 48, 64]
-    model, batch = _setup(dev, 4, 8, 256, 2048, lens, seed=21)
+    modes = (("auto", K.GEMM_AUTO), ("bf16x3", K.GEMM_BF16X3), ("f32", K.GEMM_F32))
     old_min = EO.AUTO_F16X2_MIN_WORK
     EO.AUTO_F16X2_MIN_WORK = 1
     try:
-        ref = Fp64Trainer({k: v.detach().cpu() for k, v in model.state_dict().items()}, 8, optimizer=optimizer, lr=lr)
-        theta0 = {k: v.detach().cpu().double().clone() for k, v in model.state_dict().items()}
-        opt = (FusedAdam(model, lr=lr, betas=(0.9, 0.98), eps=1e-9, weight_decay=10e-3) if optimizer == "adam"
-               else FusedSGD(model, lr=lr, weight_decay=10e-3))
+        runs = {}
+        for name, mode in modes:
+            model, batch = _setup(dev, 4, 8, 256, 2048, lens, seed=21)
+            model.gemm_mode = mode
+            runs[name] = dict(model=model, curve=[], opt=(FusedAdam(model, lr=lr, betas=(0.9, 0.98), eps=1e-9, weight_decay=10e-3)
+                                                          if optimizer == "adam" else FusedSGD(model, lr=lr, weight_decay=10e-3)))
+        theta0 = {k: v.detach().cpu().double().clone() for k, v in runs["auto"]["model"].state_dict().items()}
+        ref = Fp64Trainer(theta0, 8, optimizer=optimizer, lr=lr)
+        g = torch.Generator().manual_seed(1)
+        ref_p = Fp64Trainer({k: (v if k.endswith(".pe") else v * (1 + 6e-8 * (2 * torch.randint(0, 2, v.shape, generator=g) - 1)))
+                             for k, v in theta0.items()}, 8, optimizer=optimizer, lr=lr)
         data = tuple(t.to(dev) for t in batch)
-        model.auto_guard.interval = 16
-        curve_dev, curve_ref = [], []
-        for _ in range(steps):
-            losses = train_step(model, opt, ARGS, *data)
-            curve_dev.append((float(losses["drmsd-full"]), float(losses["lndrmsd-full"])))
-            r = ref.step(batch[0], batch[2])
-            curve_ref.append((r["drmsd"], r["lndrmsd"]))
-        cd, cr = np.array(curve_dev), np.array(curve_ref)
-        rel_curve = np.abs(cd[:, 0] - cr[:, 0]) / cr[:, 0]
-        moved = params_rel_l2({k: v for k, v in ref.state().items()}, theta0)          # how far the weights went
-        final = params_rel_l2(model.state_dict(), ref.state())
-        upd_num = sum(float(((model.state_dict()[k].detach().cpu().double() - ref.state()[k]) ** 2).sum()) for k in theta0 if not k.endswith(".pe"))
-        upd_den = sum(float(((ref.state()[k] - theta0[k]) ** 2).sum()) for k in theta0 if not k.endswith(".pe"))
-        # single-step parity AT the moved weights: the device model's own step-N weights through both paths
-        params = {k: v.detach().cpu().double() for k, v in model.state_dict().items()}
-        ref1 = fp64_reference(params, batch[0], batch[2], 8)
-        at_end = {m: _errors(model, batch, dev, ref1, mode) for m, mode in (("auto", K.GEMM_AUTO), ("bf16x3", K.GEMM_BF16X3), ("f32", K.GEMM_F32))}
-        guard = model.auto_guard.report()
+        curve_ref, curve_p, snap = [], [], {}
+        for step in range(steps):
+            for name, _ in modes:
+                losses = train_step(runs[name]["model"], runs[name]["opt"], ARGS, *data)
+                runs[name]["curve"].append(float(losses["drmsd-full"]))
+            curve_ref.append(ref.step(batch[0], batch[2])["drmsd"])
+            if step < control:
+                curve_p.append(ref_p.step(batch[0], batch[2])["drmsd"])
+            if step + 1 == control:        # distances from the fp64 trajectory at the control horizon
+                snap = {name: params_rel_l2(runs[name]["model"].state_dict(), ref.state()) for name, _ in modes}
+                snap["fp64_perturbed"] = params_rel_l2(ref_p.state(), ref.state())
+        cr = np.array(curve_ref)
+        moved = params_rel_l2(ref.state(), theta0)
+        rec = {"model": "enc-only d256 nl4 nh8 dff2048", "lengths": lens, "optimizer": optimizer, "lr": lr, "steps": steps,
+               "control_steps": control, "drmsd_first_last_fp64": [cr[0], cr[-1]], "weights_moved_rel_l2": moved,
+               "parameters_rel_l2_from_the_fp64_run_at_the_control_step": snap, "runs": {}}
+        for name, mode in modes:
+            cd = np.array(runs[name]["curve"])
+            rel = np.abs(cd - cr) / cr
+            model = runs[name]["model"]
+            params = {k: v.detach().cpu().double() for k, v in model.state_dict().items()}
+            model.gemm_mode = None
+            rec["runs"][name] = {
+                "drmsd_first_last": [cd[0], cd[-1]], "loss_curve_rel_first_3_steps": rel[:3].tolist(),
+                "loss_curve_rel_at_control": float(rel[control - 1]), "loss_curve_rel_max": float(rel.max()),
+                "loss_curve_rel_median": float(np.median(rel)), "final_parameters_rel_l2_from_fp64": params_rel_l2(model.state_dict(), ref.state()),
+                # single-step parity AT the moved weights: this run's own final weights through the device and through fp64
+                "single_step_parity_at_the_last_step": _errors(model, batch, dev, fp64_reference(params, batch[0], batch[2], 8), mode)}
+        relp = np.abs(np.array(curve_p) - cr[:control]) / cr[:control]
+        rec["runs"]["fp64_perturbed_by_one_fp32_rounding"] = {"loss_curve_rel_first_3_steps": relp[:3].tolist(),
+                                                               "loss_curve_rel_at_control": float(relp[-1]), "loss_curve_rel_max": float(relp.max())}
+        guard = runs["auto"]["model"].auto_guard.report()
+        rec["auto_guard"] = guard
     finally:
         EO.AUTO_F16X2_MIN_WORK = old_min
-    rec = {"model": "enc-only d256 nl4 nh8 dff2048", "lengths": lens, "optimizer": optimizer, "lr": lr, "steps": steps,
-           "drmsd_first_last_fp64": [cr[0, 0], cr[-1, 0]], "drmsd_first_last_device": [cd[0, 0], cd[-1, 0]],
-           "loss_curve_rel_max": float(rel_curve.max()), "loss_curve_rel_median": float(np.median(rel_curve)),
-           "loss_curve_rel_last": float(rel_curve[-1]), "lndrmsd_curve_abs_max": float(np.abs(cd[:, 1] - cr[:, 1]).max()),
-           "weights_moved_rel_l2": moved, "final_parameters_rel_l2": final,
-           "trajectory_error_over_total_update": (upd_num / upd_den) ** 0.5,
-           "single_step_parity_at_the_last_step": at_end, "auto_guard": guard}
     update_record(OUT, f"trajectory_{optimizer}", rec)
-    assert guard["bound_violations"] == 0 and guard["fallbacks_per_step"] == 0.0 and guard["measured_steps"] >= steps // 16 - 1
-    assert cr[-1, 0] < cr[0, 0]                                            # it trains
-    assert rel_curve.max() < 1e-4, rel_curve.max()                         # the loss curve, every step
-    assert final < 1e-3, final                                             # the parameters after `steps` steps
-    e = at_end["auto"]
-    assert e["pred_max_abs"] < 1e-5 and e["drmsd_rel_max"] < 1e-4 and e["lndrmsd_abs_max"] < 1e-6 and e["grad_rel_l2"] < 1e-3, e
-    for gname, v in e["grad_rel_l2_per_group"].items():
-        assert v < 2e-3, (gname, v)
+    A, F32 = rec["runs"]["auto"], rec["runs"]["f32"]
+    assert guard["bound_violations"] == 0 and guard["sites_off_bounds_now"] == 0 and guard["measured_steps"] >= steps // 16 - 1
+    assert max(guard["max_slack_binades_seen"].values()) <= 8                      # (e)
+    assert max(A["loss_curve_rel_first_3_steps"][:1]) < 1e-5                       # (a) the first step: the single-step tolerance
+    for name, _ in modes:
+        r = rec["runs"][name]
+        assert r["drmsd_first_last"][1] < 0.9 * r["drmsd_first_last"][0], name    # (c) it trains, in every arithmetic
+        e = r["single_step_parity_at_the_last_step"]                              # (d)
+        assert e["pred_max_abs"] < 1e-5 and e["drmsd_rel_max"] < 1e-4 and e["lndrmsd_abs_max"] < 1e-6 and e["grad_rel_l2"] < 1e-3, (name, e)
+        for gname, v in e["grad_rel_l2_per_group"].items():
+            assert v < 2e-3, (name, gname, v)
+    yard = max(snap["f32"], snap["fp64_perturbed"])                                # (b)
+    assert snap["auto"] < 3 * yard, snap
+    assert A["final_parameters_rel_l2_from_fp64"] < 3 * max(F32["final_parameters_rel_l2_from_fp64"], rec["runs"]["bf16x3"]["final_parameters_rel_l2_from_fp64"]), rec["runs"]
 
 
 def test_side_stream_is_bit_identical(dev):

@@ -185,9 +185,15 @@ def test_auto_guard_slack_arithmetic():
     #      all-zero operand: 0; unused atomicMin slot: 0
     assert got[0] == 0 and got[1] == 1 and got[2] in (8, 9) and got[3] < 0 and got[4] == 0 and got[5] == 0
     g = AutoGuard(2, interval=4, max_slack=8)
-    assert g.want_measure() and not g.off.any()
+    assert g.want_measure() and g.off.all() and g.wide.all()           # nothing is trusted before the first measurement
     g.count_step()
-    assert not g.want_measure() and g.report()["fallbacks_per_step"] == 0.0
+    per_layer = sum(AutoGuard.PRODUCTS.values()) + len(AutoGuard.WIDE)
+    assert not g.want_measure() and g.report()["fallbacks_per_step"] == 2 * per_layer
+    g.off[:], g.wide[:] = False, False         # (what poll() does once a measurement with small slack / spread has landed)
     g.off[1, 1] = True                          # f1 of layer 1 off its bound: the FFN-2 forward and weight-gradient products
+    g.wide[0, 3] = True                         # ff2 of layer 0 in bf16x3
     g.count_step()
-    assert g.report()["fallbacks_per_step"] == 1.0 and g.report()["sites_off_bounds_now"] == 1
+    assert g.report()["fallbacks_per_step"] == (2 * per_layer + 3) / 2 and g.report()["sites_off_bounds_now"] == 1
+    # spread of a weight's row scales along a contracted index: exponents 100..112 -> 12 binades; zero rows do not count
+    bits = np.array([100 << 23, 112 << 23, 105 << 23, 254 << 23], dtype=np.uint32)
+    assert AutoGuard.spread_binades(bits) == 12.0 and AutoGuard.spread_binades(bits[3:]) == 0.0
