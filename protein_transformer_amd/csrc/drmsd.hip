@@ -191,10 +191,8 @@ __global__ __launch_bounds__(RS) void drmsd_tri_kernel(const float4 *__restrict_
   float offA = 0.f, offB = 0.f, diagA = 0.f, diagB = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
   float *const cf_row = s_cf + (w * TS + lane) * CF_LD;     // phase 1: this lane's row of coefficients
 
-  // one pair: e^2 into acc, cf (x_i - x_j) into the row gradient; returns cf (0 for a dead row)
-  auto pair = [&](int j, float &acc) __attribute__((always_inline)) {
-    const float4 a = s_xy[j];  // same address in every lane: LDS broadcast
-    const float2 c = s_z[j];
+  // one pair from its column coordinates: e^2 into acc, cf (x_i - x_j) into the row gradient; returns cf (0 for a dead row)
+  auto pair_of = [&](const float4 a, const float2 c, float &acc) __attribute__((always_inline)) {
     const f32x2 dx = ix - (f32x2){a.x, a.y}, dy = iy - (f32x2){a.z, a.w}, dz = iz - (f32x2){c.x, c.y};  // (pred, true)
     f32x2 q = dx * dx;
     q = __builtin_elementwise_fma(dy, dy, q);
@@ -213,6 +211,30 @@ __global__ __launch_bounds__(RS) void drmsd_tri_kernel(const float4 *__restrict_
     }
     return cf;
   };
+  auto pair = [&](int j, float &acc) __attribute__((always_inline)) {
+    return pair_of(s_xy[j], s_z[j], acc);  // same address in every lane: LDS broadcast
+  };
+  // U pairs at once: ALL column reads first, then the U independent chains, then the U coefficient stores.  Written pair
+  // by pair (read - chain - ds_write, read - ...) the compiler must keep every coefficient store in front of the next
+  // pair's column read (same LDS array: they may alias), which strings the U chains - LDS latency, two transcendentals
+  // and a dozen dependent VALU instructions each - one behind the other: ~200 cycles per 64-pair step, measured.
+  constexpr int U = PT_DRMSD_UNROLL;
+  auto pairs_u = [&](int j, float &acc, float *cf_out) __attribute__((always_inline)) {
+    float4 a[U];
+    float2 c[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      a[u] = s_xy[j + u];
+      c[u] = s_z[j + u];
+    }
+    float cf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) cf[u] = pair_of(a[u], c[u], acc);
+    if (WITH_GRAD) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) cf_out[u] = cf[u];
+    }
+  };
 
   for (int J = J0; J < J1; ++J) {
     __syncthreads();  // everybody is done with the previous column tile and its (S, V) slots
@@ -227,30 +249,17 @@ __global__ __launch_bounds__(RS) void drmsd_tri_kernel(const float4 *__restrict_
     const int ja = max(0, min(cnt, nbb - J * TS));   // columns below ja are backbone atoms (then so is every row i < j)
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);   // (S, Vx, Vy, Vz) of column lane of the tile, in lanes 0..cnt-1
     if (I < J) {  // wavefront-uniform: a full tile above the diagonal
-      constexpr int U = PT_DRMSD_UNROLL;
       const float4 *rows = s_row + w * TS + (lane >> 4) * SUB;          // phase 2: this lane's quarter of the rows
       const float *cf_q = s_cf + (w * TS + (lane >> 4) * SUB) * CF_LD + (lane & (SUB - 1));
       for (int j0 = 0; j0 < cnt; j0 += SUB) {
         const int j1 = min(cnt, j0 + SUB), jb = max(j0, min(j1, ja));   // [j0, jb) backbone columns, [jb, j1) the rest
         int j = j0;
-        for (; j + U - 1 < jb; j += U) {
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const float cf = pair(j + u, offA);
-            if (WITH_GRAD) cf_row[j + u - j0] = cf;
-          }
-        }
+        for (; j + U - 1 < jb; j += U) pairs_u(j, offA, cf_row + (j - j0));
         for (; j < jb; ++j) {
           const float cf = pair(j, offA);
           if (WITH_GRAD) cf_row[j - j0] = cf;
         }
-        for (; j + U - 1 < j1; j += U) {
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const float cf = pair(j + u, offB);
-            if (WITH_GRAD) cf_row[j + u - j0] = cf;
-          }
-        }
+        for (; j + U - 1 < j1; j += U) pairs_u(j, offB, cf_row + (j - j0));
         for (; j < j1; ++j) {
           const float cf = pair(j, offB);
           if (WITH_GRAD) cf_row[j - j0] = cf;
@@ -276,7 +285,9 @@ __global__ __launch_bounds__(RS) void drmsd_tri_kernel(const float4 *__restrict_
       }
     } else if (I == J) {  // the diagonal tile: both sides inside the tile, j == i contributes exactly 0
       int j = 0;
+      for (; j + U - 1 < ja; j += U) pairs_u(j, diagA, nullptr);
       for (; j < ja; ++j) pair(j, diagA);
+      for (; j + U - 1 < cnt; j += U) pairs_u(j, diagB, nullptr);
       for (; j < cnt; ++j) pair(j, diagB);
     }
     if (WITH_GRAD) {

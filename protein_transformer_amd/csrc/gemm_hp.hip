@@ -246,8 +246,294 @@ int launch_hp_g(const HpParams &p, int splits, hipStream_t st) {
 typedef HpGeom<4, 2, 2, true> Geom;
 
 template <int EPI>
+int launch_hp3(const HpParams &p, int splits, hipStream_t st);
+// the three-stage kernel (below) wherever the float4 epilogue applies; PTAMD_HP_STAGES=2 in the environment (read at every
+// call) selects the two-buffer kernel for A/B measurements
+template <int EPI>
 int launch_hp(const HpParams &p, int splits, hipStream_t st) {
+  const char *e = getenv("PTAMD_HP_STAGES");
+  if (p.g.vec_epilogue && !(e && e[0] == '2')) return launch_hp3<EPI>(p, splits, st);
   return launch_hp_g<Geom, EPI>(p, splits, st);
+}
+
+// ---------------------------------------------------------------------------------------------- three-stage variant (round 4)
+// Same tile (256 x 128, eight wavefronts of 64 x 64), same stages of 32 k, same epilogue arithmetic and masks as
+// gemm_hp_kernel above, with the stage stream restructured around what the ISA of that kernel showed:
+//   * THREE stage buffers: the pieces of stage s + 2 are issued while stage s computes, and the wait at the top of a
+//     stage is a COUNTED `s_waitcnt vmcnt(6)` - this wavefront's six pieces of stage s + 1 stay in flight across the
+//     barrier (a raw s_barrier: __syncthreads() would drain the LDS-DMA queue).  In the two-buffer kernel the last piece
+//     of the next stage is issued near the end of a stage and `vmcnt(0)` at the top waits out its whole latency - every
+//     32 k.  LDS: 3 x 48 KiB of stages + 16 KiB of epilogue scratch (2 KiB per wavefront: the accumulators go out eight
+//     rows at a time) = 160 KiB;
+//   * a wavefront's six pieces are the same (operand, block row, k block, plane) in every stage: four of A, two of B.
+//     Their addresses are advanced on the scalar unit from values computed once per tile; the old kernel re-loaded the
+//     selected operand pointer from the kernel-argument segment in every DMA slot and waited lgkmcnt(0) for it - which
+//     also waited for the fragment reads in flight;
+//   * the sixteen fragment reads of a stage are issued in one burst behind the barrier (inline asm, counted lgkmcnt): the
+//     first twelve MFMAs start when the first eight have returned.
+struct Hp3 {
+  static constexpr int NW = 8, THREADS = 512, TILE_M = 256, BK = 32, NSTAGE = 3, PER_WAVE = 6;
+  static constexpr int RB_BYTES = 4096, A_STAGE = 8 * RB_BYTES, STAGE_BYTES = 12 * RB_BYTES;
+  static constexpr int SCRATCH_BYTES = NW * 2048;
+  static constexpr size_t LDS = (size_t)NSTAGE * STAGE_BYTES + SCRATCH_BYTES;
+  static_assert(LDS == 160 * 1024, "the whole LDS of a CU");
+};
+
+// the epilogue of one wavefront's 64 x 64 block (TI = 2), eight rows at a time through `scratch` (512 floats): bias / ReLU /
+// dropout in the MFMA layout, residual / gate / accumulate operands and the stores as float4 rows.  Arithmetic, order of
+// operations and dropout masks are those of ptgemm::tile_epilogue_vec (gemm_common.h).
+template <int EPI>
+__device__ __forceinline__ void hp3_epilogue(const GemmParams &p, const f32x16 (&acc)[2][2], float *C, int ldc, bool partial,
+                                             int row0, int col0, int lane, uint32_t thr, float keep_scale, float *scratch) {
+  using ptgemm::EPI_FULL;
+  using ptgemm::EPI_PLAIN;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int l31 = lane & 31, lh = lane >> 5;
+  uint32_t keep[2] = {0xffffffffu, 0xffffffffu};
+  if (EPI == EPI_FULL && !partial && p.dropout_p > 0.f) {
+    keep[0] = keep[1] = 0u;
+#pragma unroll 4
+    for (int idx = 0; idx < 8; ++idx) {  // one call = the lane's 8 rows of two register groups (common.h)
+      const int i = idx >> 2, j = (idx >> 1) & 1, gp = idx & 1;
+      const int row = row0 + i * 32 + 16 * gp + 4 * lh, col = col0 + j * 32 + l31;
+      const uint4 rnd = pt_rand4(p.seed, drop_call_index(row, col, p.N), p.stream_id);
+      const uint32_t t16 = thr >> 16;
+      uint32_t bits = 0;
+#pragma unroll
+      for (int f = 0; f < 8; ++f)
+        bits |= (drop_field_value(rnd, f) >= t16 ? 1u : 0u) << (j * 16 + (2 * gp + (f >> 2)) * 4 + (f & 3));
+      keep[0] |= i == 0 ? bits : 0u;
+      keep[1] |= i == 1 ? bits : 0u;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    f32x4 pre4[8];
+    const bool want_res = EPI != EPI_PLAIN && !partial && p.residual != nullptr;
+    const bool want_old = EPI != EPI_PLAIN && !partial && (p.flags & PTAMD_EPI_ACCUM) && !want_res;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int f = lane + 64 * t, rr = f >> 4, c4 = (f & 15) * 4;
+      const int row = min(row0 + i * 32 + rr, p.M - 1), col = min(col0 + c4, p.N - 4);
+      const float *src = want_res ? p.residual + (size_t)row * p.ldr + col : C + (size_t)row * ldc + col;
+      pre4[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (want_res || want_old) pre4[t] = *reinterpret_cast<const f32x4 *>(src);
+    }
+    float bias[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = col0 + j * 32 + l31;
+      bias[j] = (EPI != EPI_PLAIN && !partial && p.bias && col < p.N) ? p.bias[col] : 0.f;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[i][j][g * 4 + e];
+          if (EPI != EPI_PLAIN && !partial) {
+            v += bias[j];
+            if (p.flags & PTAMD_EPI_RELU) v = fmaxf(v, 0.f);
+            if (EPI == EPI_FULL && p.dropout_p > 0.f) v = (keep[i] >> (j * 16 + g * 4 + e)) & 1u ? v * keep_scale : 0.f;
+          }
+          scratch[(4 * lh + e) * 64 + j * 32 + l31] = v;
+        }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int f = lane + 64 * u, rr = f >> 4, c4 = (f & 15) * 4;   // rr: 0..7 of this group of eight rows
+        const int row = row0 + i * 32 + 8 * g + rr, col = col0 + c4;
+        float4 v = *reinterpret_cast<const float4 *>(scratch + rr * 64 + c4);
+        if (row < p.M && col < p.N) {
+          if (EPI != EPI_PLAIN && !partial) {
+            // (pre4[t] of tile_epilogue_vec holds rows (lane >> 4) + 4 t of the 32-row block: t = 2 g + u here)
+            const f32x4 r4 = pre4[2 * g + u];
+            if (p.residual) {
+              if (p.flags & PTAMD_EPI_GATE) {
+                v.x = r4.x > 0.f ? v.x * p.gate_scale : 0.f; v.y = r4.y > 0.f ? v.y * p.gate_scale : 0.f;
+                v.z = r4.z > 0.f ? v.z * p.gate_scale : 0.f; v.w = r4.w > 0.f ? v.w * p.gate_scale : 0.f;
+              } else {
+                v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+              }
+            }
+            if (p.flags & PTAMD_EPI_TANH) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+            if (p.flags & PTAMD_EPI_ACCUM) {
+              const f32x4 o4 = want_old ? r4 : *reinterpret_cast<const f32x4 *>(C + (size_t)row * ldc + col);
+              v.x += o4.x; v.y += o4.y; v.z += o4.z; v.w += o4.w;
+            }
+          }
+          *reinterpret_cast<float4 *>(C + (size_t)row * ldc + col) = v;
+        }
+      }
+    }
+  }
+}
+
+#define PT_DS_READ_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+
+template <int EPI>
+__global__ __launch_bounds__(Hp3::THREADS, 2) void gemm_hp3_kernel(const HpParams p) {
+  using G = Hp3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *const scratch = reinterpret_cast<float *>(smem + G::NSTAGE * G::STAGE_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const ptgemm::WorkRange work(p.g, G::TILE_M, HBN);
+  if (work.begin >= work.end) return;
+  const int Kp = p.kb16 * 16;
+  auto item_at = [&](int logical) __attribute__((always_inline)) {
+    Item it;
+    work.decode(logical, it.bm0, it.bn0, it.z);
+    it.kbeg = it.z * p.g.k_per_split;
+    it.kend = min(Kp, it.kbeg + p.g.k_per_split);
+    return it;
+  };
+  auto advance = [&](Cursor &c) __attribute__((always_inline)) {
+    if (c.k0 + G::BK < c.it.kend) {
+      c.k0 += G::BK;
+      return true;
+    }
+    if (c.w + 1 < work.end) {
+      c.it = item_at(++c.w);
+      c.k0 = c.it.kbeg;
+      return true;
+    }
+    return false;
+  };
+  // piece i of this wavefront: q = wave + 8 i of the 48 KiB stage = block row q >> 2 (A: 0..7, B: 8..11), (k block, plane)
+  // = q & 3 = wave & 3.  So pieces 0..3 are A block rows 2 i + (wave >> 2) and pieces 4, 5 B block rows 2 (i - 4) + (wave >> 2).
+  const int rb_in_tile = wave >> 2, rest_bytes = (wave & 3) * 1024;
+  const char *const a_base = p.a_planes + rest_bytes + lane * 16, *const b_base = p.b_planes + rest_bytes + lane * 16;
+  const int64_t row_bytes = (int64_t)p.kb16 * 2048;     // bytes of one block row of an operand: KB16 blocks x 2 planes x 1 KiB
+  auto issue_piece = [&](const Cursor &c, int buf, int i) __attribute__((always_inline)) {
+    const int q = wave + G::NW * i;
+    const bool is_b = i >= 4;                                // (compile-time per call site)
+    const int rb = is_b ? min((c.it.bn0 >> 5) + 2 * (i - 4) + rb_in_tile, p.b_rb_last) : min((c.it.bm0 >> 5) + 2 * i + rb_in_tile, p.a_rb_last);
+    const char *g = (is_b ? b_base : a_base) + (int64_t)rb * row_bytes + (int64_t)(c.k0 >> 4) * 2048;
+    dma16(g, smem + buf * G::STAGE_BYTES + q * 1024);
+  };
+
+  f32x16 acc[2][2];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  zero_acc();
+  const uint32_t thr = dropout_threshold(p.g.dropout_p);
+  const float keep_scale = 1.f / (1.f - p.g.dropout_p);
+  const bool partial = p.g.slab != 0;
+  // LDS byte addresses of this lane's fragment chunk in the wavefront's first A / B block row of stage buffer 0
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+  const uint32_t frag = (uint32_t)chunk_index(lane & 31, lane >> 5) * 16u;
+  const uint32_t va0 = lds0 + (uint32_t)(2 * wm) * G::RB_BYTES + frag, vb0 = lds0 + G::A_STAGE + (uint32_t)(2 * wn) * G::RB_BYTES + frag;
+
+  Cursor ld = {work.begin, 0, item_at(work.begin)};
+  ld.k0 = ld.it.kbeg;
+  Cursor cc = ld;
+#pragma unroll
+  for (int i = 0; i < G::PER_WAVE; ++i) issue_piece(ld, 0, i);
+  bool more_loads = advance(ld);
+  int ahead = 1;                 // stages issued and not yet waited for (this one included)
+  if (more_loads) {
+#pragma unroll
+    for (int i = 0; i < G::PER_WAVE; ++i) issue_piece(ld, 1, i);
+    more_loads = advance(ld);
+    ahead = 2;
+  }
+  bool drain = false;            // an epilogue ran since the last wait: loads and stores of another kind are in the queue
+  int buf = 0;
+  for (;;) {
+    // this wavefront's pieces of the stage have landed; those of the next stage may stay in flight
+    if (ahead >= 2 && !drain) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    drain = false;
+    __builtin_amdgcn_s_barrier();   // ... and everybody's; everybody is done with the buffer that is refilled below
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t va = va0 + (uint32_t)buf * G::STAGE_BYTES, vb = vb0 + (uint32_t)buf * G::STAGE_BYTES;
+    const int nbuf = buf >= 1 ? buf - 1 : 2;   // (buf + 2) % 3: the buffer stage c + 2 goes to, read last in stage c - 1
+    f16x8 fa[2][2][2], fb[2][2][2];            // [k block][tile][plane]
+    PT_DS_READ_B128(fa[0][0][0], va, 0);
+    PT_DS_READ_B128(fa[0][0][1], va, 1024);
+    PT_DS_READ_B128(fb[0][0][0], vb, 0);
+    PT_DS_READ_B128(fb[0][0][1], vb, 1024);
+    PT_DS_READ_B128(fa[0][1][0], va, 4096);
+    PT_DS_READ_B128(fa[0][1][1], va, 4096 + 1024);
+    PT_DS_READ_B128(fb[0][1][0], vb, 4096);
+    PT_DS_READ_B128(fb[0][1][1], vb, 4096 + 1024);
+    PT_DS_READ_B128(fa[1][0][0], va, 2048);
+    PT_DS_READ_B128(fa[1][0][1], va, 2048 + 1024);
+    PT_DS_READ_B128(fb[1][0][0], vb, 2048);
+    PT_DS_READ_B128(fb[1][0][1], vb, 2048 + 1024);
+    PT_DS_READ_B128(fa[1][1][0], va, 4096 + 2048);
+    PT_DS_READ_B128(fa[1][1][1], va, 4096 + 2048 + 1024);
+    PT_DS_READ_B128(fb[1][1][0], vb, 4096 + 2048);
+    PT_DS_READ_B128(fb[1][1][1], vb, 4096 + 2048 + 1024);
+    const bool issue = more_loads;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      if (kb == 0) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pr = 0; pr < 3; ++pr) {      // smallest products first: lo hi', hi lo', hi hi'
+        const int ta = pr == 0 ? 1 : 0, tb = pr == 1 ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kb][i][ta], fb[kb][j][tb], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (issue) issue_piece(ld, nbuf, kb * 3 + pr);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (issue) {
+      more_loads = advance(ld);
+      ++ahead;
+    }
+    --ahead;
+    if (cc.k0 + G::BK >= cc.it.kend) {  // that was the item's last stage (uniform)
+      float *C = p.g.C + (partial ? (size_t)cc.it.z * p.g.slab : 0);
+      const int ldc = partial ? p.g.N : p.g.ldc;
+      const int row0 = cc.it.bm0 + wm * 64, col0 = cc.it.bn0 + wn * 64;
+      {
+        const int l31 = lane & 31, lh = lane >> 5;
+        float ib[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ib[j] = inverse_of_scale(p.b_scale[min(col0 + j * 32 + l31, p.g.N - 1)]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float ia = inverse_of_scale(p.a_scale[min(row0 + i * 32 + 8 * g + 4 * lh + e, p.g.M - 1)]);
+#pragma unroll
+              for (int j = 0; j < 2; ++j) acc[i][j][g * 4 + e] = acc[i][j][g * 4 + e] * ia * ib[j];
+            }
+      }
+      hp3_epilogue<EPI>(p.g, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 512);
+      zero_acc();
+      drain = true;
+    }
+    if (!advance(cc)) break;
+    buf = buf == 2 ? 0 : buf + 1;
+  }
+}
+
+template <int EPI>
+int launch_hp3(const HpParams &p, int splits, hipStream_t st) {
+  const int work = ((p.g.M + Hp3::TILE_M - 1) / Hp3::TILE_M) * ((p.g.N + HBN - 1) / HBN) * splits;
+  auto kern = gemm_hp3_kernel<EPI>;
+  PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Hp3::LDS));
+  const int slots = ptgemm::persistent_grid(p.g.reserved_cus);
+  hipLaunchKernelGGL(kern, dim3(work < slots ? work : slots), dim3(Hp3::THREADS), Hp3::LDS, st, p);
+  return pt_check_launch();
 }
 
 // ---------------------------------------------------------------------------------------------- writers of the format
