@@ -217,6 +217,11 @@ typedef struct {
   void *planes; float *scale;
 } ptamd_hp_split_job;
 int ptamd_hp_split_rows(const ptamd_hp_split_job *jobs_host, int njobs, void *stream);
+/* ptamd_hp_split_cols: up to 16 ROW-contiguous matrices x [K, rows] (row stride ld) -> the planes of their TRANSPOSES (operand
+ * rows = the columns of x: the weights as B operands of the dX products dy W, Sublayers.py:28-34 backward) in ONE launch,
+ * with the operand rows' scales GIVEN in `scale` (an INPUT here: floats that are powers of two, e.g. the column scales
+ * ptamd_weight_scales wrote, reinterpreted). */
+int ptamd_hp_split_cols(const ptamd_hp_split_job *jobs_host, int njobs, void *stream);
 typedef struct {
   int M, N, K;
   const void *A; const float *A_scale;
@@ -286,11 +291,14 @@ int ptamd_layernorm_bwd(const float *dy, const float *x, const float *gamma, con
  * the scale of a row bounded by |dropped[t]|_2 * *bound_factor (device scalar, e.g. from ptamd_bound_scales): the scale of
  * row t of dropped W.  row_scale_min[0..3] / bound_scale_min[0..3] (may be NULL): the smallest of those scales over all
  * rows, i.e. the scale of the largest row - atomicMin into four copies that the caller preset to 0x7F000000; the uniform
- * scale of `dropped` / `dropped W` as an operand of a weight-gradient product.  Any of the outputs may be NULL.  D <= 1024. */
+ * scale of `dropped` / `dropped W` as an operand of a weight-gradient product.  dropped_planes (may be NULL; needs row_scale,
+ * D % 32 == 0): `dropped` a second time in the pre-split hp format (ptamd_hp_bytes(T, D) bytes) with the scales of
+ * row_scale - the A operand of ptamd_gemm_hp for the dX product behind it.  Any of the outputs may be NULL.  D <= 1024. */
 int ptamd_layernorm_bwd_dropout(const float *dy, const float *x, const float *gamma, const float *mean, const float *rstd,
                                 const float *dres, int64_t T, int D, float dropout_p, uint64_t seed, uint32_t stream_id,
                                 float *dx, float *dropped, uint32_t *row_scale, const float *bound_factor,
-                                uint32_t *bound_scale, uint32_t *row_scale_min, uint32_t *bound_scale_min, float *dgamma,
+                                uint32_t *bound_scale, uint32_t *row_scale_min, uint32_t *bound_scale_min,
+                                void *dropped_planes, float *dgamma,
                                 float *dbeta, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Embeddings * sqrt(D) and the doubled positional add of Encoder.py:30 + Sublayers.py:59-62,72:

@@ -973,22 +973,33 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   const int db = 16 * (wave & 3), qb = 16 * (wave >> 2);   // this wavefront's piece of a tile's dQ^T
   auto tile = [&](int buf) __attribute__((always_inline)) { return smem + buf * BUF; };
   uint32_t my_min = 0x7F000000u;                          // smallest f16x2 scale of the dQ rows this thread published
+  // this lane's transposing reads of a 32-key step st: rows 32 st + 4 g16 + (i16 >> 2) (+ 16), four columns from db / qb +
+  // 4 (i16 & 3); the swizzles depend on the row only through bits that 32 st and 16 leave alone, so a step is + 32 rows
+  // this lane's own key row in the K planes: chunk c = 2 st + lh of row r sits at c ^ (2 ((r >> 1) & 3))
+  const int kswz = (2 * (((wave * 32 + l31) >> 1) & 3)) ^ lh;
+  const unsigned short *const kself = sKP + (wave * 32 + l31) * 64;
+  const unsigned short *const ka0 = sKP + kp_off(4 * g16 + (i16 >> 2), db + 4 * (i16 & 3));
+  const unsigned short *const da0 = sDS + ds_off(4 * g16 + (i16 >> 2), qb + 4 * (i16 & 3));
 
   for (int kb = 0; kb < nkb; ++kb) {
     const int key = kb * FK + wave * 32 + l31;
     const bool k_ok = key < L;
     const bool k_valid = k_ok && seq[(size_t)b * L + key] != PTAMD_PAD_ID;
-    f16x8 kf[KS][2], vf[KS][2];
-    const float ikl = load_row_scaled<KS>(base + D, D3, min(key, L - 1), k_ok, lh, kf);
-    const float ivl = load_row_scaled<KS>(base + 2 * D, D3, min(key, L - 1), k_ok, lh, vf);
-    const float ck = scale * LOG2E * ikl, gk = ivl * ks;
-    {  // the scaled K rows of the block as LDS planes (the previous block's readers are behind the last barrier of its loop)
+    f16x8 vf[KS][2];
+    float ikl;
+    {  // the scaled K rows of the block go to LDS as planes and are read from there by BOTH products that need them (S = Q K^T
+       // as row fragments, dQ^T += K^T dS^T by transposing reads): 32 registers less than holding them (the dK/dV kernel's 256
+       // are all taken).  (The previous block's readers are behind the last barrier of its loop.)
+      f16x8 kf[KS][2];
+      ikl = load_row_scaled<KS>(base + D, D3, min(key, L - 1), k_ok, lh, kf);
       const int row = wave * 32 + l31;
 #pragma unroll
       for (int st = 0; st < KS; ++st)
 #pragma unroll
         for (int t = 0; t < 2; ++t) *reinterpret_cast<f16x8 *>(sKP + t * KP_PLANE + kp_off(row, 16 * st + 8 * lh)) = kf[st][t];
     }
+    const float ivl = load_row_scaled<KS>(base + 2 * D, D3, min(key, L - 1), k_ok, lh, vf);
+    const float ck = scale * LOG2E * ikl, gk = ivl * ks;
     f32x16 dk[NT], dv[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -1034,7 +1045,10 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         f16x8 qa[2], ga[2];
         Tile2::frag_rows(sQ, st, lane, qa);
         Tile2::frag_rows(sG, st, lane, ga);
-        s = mfma3(qa, kf[st], s);     // S[q][key]
+        f16x8 kfr[2];   // this lane's key row, d = 16 st + 8 lh + 0..7, from the K planes
+#pragma unroll
+        for (int t = 0; t < 2; ++t) kfr[t] = *reinterpret_cast<const f16x8 *>(kself + t * KP_PLANE + ((((2 * st) ^ kswz) & 7) << 3));
+        s = mfma3(qa, kfr, s);     // S[q][key]
         dp = mfma3(ga, vf[st], dp);   // dP[q][key] = dO V^T
       }
       if (more) {
@@ -1098,7 +1112,9 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         uint32_t w2 = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          fq[j] = ikl * inv_pow2(iq[j]);
+          // (a register quadruple that is all zero - masked keys, query rows beyond L, dO = 0 - takes the factor 0: its Q
+          // group scale may be 2^127 and the wavefront's scale below 2^127, and 0 * inf is not 0)
+          fq[j] = gm[j] > 0.f ? ikl * inv_pow2(iq[j]) : 0.f;
           w2 = max(w2, abs_bits(gm[j] * fq[j]));
           wmax = fmaxf(wmax, gm[j]);
         }
@@ -1108,7 +1124,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           uint2 h1, h2;
-          const float cj = cw * fq[j];
+          const float cj = fminf(cw * fq[j], 8.507059173023462e37f);   // 2^126: finite whatever the magnitudes (see above)
           split_quad_f16(s[4 * j], s[4 * j + 1], s[4 * j + 2], s[4 * j + 3], cj, cj, cj, cj, h1, h2);
           const int off = ds_off(row, 8 * j + 4 * lh);
           *reinterpret_cast<uint2 *>(sDS + off) = h1;
@@ -1149,17 +1165,16 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       __syncthreads();  // every wavefront's dS tile (and the next staged tiles) is in LDS; nobody reads the current tiles any more
       // ---- dQ^T[db .. db + 16][qb .. qb + 16] of this query tile over the 256 keys of the block
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-      for (int st = 0; st < NW; ++st) {
-        const int r1 = st * 32 + 4 * g16 + (i16 >> 2);
+#pragma unroll 2
+      for (int st = 0; st < NW; ++st) {   // keys 32 st .. 32 st + 31 = the rows wavefront st wrote; offsets: see ka0 / da0
         f16x8 a[2], bq[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const unsigned short *ka = sKP + t * KP_PLANE, *da = sDS + t * DS_PLANE;
-          const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(ka + kp_off(r1, db + 4 * (i16 & 3))));
-          const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(ka + kp_off(r1 + 16, db + 4 * (i16 & 3))));
-          const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(da + ds_off(r1, qb + 4 * (i16 & 3))));
-          const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(da + ds_off(r1 + 16, qb + 4 * (i16 & 3))));
+          const unsigned short *ka = ka0 + t * KP_PLANE + st * (32 * 64), *da = da0 + t * DS_PLANE + st * (32 * 32);
+          const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)ka);
+          const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(ka + 16 * 64));
+          const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)da);
+          const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(da + 16 * 32));
           a[t] = __builtin_bit_cast(f16x8, (s16x8)__builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
           bq[t] = __builtin_bit_cast(f16x8, (s16x8)__builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
         }

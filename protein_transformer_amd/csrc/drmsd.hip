@@ -18,6 +18,8 @@
 //             tile through LDS.  ALU/transcendental bound, O(n) bytes + O(n^2 / 256) partial-sum bytes.
 //   finalize  fixed-order fp64 reduction of the block partials, loss statistics, gradient assembly (row + column
 //             partials, fixed order), scale and scatter back to the [L*14,3] slot layout.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -25,7 +27,7 @@ namespace {
 constexpr int CB = 256;  // threads per block of the compaction / finalize kernels
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef PT_DRMSD_UNROLL
-#define PT_DRMSD_UNROLL 4
+#define PT_DRMSD_UNROLL 8   // (8 chains in flight at 116 VGPRs = 4 wavefronts per SIMD: 370 us against 398 with 4 chains at 6 wavefronts, config 4)
 #endif
 
 struct Counts {
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(RS) void drmsd_tri_kernel(const float4 *__restrict_
   // pair's column read (same LDS array: they may alias), which strings the U chains - LDS latency, two transcendentals
   // and a dozen dependent VALU instructions each - one behind the other: ~200 cycles per 64-pair step, measured.
   constexpr int U = PT_DRMSD_UNROLL;
-  auto pairs_u = [&](int j, float &acc, float *cf_out) __attribute__((always_inline)) {
+  auto pairs_u = [&](int j, float &acc, float *cf_out, auto keep) __attribute__((always_inline)) {
     float4 a[U];
     float2 c[U];
 #pragma unroll
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(RS) void drmsd_tri_kernel(const float4 *__restrict_
     float cf[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) cf[u] = pair_of(a[u], c[u], acc);
-    if (WITH_GRAD) {
+    if (WITH_GRAD && decltype(keep)::value) {   // (the diagonal tile keeps no coefficients)
 #pragma unroll
       for (int u = 0; u < U; ++u) cf_out[u] = cf[u];
     }
@@ -254,12 +256,12 @@ __global__ __launch_bounds__(RS) void drmsd_tri_kernel(const float4 *__restrict_
       for (int j0 = 0; j0 < cnt; j0 += SUB) {
         const int j1 = min(cnt, j0 + SUB), jb = max(j0, min(j1, ja));   // [j0, jb) backbone columns, [jb, j1) the rest
         int j = j0;
-        for (; j + U - 1 < jb; j += U) pairs_u(j, offA, cf_row + (j - j0));
+        for (; j + U - 1 < jb; j += U) pairs_u(j, offA, cf_row + (j - j0), std::true_type{});
         for (; j < jb; ++j) {
           const float cf = pair(j, offA);
           if (WITH_GRAD) cf_row[j - j0] = cf;
         }
-        for (; j + U - 1 < j1; j += U) pairs_u(j, offB, cf_row + (j - j0));
+        for (; j + U - 1 < j1; j += U) pairs_u(j, offB, cf_row + (j - j0), std::true_type{});
         for (; j < j1; ++j) {
           const float cf = pair(j, offB);
           if (WITH_GRAD) cf_row[j - j0] = cf;
@@ -285,9 +287,9 @@ __global__ __launch_bounds__(RS) void drmsd_tri_kernel(const float4 *__restrict_
       }
     } else if (I == J) {  // the diagonal tile: both sides inside the tile, j == i contributes exactly 0
       int j = 0;
-      for (; j + U - 1 < ja; j += U) pairs_u(j, diagA, nullptr);
+      for (; j + U - 1 < ja; j += U) pairs_u(j, diagA, nullptr, std::false_type{});
       for (; j < ja; ++j) pair(j, diagA);
-      for (; j + U - 1 < cnt; j += U) pairs_u(j, diagB, nullptr);
+      for (; j + U - 1 < cnt; j += U) pairs_u(j, diagB, nullptr, std::false_type{});
       for (; j < cnt; ++j) pair(j, diagB);
     }
     if (WITH_GRAD) {

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dropout_kernel(
     const float *__restrict__ rstd, const float *__restrict__ dres, int64_t T, int D, float *__restrict__ dx,
     float *__restrict__ part, float p, uint64_t seed, uint32_t stream_id, float *__restrict__ dropped,
     uint32_t *__restrict__ row_scale, const float *__restrict__ bound_factor, uint32_t *__restrict__ bound_scale,
-    uint32_t *__restrict__ row_scale_min, uint32_t *__restrict__ bound_scale_min) {
+    uint32_t *__restrict__ row_scale_min, uint32_t *__restrict__ bound_scale_min, char *__restrict__ planes) {
   const int lane = threadIdx.x & 63, wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   uint32_t rmin = 0x7F000000u, bmin = 0x7F000000u;  // smallest scale = largest row seen by this wavefront
   float4 g[NV], dg[NV], db[NV];
@@ -331,9 +331,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dropout_kernel(
       }
       const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
       float amax = 0.f, sq = 0.f;
+      float4 od[NV];   // the dropped row, kept for the plane output below (its scale is known only after the whole row)
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
         const int c = (j * 64 + lane) * 4;
+        od[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < D) {
           // rs * (..) + r as ONE fma each (r * rflag is exact: rflag is 0 or 1, no residual gradient -> + 0).  The unfused
           // layernorm_bwd_kernel contracts differently, so the two agree to rounding, not bit for bit
@@ -351,11 +353,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dropout_kernel(
           }
           amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
           sq += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+          od[j] = o;
         }
       }
       amax = wave_max(amax);
       sq = wave_sum(sq);
       const uint32_t rs_bits = pt_row_scale_bits(__float_as_uint(amax)), bs_bits = pt_row_scale_bits(__float_as_uint(sqrtf(sq) * bf));
+      if (planes) {   // the dropped row a second time, pre-split for ptamd_gemm_hp (csrc/hp_format.h): the A operand of the dX
+                      // product behind it reads these by LDS-DMA instead of splitting the fp32 copy while it stages it
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          const int c = (j * 64 + lane) * 4;
+          if (c < D) pthp::store4_split(planes, D >> 4, row, c, od[j], __uint_as_float(rs_bits));
+        }
+      }
       rmin = min(rmin, rs_bits);
       bmin = min(bmin, bs_bits);
       if (lane == 0) {
@@ -577,9 +588,12 @@ int ptamd_layernorm_bwd(const float *dy, const float *x, const float *gamma, con
 int ptamd_layernorm_bwd_dropout(const float *dy, const float *x, const float *gamma, const float *mean, const float *rstd,
                                 const float *dres, int64_t T, int D, float dropout_p, uint64_t seed, uint32_t stream_id,
                                 float *dx, float *dropped, uint32_t *row_scale, const float *bound_factor,
-                                uint32_t *bound_scale, uint32_t *row_scale_min, uint32_t *bound_scale_min, float *dgamma,
+                                uint32_t *bound_scale, uint32_t *row_scale_min, uint32_t *bound_scale_min,
+                                void *dropped_planes, float *dgamma,
                                 float *dbeta, void *workspace, size_t workspace_bytes, void *stream) {
   if (T <= 0 || D <= 0 || (D & 3) || D > 1024) return PTAMD_ERR_BAD_SHAPE;  // 4 D / 256 generator words per lane stay in registers
+  if (dropped_planes && ((D & 31) || !pt_aligned16(dropped_planes))) return PTAMD_ERR_BAD_SHAPE;
+  char *planes = static_cast<char *>(dropped_planes);
   if (dropout_p < 0.f || dropout_p >= 1.f || (dropout_p > 0.f && !dropped)) return PTAMD_ERR_BAD_SHAPE;
   if ((bound_scale || bound_scale_min) && !bound_factor) return PTAMD_ERR_BAD_SHAPE;
   if (!workspace || workspace_bytes < ptamd_layernorm_bwd_workspace_bytes(D)) return PTAMD_ERR_WORKSPACE;
@@ -591,7 +605,7 @@ int ptamd_layernorm_bwd_dropout(const float *dy, const float *x, const float *ga
   const int halves = ngroups * 4 <= nwaves ? 4 : ngroups * 2 <= nwaves ? 2 : 1;
 #define PT_LN_FUSED(NV, HV)                                                                                                   \
   hipLaunchKernelGGL((layernorm_bwd_dropout_kernel<NV, HV>), grid, block, 0, st, dy, x, gamma, mean, rstd, dres, T, D, dx, part, \
-                     dropout_p, seed, stream_id, dropped, row_scale, bound_factor, bound_scale, row_scale_min, bound_scale_min)
+                     dropout_p, seed, stream_id, dropped, row_scale, bound_factor, bound_scale, row_scale_min, bound_scale_min, planes)
 #define PT_LN_FUSED_BY_T(NV) do { if (halves == 4) PT_LN_FUSED(NV, 4); else if (halves == 2) PT_LN_FUSED(NV, 2); else PT_LN_FUSED(NV, 1); } while (0)
   if (D <= 256) PT_LN_FUSED_BY_T(1);
   else if (D <= 512) PT_LN_FUSED_BY_T(2);

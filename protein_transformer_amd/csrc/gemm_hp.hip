@@ -252,7 +252,10 @@ int launch_hp3(const HpParams &p, int splits, hipStream_t st);
 template <int EPI>
 int launch_hp(const HpParams &p, int splits, hipStream_t st) {
   const char *e = getenv("PTAMD_HP_STAGES");
-  if (p.g.vec_epilogue && !(e && e[0] == '2')) return launch_hp3<EPI>(p, splits, st);
+  // (the no-dropout epilogue instantiation of the three-stage kernel spills 45 registers - its epilogue has no generator
+  // loop to keep the two 32-row blocks apart - so those launches take the full instantiation, whose dropout branch is a
+  // run-time no-op at p = 0: same results, no spills)
+  if (p.g.vec_epilogue && !(e && e[0] == '2')) return launch_hp3<EPI == ptgemm::EPI_NODROP ? ptgemm::EPI_FULL : EPI>(p, splits, st);
   return launch_hp_g<Geom, EPI>(p, splits, st);
 }
 
@@ -308,6 +311,9 @@ __device__ __forceinline__ void hp3_epilogue(const GemmParams &p, const f32x16 (
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
+    // (one 32-row block at a time: without the fence the compiler requests the residual / gate operands of BOTH blocks up
+    // front - 64 registers - and the no-dropout instantiation, which has no generator loop between them, spills 45)
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 pre4[8];
     const bool want_res = EPI != EPI_PLAIN && !partial && p.residual != nullptr;
     const bool want_old = EPI != EPI_PLAIN && !partial && (p.flags & PTAMD_EPI_ACCUM) && !want_res;
@@ -344,7 +350,11 @@ __device__ __forceinline__ void hp3_epilogue(const GemmParams &p, const f32x16 (
         const int f = lane + 64 * u, rr = f >> 4, c4 = (f & 15) * 4;   // rr: 0..7 of this group of eight rows
         const int row = row0 + i * 32 + 8 * g + rr, col = col0 + c4;
         float4 v = *reinterpret_cast<const float4 *>(scratch + rr * 64 + c4);
+#ifdef PT_ABLATE_NOSTORE   // ablation build: everything but the global store of the tile (the condition is never true)
+        if (row < p.M && col < p.N && p.M < 0) {
+#else
         if (row < p.M && col < p.N) {
+#endif
           if (EPI != EPI_PLAIN && !partial) {
             // (pre4[t] of tile_epilogue_vec holds rows (lane >> 4) + 4 t of the 32-row block: t = 2 g + u here)
             const f32x4 r4 = pre4[2 * g + u];
@@ -652,6 +662,52 @@ __global__ __launch_bounds__(256) void hp_split_rows_kernel(const SplitJobs j) {
   if (lane == 0) j.scale[job][row] = s;
 }
 
+// ---- several ROW-contiguous matrices [K][rows] (operand rows = source columns: the weights of the dX products, B = W^T)
+// with the operand rows' scales GIVEN (the column scales ptamd_weight_scales computes every step anyway): one thread per
+// 16-byte chunk of the planes, one launch for all of them
+struct SplitColsJobs {
+  const float *x[MAX_SPLIT_JOBS];
+  char *planes[MAX_SPLIT_JOBS];
+  const float *scale[MAX_SPLIT_JOBS];
+  int ld[MAX_SPLIT_JOBS], rows[MAX_SPLIT_JOBS], K[MAX_SPLIT_JOBS];
+  int first_block[MAX_SPLIT_JOBS + 1];   // blocks of 256 chunks
+  int njobs;
+};
+__global__ __launch_bounds__(256) void hp_split_cols_kernel(const SplitColsJobs j) {
+  int job = 0;
+#pragma unroll 1
+  while (job + 1 < j.njobs && (int)blockIdx.x >= j.first_block[job + 1]) ++job;
+  const int rows = j.rows[job], K = j.K[job], kbv = kb16(K), ld = j.ld[job];
+  const int64_t nchunks = (int64_t)(round_up(rows, 32) / 32) * kbv * 64;
+  const int64_t id = (int64_t)((int)blockIdx.x - j.first_block[job]) * 256 + threadIdx.x;
+  if (id >= nchunks) return;
+  const int c = (int)(id & 63);
+  const int64_t blk = id >> 6;
+  const int kb = (int)(blk % kbv), rb = (int)(blk / kbv);
+  int r, h;
+  chunk_coords(c, r, h);
+  const int row = rb * 32 + r, k0 = kb * 16 + h * 8;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  float sc = 1.f;
+  if (row < rows) {
+    sc = j.scale[job][row];
+    const float *x = j.x[job];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (k0 + e < K) v[e] = x[(size_t)(k0 + e) * ld + row];
+  }
+  uint4 hi, lo;
+  ptsplit::split_pair_f16(v[0], v[1], sc, sc, hi.x, lo.x);
+  ptsplit::split_pair_f16(v[2], v[3], sc, sc, hi.y, lo.y);
+  ptsplit::split_pair_f16(v[4], v[5], sc, sc, hi.z, lo.z);
+  ptsplit::split_pair_f16(v[6], v[7], sc, sc, hi.w, lo.w);
+  char *dst = j.planes[job] + block_offset(rb, kb, 0, kbv) + c * 16;
+  *reinterpret_cast<uint4 *>(dst) = hi;
+  *reinterpret_cast<uint4 *>(dst + BLK_BYTES) = lo;
+}
+
 size_t slab_bytes(int M, int N, int split_k) {
   if (split_k <= 1) return 0;
   return ((size_t)split_k * M * N * sizeof(float) + 15) & ~(size_t)15;
@@ -712,6 +768,26 @@ int ptamd_hp_split_rows(const ptamd_hp_split_job *jobs, int njobs, void *stream)
   else if (kmax <= 512) hipLaunchKernelGGL(hp_split_rows_kernel<2>, dim3(blocks), dim3(256), 0, st, j);
   else if (kmax <= 1024) hipLaunchKernelGGL(hp_split_rows_kernel<4>, dim3(blocks), dim3(256), 0, st, j);
   else hipLaunchKernelGGL(hp_split_rows_kernel<8>, dim3(blocks), dim3(256), 0, st, j);
+  return pt_check_launch();
+}
+
+int ptamd_hp_split_cols(const ptamd_hp_split_job *jobs, int njobs, void *stream) {
+  if (!jobs || njobs <= 0 || njobs > MAX_SPLIT_JOBS) return PTAMD_ERR_BAD_SHAPE;
+  SplitColsJobs j;
+  int blocks = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const ptamd_hp_split_job &q = jobs[i];
+    if (!q.x || !q.planes || !q.scale || q.rows <= 0 || q.K <= 0 || q.ld < q.rows) return PTAMD_ERR_BAD_SHAPE;
+    if (!pt_aligned16(q.planes)) return PTAMD_ERR_ALIGN;
+    j.x[i] = q.x; j.planes[i] = static_cast<char *>(q.planes); j.scale[i] = q.scale;
+    j.ld[i] = q.ld; j.rows[i] = q.rows; j.K[i] = q.K;
+    j.first_block[i] = blocks;
+    const int64_t nchunks = (int64_t)(round_up(q.rows, 32) / 32) * kb16(q.K) * 64;
+    blocks += (int)((nchunks + 255) / 256);
+  }
+  for (int i = njobs; i <= MAX_SPLIT_JOBS; ++i) j.first_block[i] = blocks;
+  j.njobs = njobs;
+  hipLaunchKernelGGL(hp_split_cols_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, j);
   return pt_check_launch();
 }
 

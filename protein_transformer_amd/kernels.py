@@ -242,6 +242,20 @@ def hp_split_rows(mats, outs):
     return outs
 
 
+def hp_split_cols(mats, scales, outs):
+    """Row-contiguous matrices [K, rows] -> HpOperands of their transposes (rows x K) with GIVEN row scales (int32 / float32
+    tensors holding powers of two, e.g. the column scales of ptamd_weight_scales) in one launch per 16 matrices."""
+    from ._lib import HpSplitJob
+    for i in range(0, len(mats), 16):
+        chunk = list(zip(mats[i:i + 16], scales[i:i + 16], outs[i:i + 16]))
+        arr = (HpSplitJob * len(chunk))()
+        for k, (w, sc, o) in enumerate(chunk):
+            assert w.dim() == 2 and w.stride(1) == 1 and (o.rows, o.K) == (w.shape[1], w.shape[0]) and sc.numel() >= o.rows
+            arr[k] = HpSplitJob(x=w.data_ptr(), ld=w.stride(0), rows=o.rows, K=o.K, planes=o.planes.data_ptr(), scale=sc.data_ptr())
+        check(lib().ptamd_hp_split_cols(arr, len(chunk), stream()), "hp_split_cols")
+    return outs
+
+
 def _ln_workspace(D, device, pending):
     """Workspace of one LayerNorm backward; with a `pending` list (deferred reduction) every pending site gets its own."""
     tag = "ln" if pending is None else f"ln{len(pending)}"
@@ -261,9 +275,11 @@ def layernorm_bwd_flush(pending):
 
 
 def layernorm_bwd_dropout(dy, x, gamma, mean, rstd, dgamma, dbeta, dres, dropout_p, seed, stream_id, row_scale=None,
-                          bound_factor=None, bound_scale=None, row_scale_min=None, bound_scale_min=None, pending=None):
+                          bound_factor=None, bound_scale=None, row_scale_min=None, bound_scale_min=None, pending=None,
+                          planes=None):
     """LayerNorm backward fused with the dropout backward of its output (ptamd_layernorm_bwd_dropout): returns
-    (dx, dropped); dropped is dx itself when dropout_p == 0.  Fills row_scale / bound_scale [T] when given."""
+    (dx, dropped); dropped is dx itself when dropout_p == 0.  Fills row_scale / bound_scale [T] when given; `planes`
+    (uint8 buffer of ptamd_hp_bytes(T, D), needs row_scale) receives `dropped` once more in the pre-split hp format."""
     T, D = x.shape
     dx = torch.empty_like(x)
     dropped = torch.empty_like(x) if dropout_p > 0 else None
@@ -274,7 +290,7 @@ def layernorm_bwd_dropout(dy, x, gamma, mean, rstd, dgamma, dbeta, dres, dropout
     check(lib().ptamd_layernorm_bwd_dropout(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), T, D, float(dropout_p),
                                             int(seed), int(stream_id), ptr(dx), ptr(dropped), ptr(row_scale),
                                             ptr(bound_factor), ptr(bound_scale), ptr(row_scale_min), ptr(bound_scale_min),
-                                            None if defer else ptr(dgamma), None if defer else ptr(dbeta), ptr(ws), ws.numel(),
+                                            ptr(planes), None if defer else ptr(dgamma), None if defer else ptr(dbeta), ptr(ws), ws.numel(),
                                             stream()), "layernorm_bwd_dropout")
     if defer:
         pending.append((ws, D, dgamma, dbeta))

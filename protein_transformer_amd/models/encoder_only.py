@@ -272,6 +272,8 @@ class _TransformerBase(nn.Module):
         self.attn_mode = None                        # arithmetic of the attention kernels alone (ablations); None = gemm_mode
         self.gemm_mode = None                        # kernels.GEMM_* arithmetic of THIS model; None = kernels.get_gemm_mode()
         self.hp_forward = True                       # FFN-layer-1 forward product on ptamd_gemm_hp from LayerNorm-written planes (read every pass)
+        self.hp_qkv = True                           # ... the QKV product too (three-stage kernel of round 4)
+        self.hp_dx = True                            # ... and dX of FFN layer 2 (A: planes from the fused LayerNorm backward, B: W2^T planes)
         self.side_stream_dw = True                   # small batches: weight-gradient products on a side stream
         self.auto_guard = AutoGuard(nlayers)         # measures the slack of the bound-derived f16x2 scales, falls back per site
         self._init_parameters()
@@ -474,16 +476,28 @@ class _TransformerBase(nn.Module):
             # 34.7 / 58.5 / 106.8 us on it at 4096 / 8192 / 16384 tokens against 35.4 / 70.5 / 110.3 on ptamd_gemm_hp, and the
             # first LayerNorm no longer writes planes; FFN-1, with its ReLU + dropout epilogue, stays: 142 against 167 us.)
             cache["hp_mats"], cache["hp_outs"] = [], []
+            cache["hpT_mats"], cache["hpT_scales"], cache["hpT_outs"] = [], [], []
             if D % 32 == 0 and D <= 2048:         # (built whatever `hp_forward` says now: the flag is read at use time)
                 for i, L in enumerate(layers):
                     w1 = W(f"encoder.enc_layers.{i}.pwff.layer1.weight")
                     L["hp_1"] = K.HpOperand(F, D, dev)
-                    cache["hp_mats"] += [w1]
-                    cache["hp_outs"] += [L["hp_1"]]
+                    L["hp_qkv"] = K.HpOperand(3 * D, D, dev)
+                    cache["hp_mats"] += [w1, self._qkv(flat, i)[0]]
+                    cache["hp_outs"] += [L["hp_1"], L["hp_qkv"]]
+                    # W2^T as the B operand of dX = dy2 W2 (operand rows = the F columns of W2 [D, F], contraction over D): split
+                    # with the column scales computed above
+                    w2 = W(f"encoder.enc_layers.{i}.pwff.layer2.weight")
+                    planes2 = torch.empty(K.lib().ptamd_hp_bytes(F, D), dtype=torch.uint8, device=dev)
+                    L["hp_2t"] = K.hp_view(planes2, L["cs_2"], F, D)
+                    cache["hpT_mats"] += [w2]
+                    cache["hpT_scales"] += [L["cs_2"]]
+                    cache["hpT_outs"] += [L["hp_2t"]]
         K.weight_scales(cache["wjobs"])
         K.bound_scales(cache["bjobs"])
         if cache["hp_mats"] and hp:
             K.hp_split_rows(cache["hp_mats"], cache["hp_outs"])
+            if self.hp_dx and F % 32 == 0:
+                K.hp_split_cols(cache["hpT_mats"], cache["hpT_scales"], cache["hpT_outs"])
         return cache["layers"]
 
     def _slice(self, buf, name):
@@ -610,9 +624,15 @@ class _EncoderFn(torch.autograd.Function):
             sc = scales[i] if scales is not None else None
             wqkv, bqkv = m._qkv(flat, i)
             s_h1 = torch.empty(Tn, dtype=torch.int32, device=x.device) if sc else None
+            hp_q = use_hp and m.hp_qkv and not (wide is not None and wide[i, 0])
             h1, mean1, rstd1 = K.layernorm_fwd(x, W(b + "sublayer_connections.0.norm.weight"),
-                                               W(b + "sublayer_connections.0.norm.bias"), row_scale=s_h1)
-            qkv = K.linear_fwd(h1, wqkv, bqkv, **prod(i, 0, a_scale=s_h1, b_scale=sc and sc["rs_qkv"]))
+                                               W(b + "sublayer_connections.0.norm.bias"), row_scale=s_h1,
+                                               planes=hplanes if hp_q else None)
+            if hp_q:
+                qkv = K.gemm_hp(K.hp_view(hplanes, s_h1, Tn, D), sc["hp_qkv"],
+                                torch.empty(Tn, 3 * D, dtype=torch.float32, device=x.device), bias=bqkv)
+            else:
+                qkv = K.linear_fwd(h1, wqkv, bqkv, **prod(i, 0, a_scale=s_h1, b_scale=sc and sc["rs_qkv"]))
             att, lse = K.attention_fwd(qkv, seq, H, pa, seed, sid + _SITE_ATTN,
                                         arith=attn_default if m.attn_mode is None else m.attn_mode)
             use_b = sc is not None and not (off is not None and off[i, 0])          # att on its bound (else: exact row scales)
@@ -643,6 +663,7 @@ class _EncoderFn(torch.autograd.Function):
         ctx.model, ctx.seed, ctx.seq, ctx.flat, ctx.arith, ctx.attn_arith = m, seed, seq, flat, ar, attn_default
         ctx.p, ctx.pa = p, pa
         ctx.guard, ctx.measure, ctx.off = guard, measure, ctx_off
+        ctx.use_hp = use_hp
         ctx.saved, ctx.conv_saved, ctx.scales = saved, conv_saved, scales
         ctx.x_last, ctx.pred = x, pred
         return pred
@@ -716,6 +737,10 @@ class _EncoderFn(torch.autograd.Function):
         have_min = False                                   # ... together with the uniform scales of dy2 / dz1 for the dW products
         if scales is not None:
             scales[0]["minbuf"].fill_(0x7F000000)          # atomicMin targets of this backward pass (largest scale)
+        # dX of FFN layer 2 on ptamd_gemm_hp: the fused LayerNorm backward that makes dy2 writes it a second time as planes
+        dy2_planes, have_planes = None, False
+        if ctx.use_hp and m.hp_dx and fuse and scales is not None and "hp_2t" in scales[0] and m.dff % 32 == 0:
+            dy2_planes = torch.empty(K.lib().ptamd_hp_bytes(B * L, D), dtype=torch.uint8, device=dx.device)
         for i in reversed(range(m.nlayers)):
             b = f"encoder.enc_layers.{i}."
             sid = i * 8
@@ -729,8 +754,14 @@ class _EncoderFn(torch.autograd.Function):
             dw(dy2, f1, G(b + "pwff.layer2.weight"), G(b + "pwff.layer2.bias"), arith=ar,
                                 dy_scale=sc["dy2_min"] if uni and not o_f1 else None, x_scale=sc["f1_scale"] if uni and not o_f1 else None)
             # backward of layer2 and, in its epilogue, of the ReLU + dropout in front of it (gate = saved f1)
-            dz1 = K.linear_bwd_input(dy2, W(b + "pwff.layer2.weight"), gate=f1, gate_dropout_p=p,
-                                     **prod(i, 7, a_scale=s_dy2 if sc else None, b_scale=sc and sc["cs_2"]))
+            if dy2_planes is not None and have_planes and not (wide is not None and wide[i, 7]):
+                # dy2 came from the fused LayerNorm backward of the layer above together with its planes: LDS-DMA kernel
+                dz1 = K.gemm_hp(K.hp_view(dy2_planes, s_dy2, B * L, D), sc["hp_2t"],
+                                torch.empty(B * L, m.dff, dtype=torch.float32, device=dx.device), residual=f1, ldr=f1.stride(0),
+                                flags=K.EPI_GATE, gate_scale=1.0 / (1.0 - p))
+            else:
+                dz1 = K.linear_bwd_input(dy2, W(b + "pwff.layer2.weight"), gate=f1, gate_dropout_p=p,
+                                         **prod(i, 7, a_scale=s_dy2 if sc else None, b_scale=sc and sc["cs_2"]))
             if ctx.measure:     # the true maxima of the five bound-scaled operands of this layer (AutoGuard; every 16th step)
                 gs = sc["guard_stats"][i]
                 K.weight_scales([dict(w=t, stats=gs[j], rows_only=True) for j, t in enumerate((att, f1, dz1, h1, h2))])
@@ -784,13 +815,15 @@ class _EncoderFn(torch.autograd.Function):
                                                   dx2, p, seed, (i - 1) * 8 + _SITE_FFN_OUT, row_scale=s_dy2,
                                                   bound_factor=below["dz1_factor"] if below else None, bound_scale=bs_dz1,
                                                   row_scale_min=below["dy2_min"] if below else None,
-                                                  bound_scale_min=below["dz1_min"] if below else None, pending=ln_pending)
+                                                  bound_scale_min=below["dz1_min"] if below else None, pending=ln_pending,
+                                                  planes=dy2_planes if below else None)
                 have_min = below is not None
+                have_planes = below is not None and dy2_planes is not None
             else:
                 dx = K.layernorm_bwd(dh1, x, W(b + "sublayer_connections.0.norm.weight"), mean1, rstd1, g1w, g1b, dres=dx2,
                                      pending=ln_pending)
                 dy2 = s_dy2 = bs_dz1 = None
-                have_min = False
+                have_min = have_planes = False
             done(b + "self_attn.wq.weight", b + "sublayer_connections.1.norm.bias")
             ctx.saved[i] = None
         K.layernorm_bwd_flush(ln_pending)

@@ -140,3 +140,45 @@ def test_layernorm_writes_planes_and_weights_split_in_one_launch(dev):
     ref = y.cpu().double() @ ws[0].cpu().double().t()
     bound = y.cpu().double().abs() @ ws[0].cpu().double().abs().t()
     assert float(((C.cpu().double() - ref).abs() / bound).max()) < 6e-7
+
+
+def test_backward_writers_of_the_format(dev):
+    """Round 4: the two writers behind the hp dX product of FFN layer 2 - ptamd_layernorm_bwd_dropout(planes=...) (the
+    dropped gradient rows, with the row scales it computes anyway) and ptamd_hp_split_cols (the transposed weights, with the
+    column scales of ptamd_weight_scales) - produce exactly what ptamd_hp_split makes of the same fp32 matrices, and the gated
+    product from them equals the staging kernel's."""
+    from protein_transformer_amd import kernels as K_
+    g = torch.Generator().manual_seed(12)
+    T, D, F, p, seed, sid = 200, 96, 160, 0.1, 77, 3
+    x = torch.randn(T, D, generator=g).to(dev)
+    dy = (torch.randn(T, D, generator=g) * torch.exp(torch.randn(T, 1, generator=g))).to(dev)
+    dres = torch.randn(T, D, generator=g).to(dev)
+    gamma = (1 + 0.2 * torch.randn(D, generator=g)).to(dev)
+    _, mean, rstd = K_.layernorm_fwd(x, gamma, torch.zeros(D, device=dev))
+    dgam, dbet = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    scale = torch.empty(T, dtype=torch.int32, device=dev)
+    planes = torch.zeros(K_.lib().ptamd_hp_bytes(T, D), dtype=torch.uint8, device=dev)
+    dx, dropped = K_.layernorm_bwd_dropout(dy, x, gamma, mean, rstd, dgam, dbet, dres, p, seed, sid, row_scale=scale, planes=planes)
+    dx2, dropped2 = K_.layernorm_bwd_dropout(dy, x, gamma, mean, rstd, torch.zeros(D, device=dev), torch.zeros(D, device=dev), dres,
+                                             p, seed, sid)
+    assert torch.equal(dx, dx2) and torch.equal(dropped, dropped2)                 # the by-product does not touch the results
+    ref_op = K_.hp_split(dropped)
+    got = K_.hp_view(planes, scale, T, D)
+    assert torch.equal(got.scale[:T], ref_op.scale[:T])
+    back_ref = unpack(ref_op, dev)[0]
+    back_got = unpack(K_.hp_view(planes, torch.cat([got.scale, torch.ones(24, device=dev)]), T, D), dev)[0]
+    assert np.array_equal(back_got[:T], back_ref[:T])
+    # W [D, F] -> planes of W^T [F, D] with the column scales of ptamd_weight_scales
+    w = (torch.randn(D, F, generator=g) * 0.05 * torch.exp(torch.randn(1, F, generator=g))).to(dev)
+    cs = torch.empty(F, dtype=torch.int32, device=dev)
+    K_.weight_scales([dict(w=w, col_scale=cs)])
+    out = K_.hp_view(torch.zeros(K_.lib().ptamd_hp_bytes(F, D), dtype=torch.uint8, device=dev), cs, F, D)
+    K_.hp_split_cols([w], [cs], [out])
+    r = K_.hp_split(w, transposed=True)
+    assert torch.equal(out.scale[:F], r.scale[:F]) and torch.equal(out.planes, r.planes)
+    # dz = gate(dropped W): LDS-DMA kernel from the two writers against the staging kernel on the fp32 operands
+    f1 = torch.relu(torch.randn(T, F, generator=g)).to(dev)
+    a = K_.gemm_hp(got, out, torch.empty(T, F, device=dev), residual=f1, ldr=F, flags=K_.EPI_GATE, gate_scale=1.0 / (1.0 - p))
+    b = K_.linear_bwd_input(dropped, w, gate=f1, gate_dropout_p=p, arith=K_.GEMM_F16X2)
+    assert torch.equal(a == 0, b == 0)
+    assert float((a - b).abs().max()) <= 3e-6 * float(b.abs().max())
