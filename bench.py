@@ -79,7 +79,7 @@ def parse():
     ap.add_argument("--no-side-stream", action="store_true", help="ablation: weight-gradient products of small batches on the main stream")
     ap.add_argument("--no-hp-forward", action="store_true", help="ablation: the FFN-layer-1 forward product on ptamd_gemm instead of ptamd_gemm_hp")
     ap.add_argument("--no-hp-qkv", action="store_true", help="ablation: the QKV product on ptamd_gemm instead of ptamd_gemm_hp")
-    ap.add_argument("--no-hp-dx", action="store_true", help="ablation: dX of FFN layer 2 on ptamd_gemm instead of ptamd_gemm_hp")
+    ap.add_argument("--hp-dx", action="store_true", help="ablation: dX of FFN layer 2 on ptamd_gemm_hp (off by default: +-0 in the step)")
     ap.add_argument("--attn-mode", default=None, choices=["f32", "bf16x3", "f16x2"],
                     help="arithmetic of the attention kernels alone (ablation; default: that of --gemm-mode)")
     ap.add_argument("--gemm-mode", default="auto", choices=["f32", "bf16x3", "bf16x3full", "f16x2", "auto"],
@@ -291,7 +291,7 @@ def main():
     if os.environ.get("PTAMD_DW_SLOTS"):
         kernels.DW_SLOTS = int(os.environ["PTAMD_DW_SLOTS"])
     model.hp_forward = not a.no_hp_forward
-    model.hp_qkv, model.hp_dx = not a.no_hp_qkv, not a.no_hp_dx
+    model.hp_qkv, model.hp_dx = not a.no_hp_qkv, bool(a.hp_dx)
     model.dropout_seed += 7919 * rank
     dp.attach(model)
     opt = (FusedAdam(model, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=10e-3) if a.optimizer == "adam"

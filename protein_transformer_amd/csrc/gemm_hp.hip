@@ -455,13 +455,15 @@ __global__ __launch_bounds__(Hp3::THREADS, 2) void gemm_hp3_kernel(const HpParam
     more_loads = advance(ld);
     ahead = 2;
   }
-  bool drain = false;            // an epilogue ran since the last wait: loads and stores of another kind are in the queue
+  int landed = 0;                // stages whose pieces this wavefront has already waited for (in front of an epilogue)
   int buf = 0;
   for (;;) {
-    // this wavefront's pieces of the stage have landed; those of the next stage may stay in flight
-    if (ahead >= 2 && !drain) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    // this wavefront's pieces of the stage have landed; those of the next stage may stay in flight.  (Loads complete in
+    // order among themselves, so "at most 6 outstanding" implies the older six pieces are in - the tile stores of an
+    // epilogue that may still be in the queue only make the wait conservative, never wrong.)
+    if (landed > 0) --landed;
+    else if (ahead >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    drain = false;
     __builtin_amdgcn_s_barrier();   // ... and everybody's; everybody is done with the buffer that is refilled below
     __builtin_amdgcn_sched_barrier(0);
     const uint32_t va = va0 + (uint32_t)buf * G::STAGE_BYTES, vb = vb0 + (uint32_t)buf * G::STAGE_BYTES;
@@ -508,6 +510,10 @@ __global__ __launch_bounds__(Hp3::THREADS, 2) void gemm_hp3_kernel(const HpParam
     }
     --ahead;
     if (cc.k0 + G::BK >= cc.it.kend) {  // that was the item's last stage (uniform)
+      // The pieces of the next two stages (the first stages of the next tile) are waited for HERE, in front of the tile
+      // stores: behind them a counted wait would also sit out the stores (2+ us when every CU writes its tile at once).
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      landed = ahead;
       float *C = p.g.C + (partial ? (size_t)cc.it.z * p.g.slab : 0);
       const int ldc = partial ? p.g.N : p.g.ldc;
       const int row0 = cc.it.bm0 + wm * 64, col0 = cc.it.bn0 + wn * 64;
@@ -529,7 +535,6 @@ __global__ __launch_bounds__(Hp3::THREADS, 2) void gemm_hp3_kernel(const HpParam
       }
       hp3_epilogue<EPI>(p.g, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 512);
       zero_acc();
-      drain = true;
     }
     if (!advance(cc)) break;
     buf = buf == 2 ? 0 : buf + 1;

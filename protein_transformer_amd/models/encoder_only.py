@@ -273,7 +273,8 @@ class _TransformerBase(nn.Module):
         self.gemm_mode = None                        # kernels.GEMM_* arithmetic of THIS model; None = kernels.get_gemm_mode()
         self.hp_forward = True                       # FFN-layer-1 forward product on ptamd_gemm_hp from LayerNorm-written planes (read every pass)
         self.hp_qkv = True                           # ... the QKV product too (three-stage kernel of round 4)
-        self.hp_dx = True                            # ... and dX of FFN layer 2 (A: planes from the fused LayerNorm backward, B: W2^T planes)
+        self.hp_dx = False                           # dX of FFN layer 2 there too (A: planes from the fused LayerNorm backward, B: W2^T planes): built and
+                                                     # tested, measured +-0 in the step (profiles/r04/NOTES.md), off
         self.side_stream_dw = True                   # small batches: weight-gradient products on a side stream
         self.auto_guard = AutoGuard(nlayers)         # measures the slack of the bound-derived f16x2 scales, falls back per site
         self._init_parameters()

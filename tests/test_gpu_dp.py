@@ -65,17 +65,20 @@ def _shard(batch, lens, world, rank, pad_to_global=False):
     return (seq[keep, :Lr].contiguous(), ang[keep, :Lr].contiguous(), crd[keep, :Lr * 14].contiguous()), sum(lens[i] for i in keep)
 
 
-def _worker(rank, world, port, out_dir, loss, case):
+def _worker(rank, world, port, out_dir, loss, case, backend="gloo"):
+    # gloo: both ranks on cuda:0 (RCCL refuses two ranks per device); nccl (= RCCL): one GPU per rank
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0", PTAMD_DIST_BACKEND="gloo")
+                      LOCAL_RANK=str(rank) if backend == "nccl" else "0", PTAMD_DIST_BACKEND=backend,
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from protein_transformer_amd import dp
     from protein_transformer_amd.log import init_metrics
     from protein_transformer_amd.train import eval_epoch, train_step
-    dev = torch.device("cuda:0")
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
     torch.cuda.set_device(dev)
     dp.init_from_env()
+    assert torch.distributed.get_backend() == backend
     conv = case.startswith("conv-")
     case = case[5:] if conv else case
     model, opt, args, batch, lens = _make(dev, loss, case, conv)
@@ -99,14 +102,22 @@ def _worker(rank, world, port, out_dir, loss, case):
     dp.shutdown()
 
 
+def test_two_rank_step_on_two_gpus_nccl(tmp_path):
+    """The same check over RCCL, one GPU per rank - the asynchronous path gloo cannot exercise (per-layer all-reduce issued
+    from the backward pass on RCCL's stream, `work.wait()` on the compute stream).  Needs two GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the driver's multi-GPU node); one GPU: the gloo variants below")
+    test_two_rank_step_equals_full_batch(tmp_path, "combined", "ragged", backend="nccl")
+
+
 @pytest.mark.parametrize("loss,case", [("drmsd", "ragged"), ("combined", "ragged"), ("mse", "ragged"), ("lndrmsd", "equal"),
                                        ("combined", "single"), ("combined", "conv-ragged")])
-def test_two_rank_step_equals_full_batch(tmp_path, loss, case):
+def test_two_rank_step_equals_full_batch(tmp_path, loss, case, backend="gloo"):
     """`conv-ragged`: a conv-enc model (Conv1d windows cross the end of a protein) with the shards padded to the longest
     protein of the GLOBAL batch, as dataset.ShardedBatchSampler does: only then does a rank's longest protein see the same
     columns behind its end as in the single-process batch."""
     assert torch.cuda.is_available()
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), loss, case), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), loss, case, backend), nprocs=2, join=True)
     from protein_transformer_amd.log import init_metrics
     from protein_transformer_amd.train import eval_epoch, train_step
     dev = torch.device("cuda:0")
