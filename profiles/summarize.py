@@ -14,7 +14,7 @@ import csv
 import json
 import sys
 
-KERNEL = ("_mfma_kernel", "gemm_hp_kernel")   # gemm_bf16x3_mfma_kernel<.., NPROD, ..> (NPROD = 3: f16x2, 6: bf16x3), gemm_f32_mfma_kernel, and the LDS-DMA kernel
+KERNEL = ("_mfma_kernel", "gemm_hp_kernel", "gemm_hp3_kernel")   # gemm_bf16x3_mfma_kernel<.., NPROD, ..> (NPROD = 3: f16x2, 6: bf16x3), gemm_f32_mfma_kernel, and the LDS-DMA kernel
 
 
 def stats(path, steps):

@@ -45,7 +45,7 @@ g = torch.Generator(device=dev).manual_seed(3)
 rn = lambda *s: torch.randn(*s, device=dev, generator=g)          # noqa: E731
 tot = {"gemm": 0.0, "hp": 0.0}
 print(f"T = {T}")
-print(f"{'product':10s} {'M':>6} {'N':>5} {'K':>6} {'epilogue':24s} | {'ptamd_gemm us':>13} {'TF/s':>6} | {'hp 2-buf us':>10} {'TF/s':>6} | {'hp 3-stage':>10} {'TF/s':>6}")
+print(f"{'product':10s} {'M':>6} {'N':>5} {'K':>6} {'epilogue':24s} | {'ptamd_gemm us':>13} {'TF/s':>6} | {'hp 2-buf us':>10} {'TF/s':>6} | {'hp3 256x128':>10} {'TF/s':>6} | {'hp3 128x128 x2':>10} {'TF/s':>6}")
 
 fwd = [("qkv fwd", 3 * D, D, dict()),
        ("wo fwd", D, D, dict(res=True, drop=True)),
@@ -63,11 +63,15 @@ for name, N, Kd, e in fwd:
     os.environ["PTAMD_HP_STAGES"] = "2"
     t2o = timeit(lambda: K.gemm_hp(A, B, C, **kw))
     os.environ.pop("PTAMD_HP_STAGES")
+    os.environ["PTAMD_HP_TILE"] = "256"
     t2 = timeit(lambda: K.gemm_hp(A, B, C, **kw))
+    os.environ["PTAMD_HP_TILE"] = "128"
+    t3 = timeit(lambda: K.gemm_hp(A, B, C, **kw))
+    os.environ.pop("PTAMD_HP_TILE")
     fl = 2.0 * T * N * Kd
     tot["gemm"] += t1
     tot["hp"] += t2
-    print(f"{name:10s} {T:6d} {N:5d} {Kd:6d} {str(sorted(e)):24s} | {t1:13.1f} {fl / t1 / 1e6:6.1f} | {t2o:10.1f} {fl / t2o / 1e6:6.1f} | {t2:10.1f} {fl / t2 / 1e6:6.1f}")
+    print(f"{name:10s} {T:6d} {N:5d} {Kd:6d} {str(sorted(e)):24s} | {t1:13.1f} {fl / t1 / 1e6:6.1f} | {t2o:10.1f} {fl / t2o / 1e6:6.1f} | {t2:10.1f} {fl / t2 / 1e6:6.1f} | {t3:10.1f} {fl / t3 / 1e6:6.1f}")
 
 # dX = dy[T, N] w[N, K]: output columns K, contraction N
 dxs = [("dX ff2", F, D, dict(gate=True)), ("dX ff1", D, F, dict()), ("dX wo", D, D, dict()), ("dX qkv", D, 3 * D, dict())]
@@ -84,11 +88,15 @@ for name, Nout, Kc, e in dxs:
     os.environ["PTAMD_HP_STAGES"] = "2"
     t2o = timeit(lambda: K.gemm_hp(A, B, C, **kw))
     os.environ.pop("PTAMD_HP_STAGES")
+    os.environ["PTAMD_HP_TILE"] = "256"
     t2 = timeit(lambda: K.gemm_hp(A, B, C, **kw))
+    os.environ["PTAMD_HP_TILE"] = "128"
+    t3 = timeit(lambda: K.gemm_hp(A, B, C, **kw))
+    os.environ.pop("PTAMD_HP_TILE")
     fl = 2.0 * T * Nout * Kc
     tot["gemm"] += t1
     tot["hp"] += t2
-    print(f"{name:10s} {T:6d} {Nout:5d} {Kc:6d} {str(sorted(e)):24s} | {t1:13.1f} {fl / t1 / 1e6:6.1f} | {t2o:10.1f} {fl / t2o / 1e6:6.1f} | {t2:10.1f} {fl / t2 / 1e6:6.1f}")
+    print(f"{name:10s} {T:6d} {Nout:5d} {Kc:6d} {str(sorted(e)):24s} | {t1:13.1f} {fl / t1 / 1e6:6.1f} | {t2o:10.1f} {fl / t2o / 1e6:6.1f} | {t2:10.1f} {fl / t2 / 1e6:6.1f} | {t3:10.1f} {fl / t3 / 1e6:6.1f}")
 
 # dW[N, K] += dy[T, N]^T x[T, K]
 dws = [("dW ff2", D, F), ("dW ff1", F, D), ("dW wo", D, D), ("dW qkv", 3 * D, D)]

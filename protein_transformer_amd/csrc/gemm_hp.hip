@@ -274,13 +274,21 @@ int launch_hp(const HpParams &p, int splits, hipStream_t st) {
 //     also waited for the fragment reads in flight;
 //   * the sixteen fragment reads of a stage are issued in one burst behind the barrier (inline asm, counted lgkmcnt): the
 //     first twelve MFMAs start when the first eight have returned.
-struct Hp3 {
-  static constexpr int NW = 8, THREADS = 512, TILE_M = 256, BK = 32, NSTAGE = 3, PER_WAVE = 6;
-  static constexpr int RB_BYTES = 4096, A_STAGE = 8 * RB_BYTES, STAGE_BYTES = 12 * RB_BYTES;
+// Two geometries: WM = 4 - eight wavefronts, 256 x 128 tile, three stage buffers, one workgroup per CU (160 KiB); WM = 2 - four
+// wavefronts, 128 x 128 tile, two stage buffers, TWO workgroups per CU (72 KiB each): the tile epilogue of one workgroup (LDS
+// transposes, dropout generator, gate / residual reads, the tile's stores) runs beside the main loop of the other instead
+// of leaving the matrix pipe idle - for the K = 512 products, whose epilogue is a third of a tile's time.
+template <int WM_>
+struct Hp3G {
+  static constexpr int WM = WM_, NW = 2 * WM, THREADS = 64 * NW, TILE_M = 64 * WM, BK = 32, NSTAGE = WM == 4 ? 3 : 2;
+  static constexpr int A_BLOCKS = 2 * WM, B_BLOCKS = 4, PER_WAVE = (A_BLOCKS + B_BLOCKS) * 4 / NW;   // 6 or 8 pieces of 1 KiB
+  static constexpr int RB_BYTES = 4096, A_STAGE = A_BLOCKS * RB_BYTES, STAGE_BYTES = (A_BLOCKS + B_BLOCKS) * RB_BYTES;
   static constexpr int SCRATCH_BYTES = NW * 2048;
   static constexpr size_t LDS = (size_t)NSTAGE * STAGE_BYTES + SCRATCH_BYTES;
-  static_assert(LDS == 160 * 1024, "the whole LDS of a CU");
+  static constexpr int WG_PER_CU = WM == 4 ? 1 : 2;
+  static_assert(LDS * WG_PER_CU <= 160 * 1024, "the LDS of a CU");
 };
+typedef Hp3G<4> Hp3;
 
 // the epilogue of one wavefront's 64 x 64 block (TI = 2), eight rows at a time through `scratch` (512 floats): bias / ReLU /
 // dropout in the MFMA layout, residual / gate / accumulate operands and the stores as float4 rows.  Arithmetic, order of
@@ -381,9 +389,9 @@ __device__ __forceinline__ void hp3_epilogue(const GemmParams &p, const f32x16 (
 
 #define PT_DS_READ_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 
-template <int EPI>
-__global__ __launch_bounds__(Hp3::THREADS, 2) void gemm_hp3_kernel(const HpParams p) {
-  using G = Hp3;
+template <int EPI, int WM>
+__global__ __launch_bounds__(Hp3G<WM>::THREADS, 2) void gemm_hp3_kernel(const HpParams p) {
+  using G = Hp3G<WM>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *const scratch = reinterpret_cast<float *>(smem + G::NSTAGE * G::STAGE_BYTES);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -411,15 +419,18 @@ __global__ __launch_bounds__(Hp3::THREADS, 2) void gemm_hp3_kernel(const HpParam
     }
     return false;
   };
-  // piece i of this wavefront: q = wave + 8 i of the 48 KiB stage = block row q >> 2 (A: 0..7, B: 8..11), (k block, plane)
-  // = q & 3 = wave & 3.  So pieces 0..3 are A block rows 2 i + (wave >> 2) and pieces 4, 5 B block rows 2 (i - 4) + (wave >> 2).
+  // piece i of this wavefront: q = wave + NW i of the stage = block row q >> 2 (A first, then the 4 of B), (k block, plane) =
+  // q & 3 = wave & 3.  Eight wavefronts: pieces 0..3 are A block rows 2 i + (wave >> 2), pieces 4, 5 B block rows 2 (i - 4) +
+  // (wave >> 2); four wavefronts: pieces 0..3 A block rows i, pieces 4..7 B block rows i - 4.
+  constexpr int RSTEP = G::NW / 4;                          // block rows between consecutive pieces of a wavefront
   const int rb_in_tile = wave >> 2, rest_bytes = (wave & 3) * 1024;
   const char *const a_base = p.a_planes + rest_bytes + lane * 16, *const b_base = p.b_planes + rest_bytes + lane * 16;
   const int64_t row_bytes = (int64_t)p.kb16 * 2048;     // bytes of one block row of an operand: KB16 blocks x 2 planes x 1 KiB
   auto issue_piece = [&](const Cursor &c, int buf, int i) __attribute__((always_inline)) {
     const int q = wave + G::NW * i;
     const bool is_b = i >= 4;                                // (compile-time per call site)
-    const int rb = is_b ? min((c.it.bn0 >> 5) + 2 * (i - 4) + rb_in_tile, p.b_rb_last) : min((c.it.bm0 >> 5) + 2 * i + rb_in_tile, p.a_rb_last);
+    const int rb = is_b ? min((c.it.bn0 >> 5) + RSTEP * (i - 4) + rb_in_tile, p.b_rb_last)
+                        : min((c.it.bm0 >> 5) + RSTEP * i + rb_in_tile, p.a_rb_last);
     const char *g = (is_b ? b_base : a_base) + (int64_t)rb * row_bytes + (int64_t)(c.k0 >> 4) * 2048;
     dma16(g, smem + buf * G::STAGE_BYTES + q * 1024);
   };
@@ -449,7 +460,7 @@ __global__ __launch_bounds__(Hp3::THREADS, 2) void gemm_hp3_kernel(const HpParam
   for (int i = 0; i < G::PER_WAVE; ++i) issue_piece(ld, 0, i);
   bool more_loads = advance(ld);
   int ahead = 1;                 // stages issued and not yet waited for (this one included)
-  if (more_loads) {
+  if (G::NSTAGE == 3 && more_loads) {
 #pragma unroll
     for (int i = 0; i < G::PER_WAVE; ++i) issue_piece(ld, 1, i);
     more_loads = advance(ld);
@@ -462,12 +473,13 @@ __global__ __launch_bounds__(Hp3::THREADS, 2) void gemm_hp3_kernel(const HpParam
     // order among themselves, so "at most 6 outstanding" implies the older six pieces are in - the tile stores of an
     // epilogue that may still be in the queue only make the wait conservative, never wrong.)
     if (landed > 0) --landed;
-    else if (ahead >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (G::NSTAGE == 3 && ahead >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // ... and everybody's; everybody is done with the buffer that is refilled below
     __builtin_amdgcn_sched_barrier(0);
     const uint32_t va = va0 + (uint32_t)buf * G::STAGE_BYTES, vb = vb0 + (uint32_t)buf * G::STAGE_BYTES;
-    const int nbuf = buf >= 1 ? buf - 1 : 2;   // (buf + 2) % 3: the buffer stage c + 2 goes to, read last in stage c - 1
+    // the buffer the stage issued during this one goes to: (buf + 2) % 3, read last in stage c - 1 - or the other of two
+    const int nbuf = G::NSTAGE == 3 ? (buf >= 1 ? buf - 1 : 2) : buf ^ 1;
     f16x8 fa[2][2][2], fb[2][2][2];            // [k block][tile][plane]
     PT_DS_READ_B128(fa[0][0][0], va, 0);
     PT_DS_READ_B128(fa[0][0][1], va, 1024);
@@ -500,7 +512,10 @@ __global__ __launch_bounds__(Hp3::THREADS, 2) void gemm_hp3_kernel(const HpParam
           for (int j = 0; j < 2; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kb][i][ta], fb[kb][j][tb], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (issue) issue_piece(ld, nbuf, kb * 3 + pr);
+        if (issue) {
+          issue_piece(ld, nbuf, kb * 3 + pr);
+          if (G::PER_WAVE == 8 && pr == 2) issue_piece(ld, nbuf, 6 + kb);   // eight pieces in six slots
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -537,18 +552,28 @@ __global__ __launch_bounds__(Hp3::THREADS, 2) void gemm_hp3_kernel(const HpParam
       zero_acc();
     }
     if (!advance(cc)) break;
-    buf = buf == 2 ? 0 : buf + 1;
+    buf = buf == G::NSTAGE - 1 ? 0 : buf + 1;
   }
 }
 
+template <int EPI, int WM>
+int launch_hp3_g(const HpParams &p, int splits, hipStream_t st) {
+  using G = Hp3G<WM>;
+  const int work = ((p.g.M + G::TILE_M - 1) / G::TILE_M) * ((p.g.N + HBN - 1) / HBN) * splits;
+  auto kern = gemm_hp3_kernel<EPI, WM>;
+  PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
+  const int slots = ptgemm::persistent_grid(p.g.reserved_cus) * G::WG_PER_CU;
+  hipLaunchKernelGGL(kern, dim3(work < slots ? work : slots), dim3(G::THREADS), G::LDS, st, p);
+  return pt_check_launch();
+}
+// The 256-row geometry is the one in use.  The 128-row one (two workgroups per CU, so that one's epilogue runs beside the
+// other's main loop) measured the SAME per product (QKV 99.8 against 102.5 us, FFN-1 139 against 137, gated dX 146 against
+// 147) and +0.1 ms in the step (profiles/r04/NOTES.md section 4): at the package power cap a better overlap buys nothing, only
+// less energy per tile does.  PTAMD_HP_TILE = 128 in the environment (read at every call) selects it for measurements.
 template <int EPI>
 int launch_hp3(const HpParams &p, int splits, hipStream_t st) {
-  const int work = ((p.g.M + Hp3::TILE_M - 1) / Hp3::TILE_M) * ((p.g.N + HBN - 1) / HBN) * splits;
-  auto kern = gemm_hp3_kernel<EPI>;
-  PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Hp3::LDS));
-  const int slots = ptgemm::persistent_grid(p.g.reserved_cus);
-  hipLaunchKernelGGL(kern, dim3(work < slots ? work : slots), dim3(Hp3::THREADS), Hp3::LDS, st, p);
-  return pt_check_launch();
+  const char *e = getenv("PTAMD_HP_TILE");
+  return (e && e[0] == '1') ? launch_hp3_g<EPI, 2>(p, splits, st) : launch_hp3_g<EPI, 4>(p, splits, st);
 }
 
 // ---------------------------------------------------------------------------------------------- writers of the format

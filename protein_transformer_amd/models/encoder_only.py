@@ -609,6 +609,10 @@ class _EncoderFn(torch.autograd.Function):
             if train and m.__dict__.get("_fwd_grad", False):          # a training step: a backward pass will follow
                 measure = guard.want_measure()
                 guard.count_step()
+        # a model that is only ever evaluated (no backward pass to measure in) takes its first measurement from a forward pass:
+        # the four forward operands (dz1 exists in backward only), so that inference does not stay on the untrusting path
+        measure_fwd = (guard is not None and not measure and guard.measured_steps == 0 and guard._pending is None
+                       and not (train and m.__dict__.get("_fwd_grad", False)))
         off = guard.off if guard is not None else None
         wide = guard.wide if guard is not None else None
         ctx_off = None if off is None else (off.copy(), wide.copy())
@@ -658,9 +662,16 @@ class _EncoderFn(torch.autograd.Function):
                               **prod(i, 3, a_scale=sc["f1_scale"] if use_b else None, a_scale_stride=0 if use_b else 1,
                                      b_scale=sc and sc["rs_2"]))
             saved.append((x, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, f1))
+            if measure_fwd:
+                gs = sc["guard_stats"][i]
+                K.weight_scales([dict(w=t, stats=gs[j], rows_only=True) for j, t in ((0, att), (1, f1), (3, h1), (4, h2))])
             x = x3
         pred = K.linear_fwd(x, W("output_projection.weight"), W("output_projection.bias"),
                             flags=K.EPI_TANH if m.use_tanh_out else 0, arith=ar)
+        if measure_fwd:
+            scales[0]["guard_stats"][:, 2].zero_()                 # dz1: not measured here (slack 0 = "as good as its bound")
+            scales[0]["minbuf"].fill_(0x7F000000)                  # ... and its scale slot reads "unused"
+            guard.submit(scales[0]["guard_stats"], scales[0]["ints"], scales[0]["minbuf"], scales)
         ctx.model, ctx.seed, ctx.seq, ctx.flat, ctx.arith, ctx.attn_arith = m, seed, seq, flat, ar, attn_default
         ctx.p, ctx.pa = p, pa
         ctx.guard, ctx.measure, ctx.off = guard, measure, ctx_off

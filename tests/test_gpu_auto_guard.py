@@ -132,6 +132,18 @@ def test_guard_measures_slack(dev):
         w2 = dict(model.named_parameters())[f"encoder.enc_layers.{i}.pwff.layer2.weight"].detach()
         e = torch.frexp(w2.abs().amax(dim=0))[1]                    # exponents of the column maxima of W2
         assert guard.spread[i, 3] == float(e.max() - e.min())       # ... whose spread is what FFN-2's product is judged by
+    # a model that is only ever EVALUATED takes its first measurement from a forward pass (no backward pass to measure in)
+    model2, batch2 = _setup(dev, 2, 8, 512, 2048, [256] * 8, seed=6)
+    model2.eval()
+    g2 = model2.auto_guard
+    with torch.no_grad():
+        seq2 = batch2[0].to(dev)
+        p1 = model2(seq2)
+        assert g2.off.all() and g2.measured_steps == 0
+        torch.cuda.synchronize()
+        p2 = model2(seq2)                       # its forward reads the measurement: bounds with small slack are trusted now
+        assert g2.measured_steps == 1 and not g2.off.any() and not g2.wide.any() and (g2.slack <= 8).all()
+        assert float((p1 - p2).abs().max()) < 1e-5          # two fp32-grade arithmetics
     update_record(OUT, "guard_on_a_plain_model", {"slack_binades[layer][att,f1,dz1,h1,h2]": guard.slack.tolist(),
                                                   "weight_scale_spread_binades[layer][product]": guard.spread.tolist(), **rep})
 

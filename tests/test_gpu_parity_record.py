@@ -121,26 +121,30 @@ def _run_draw(case, draw):
     # and the oracle's fp32 chain 1 - 4e-3 A off from there to the end of the chain.)
     skipped = []
     gen = torch.Generator().manual_seed(1234 + cfg + 7919 * draw)
-    for attempt in range(8):
+    for attempt in range(32):     # (L = 1500 chains of a random-init model: most draws hold a near-straight bond angle somewhere)
         seed = 100 + cfg + 1000 * attempt + 100000 * draw
         batch = synthetic.make_batch(lens, L_pad=L, seed=seed, build_coords=build, frac_missing=0.02)
         seq, ang, crd = (batch[k].to(dev) for k in ("seq", "true_ang", "true_crd"))
         model = _make_model(dev, model_s, dm, nl, nh, dff, L, synthetic.angle_means(batch["true_ang"]),
                             seed=7 + cfg + attempt + 131 * draw)
         rad_probe = angles_forward(model(seq, ang).detach()).cpu().double()
+        # three backbone atoms within 5e-4 rad of a straight line (angles 3..5 = N-CA-C, CA-C-N, C-N-CA): the direction of the
+        # 1e-4 A component that defines the next frame is then at the mercy of the 1e-7 A rounding of the coordinates
+        # (checked first: it needs no fp64 build of the chain)
+        sin_bond = np.array([np.abs(np.sin(rad_probe[b, :n, 3:6].numpy())).min() for b, n in enumerate(lens)])
+        if sin_bond.min() < 5e-4:
+            skipped.append({"seed": seed, "smallest_abs_sin_of_a_backbone_bond_angle": [float(x) for x in sin_bond]})
+            continue
         c64 = obat.generate_coords_batched(rad_probe, seq.cpu(), torch.float64).numpy()
         sign = torch.randint(0, 2, rad_probe.shape, generator=gen).double() * 2 - 1
         c64p = obat.generate_coords_batched(rad_probe + 6e-8 * sign, seq.cpu(), torch.float64).numpy()
         resp = np.array([np.abs(c64p[b, :n * 14] - c64[b, :n * 14]).max() for b, n in enumerate(lens)]) / coord_unit
-        # ... or three backbone atoms within 5e-4 rad of a straight line (angles 3..5 = N-CA-C, CA-C-N, C-N-CA): the direction
-        # of the 1e-4 A component that defines the next frame is then at the mercy of the 1e-7 A rounding of the coordinates
-        sin_bond = np.array([np.abs(np.sin(rad_probe[b, :n, 3:6].numpy())).min() for b, n in enumerate(lens)])
-        if resp.max() <= 1.0 and sin_bond.min() >= 5e-4:
+        if resp.max() <= 1.0:
             break
         skipped.append({"seed": seed, "response_to_6e-8_rad_on_every_angle_units": [float(x) for x in resp],
                         "smallest_abs_sin_of_a_backbone_bond_angle": [float(x) for x in sin_bond]})
     else:
-        pytest.fail("no well-conditioned draw in 8 seeds")
+        pytest.fail("no well-conditioned draw in 32 seeds")
 
     # ---- fp64 on the CPU: the oracle's formulas end to end
     params = {k: v.detach().cpu().double() for k, v in model.state_dict().items()}
@@ -159,6 +163,12 @@ def _run_draw(case, draw):
            "loss": loss, "dropout": 0.0, "reference": "fp64 evaluation of the oracle (oracle.encoder + oracle.batched)",
            "seed": seed, "draw": draw, "skipped_draws": skipped, "modes": {}}
     old = K_.get_gemm_mode()
+    # AUTO is recorded as the arithmetic the BENCH workloads of configs 2-5 run in (f16x2 with the guard): the 4-protein slices
+    # here are below the tokens x d_model threshold at which AUTO leaves bf16x3 (config 1's real workload is below it too)
+    from protein_transformer_amd.models import encoder_only as EO
+    old_min = EO.AUTO_F16X2_MIN_WORK
+    if cfg >= 2:
+        EO.AUTO_F16X2_MIN_WORK = 1
     # The ReLU of the FFN is not differentiable at 0: an element of the hidden layer within rounding of 0 is "on" in one
     # arithmetic and "off" in another (or in fp64), and its whole back-propagated term then differs - with per-token
     # gradients spanning six decades one such element on a dominant token moves the FFN-layer-1 bias gradient and the
@@ -247,6 +257,7 @@ def _run_draw(case, draw):
                                      "measured": g.measured_steps}
     finally:
         K_.set_gemm_mode(old)
+        EO.AUTO_F16X2_MIN_WORK = old_min
 
     # gates in reverse layer order (the backward pass): elements whose ReLU state differs between two arithmetics
     flips = {f"{a}_vs_{b}": [int((x != y).sum().item()) for x, y in zip(gates[a], gates[b])][::-1]
