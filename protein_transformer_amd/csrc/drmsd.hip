@@ -12,13 +12,15 @@
 //   compact   NaN-mask compaction of (pred, true) atoms per protein; backbone atoms (slots 0..2) are packed
 //             FIRST so the backbone-only dRMSD falls out of the same sweep (dRMSD is permutation invariant).
 //   pairs     the UPPER TRIANGLE of the pair matrix, every unordered pair once (drmsd_tri_kernel below): each lane owns one
-//             row atom i, column tiles of 64 atoms are staged in LDS and read as broadcasts; per pair 2 transcendentals
+//             row atom i, the column atom of a step is wavefront-uniform and arrives by SCALAR loads (its coordinates are
+//             SGPR operands of the packed subtractions - no LDS, no vector registers); per pair 2 transcendentals
 //             (one v_rsq_f32 each for the predicted and the true distance; the predicted one doubles as 1/d for the
 //             gradient); the column atoms' share of the gradient comes from a transposed re-read of the coefficient
 //             tile through LDS.  ALU/transcendental bound, O(n) bytes + O(n^2 / 256) partial-sum bytes.
 //   finalize  fixed-order fp64 reduction of the block partials, loss statistics, gradient assembly (row + column
 //             partials, fixed order), scale and scatter back to the [L*14,3] slot layout.
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -32,6 +34,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct Counts {
   int n, n_bb, len, pad;
+};
+// a compacted atom as the pair sweep wants a COLUMN atom: (predicted, true) interleaved per axis - the pairs are SGPR operands
+// of v_pk_add_f32 - one s_load_dwordx4 + one s_load_dwordx2 per atom
+struct __attribute__((aligned(32))) Col8 {
+  float px, tx, py, ty, pz, tz, r0, r1;
 };
 
 __device__ int protein_len_block(const int64_t *seq, int L, int *s_tmp) {
@@ -55,7 +62,7 @@ constexpr int COMPACT_THREADS = 1024;  // 16 wavefronts: 7 rows of 64 slots each
 __global__ __launch_bounds__(COMPACT_THREADS) void drmsd_compact_kernel(const float *__restrict__ pred,
                                                            const float *__restrict__ truth,
                                                            const int64_t *__restrict__ seq, int L,
-                                                           float4 *__restrict__ pred4, float4 *__restrict__ true4,
+                                                           float4 *__restrict__ pred4, Col8 *__restrict__ col8,
                                                            int *__restrict__ idx, Counts *__restrict__ counts) {
   constexpr int NWAVE = COMPACT_THREADS / 64;
   __shared__ int s_bb[NWAVE], s_ot[NWAVE], s_tmp[NWAVE];
@@ -64,7 +71,7 @@ __global__ __launch_bounds__(COMPACT_THREADS) void drmsd_compact_kernel(const fl
   pred += (size_t)b * nmax * 3;
   truth += (size_t)b * nmax * 3;
   pred4 += (size_t)b * nmax;
-  true4 += (size_t)b * nmax;
+  col8 += (size_t)b * nmax;
   idx += (size_t)b * nmax;
   const int len = protein_len_block(seq + (size_t)b * L, L, s_tmp);
   const int nslot = len * 14;
@@ -107,8 +114,9 @@ __global__ __launch_bounds__(COMPACT_THREADS) void drmsd_compact_kernel(const fl
     const unsigned long long below = (1ull << lane) - 1ull;
     if (ok) {
       const int pos = bb ? pb + __popcll(mb & below) : po + __popcll(mo & below);
-      pred4[pos] = make_float4(pred[s * 3], pred[s * 3 + 1], pred[s * 3 + 2], 0.f);
-      true4[pos] = make_float4(tx, ty, tz, 0.f);
+      const float px = pred[s * 3], py = pred[s * 3 + 1], pz = pred[s * 3 + 2];
+      pred4[pos] = make_float4(px, py, pz, 0.f);
+      col8[pos] = Col8{px, tx, py, ty, pz, tz, 0.f, 0.f};
       idx[pos] = s;
     }
     pb += __popcll(mb);
@@ -158,21 +166,39 @@ __host__ __device__ inline TriLayout tri_layout(int nmax, int B) {
   return t;
 }
 
+// acc += (value of `rowval` in lane r of this lane's row of 16 lanes) * c: the DPP broadcast rides on the multiply-add
+template <int R>
+__device__ __forceinline__ void fmac_row16(float &acc, float rowval, float c) {
+  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(rowval), "v"(c), "n"(R));
+}
+// one row r of phase 2: q += cf[r] * (1, x_r, y_r, z_r), the row atom's coordinates straight from the lane that owns it
+template <int R>
+__device__ __forceinline__ void colsum_row(float4 &q, const float *__restrict__ cf_q, float px, float py, float pz) {
+  const float c = cf_q[R * CF_LD];
+  q.x += c;
+  fmac_row16<R>(q.y, px, c);
+  fmac_row16<R>(q.z, py, c);
+  fmac_row16<R>(q.w, pz, c);
+}
+template <int... R>
+__device__ __forceinline__ void colsum_rows(float4 &q, const float *__restrict__ cf_q, float px, float py, float pz,
+                                            std::integer_sequence<int, R...>) {
+  (colsum_row<R>(q, cf_q, px, py, pz), ...);
+}
+
 template <bool WITH_GRAD>
-__global__ __launch_bounds__(RS) void drmsd_tri_kernel(const float4 *__restrict__ pred4, const float4 *__restrict__ true4,
+__global__ __launch_bounds__(RS) void drmsd_tri_kernel(const Col8 *__restrict__ col8,
                                                        const Counts *__restrict__ counts, int L,
                                                        float4 *__restrict__ rowpart, float4 *__restrict__ colpart,
                                                        double *__restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];
   float *const s_cf = s_dyn;                                                  // [4][64][17] coefficient tiles
-  float4 *const s_xy = reinterpret_cast<float4 *>(s_dyn + STRIP_TILES * TS * CF_LD);   // column tile: (px, tx, py, ty)
-  float2 *const s_z = reinterpret_cast<float2 *>(s_xy + TS);                  //              (pz, tz)
-  float4 *const s_row = reinterpret_cast<float4 *>(s_z + TS);                 // [4][64] predicted coordinates of the rows
-  float4 *const s_cs = s_row + RS;                                            // [4][64] (S, Vx, Vy, Vz) per wavefront
+  float4 *const s_cs = reinterpret_cast<float4 *>(s_dyn + STRIP_TILES * TS * CF_LD);   // [2][4][64] (S, Vx, Vy, Vz) per wavefront, two column tiles
   __shared__ double s_red[2 * STRIP_TILES];
   const size_t nmax = (size_t)L * 14;
   const TriLayout tl = tri_layout((int)nmax, (int)gridDim.y);
-  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // (told to the compiler: what depends on w only stays scalar)
   const int strip = blockIdx.x / tl.chunks, chunk = blockIdx.x % tl.chunks;
   const Counts cn = counts[b];
   const int n = cn.n, nbb = cn.n_bb, nT = (n + TS - 1) / TS;
@@ -182,20 +208,19 @@ __global__ __launch_bounds__(RS) void drmsd_tri_kernel(const float4 *__restrict_
     if (tid == 0) part[0] = part[1] = 0.0;
     return;
   }
-  pred4 += (size_t)b * nmax;
-  true4 += (size_t)b * nmax;
+  col8 += (size_t)b * nmax;
   const int I = STRIP_TILES * strip + w, i = I * TS + lane;
   const bool live = i < n;
-  const float4 pi = live ? pred4[i] : make_float4(0, 0, 0, 0);
-  const float4 ti = live ? true4[i] : make_float4(0, 0, 0, 0);
-  s_row[w * TS + lane] = pi;
-  const f32x2 ix = {pi.x, ti.x}, iy = {pi.y, ti.y}, iz = {pi.z, ti.z};
+  Col8 me = Col8{0, 0, 0, 0, 0, 0, 0, 0};
+  if (live) me = col8[i];
+  const f32x2 ix = {me.px, me.tx}, iy = {me.py, me.ty}, iz = {me.pz, me.tz};
   float offA = 0.f, offB = 0.f, diagA = 0.f, diagB = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
   float *const cf_row = s_cf + (w * TS + lane) * CF_LD;     // phase 1: this lane's row of coefficients
 
-  // one pair from its column coordinates: e^2 into acc, cf (x_i - x_j) into the row gradient; returns cf (0 for a dead row)
-  auto pair_of = [&](const float4 a, const float2 c, float &acc) __attribute__((always_inline)) {
-    const f32x2 dx = ix - (f32x2){a.x, a.y}, dy = iy - (f32x2){a.z, a.w}, dz = iz - (f32x2){c.x, c.y};  // (pred, true)
+  // one pair from its column atom (wavefront-uniform: SGPRs): e^2 into acc, cf (x_i - x_j) into the row gradient; returns
+  // cf (0 for a dead row)
+  auto pair_of = [&](const Col8 &c, float &acc) __attribute__((always_inline)) {
+    const f32x2 dx = ix - (f32x2){c.px, c.tx}, dy = iy - (f32x2){c.py, c.ty}, dz = iz - (f32x2){c.pz, c.tz};  // (pred, true)
     f32x2 q = dx * dx;
     q = __builtin_elementwise_fma(dy, dy, q);
     q = __builtin_elementwise_fma(dz, dz, q);
@@ -213,25 +238,17 @@ __global__ __launch_bounds__(RS) void drmsd_tri_kernel(const float4 *__restrict_
     }
     return cf;
   };
-  auto pair = [&](int j, float &acc) __attribute__((always_inline)) {
-    return pair_of(s_xy[j], s_z[j], acc);  // same address in every lane: LDS broadcast
-  };
-  // U pairs at once: ALL column reads first, then the U independent chains, then the U coefficient stores.  Written pair
-  // by pair (read - chain - ds_write, read - ...) the compiler must keep every coefficient store in front of the next
-  // pair's column read (same LDS array: they may alias), which strings the U chains - LDS latency, two transcendentals
-  // and a dozen dependent VALU instructions each - one behind the other: ~200 cycles per 64-pair step, measured.
+  // U pairs at once: ALL column loads first (scalar, one wait), then the U independent chains, then the U coefficient
+  // stores.  (Pair by pair the compiler strings the chains - two transcendentals and a dozen dependent VALU instructions
+  // each - one behind the other.)
   constexpr int U = PT_DRMSD_UNROLL;
-  auto pairs_u = [&](int j, float &acc, float *cf_out, auto keep) __attribute__((always_inline)) {
-    float4 a[U];
-    float2 c[U];
+  auto pairs_u = [&](const Col8 *__restrict__ col, float &acc, float *cf_out, auto keep) __attribute__((always_inline)) {
+    Col8 c[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      a[u] = s_xy[j + u];
-      c[u] = s_z[j + u];
-    }
+    for (int u = 0; u < U; ++u) c[u] = col[u];
     float cf[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) cf[u] = pair_of(a[u], c[u], acc);
+    for (int u = 0; u < U; ++u) cf[u] = pair_of(c[u], acc);
     if (WITH_GRAD && decltype(keep)::value) {   // (the diagonal tile keeps no coefficients)
 #pragma unroll
       for (int u = 0; u < U; ++u) cf_out[u] = cf[u];
@@ -239,64 +256,54 @@ __global__ __launch_bounds__(RS) void drmsd_tri_kernel(const float4 *__restrict_
   };
 
   for (int J = J0; J < J1; ++J) {
-    __syncthreads();  // everybody is done with the previous column tile and its (S, V) slots
-    if (w == 0) {
-      const int jj = J * TS + lane;
-      const float4 pj = jj < n ? pred4[jj] : make_float4(0, 0, 0, 0), tj = jj < n ? true4[jj] : make_float4(0, 0, 0, 0);
-      s_xy[lane] = make_float4(pj.x, tj.x, pj.y, tj.y);
-      s_z[lane] = make_float2(pj.z, tj.z);
-    }
-    __syncthreads();
+    const Col8 *const col = col8 + (size_t)J * TS;   // this column tile: wavefront-uniform addresses from here on
     const int cnt = min(TS, n - J * TS);
     const int ja = max(0, min(cnt, nbb - J * TS));   // columns below ja are backbone atoms (then so is every row i < j)
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);   // (S, Vx, Vy, Vz) of column lane of the tile, in lanes 0..cnt-1
     if (I < J) {  // wavefront-uniform: a full tile above the diagonal
-      const float4 *rows = s_row + w * TS + (lane >> 4) * SUB;          // phase 2: this lane's quarter of the rows
-      const float *cf_q = s_cf + (w * TS + (lane >> 4) * SUB) * CF_LD + (lane & (SUB - 1));
+      const float *cf_q = s_cf + (w * TS + (lane >> 4) * SUB) * CF_LD + (lane & (SUB - 1));   // phase 2: this lane's quarter of the rows
       for (int j0 = 0; j0 < cnt; j0 += SUB) {
         const int j1 = min(cnt, j0 + SUB), jb = max(j0, min(j1, ja));   // [j0, jb) backbone columns, [jb, j1) the rest
         int j = j0;
-        for (; j + U - 1 < jb; j += U) pairs_u(j, offA, cf_row + (j - j0), std::true_type{});
+        for (; j + U - 1 < jb; j += U) pairs_u(col + j, offA, cf_row + (j - j0), std::true_type{});
         for (; j < jb; ++j) {
-          const float cf = pair(j, offA);
+          const float cf = pair_of(col[j], offA);
           if (WITH_GRAD) cf_row[j - j0] = cf;
         }
-        for (; j + U - 1 < j1; j += U) pairs_u(j, offB, cf_row + (j - j0), std::true_type{});
+        for (; j + U - 1 < j1; j += U) pairs_u(col + j, offB, cf_row + (j - j0), std::true_type{});
         for (; j < j1; ++j) {
-          const float cf = pair(j, offB);
+          const float cf = pair_of(col[j], offB);
           if (WITH_GRAD) cf_row[j - j0] = cf;
         }
-        if (WITH_GRAD) {  // phase 2 for these 16 columns (LDS is in order per wavefront); columns >= j1 read stale finite data
+        if (WITH_GRAD) {
+          // phase 2 for these 16 columns (LDS is in order per wavefront): lane = (column j0 + (lane & 15), quarter lane >> 4
+          // of the rows); the coordinates of row 16 quarter + r live in lane r of this lane's row of 16 lanes.  Every lane
+          // takes part (a DPP operand of a disabled lane is not readable): columns >= j1 sum stale tile contents and are
+          // dropped below - a lane only ever meets lanes of its own column
           float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (j0 + (lane & (SUB - 1)) < j1) {
-#pragma unroll
-            for (int r = 0; r < SUB; ++r) {
-              const float c = cf_q[r * CF_LD];
-              const float4 xr = rows[r];
-              q.x += c;
-              q.y = fmaf(c, xr.x, q.y);
-              q.z = fmaf(c, xr.y, q.z);
-              q.w = fmaf(c, xr.z, q.w);
-            }
-          }
+          colsum_rows(q, cf_q, me.px, me.py, me.pz, std::make_integer_sequence<int, SUB>{});
           // fold the four row quarters (lanes l, l ^ 16, l ^ 32, l ^ 48) in a fixed order: every lane ends with the sum
           q.x += __shfl_xor(q.x, 16, 64); q.y += __shfl_xor(q.y, 16, 64); q.z += __shfl_xor(q.z, 16, 64); q.w += __shfl_xor(q.w, 16, 64);
           q.x += __shfl_xor(q.x, 32, 64); q.y += __shfl_xor(q.y, 32, 64); q.z += __shfl_xor(q.z, 32, 64); q.w += __shfl_xor(q.w, 32, 64);
-          if ((lane >> 4) == (j0 >> 4)) cs = q;   // lane l keeps column l of the tile: quarter j0 / 16 holds columns j0 .. j0 + 15
+          // lane l keeps column l of the tile: quarter j0 / 16 holds columns j0 .. j0 + 15
+          if ((lane >> 4) == (j0 >> 4) && j0 + (lane & (SUB - 1)) < j1) cs = q;
         }
       }
     } else if (I == J) {  // the diagonal tile: both sides inside the tile, j == i contributes exactly 0
       int j = 0;
-      for (; j + U - 1 < ja; j += U) pairs_u(j, diagA, nullptr, std::false_type{});
-      for (; j < ja; ++j) pair(j, diagA);
-      for (; j + U - 1 < cnt; j += U) pairs_u(j, diagB, nullptr, std::false_type{});
-      for (; j < cnt; ++j) pair(j, diagB);
+      for (; j + U - 1 < ja; j += U) pairs_u(col + j, diagA, nullptr, std::false_type{});
+      for (; j < ja; ++j) pair_of(col[j], diagA);
+      for (; j + U - 1 < cnt; j += U) pairs_u(col + j, diagB, nullptr, std::false_type{});
+      for (; j < cnt; ++j) pair_of(col[j], diagB);
     }
     if (WITH_GRAD) {
-      s_cs[w * TS + lane] = cs;
+      // two sets of slots, alternating: wavefront 0 reads set p behind this barrier while the others fill set p ^ 1 for
+      // the next column tile and meet it at the next barrier - one barrier per column tile
+      float4 *const slots = s_cs + ((J - J0) & 1) * RS;
+      slots[w * TS + lane] = cs;
       __syncthreads();
       if (w == 0) {  // fixed order over the four wavefronts
-        const float4 a0 = s_cs[lane], a1 = s_cs[TS + lane], a2 = s_cs[2 * TS + lane], a3 = s_cs[3 * TS + lane];
+        const float4 a0 = slots[lane], a1 = slots[TS + lane], a2 = slots[2 * TS + lane], a3 = slots[3 * TS + lane];
         const float4 t = make_float4(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y,
                                      ((a0.z + a1.z) + a2.z) + a3.z, ((a0.w + a1.w) + a2.w) + a3.w);
         colpart[(((size_t)b * tl.strips + strip) * tl.tiles + J) * TS + lane] = t;
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(RS) void drmsd_tri_kernel(const float4 *__restrict_
     part[1] = c;
   }
 }
-constexpr size_t TRI_LDS = (size_t)(STRIP_TILES * TS * CF_LD) * 4 + TS * 16 + TS * 8 + RS * 16 + RS * 16;
+constexpr size_t TRI_LDS = (size_t)(STRIP_TILES * TS * CF_LD) * 4 + 2 * RS * 16;
 
 // statistics, gradient assembly and scatter back to the slot layout: grid (ceil(nmax / 256), B); dcrd was zeroed before
 __global__ __launch_bounds__(CB) void drmsd_finalize_kernel(const Counts *__restrict__ counts,
@@ -432,7 +439,7 @@ __global__ __launch_bounds__(CB) void drmsd_finalize_kernel(const Counts *__rest
 }
 
 struct Layout {
-  size_t pred4, true4, rowpart, colpart, idx, counts, partials, total;
+  size_t pred4, col8, rowpart, colpart, idx, counts, partials, total;
   TriLayout tl;
 };
 Layout layout(int B, int L) {
@@ -446,7 +453,7 @@ Layout layout(int B, int L) {
     return o;
   };
   l.pred4 = take(BN * sizeof(float4));
-  l.true4 = take(BN * sizeof(float4));
+  l.col8 = take(BN * sizeof(Col8));
   l.rowpart = take((size_t)B * l.tl.strips * l.tl.chunks * RS * sizeof(float4));
   l.colpart = take((size_t)B * l.tl.strips * l.tl.tiles * TS * sizeof(float4));
   l.idx = take(BN * sizeof(int));
@@ -472,13 +479,14 @@ int ptamd_drmsd_fwd_bwd(const float *pred_crd, const float *true_crd, const int6
   if (!workspace || workspace_bytes < l.total) return PTAMD_ERR_WORKSPACE;
   if (!pt_aligned16(workspace)) return PTAMD_ERR_ALIGN;
   char *ws = static_cast<char *>(workspace);
-  float4 *pred4 = reinterpret_cast<float4 *>(ws + l.pred4), *true4 = reinterpret_cast<float4 *>(ws + l.true4),
+  Col8 *col8 = reinterpret_cast<Col8 *>(ws + l.col8);
+  float4 *pred4 = reinterpret_cast<float4 *>(ws + l.pred4),
          *rowpart = reinterpret_cast<float4 *>(ws + l.rowpart), *colpart = reinterpret_cast<float4 *>(ws + l.colpart);
   int *idx = reinterpret_cast<int *>(ws + l.idx);
   Counts *counts = reinterpret_cast<Counts *>(ws + l.counts);
   double *partials = reinterpret_cast<double *>(ws + l.partials);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(drmsd_compact_kernel, dim3(B), dim3(COMPACT_THREADS), 0, st, pred_crd, true_crd, seq, L, pred4, true4, idx,
+  hipLaunchKernelGGL(drmsd_compact_kernel, dim3(B), dim3(COMPACT_THREADS), 0, st, pred_crd, true_crd, seq, L, pred4, col8, idx,
                      counts);
   int rc = pt_check_launch();
   if (rc) return rc;
@@ -487,11 +495,11 @@ int ptamd_drmsd_fwd_bwd(const float *pred_crd, const float *true_crd, const int6
     PT_HIP_TRY(hipMemsetAsync(dcrd, 0, (size_t)B * L * 14 * 3 * sizeof(float), st));   // slots of absent atoms stay 0
     auto kern = drmsd_tri_kernel<true>;
     PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRI_LDS));
-    hipLaunchKernelGGL(kern, grid, dim3(RS), TRI_LDS, st, pred4, true4, counts, L, rowpart, colpart, partials);
+    hipLaunchKernelGGL(kern, grid, dim3(RS), TRI_LDS, st, col8, counts, L, rowpart, colpart, partials);
   } else {
     auto kern = drmsd_tri_kernel<false>;
     PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRI_LDS));
-    hipLaunchKernelGGL(kern, grid, dim3(RS), TRI_LDS, st, pred4, true4, counts, L, rowpart, colpart, partials);
+    hipLaunchKernelGGL(kern, grid, dim3(RS), TRI_LDS, st, col8, counts, L, rowpart, colpart, partials);
   }
   rc = pt_check_launch();
   if (rc) return rc;

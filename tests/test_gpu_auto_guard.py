@@ -331,8 +331,12 @@ def test_moved_weights_trajectory(dev, optimizer, lr, default_steps):
     for k, tol in (("drmsd_rel_max", 1e-4), ("lndrmsd_abs_max", 1e-6), ("grad_rel_l2", 1e-3)):
         # never in another class than the strictly fp32-grade arithmetics on the same weights ...
         assert e[k] < max(tol, 3 * worst[k]), (k, e[k], worst[k], end["well_conditioned"])
-        # ... and inside the tolerance wherever the point is well-conditioned
-        if end["well_conditioned"]:
+        # ... and inside the tolerance wherever the point is well-conditioned FOR THIS QUANTITY - the probe is the exact
+        # arithmetics themselves: where the fma-chain fp32 product and the exact three-term split sit in a third of the
+        # tolerance, so must AUTO.  (200 Adam steps can end where one backbone bond angle is within 6e-4 rad of a straight
+        # line: the NeRF gradient carries 1 / sin there, the predictions agree to 1e-6 and the gradients of ALL THREE
+        # arithmetics are 0.5 - 2 % off the fp64 ones, uniformly over every parameter group - profiles/r04/NOTES.md, section 2.)
+        if end["well_conditioned"] and worst[k] < tol / 3:
             assert e[k] < tol, (k, e[k])
     yard = max(snap["f32"], snap["fp64_perturbed"])                                # (b)
     assert snap["auto"] < 3 * yard, snap
