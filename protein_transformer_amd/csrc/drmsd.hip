@@ -29,7 +29,7 @@ namespace {
 constexpr int CB = 256;  // threads per block of the compaction / finalize kernels
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef PT_DRMSD_UNROLL
-#define PT_DRMSD_UNROLL 8   // (8 chains in flight at 116 VGPRs = 4 wavefronts per SIMD: 370 us against 398 with 4 chains at 6 wavefronts, config 4)
+#define PT_DRMSD_UNROLL 8   // column atoms per batch = independent chains in flight per wavefront (4: the same time)
 #endif
 
 struct Counts {
@@ -195,6 +195,7 @@ __global__ __launch_bounds__(RS) void drmsd_tri_kernel(const Col8 *__restrict__ 
   float *const s_cf = s_dyn;                                                  // [4][64][17] coefficient tiles
   float4 *const s_cs = reinterpret_cast<float4 *>(s_dyn + STRIP_TILES * TS * CF_LD);   // [2][4][64] (S, Vx, Vy, Vz) per wavefront, two column tiles
   __shared__ double s_red[2 * STRIP_TILES];
+  __shared__ Col8 s_col[2][TS];   // the column tile (all four wavefronts walk the same one), two buffers
   const size_t nmax = (size_t)L * 14;
   const TriLayout tl = tri_layout((int)nmax, (int)gridDim.y);
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
@@ -211,24 +212,28 @@ __global__ __launch_bounds__(RS) void drmsd_tri_kernel(const Col8 *__restrict__ 
   col8 += (size_t)b * nmax;
   const int I = STRIP_TILES * strip + w, i = I * TS + lane;
   const bool live = i < n;
-  Col8 me = Col8{0, 0, 0, 0, 0, 0, 0, 0};
+  // A dead row (behind the protein's last atom) sits at (2^60, 2^60, 2^60) in BOTH structures: every difference to a real
+  // atom rounds to 2^60 in both, d == tau exactly, e = cf = 0 - no select per pair, nothing non-finite anywhere.
+  constexpr float FAR = 1152921504606846976.f;
+  Col8 me = Col8{FAR, FAR, FAR, FAR, FAR, FAR, 0, 0};
   if (live) me = col8[i];
   const f32x2 ix = {me.px, me.tx}, iy = {me.py, me.ty}, iz = {me.pz, me.tz};
   float offA = 0.f, offB = 0.f, diagA = 0.f, diagB = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
   float *const cf_row = s_cf + (w * TS + lane) * CF_LD;     // phase 1: this lane's row of coefficients
 
-  // one pair from its column atom (wavefront-uniform: SGPRs): e^2 into acc, cf (x_i - x_j) into the row gradient; returns
-  // cf (0 for a dead row)
+  // one pair from its column atom: e^2 into acc, cf (x_i - x_j) into the row gradient; returns cf (0 for a dead row).
+  // 3 packed subtractions + 3 packed fma + 2 v_rsq_f32 + 1 packed multiply + 3 scalar ops for the loss, 4 more for the
+  // row gradient.  clamp_min(1e-30) of losses.py:252 is the 1e-30 the squares are added to: the same number bit for
+  // bit unless two atoms are within 1e-11 A of each other, 1e-30 (as there) when they coincide, and no v_max per distance.
   auto pair_of = [&](const Col8 &c, float &acc) __attribute__((always_inline)) {
     const f32x2 dx = ix - (f32x2){c.px, c.tx}, dy = iy - (f32x2){c.py, c.ty}, dz = iz - (f32x2){c.pz, c.tz};  // (pred, true)
-    f32x2 q = dx * dx;
+    f32x2 q = __builtin_elementwise_fma(dx, dx, (f32x2){1e-30f, 1e-30f});
     q = __builtin_elementwise_fma(dy, dy, q);
     q = __builtin_elementwise_fma(dz, dz, q);
-    const float d2 = fmaxf(q[0], 1e-30f), t2 = fmaxf(q[1], 1e-30f);  // clamp_min(1e-30) of losses.py:252
-    const float inv = __builtin_amdgcn_rsqf(d2), invt = __builtin_amdgcn_rsqf(t2);
-    f32x2 dt = (f32x2){d2, t2} * (f32x2){inv, invt};  // (d, tau)
+    const float inv = __builtin_amdgcn_rsqf(q[0]), invt = __builtin_amdgcn_rsqf(q[1]);
+    f32x2 dt = q * (f32x2){inv, invt};  // (d, tau)
     asm("" : "+v"(dt));  // keep the rounded products: no FMA contraction into e, so pred == true gives e == 0 exactly
-    const float e = live ? dt[0] - dt[1] : 0.f;
+    const float e = dt[0] - dt[1];
     acc = fmaf(e, e, acc);
     const float cf = e * inv;
     if (WITH_GRAD) {
@@ -238,42 +243,71 @@ __global__ __launch_bounds__(RS) void drmsd_tri_kernel(const Col8 *__restrict__ 
     }
     return cf;
   };
-  // U pairs at once: ALL column loads first (scalar, one wait), then the U independent chains, then the U coefficient
-  // stores.  (Pair by pair the compiler strings the chains - two transcendentals and a dozen dependent VALU instructions
-  // each - one behind the other.)
+  // The column tile is staged in LDS by the strip's last wavefront (the one with the least work in the strip's first
+  // tiles), tile J + 1 into the other buffer in front of the barrier that ends tile J, and read as broadcasts in batches of
+  // U atoms: per batch the U independent chains, then the U coefficient stores (pair by pair the compiler strings the
+  // chains - two transcendentals and a dozen dependent VALU instructions each - one behind the other).  (Measured
+  // alternative, round 4: the column atoms as a double-buffered stream of scalar loads, coordinates as SGPR operands -
+  // no LDS reads at all, and 10 % slower: profiles/r04/NOTES.md section 5.)
   constexpr int U = PT_DRMSD_UNROLL;
-  auto pairs_u = [&](const Col8 *__restrict__ col, float &acc, float *cf_out, auto keep) __attribute__((always_inline)) {
+  static_assert(SUB % U == 0, "a sub-block of coefficient columns is a whole number of batches");
+  struct Batch {
     Col8 c[U];
+  };
+  auto fetch = [&](int buf, int j) __attribute__((always_inline)) {
+    Batch t;
 #pragma unroll
-    for (int u = 0; u < U; ++u) c[u] = col[u];
-    float cf[U];
+    for (int u = 0; u < U; ++u) t.c[u] = s_col[buf][j + u];
+    return t;
+  };
+  auto stage = [&](int J, int buf) __attribute__((always_inline)) {   // one wavefront's job: tile J -> s_col[buf]
+    const int jj = J * TS + lane;
+    s_col[buf][lane] = jj < n ? col8[jj] : Col8{0, 0, 0, 0, 0, 0, 0, 0};
+  };
+  // columns [j, j + U) of a tile whose live columns are [0, j1), backbone columns [0, jb): whole batches on one accumulator
+  // without a test per column, the (at most two per tile) ragged ones column by column; cf_out = nullptr_t: keep nothing
+  auto batch = [&](const Batch &t, int j, int jb, int j1, auto cf_out) __attribute__((always_inline)) {
+    constexpr bool keep = WITH_GRAD && !std::is_same<decltype(cf_out), std::nullptr_t>::value;
+    if (j + U <= jb || (j >= jb && j + U <= j1)) {
+      float acc = 0.f, cf[U];   // (a batch sums its U squares first: a reference to one of two accumulators would put both in memory)
 #pragma unroll
-    for (int u = 0; u < U; ++u) cf[u] = pair_of(c[u], acc);
-    if (WITH_GRAD && decltype(keep)::value) {   // (the diagonal tile keeps no coefficients)
+      for (int u = 0; u < U; ++u) cf[u] = pair_of(t.c[u], acc);
+      const bool bb = j + U <= jb;   // (wavefront-uniform; written as a branch the compiler selects between the ADDRESSES of the two
+      offA += bb ? acc : 0.f;        //  accumulators and keeps both in scratch memory)
+      offB += bb ? 0.f : acc;
+      if constexpr (keep) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) cf_out[u] = cf[u];
+        for (int u = 0; u < U; ++u) cf_out[u] = cf[u];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (j + u < j1) {
+          float e2 = 0.f;
+          const float cf = pair_of(t.c[u], e2);
+          offA += j + u < jb ? e2 : 0.f;
+          offB += j + u < jb ? 0.f : e2;
+          if constexpr (keep) cf_out[u] = cf;
+        }
+      }
     }
   };
 
+  if (w == STRIP_TILES - 1) stage(J0, 0);
+  __syncthreads();
   for (int J = J0; J < J1; ++J) {
-    const Col8 *const col = col8 + (size_t)J * TS;   // this column tile: wavefront-uniform addresses from here on
+    const int cbuf = (J - J0) & 1;
+    if (w == STRIP_TILES - 1 && J + 1 < J1) stage(J + 1, cbuf ^ 1);
     const int cnt = min(TS, n - J * TS);
     const int ja = max(0, min(cnt, nbb - J * TS));   // columns below ja are backbone atoms (then so is every row i < j)
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);   // (S, Vx, Vy, Vz) of column lane of the tile, in lanes 0..cnt-1
     if (I < J) {  // wavefront-uniform: a full tile above the diagonal
       const float *cf_q = s_cf + (w * TS + (lane >> 4) * SUB) * CF_LD + (lane & (SUB - 1));   // phase 2: this lane's quarter of the rows
       for (int j0 = 0; j0 < cnt; j0 += SUB) {
-        const int j1 = min(cnt, j0 + SUB), jb = max(j0, min(j1, ja));   // [j0, jb) backbone columns, [jb, j1) the rest
-        int j = j0;
-        for (; j + U - 1 < jb; j += U) pairs_u(col + j, offA, cf_row + (j - j0), std::true_type{});
-        for (; j < jb; ++j) {
-          const float cf = pair_of(col[j], offA);
-          if (WITH_GRAD) cf_row[j - j0] = cf;
-        }
-        for (; j + U - 1 < j1; j += U) pairs_u(col + j, offB, cf_row + (j - j0), std::true_type{});
-        for (; j < j1; ++j) {
-          const float cf = pair_of(col[j], offB);
-          if (WITH_GRAD) cf_row[j - j0] = cf;
+        const int j1 = min(cnt, j0 + SUB), jb = min(j1, ja);
+#pragma unroll
+        for (int k = 0; k < SUB / U; ++k) {
+          batch(fetch(cbuf, j0 + k * U), j0 + k * U, jb, j1, cf_row + k * U);
         }
         if (WITH_GRAD) {
           // phase 2 for these 16 columns (LDS is in order per wavefront): lane = (column j0 + (lane & 15), quarter lane >> 4
@@ -290,16 +324,31 @@ __global__ __launch_bounds__(RS) void drmsd_tri_kernel(const Col8 *__restrict__ 
         }
       }
     } else if (I == J) {  // the diagonal tile: both sides inside the tile, j == i contributes exactly 0
-      int j = 0;
-      for (; j + U - 1 < ja; j += U) pairs_u(col + j, diagA, nullptr, std::false_type{});
-      for (; j < ja; ++j) pair_of(col[j], diagA);
-      for (; j + U - 1 < cnt; j += U) pairs_u(col + j, diagB, nullptr, std::false_type{});
-      for (; j < cnt; ++j) pair_of(col[j], diagB);
+      float &accA = diagA, &accB = diagB;
+      auto dbatch = [&](const Batch &t, int j) __attribute__((always_inline)) {
+        if (j + U <= ja || (j >= ja && j + U <= cnt)) {
+          float acc = 0.f;
+#pragma unroll
+          for (int u = 0; u < U; ++u) pair_of(t.c[u], acc);
+          accA += j + U <= ja ? acc : 0.f;
+          accB += j + U <= ja ? 0.f : acc;
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (j + u < cnt) {
+              float e2 = 0.f;
+              pair_of(t.c[u], e2);
+              accA += j + u < ja ? e2 : 0.f;
+              accB += j + u < ja ? 0.f : e2;
+            }
+        }
+      };
+      for (int j = 0; j < cnt; j += U) dbatch(fetch(cbuf, j), j);
     }
     if (WITH_GRAD) {
       // two sets of slots, alternating: wavefront 0 reads set p behind this barrier while the others fill set p ^ 1 for
       // the next column tile and meet it at the next barrier - one barrier per column tile
-      float4 *const slots = s_cs + ((J - J0) & 1) * RS;
+      float4 *const slots = s_cs + cbuf * RS;
       slots[w * TS + lane] = cs;
       __syncthreads();
       if (w == 0) {  // fixed order over the four wavefronts
@@ -308,6 +357,8 @@ __global__ __launch_bounds__(RS) void drmsd_tri_kernel(const Col8 *__restrict__ 
                                      ((a0.z + a1.z) + a2.z) + a3.z, ((a0.w + a1.w) + a2.w) + a3.w);
         colpart[(((size_t)b * tl.strips + strip) * tl.tiles + J) * TS + lane] = t;
       }
+    } else {
+      __syncthreads();   // the next column tile is staged; this one is free
     }
   }
   if (WITH_GRAD) rowpart[(((size_t)b * tl.strips + strip) * tl.chunks + chunk) * RS + tid] = make_float4(gx, gy, gz, 0.f);
