@@ -127,9 +127,10 @@ __global__ __launch_bounds__(COMPACT_THREADS) void drmsd_compact_kernel(const fl
 
 // ---- the pair sweep over the UPPER TRIANGLE: every unordered pair {i, j} is evaluated ONCE.
 // Atoms are cut into tiles of 64 (one wavefront's lanes); a workgroup of 4 wavefronts owns a STRIP of 4 row tiles
-// (256 atoms) and walks a CHUNK of up to 16 column tiles J >= its first tile (the chunks of a strip are separate work
-// items: a strip's work shrinks with its index, 16-tile chunks keep the items balanced - 1824 items of <= 16 tile steps at
-// 32 proteins x 4275 atoms).  For a column tile J above a wavefront's row tile I (I < J) the wavefront
+// (256 atoms) and walks a CHUNK of up to 8 column tiles J >= its first tile (the chunks of a strip are separate work
+// items: a strip's work shrinks with its index, and a CU holds three workgroups at a time - with 16-tile chunks the
+// benchmark batch was 1824 items, 7 per CU in 2.4 rounds of 3, and the CUs that drew a third round set the time: 8-tile
+// chunks 315 us against 352 for the whole loss, 4-tile chunks 320 - the partials of the finalize kernel double each time).  For a column tile J above a wavefront's row tile I (I < J) the wavefront
 //   phase 1  walks 16 columns like the old two-sided kernel did (lane = row atom i, column coordinates broadcast from
 //            LDS, one v_rsq_f32 each for the predicted and the true distance), adds e^2 to the loss, cf (x_i - x_j) to
 //            its row gradient - and leaves the coefficient cf_ij = e / d in LDS, row-major with a 17-word row stride;
@@ -144,10 +145,13 @@ __global__ __launch_bounds__(COMPACT_THREADS) void drmsd_compact_kernel(const fl
 // the column partials of all strips at or above it: no atomics anywhere, bit-reproducible.  The diagonal tile (I == J) is
 // still swept from both sides inside the tile (its loss terms count half).
 constexpr int TS = 64, STRIP_TILES = 4, RS = TS * STRIP_TILES;
-// column tiles per work item: 16, or fewer (8, 4) when the batch would otherwise leave most of the 5 x 256 workgroup slots
+// column tiles per work item: 8, or fewer (4) when the batch would otherwise leave most of the 5 x 256 workgroup slots
 // empty (few or short proteins) - a function of (B, L) only, so a given batch is always cut the same way
-constexpr int MAX_CHUNK_TILES = 16, MIN_CHUNK_TILES = 4, TARGET_ITEMS = 2560;
-constexpr int SUB = 16, CF_LD = SUB + 1;   // the coefficient tile is kept for 16 columns at a time: 4.3 KB per wavefront, 5 workgroups per CU
+#ifndef PT_DRMSD_MAX_CHUNK
+#define PT_DRMSD_MAX_CHUNK 8
+#endif
+constexpr int MAX_CHUNK_TILES = PT_DRMSD_MAX_CHUNK, MIN_CHUNK_TILES = 4, TARGET_ITEMS = 2560;
+constexpr int SUB = 16, CF_LD = SUB + 1;   // the coefficient tile is kept for 16 columns at a time: 4.3 KB per wavefront
 
 struct TriLayout {  // per protein: strips x chunks work items, column tiles
   int strips, chunks, tiles, chunk_tiles;
