@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--no-side-stream", action="store_true", help="ablation: weight-gradient products of small batches on the main stream")
     ap.add_argument("--no-hp-forward", action="store_true", help="ablation: the FFN-layer-1 forward product on ptamd_gemm instead of ptamd_gemm_hp")
     ap.add_argument("--no-hp-qkv", action="store_true", help="ablation: the QKV product on ptamd_gemm instead of ptamd_gemm_hp")
+    ap.add_argument("--no-top-layer-scales", action="store_true", help="ablation: the top layer's FFN weight-gradient products in bf16x3 (no pass over its dy2)")
+    ap.add_argument("--dw-group", default="auto", choices=["auto", "pairs", "layer", "off"],
+                    help="grouping of the weight-gradient products of a layer (ptamd_gemm_group); off = one by one (ablation)")
     ap.add_argument("--hp-dx", action="store_true", help="ablation: dX of FFN layer 2 on ptamd_gemm_hp (off by default: +-0 in the step)")
     ap.add_argument("--attn-mode", default=None, choices=["f32", "bf16x3", "f16x2"],
                     help="arithmetic of the attention kernels alone (ablation; default: that of --gemm-mode)")
@@ -292,6 +295,8 @@ def main():
         kernels.DW_SLOTS = int(os.environ["PTAMD_DW_SLOTS"])
     model.hp_forward = not a.no_hp_forward
     model.hp_qkv, model.hp_dx = not a.no_hp_qkv, bool(a.hp_dx)
+    model.dw_group = a.dw_group
+    model.top_layer_scales = not a.no_top_layer_scales
     model.dropout_seed += 7919 * rank
     dp.attach(model)
     opt = (FusedAdam(model, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=10e-3) if a.optimizer == "adam"

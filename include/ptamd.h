@@ -194,6 +194,15 @@ int ptamd_gemm(const ptamd_gemm_args *args, void *stream);
 /* matrix-pipe products per fp32 product that ptamd_gemm would use for these arguments (shapes, layouts, `arith`):
  * 1 (F32), 3 (F16X2), 6 (BF16X3), 9 (BF16X3_FULL); host only, nothing is launched */
 int ptamd_gemm_products(const ptamd_gemm_args *args);
+/* Up to four INDEPENDENT weight-gradient products in ONE launch (+ one launch for all their split-K reductions): the four
+ * dW = dy^T x of an encoder layer (autograd of the nn.Linear layers of Attention.py:49,69 and Sublayers.py:28-34), whose
+ * output matrices are too few tiles to fill the chip one by one.  The work items (256 x 128 tile, K split) of the members
+ * are concatenated and dealt out in contiguous ranges, so the launch is balanced when the members' K per split agree (four
+ * members with 96 tiles and split_k = 8: three items per CU).  Same results, bit for bit, as ptamd_gemm called on each member
+ * with the same split_k.  Every member must be: a_kmajor and b_kmajor, PTAMD_GEMM_F16X2 with a_scale and b_scale given,
+ * split_k >= 2 with its own workspace (ptamd_gemm_workspace_bytes), flags == PTAMD_EPI_ACCUM and no other epilogue, N and ldc
+ * multiples of 4, C 16-byte aligned, colsum in all members or in none - PTAMD_ERR_BAD_SHAPE otherwise (nothing is launched). */
+int ptamd_gemm_group(const ptamd_gemm_args *args, int n, void *stream);
 
 /* ------------------------------------------------------------------ pre-split ("half-pair", hp) operands
  * An fp32 matrix [rows, K] stored as TWO f16 planes + one power-of-two scale per row, x * scale = hi + lo to 22 bits (the

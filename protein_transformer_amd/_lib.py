@@ -91,6 +91,7 @@ SIGNATURES = {
     "ptamd_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
     "ptamd_gemm": (_i, [C.POINTER(GemmArgs), _p]),
     "ptamd_gemm_products": (_i, [C.POINTER(GemmArgs)]),
+    "ptamd_gemm_group": (_i, [C.POINTER(GemmArgs), _i, _p]),
     "ptamd_hp_bytes": (_sz, [_i, _i]),
     "ptamd_hp_padded_rows": (_i, [_i]),
     "ptamd_hp_split": (_i, [_p, _i, _i, _i, _i, _p, _p, _p]),

@@ -251,8 +251,11 @@ constexpr int BUF = 2 * Tile2::ELEMS;  // f16 elements of one {A, B} tile buffer
 constexpr size_t ATTN_LDS = (size_t)2 * BUF * sizeof(unsigned short);
 
 // =================================================================================================== forward
+#ifndef PT_ATTN_FWD_WAVES
+#define PT_ATTN_FWD_WAVES 2   // wavefronts per SIMD the forward kernel is compiled for (4 = 128 VGPRs: 27 spilled, measured in round 4)
+#endif
 template <int DK, int NW, int PARTS>
-__global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_f16x2_kernel(
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PT_ATTN_FWD_WAVES, PT_ATTN_FWD_WAVES))) void attn_fwd_f16x2_kernel(
     const float *__restrict__ qkv, const int64_t *__restrict__ seq, int L, int H, float p_drop, uint64_t seed,
     uint32_t stream_id, float *__restrict__ out, float *__restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];

@@ -210,11 +210,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_mfma_kernel(const GemmParams p
 // split-K, plain case (no bias / activation / dropout / residual; optional accumulate) with 16-byte accesses: one
 // thread sums one float4 of one output row over the slabs in a fixed order.  The column-sum slabs (fused bias gradient
 // of a dW product) are reduced by the first wavefronts of the grid.
-__global__ __launch_bounds__(256) void gemm_splitk_reduce_plain_kernel(const GemmParams p, const float *__restrict__ slabs,
-                                                                     int splits, const float *__restrict__ colsum_slabs,
-                                                                     float *__restrict__ colsum_out) {
+__device__ __forceinline__ void splitk_reduce_plain(const GemmParams &p, const float *__restrict__ slabs, int splits,
+                                                    const float *__restrict__ colsum_slabs, float *__restrict__ colsum_out,
+                                                    size_t i) {
   const int n4 = p.N >> 2;
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, total = (size_t)p.M * n4;
+  const size_t total = (size_t)p.M * n4;
   if (colsum_out) {  // M rows, one lane per (row, 16th of the slabs): 16 lanes per row
     const int nslab = splits * p.colsum_share;
     const size_t g = i >> 4;
@@ -252,6 +252,20 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_plain_kernel(const Gem
     acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
   }
   *dst = acc;
+}
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_plain_kernel(const GemmParams p, const float *__restrict__ slabs,
+                                                                     int splits, const float *__restrict__ colsum_slabs,
+                                                                     float *__restrict__ colsum_out) {
+  splitk_reduce_plain(p, slabs, splits, colsum_slabs, colsum_out, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+// the same for the members of a group launch: blocks [first_block[j], first_block[j + 1]) work on member j
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_group_kernel(const ReduceGroup g) {
+  int j = 0;
+#pragma unroll
+  for (int k = 1; k < MAX_GROUP; ++k) j += (k < g.n && (int)blockIdx.x >= g.m[k].first_block) ? 1 : 0;
+  const ReduceMember &m = g.m[j];
+  splitk_reduce_plain(m.p, m.slabs, m.splits, m.cs_slabs, m.colsum,
+                      (size_t)((int)blockIdx.x - m.first_block) * blockDim.x + threadIdx.x);
 }
 
 // split-K: sum the slabs in a fixed order, then the same epilogue
@@ -352,6 +366,11 @@ int launch_splitk_reduce(const GemmParams &p, const float *slabs, int splits, co
   return pt_check_launch();
 }
 
+int launch_splitk_reduce_group(const ReduceGroup &g, hipStream_t st) {
+  hipLaunchKernelGGL(gemm_splitk_reduce_group_kernel, dim3(g.blocks), dim3(256), 0, st, g);
+  return pt_check_launch();
+}
+
 }  // namespace ptgemm
 
 using namespace ptgemm;
@@ -398,7 +417,9 @@ int ptamd_gemm_products(const ptamd_gemm_args *a) {
   return mode == PTAMD_GEMM_F32 ? 1 : mode == PTAMD_GEMM_F16X2 ? 3 : mode == PTAMD_GEMM_BF16X3_FULL ? 9 : 6;
 }
 
-int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
+namespace {
+// arguments -> launch parameters: checks, K splits, slabs in the workspace; the f16x2 row scales are left to the caller
+int build_params(const ptamd_gemm_args *a, GemmParams &p, int &splits, int &mode, float *&user_c) {
   if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0 || !valid_arith(a->arith)) return PTAMD_ERR_BAD_SHAPE;
   if ((a->lda & 3) || (a->ldb & 3)) return PTAMD_ERR_BAD_SHAPE;
   if ((!a->a_kmajor || !a->b_kmajor) && (a->K & 3)) return PTAMD_ERR_BAD_SHAPE;  // K-contiguous rows are read 16 B at a time
@@ -406,11 +427,10 @@ int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
   if (a->b_kmajor && (a->N & 3)) return PTAMD_ERR_BAD_SHAPE;
   if (!pt_aligned16(a->A) || !pt_aligned16(a->B)) return PTAMD_ERR_ALIGN;
   if (a->dropout_p < 0.f || a->dropout_p >= 1.f) return PTAMD_ERR_BAD_SHAPE;
-  int splits = a->split_k > 1 ? a->split_k : 1;
+  splits = a->split_k > 1 ? a->split_k : 1;
   constexpr int BK = 32;
   const int kblocks = (a->K + BK - 1) / BK;
   if (splits > kblocks) splits = kblocks;
-  GemmParams p;
   p.M = a->M; p.N = a->N; p.K = a->K;
   p.A = a->A; p.lda = a->lda; p.B = a->B; p.ldb = a->ldb; p.C = a->C; p.ldc = a->ldc;
   p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr; p.flags = a->flags;
@@ -431,22 +451,33 @@ int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
   }
   if (a->colsum && !a->a_kmajor) return PTAMD_ERR_BAD_SHAPE;
   if ((a->flags & PTAMD_EPI_GATE) && !a->residual) return PTAMD_ERR_BAD_SHAPE;
-  float *user_c = a->C;
+  user_c = a->C;
   if (splits > 1) {
     if (!a->workspace || a->workspace_bytes < slab_bytes(a->M, a->N, splits)) return PTAMD_ERR_WORKSPACE;
     p.slab = (size_t)a->M * a->N;
     p.C = static_cast<float *>(a->workspace);
     if (a->colsum) p.colsum = p.C + (size_t)splits * p.slab;
   }
-  hipStream_t st = (hipStream_t)stream;
-  const int mode = resolve_mode(a);
+  mode = resolve_mode(a);
   p.scale_a = p.scale_b = nullptr;
   p.scale_a_stride = p.scale_b_stride = 1;
   if (mode == PTAMD_GEMM_F16X2) {
-    // row scales: the caller's (a_scale / b_scale: written by the kernels that produced the operands, or bounds of the row
-    // maxima) or, for an operand that comes without, a pass over it here; those live behind the split-K slabs
     if (a->a_scale && a->a_scale_stride != 0 && a->a_scale_stride != 1) return PTAMD_ERR_BAD_SHAPE;
     if (a->b_scale && a->b_scale_stride != 0 && a->b_scale_stride != 1) return PTAMD_ERR_BAD_SHAPE;
+  }
+  return PTAMD_OK;
+}
+}  // namespace
+
+int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
+  GemmParams p;
+  int splits, mode;
+  float *user_c;
+  if (const int rc = build_params(a, p, splits, mode, user_c)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == PTAMD_GEMM_F16X2) {
+    // row scales: the caller's (a_scale / b_scale: written by the kernels that produced the operands, or bounds of the row
+    // maxima) or, for an operand that comes without, a pass over it here; those live behind the split-K slabs
     uint32_t *sa = nullptr, *sb = nullptr;
     if (!a->a_scale || !a->b_scale) {
       if (!a->workspace || !pt_aligned16(a->workspace) || a->workspace_bytes < ptamd_gemm_workspace_bytes(a->M, a->N, splits))
@@ -469,6 +500,52 @@ int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
   p.C = user_c;
   const float *cs_slabs = a->colsum ? slabs + (size_t)splits * p.slab : nullptr;
   return launch_splitk_reduce(p, slabs, splits, cs_slabs, a->colsum, st);
+}
+
+int ptamd_gemm_group(const ptamd_gemm_args *args, int n, void *stream) {
+  if (!args || n <= 0 || n > MAX_GROUP) return PTAMD_ERR_BAD_SHAPE;
+  GemmGroup g;
+  ReduceGroup r;
+  g.n = r.n = n;
+  int items = 0, blocks = 0;
+  for (int j = 0; j < n; ++j) {
+    const ptamd_gemm_args *a = args + j;
+    GemmParams &p = g.p[j];
+    int splits, mode;
+    float *user_c;
+    if (const int rc = build_params(a, p, splits, mode, user_c)) return rc;
+    // what a member has to be: a k-major x k-major product (a weight gradient) in f16x2 arithmetic with the scales of both
+    // operands given, written as split-K slabs (so: split_k >= 2) and accumulated into C; a bias gradient in all or in none
+    if (!a->a_kmajor || !a->b_kmajor || mode != PTAMD_GEMM_F16X2 || !a->a_scale || !a->b_scale || splits < 2 ||
+        a->flags != PTAMD_EPI_ACCUM || a->bias || a->residual || a->dropout_p != 0.f || (a->N & 3) || (a->ldc & 3) ||
+        !pt_aligned16(a->C) || !pt_aligned16(a->workspace) || (a->colsum != nullptr) != (args[0].colsum != nullptr) ||
+        a->reserved_cus != args[0].reserved_cus)
+      return PTAMD_ERR_BAD_SHAPE;
+    p.scale_a = a->a_scale; p.scale_b = a->b_scale;
+    p.scale_a_stride = a->a_scale_stride; p.scale_b_stride = a->b_scale_stride;
+    g.first[j] = items;
+    items += ((p.M + 255) / 256) * ((p.N + BN - 1) / BN) * splits;
+    ReduceMember &m = r.m[j];
+    m.p = p;
+    m.p.C = user_c;
+    m.slabs = p.C;
+    m.cs_slabs = a->colsum ? p.C + (size_t)splits * p.slab : nullptr;
+    m.colsum = a->colsum;
+    m.splits = splits;
+    m.first_block = blocks;
+    const size_t work = (size_t)p.M * (p.N >> 2), cs_work = a->colsum ? (size_t)p.M * 16 : 0;
+    blocks += (int)(((work > cs_work ? work : cs_work) + 255) / 256);
+  }
+  for (int j = n; j <= MAX_GROUP; ++j) g.first[j] = items;
+  for (int j = n; j < MAX_GROUP; ++j) {
+    g.p[j] = g.p[0];
+    r.m[j] = r.m[0];
+    r.m[j].first_block = blocks;
+  }
+  r.blocks = blocks;
+  hipStream_t st = (hipStream_t)stream;
+  if (const int rc = launch_group_f16x2(g, st)) return rc;
+  return launch_splitk_reduce_group(r, st);
 }
 
 }  // extern "C"

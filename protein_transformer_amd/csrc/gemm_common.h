@@ -227,7 +227,53 @@ struct WorkRange {
   }
 };
 
+// ---- a GROUP of independent products in one persistent launch (ptamd_gemm_group: the weight-gradient products of a layer).
+// The work items of the members are concatenated (member 0's first); a workgroup owns a contiguous range of the whole list
+// exactly as in WorkRange, so a launch of four members with 768 items is three items per workgroup whatever the members' sizes.
+constexpr int MAX_GROUP = 4;
+struct GemmGroup {
+  GemmParams p[MAX_GROUP];
+  int first[MAX_GROUP + 1];  // member j owns the logical ids [first[j], first[j + 1])
+  int n;
+};
+struct GroupRange {
+  int begin, end, bm, bn;
+  __device__ __forceinline__ GroupRange(const GemmGroup &g, int tile_m, int tile_n) : bm(tile_m), bn(tile_n) {
+    const int nwork = g.first[g.n];
+    const int G = gridDim.x, base = nwork / G, rem = nwork - base * G;
+    const int slot = (G & 7) == 0 ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    begin = slot * base + min(slot, rem);
+    end = begin + base + (slot < rem ? 1 : 0);
+  }
+  // logical id -> member, tile origin, K split (inside a member: as WorkRange::decode)
+  __device__ __forceinline__ void decode(const GemmGroup &g, int logical, int &member, int &bm0, int &bn0, int &z) const {
+    member = 0;
+#pragma unroll
+    for (int j = 1; j < MAX_GROUP; ++j) member += (j < g.n && logical >= g.first[j]) ? 1 : 0;
+    const GemmParams &p = g.p[member];
+    const int tiles_n = (p.N + bn - 1) / bn, ntile = ((p.M + bm - 1) / bm) * tiles_n, local = logical - g.first[member];
+    z = local / ntile;
+    const int tile = local - z * ntile;
+    bm0 = (tile / tiles_n) * bm;
+    bn0 = (tile % tiles_n) * bn;
+  }
+};
+
 int persistent_grid(int reserved_cus);  // CUs of the current device minus the reserve, at least 1 (gemm.hip)
+// a group of k-major x k-major products in f16x2 arithmetic writing split-K slabs (gemm_f16x2.hip), and the fixed-order
+// reduction of all their slabs in one launch (gemm.hip)
+int launch_group_f16x2(const GemmGroup &g, hipStream_t st);
+struct ReduceMember {
+  GemmParams p;  // C = the user's matrix again, slab = M N
+  const float *slabs, *cs_slabs;
+  float *colsum;
+  int splits, first_block;
+};
+struct ReduceGroup {
+  ReduceMember m[MAX_GROUP];
+  int n, blocks;
+};
+int launch_splitk_reduce_group(const ReduceGroup &g, hipStream_t st);
 // launchers of the two kernels: a_kmajor / b_kmajor select the instantiation
 int launch_f32(const GemmParams &p, bool a_kmajor, bool b_kmajor, int splits, hipStream_t st);
 int launch_split(const GemmParams &p, bool a_kmajor, bool b_kmajor, int splits, int products, hipStream_t st);

@@ -132,6 +132,8 @@ int launch_row_scales(const GemmParams &p, bool a_kmajor, bool b_kmajor, uint32_
   return pt_check_launch();
 }
 
+int launch_group_f16x2(const GemmGroup &g, hipStream_t st) { return launch_group<3>(g, st); }
+
 int launch_split_f16x2(const GemmParams &p, bool a_kmajor, bool b_kmajor, int splits, hipStream_t st) {
   // the smallest epilogue that does the job (instruction-cache footprint, see gemm_common.h)
   const bool plain = p.slab != 0 || (!p.bias && !p.residual && !p.flags && p.dropout_p == 0.f);

@@ -41,6 +41,8 @@
 // Workgroups are persistent and walk contiguous (tile, K-split) ranges as in gemm.hip; the stage stream runs across
 // work items, so the producers fetch and convert the first stages of the next tile under the epilogue of this one.
 #pragma once
+#include <type_traits>
+
 #include <stdlib.h>
 
 #include "gemm_common.h"
@@ -225,8 +227,8 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned short *__restrict__ s
   }
 }
 
-struct Item {  // one (output tile, K split) work item
-  int bm0, bn0, z, kbeg, kend;
+struct Item {  // one (output tile, K split) work item; pj = the member of a group launch it belongs to (0 otherwise)
+  int bm0, bn0, z, kbeg, kend, pj;
 };
 
 // Cursor over the stage stream of a workgroup: the stages (16 k each) of its work items, in order.
@@ -236,9 +238,19 @@ struct Cursor {
   bool end;  // set once the cursor was asked to step past the last stage (it then stays on that stage)
 };
 
-template <bool A_KMAJOR, bool B_KMAJOR, int NPROD, int EPI, int TI = 4>
+// GROUPED: the argument is a GemmGroup and every work item names its member; the parameters of the product are then those
+// of the member of the item a ROLE is at (the producers run ahead of the consumers and may be in another member).
+template <bool GROUPED>
+struct KernelArg {
+  typedef GemmParams type;
+};
+template <>
+struct KernelArg<true> {
+  typedef GemmGroup type;
+};
+template <bool A_KMAJOR, bool B_KMAJOR, int NPROD, int EPI, int TI = 4, bool GROUPED = false>
 __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16x3_mfma_kernel(
-    const GemmParams p) {
+    const typename KernelArg<GROUPED>::type arg) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   using G = Geo<NPROD, TI>;
   constexpr int TBM = G::TBM;
@@ -249,13 +261,21 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
 
   constexpr bool F16 = NPROD == 3;  // two scaled f16 terms and three products instead of three bf16 terms and six
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const WorkRange work(p, TBM, TBN);
+  auto P = [&](int j) __attribute__((always_inline)) -> const GemmParams & {
+    if constexpr (GROUPED) return arg.p[j];
+    else return arg;
+  };
+  typename std::conditional<GROUPED, GroupRange, WorkRange>::type work(arg, TBM, TBN);
   if (work.begin >= work.end) return;
   auto item_at = [&](int logical) __attribute__((always_inline)) {
     Item it;
-    work.decode(logical, it.bm0, it.bn0, it.z);
-    it.kbeg = it.z * p.k_per_split;
-    it.kend = min(p.K, it.kbeg + p.k_per_split);
+    if constexpr (GROUPED) work.decode(arg, logical, it.pj, it.bm0, it.bn0, it.z);
+    else {
+      work.decode(logical, it.bm0, it.bn0, it.z);
+      it.pj = 0;
+    }
+    it.kbeg = it.z * P(it.pj).k_per_split;
+    it.kend = min(P(it.pj).K, it.kbeg + P(it.pj).k_per_split);
     return it;
   };
   // one step of a cursor; past the last stage of the range it stays on that stage
@@ -275,17 +295,18 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
     total_stages += (it.kend - it.kbeg + SBK - 1) / SBK;
   }
   const int padded_stages = (total_stages + NSETS - 1) / NSETS * NSETS;  // both roles run this many barriers (+1)
-  const bool partial = p.slab != 0;
+  // (a group: every member writes slabs, and its members agree on having a bias gradient - ptamd_gemm_group checks both)
+  const bool partial = P(0).slab != 0;
   // Bias gradient = column sums of the k-major A operand.  The producers add up the f32 registers of their loader
   // (weights 0 / 1 per k row, no branch and no memory access in their loop) and publish one partial row per k group in
   // LDS at the end of an item; the consumers write it out with the tile.  With split-K slabs the N tiles of one
   // (M tile, split) share the work: N tile tn takes every cs_share-th k of a stage starting at tn; without slabs the
   // first N tile does it alone and accumulates in place.
-  const bool has_colsum = A_KMAJOR && p.colsum != nullptr;
-  const int cs_share = partial ? p.colsum_share : 1;
-  auto colsum_first = [&](const Item &it) __attribute__((always_inline)) { return (it.bn0 / TBN) & (cs_share - 1); };
+  const bool has_colsum = A_KMAJOR && P(0).colsum != nullptr;
+  auto cs_share_of = [&](const Item &it) __attribute__((always_inline)) { return partial ? P(it.pj).colsum_share : 1; };
+  auto colsum_first = [&](const Item &it) __attribute__((always_inline)) { return (it.bn0 / TBN) & (cs_share_of(it) - 1); };
   auto colsum_on = [&](const Item &it) __attribute__((always_inline)) {
-    return has_colsum && (partial ? it.bn0 / TBN < cs_share : it.bn0 == 0);
+    return has_colsum && (partial ? it.bn0 / TBN < cs_share_of(it) : it.bn0 == 0);
   };
 
   if (wave >= 4) {
@@ -298,7 +319,7 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
     int cs_parity = 0;
     auto colsum_weights = [&](const Item &it) __attribute__((always_inline)) {
       const bool on = colsum_on(it);
-      const int first = colsum_first(it);
+      const int first = colsum_first(it), cs_share = cs_share_of(it);
 #pragma unroll
       for (int i = 0; i < NVA; ++i) cs_w[i] = (on && ((pt / 64 + 4 * i) & (cs_share - 1)) == first) ? 1.f : 0.f;
     };
@@ -308,14 +329,17 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
     Cursor st = ld;                                    // next stage to convert and store
     colsum_weights(st.it);
     uint32_t voa[NVA], vob[NVB];                       // per-thread byte offsets of the item under `ld`
-    item_offsets<G, A_KMAJOR, TBM>(p.lda, p.M, ld.it.bm0, pt, voa);
-    item_offsets<G, B_KMAJOR, TBN>(p.ldb, p.N, ld.it.bn0, pt, vob);
+    // operands of the member the item under `ld` belongs to (a group: reloaded when the cursor enters another member)
+    const float *opA = P(ld.it.pj).A, *opB = P(ld.it.pj).B;
+    int op_lda = P(ld.it.pj).lda, op_ldb = P(ld.it.pj).ldb;
+    item_offsets<G, A_KMAJOR, TBM>(op_lda, P(ld.it.pj).M, ld.it.bm0, pt, voa);
+    item_offsets<G, B_KMAJOR, TBN>(op_ldb, P(ld.it.pj).N, ld.it.bn0, pt, vob);
     float4 ra[NSETS][NVA], rb[NSETS][NVB];             // NSETS stages in flight (registers)
     float rsa[NSETS][MAX_NV], rsb[NSETS][MAX_NV];      // f16x2 only: the row scales that go with them
     uint32_t soa[MAX_NV], sob[MAX_NV];
     if (F16) {
-      scale_offsets<G, A_KMAJOR, TBM>(p.M, ld.it.bm0, pt, soa, p.scale_a_stride);
-      scale_offsets<G, B_KMAJOR, TBN>(p.N, ld.it.bn0, pt, sob, p.scale_b_stride);
+      scale_offsets<G, A_KMAJOR, TBM>(P(ld.it.pj).M, ld.it.bm0, pt, soa, P(ld.it.pj).scale_a_stride);
+      scale_offsets<G, B_KMAJOR, TBN>(P(ld.it.pj).N, ld.it.bn0, pt, sob, P(ld.it.pj).scale_b_stride);
     }
     int rskip[NSETS];
     // what follows the operand loads of a stage: the row scales (see below), the cursor, the offsets of a new item
@@ -326,17 +350,21 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
       // is on the critical path of a stage: profiles/r03/r03_gemm_stage_trace.txt).  Uniform branch; the scale loads go
       // out behind the operand loads, so the in-order count of a later wait for the operands is the same on both paths.
       if (F16 && ld.k0 - ld.it.kbeg < NSETS * SBK) {
-        load_scales<G, A_KMAJOR, TBM>(p.scale_a, soa, sa_);
-        load_scales<G, B_KMAJOR, TBN>(p.scale_b, sob, sb_);
+        load_scales<G, A_KMAJOR, TBM>(P(ld.it.pj).scale_a, soa, sa_);
+        load_scales<G, B_KMAJOR, TBN>(P(ld.it.pj).scale_b, sob, sb_);
       }
       const int w_before = ld.w;
       advance(ld);
-      if (ld.w != w_before) {  // uniform, no memory access inside
-        item_offsets<G, A_KMAJOR, TBM>(p.lda, p.M, ld.it.bm0, pt, voa);
-        item_offsets<G, B_KMAJOR, TBN>(p.ldb, p.N, ld.it.bn0, pt, vob);
+      if (ld.w != w_before) {  // uniform, no vector memory access inside
+        if (GROUPED) {
+          opA = P(ld.it.pj).A; opB = P(ld.it.pj).B;
+          op_lda = P(ld.it.pj).lda; op_ldb = P(ld.it.pj).ldb;
+        }
+        item_offsets<G, A_KMAJOR, TBM>(op_lda, P(ld.it.pj).M, ld.it.bm0, pt, voa);
+        item_offsets<G, B_KMAJOR, TBN>(op_ldb, P(ld.it.pj).N, ld.it.bn0, pt, vob);
         if (F16) {
-          scale_offsets<G, A_KMAJOR, TBM>(p.M, ld.it.bm0, pt, soa, p.scale_a_stride);
-          scale_offsets<G, B_KMAJOR, TBN>(p.N, ld.it.bn0, pt, sob, p.scale_b_stride);
+          scale_offsets<G, A_KMAJOR, TBM>(P(ld.it.pj).M, ld.it.bm0, pt, soa, P(ld.it.pj).scale_a_stride);
+          scale_offsets<G, B_KMAJOR, TBN>(P(ld.it.pj).N, ld.it.bn0, pt, sob, P(ld.it.pj).scale_b_stride);
         }
       }
     };
@@ -344,8 +372,8 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
       const int klim = ld.it.kend - ld.k0;
       const int ks = klim >= SBK ? ld.k0 : ld.it.kend - SBK;  // the last stage of an item may start early
       kskip = ld.k0 - ks;
-      load_raw(p.A + (A_KMAJOR ? (size_t)ks * p.lda : (size_t)ks), voa, a);
-      load_raw(p.B + (B_KMAJOR ? (size_t)ks * p.ldb : (size_t)ks), vob, b);
+      load_raw(opA + (A_KMAJOR ? (size_t)ks * op_lda : (size_t)ks), voa, a);
+      load_raw(opB + (B_KMAJOR ? (size_t)ks * op_ldb : (size_t)ks), vob, b);
       fetch_tail(sa_, sb_);
     };
     // convert + store the stage under `st` into LDS buffer `buf`, then refill the registers two stages ahead
@@ -370,8 +398,8 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
         // is loaded into the slot that was just converted), the in-order load count is the same on every path.
         const int klim = ld.it.kend - ld.k0;
         const int ks_next = klim >= SBK ? ld.k0 : ld.it.kend - SBK;  // the last stage of an item may start early
-        const float *na = p.A + (A_KMAJOR ? (size_t)ks_next * p.lda : (size_t)ks_next);
-        const float *nb = p.B + (B_KMAJOR ? (size_t)ks_next * p.ldb : (size_t)ks_next);
+        const float *na = opA + (A_KMAJOR ? (size_t)ks_next * op_lda : (size_t)ks_next);
+        const float *nb = opB + (B_KMAJOR ? (size_t)ks_next * op_ldb : (size_t)ks_next);
         constexpr int GRP = 2;
 #pragma unroll
         for (int i0 = 0; i0 < NVA; i0 += GRP) {
@@ -445,8 +473,6 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
   } else {
     // ================================================================ consumers
     const int wm = wave >> 1, wn = wave & 1;
-    const uint32_t thr = dropout_threshold(p.dropout_p);
-    const float keep_scale = 1.f / (1.f - p.dropout_p);
     f32x16 acc[TI][2];
     auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -510,6 +536,10 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
       if (NPROD != 3) { mul(1, 1); mul(1, 0); mul(0, 1); mul(0, 0); }
       __syncthreads();  // buffer g & 1 is released, buffer (g + 1) & 1 holds stage g + 1
       if (cc.k0 + SBK >= cc.it.kend) {  // that was the item's last stage
+        const GemmParams &p = P(cc.it.pj);
+        const uint32_t thr = dropout_threshold(p.dropout_p);
+        const float keep_scale = 1.f / (1.f - p.dropout_p);
+        const int cs_share = cs_share_of(cc.it);
         float *C = p.C + (partial ? (size_t)cc.it.z * p.slab : 0);
         const int ldc = partial ? p.N : p.ldc;
         const int row0 = cc.it.bm0 + wm * (32 * TI), col0 = cc.it.bn0 + wn * 64;
@@ -574,6 +604,18 @@ int launch(const GemmParams &p, int splits, hipStream_t st) {
 #endif
   }
   return launch_ti<AK, BKM, NPROD, EPI, 4>(p, splits, st);
+}
+
+// a group (k-major x k-major, 256-row tiles, slabs): one persistent launch over the members' concatenated work items
+template <int NPROD>
+int launch_group(const GemmGroup &g, hipStream_t st) {
+  using G = Geo<NPROD, 4>;
+  auto kern = gemm_bf16x3_mfma_kernel<true, true, NPROD, EPI_PLAIN, 4, true>;
+  PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)G::LDS_BYTES));
+  const int slots = persistent_grid(g.p[0].reserved_cus), work = g.first[g.n];
+  hipLaunchKernelGGL(kern, dim3(work < slots ? work : slots), dim3(NTHREADS), G::LDS_BYTES, st, g);
+  return pt_check_launch();
 }
 
 template <int NPROD, int EPI>

@@ -38,10 +38,12 @@ __global__ void wscale_init_kernel(const WJobs js) {
   }
 }
 
-// rows: 32 per block (a wavefront per row, eight rows each, 16-byte loads where the row allows them);
-// columns: 64 per block over all rows (16 x 16 threads, a float4 of columns per thread, 8 rows in flight, LDS tree)
-constexpr int COLS_PER_BLOCK = 64, ROWS_PER_BLOCK = 32;
-__global__ __launch_bounds__(256) void wscale_kernel(const WJobs js) {
+// rows: 32 per block (a wavefront per row, two rows each, 16-byte loads where the row allows them);
+// columns: 64 per block over all rows (16 x 64 threads, a float4 of columns per thread, 8 rows in flight per thread, LDS
+// tree).  1024 threads: a column block of a [2048, 512] matrix is the launch's critical path - 128 dependent-looking rounds
+// of loads per thread at 256 threads (47 us for the model's weights), 32 at 1024.
+constexpr int COLS_PER_BLOCK = 64, ROWS_PER_BLOCK = 32, WS_THREADS = 1024, WS_WAVES = WS_THREADS / 64, WS_RY = WS_THREADS / 16;
+__global__ __launch_bounds__(WS_THREADS) void wscale_kernel(const WJobs js) {
   int j = 0;
   while (j + 1 < js.n && (int)blockIdx.x >= js.first_block[j + 1]) ++j;
   const ptamd_wscale_job jb = js.job[j];
@@ -50,12 +52,12 @@ __global__ __launch_bounds__(256) void wscale_kernel(const WJobs js) {
   uint32_t *stat_bits = reinterpret_cast<uint32_t *>(jb.stats);
   const bool vec = !(jb.cols & 3) && !(jb.ld & 3) && !(reinterpret_cast<uintptr_t>(jb.w) & 15);
   if (b < js.row_blocks[j]) {
-    // 32 rows per block, 8 per wavefront; ONE pair of atomics per block (atomics on one address serialise in the L2: a pair
+    // 32 rows per block, 2 per wavefront; ONE pair of atomics per block (atomics on one address serialise in the L2: a pair
     // per row made this the slowest part of the kernel)
-    __shared__ float s_nrm[4], s_amx[4];
+    __shared__ float s_nrm[WS_WAVES], s_amx[WS_WAVES];
     float bn = 0.f, bm = 0.f;
-    for (int rr = 0; rr < ROWS_PER_BLOCK / 4; ++rr) {
-      const int r = b * ROWS_PER_BLOCK + wave * (ROWS_PER_BLOCK / 4) + rr;
+    for (int rr = 0; rr < ROWS_PER_BLOCK / WS_WAVES; ++rr) {
+      const int r = b * ROWS_PER_BLOCK + wave * (ROWS_PER_BLOCK / WS_WAVES) + rr;
       if (r >= jb.rows) break;  // wavefront-uniform
       const float *p = jb.w + (size_t)r * jb.ld;
       float m = 0.f, sq = 0.f;
@@ -85,12 +87,18 @@ __global__ __launch_bounds__(256) void wscale_kernel(const WJobs js) {
       }
       __syncthreads();
       if (tid == 0) {  // non-negative floats order like their bit patterns
-        atomicMax(stat_bits + 0, __float_as_uint(fmaxf(fmaxf(s_nrm[0], s_nrm[1]), fmaxf(s_nrm[2], s_nrm[3]))));
-        atomicMax(stat_bits + 2, __float_as_uint(fmaxf(fmaxf(s_amx[0], s_amx[1]), fmaxf(s_amx[2], s_amx[3]))));
+        float n = 0.f, a = 0.f;
+#pragma unroll
+        for (int k = 0; k < WS_WAVES; ++k) {
+          n = fmaxf(n, s_nrm[k]);
+          a = fmaxf(a, s_amx[k]);
+        }
+        atomicMax(stat_bits + 0, __float_as_uint(n));
+        atomicMax(stat_bits + 2, __float_as_uint(a));
       }
     }
   } else {
-    __shared__ float4 s_m[16][17], s_q[16][17];
+    __shared__ float4 s_m[WS_RY][17], s_q[WS_RY][17];
     const int cb = b - js.row_blocks[j];
     const int cx = tid & 15, ry = tid >> 4, c = cb * COLS_PER_BLOCK + cx * 4;
     float4 m = make_float4(0.f, 0.f, 0.f, 0.f), sq = m;
@@ -101,9 +109,9 @@ __global__ __launch_bounds__(256) void wscale_kernel(const WJobs js) {
     if (c < jb.cols) {
       if (vec) {
 #pragma unroll 8
-        for (int r = ry; r < jb.rows; r += 16) take(*reinterpret_cast<const float4 *>(jb.w + (size_t)r * jb.ld + c));
+        for (int r = ry; r < jb.rows; r += WS_RY) take(*reinterpret_cast<const float4 *>(jb.w + (size_t)r * jb.ld + c));
       } else {
-        for (int r = ry; r < jb.rows; r += 16) {
+        for (int r = ry; r < jb.rows; r += WS_RY) {
           const float *q = jb.w + (size_t)r * jb.ld + c;
           take(make_float4(q[0], c + 1 < jb.cols ? q[1] : 0.f, c + 2 < jb.cols ? q[2] : 0.f, c + 3 < jb.cols ? q[3] : 0.f));
         }
@@ -112,9 +120,9 @@ __global__ __launch_bounds__(256) void wscale_kernel(const WJobs js) {
     s_m[ry][cx] = m;
     s_q[ry][cx] = sq;
     __syncthreads();
-    if (ry == 0 && c < jb.cols) {
-#pragma unroll
-      for (int k = 1; k < 16; ++k) {
+    if (ry == 0 && c < jb.cols) {   // (fixed order: deterministic)
+#pragma unroll 8
+      for (int k = 1; k < WS_RY; ++k) {
         const float4 a = s_m[k][cx], q = s_q[k][cx];
         m.x = fmaxf(m.x, a.x); m.y = fmaxf(m.y, a.y); m.z = fmaxf(m.z, a.z); m.w = fmaxf(m.w, a.w);
         sq.x += q.x; sq.y += q.y; sq.z += q.z; sq.w += q.w;
@@ -169,7 +177,7 @@ int ptamd_weight_scales(const ptamd_wscale_job *jobs, int njobs, void *stream) {
   js.first_block[njobs] = blocks;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(wscale_init_kernel, dim3(1), dim3(64), 0, st, js);
-  if (blocks > 0) hipLaunchKernelGGL(wscale_kernel, dim3(blocks), dim3(256), 0, st, js);
+  if (blocks > 0) hipLaunchKernelGGL(wscale_kernel, dim3(blocks), dim3(WS_THREADS), 0, st, js);
   return pt_check_launch();
 }
 

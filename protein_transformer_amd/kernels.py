@@ -200,6 +200,52 @@ def linear_bwd_weight(dy, x, dw, dbias=None, arith=None, dy_scale=None, x_scale=
                 b_kmajor=True, flags=EPI_ACCUM, split_k=pick_split_k(N, K, T), colsum=dbias, arith=arith)
 
 
+GROUP_DW = True          # the weight-gradient products of a layer in one launch where they qualify (knob for A/B and tests)
+
+
+def pick_group_split(tiles256, T, slots=256):
+    """Common K split of a GROUP of weight-gradient products (`tiles256` output tiles of 256 x 128 in all, T tokens): the
+    items are dealt out in contiguous ranges of the whole list, so what counts is rounds x (tokens per item + a fixed
+    cost per item: prologue, slab write and its reduction - about 640 tokens' worth).  0: not worth a group (too few tokens)."""
+    best, best_cost = 0, None
+    for s in range(2, max(2, T // 1024) + 1):
+        rounds = -(-tiles256 * s // slots)
+        cost = rounds * (-(-T // s) + 640)
+        if best_cost is None or cost < best_cost:
+            best, best_cost = s, cost
+    return best if T >= 2048 else 0
+
+
+def linear_bwd_weight_group(jobs, split_k):
+    """The products of `linear_bwd_weight` for several (dy, x, dw, dbias, dy_scale, x_scale) at once: ONE launch for the
+    products, one for all their split-K reductions (ptamd_gemm_group; every job f16x2 with uniform scales).  Bit for bit
+    what the separate calls give with the same `split_k`."""
+    arr = (GemmArgs * len(jobs))()
+    flops = 0.0
+    nbytes = 0
+    for j, (dy, x, dw, dbias, dy_scale, x_scale) in enumerate(jobs):
+        T, N = dy.shape
+        Kd = x.shape[1]
+        ws = workspace(f"gemm_group{j}", lib().ptamd_gemm_workspace_bytes(N, Kd, split_k), dw.device)
+        arr[j] = GemmArgs(M=N, N=Kd, K=T, A=dy.data_ptr(), lda=dy.stride(0), a_kmajor=1, B=x.data_ptr(), ldb=x.stride(0),
+                          b_kmajor=1, C=dw.data_ptr(), ldc=dw.stride(0), bias=None, residual=None, ldr=0, flags=EPI_ACCUM,
+                          dropout_p=0.0, seed=0, stream_id=0, split_k=int(split_k), workspace=ws.data_ptr(),
+                          workspace_bytes=ws.numel(), colsum=dbias.data_ptr() if dbias is not None else None, gate_scale=0.0,
+                          arith=GEMM_F16X2, reserved_cus=int(GEMM_RESERVED_CUS), a_scale=dy_scale.data_ptr(), a_scale_stride=0,
+                          b_scale=x_scale.data_ptr(), b_scale_stride=0)
+        flops += 2.0 * N * Kd * T
+        nbytes += 4 * (N * T + Kd * T + 2 * N * Kd)
+    if GEMM_TIMING is None:
+        check(lib().ptamd_gemm_group(arr, len(jobs), stream()), "gemm_group")
+    else:
+        e0, e1 = GEMM_EVENT_POOL.pop(), GEMM_EVENT_POOL.pop()
+        e0.record()
+        check(lib().ptamd_gemm_group(arr, len(jobs), stream()), "gemm_group")
+        e1.record()
+        GEMM_TIMING.append((flops, e0, e1, 3))
+        GEMM_BYTES.append(nbytes)
+
+
 def colsum(x, out, accumulate=True):
     T, N = x.shape
     ws = workspace("colsum", lib().ptamd_colsum_workspace_bytes(N), x.device)

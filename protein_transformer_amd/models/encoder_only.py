@@ -276,6 +276,8 @@ class _TransformerBase(nn.Module):
         self.hp_dx = False                           # dX of FFN layer 2 there too (A: planes from the fused LayerNorm backward, B: W2^T planes): built and
                                                      # tested, measured +-0 in the step (profiles/r04/NOTES.md), off
         self.side_stream_dw = True                   # small batches: weight-gradient products on a side stream
+        self.top_layer_scales = True                 # uniform scales of the top layer's dy2 / dz1 by a pass (backward())
+        self.dw_group = "auto"                       # grouping of the weight-gradient products of a layer (backward())
         self.auto_guard = AutoGuard(nlayers)         # measures the slack of the bound-derived f16x2 scales, falls back per site
         self._init_parameters()
 
@@ -423,7 +425,8 @@ class _TransformerBase(nn.Module):
             n_i = self.nlayers * (8 * D + 2 * F + 5 * 4)              # int32: weight scales + 5 uniform scales (4 copies each) per layer
             ints = torch.zeros(n_i, dtype=torch.int32, device=dev)
             stats = torch.zeros(self.nlayers, 9, 4, dtype=torch.float32, device=dev)
-            factor = torch.zeros(self.nlayers, dtype=torch.float32, device=dev)
+            factor = torch.zeros(self.nlayers, 4, dtype=torch.float32, device=dev)    # [i, 2] = dz1_factor (a stats-shaped record)
+            top_stats = torch.zeros(4, dtype=torch.float32, device=dev)               # row statistics of the top layer's dy2
             ones = torch.tensor([1.0, 1.0, 1.0, 0.0], dtype=torch.float32, device=dev)     # a stats record for "no weight"
             layers, wjobs, bjobs, o = [], [], [], 0
             minbuf = torch.zeros(self.nlayers, 16, dtype=torch.int32, device=dev)   # atomicMin targets, preset before every backward pass
@@ -439,7 +442,7 @@ class _TransformerBase(nn.Module):
                 wqkv, bqkv = self._qkv(flat, i)
                 L = dict(rs_qkv=take(3 * D), cs_qkv=take(D), rs_o=take(D), cs_o=take(D), rs_1=take(F), cs_1=take(D),
                          rs_2=take(D), cs_2=take(F), att_scale=take(4), f1_scale=take(4), h1_scale=take(4), h2_scale=take(4),
-                         dqkv_scale=take(4), dz1_factor=factor[i:i + 1])
+                         dqkv_scale=take(4), dz1_factor=factor[i, 2:3], dz1_factor_rec=factor[i])
                 L.update(dy2_min=minbuf[i, 0:4], dz1_min=minbuf[i, 4:8], dyo_min=minbuf[i, 8:12], dqkv_min=minbuf[i, 12:16])
                 st = stats[i]
                 wjobs += [dict(w=wqkv, row_scale=L["rs_qkv"], col_scale=L["cs_qkv"]),
@@ -470,8 +473,9 @@ class _TransformerBase(nn.Module):
                 L["dqkv_stats"] = dq_stats[i]
                 L["minbuf"] = minbuf
                 L["guard_stats"], L["ints"] = gstats, ints
+                L["top_stats"] = top_stats
             cache = caches[key] = dict(layers=layers, wjobs=wjobs, bjobs=bjobs,
-                                       keep=(ints, stats, factor, ones, dq_stats, minbuf, gstats))
+                                       keep=(ints, stats, factor, ones, dq_stats, minbuf, gstats, top_stats))
             # the FFN-layer-1 weights (behind the second LayerNorm), pre-split once per forward pass for ptamd_gemm_hp.  (The QKV
             # weights were too until the producers of the staging GEMM were trimmed at the end of round 3: QKV now runs
             # 34.7 / 58.5 / 106.8 us on it at 4096 / 8192 / 16384 tokens against 35.4 / 70.5 / 110.3 on ptamd_gemm_hp, and the
@@ -710,6 +714,49 @@ class _EncoderFn(torch.autograd.Function):
             with torch.cuda.stream(side):
                 return K.linear_bwd_weight(*tensors_then_kwargs, **kw)
 
+        # The weight-gradient products of a layer go out in GROUPS when they run in f16x2 on uniform scales (ptamd_gemm_group:
+        # one launch whose work items fill the chip in whole rounds with a longer K per item and fewer slabs, one launch for all
+        # the split-K reductions) - their operands are only read afterwards.  m.dw_group: "pairs" = the two FFN products
+        # when both exist, the two attention products at the end of the layer (best where a pair fills a round on its own:
+        # 10.39 against 10.57 ms at 32 x 512, the whole layer as one group 10.63 - it starts late and runs three rounds);
+        # "layer" = all four at the end (best for few tokens, where the step is bound by launches: config 3 7.31 / 7.44 / 7.65
+        # ms as layer / pairs / one by one); "auto" picks by the size of the FFN pair; "off" = one by one.
+        queue = []
+        dw_group = m.dw_group if K.GROUP_DW else "off"
+        if dw_group == "auto":
+            ffn_tiles = -(-D // 256) * -(-m.dff // 128) + -(-m.dff // 256) * -(-D // 128)      # 256 x 128 tiles of dW2 and dW1
+            dw_group = "pairs" if ffn_tiles * B * L >= 256 * 2048 else "layer"
+
+        def dw_later(dy, x, gw, gb, arith=None, dy_scale=None, x_scale=None):
+            if dw_group == "off":
+                return dw(dy, x, gw, gb, arith=arith, dy_scale=dy_scale, x_scale=x_scale)
+            queue.append((dy, x, gw, gb, arith, dy_scale, x_scale))
+
+        def dw_flush():
+            jobs = list(queue)
+            queue.clear()
+            # members of a group: f16x2 on uniform scales (the top layer's FFN gradients come without - no fused LayerNorm
+            # backward above them - and go one by one, like everything in the other arithmetics)
+            ok = [j for j in jobs if j[5] is not None and j[6] is not None and j[1].shape[1] % 4 == 0]
+            tiles = sum(-(-j[0].shape[1] // 256) * -(-j[1].shape[1] // 128) for j in ok)
+            sk = K.pick_group_split(tiles, ok[0][0].shape[0]) if 2 <= len(ok) <= 4 else 0
+            if sk < 2:
+                ok = []
+            for dy, x, gw, gb, a, sy, sx in jobs:
+                if not any(dy is o[0] and x is o[1] for o in ok):
+                    dw(dy, x, gw, gb, arith=a, dy_scale=sy, x_scale=sx)
+            if not ok:
+                return
+            group = [(dy, x, gw, gb, sy, sx) for dy, x, gw, gb, a, sy, sx in ok]
+            if side is None:
+                return K.linear_bwd_weight_group(group, sk)
+            side.wait_stream(main)
+            for dy, x, *_ in ok:
+                dy.record_stream(side)
+                x.record_stream(side)
+            with torch.cuda.stream(side):
+                K.linear_bwd_weight_group(group, sk)
+
         def join():
             if side is not None:
                 main.wait_stream(side)
@@ -761,9 +808,18 @@ class _EncoderFn(torch.autograd.Function):
             # x3 = x2 + drop(f1 W2^T + b2)
             if dy2 is None:
                 dy2 = K.dropout_bwd(dx, p, seed, sid + _SITE_FFN_OUT) if p > 0 else dx
+                if sc is not None and fuse and m.top_layer_scales:
+                    # the top layer: no fused LayerNorm backward above it that would leave the uniform scales of dy2 / dz1
+                    # behind - one streaming pass over dy2 (largest |x| and largest row norm) and the same bound instead,
+                    # so that its two FFN weight-gradient products run in f16x2 like those of every other layer
+                    ts = sc["top_stats"]
+                    K.weight_scales([dict(w=dy2, stats=ts, rows_only=True)])
+                    K.bound_scales([dict(w=ts, w_index=2, out_scale=sc["dy2_min"]),
+                                    dict(ln_gamma=sc["dz1_factor_rec"], sqrt_d=1.0, w=ts, w_index=0, out_scale=sc["dz1_min"])])
+                    have_min = True
             uni = sc is not None and have_min              # uniform scales of both operands: the dW product runs in f16x2
             o_att, o_f1, o_dz1, o_h1, o_h2 = (bool(v) for v in off[i]) if off is not None else (False,) * 5   # AutoGuard
-            dw(dy2, f1, G(b + "pwff.layer2.weight"), G(b + "pwff.layer2.bias"), arith=ar,
+            dw_later(dy2, f1, G(b + "pwff.layer2.weight"), G(b + "pwff.layer2.bias"), arith=ar,
                                 dy_scale=sc["dy2_min"] if uni and not o_f1 else None, x_scale=sc["f1_scale"] if uni and not o_f1 else None)
             # backward of layer2 and, in its epilogue, of the ReLU + dropout in front of it (gate = saved f1)
             if dy2_planes is not None and have_planes and not (wide is not None and wide[i, 7]):
@@ -778,8 +834,10 @@ class _EncoderFn(torch.autograd.Function):
                 gs = sc["guard_stats"][i]
                 K.weight_scales([dict(w=t, stats=gs[j], rows_only=True) for j, t in enumerate((att, f1, dz1, h1, h2))])
             uni1 = uni and not (o_dz1 or o_h2)
-            dw(dz1, h2, G(b + "pwff.layer1.weight"), G(b + "pwff.layer1.bias"), arith=ar,
+            dw_later(dz1, h2, G(b + "pwff.layer1.weight"), G(b + "pwff.layer1.bias"), arith=ar,
                                 dy_scale=sc["dz1_min"] if uni1 else None, x_scale=sc["h2_scale"] if uni1 else None)
+            if dw_group != "layer":
+                dw_flush()                                    # the two FFN products now, the two attention products at the end
             dh2 = K.linear_bwd_input(dz1, W(b + "pwff.layer1.weight"),
                                      **prod(i, 6, a_scale=bs_dz1 if sc and not o_dz1 else None, b_scale=sc and sc["cs_1"]))
             # x2 = x + drop(att Wo^T + bo)
@@ -795,7 +853,7 @@ class _EncoderFn(torch.autograd.Function):
                                       pending=ln_pending)
                 dyo = K.dropout_bwd(dx2, p, seed, sid + _SITE_ATTN_OUT) if p > 0 else dx2
             uni_o = sc is not None and fuse and not o_att
-            dw(dyo, att, G(b + "self_attn.wo.weight"), G(b + "self_attn.wo.bias"), arith=ar,
+            dw_later(dyo, att, G(b + "self_attn.wo.weight"), G(b + "self_attn.wo.bias"), arith=ar,
                                 dy_scale=sc["dyo_min"] if uni_o else None, x_scale=sc["att_scale"] if uni_o else None)
             datt = K.linear_bwd_input(dyo, W(b + "self_attn.wo.weight"), **prod(i, 5, a_scale=s_dyo, b_scale=sc and sc["cs_o"]))
             # the f16x2 attention kernels leave the row scales of dqkv (A of the dX product) and the smallest of them (the
@@ -814,10 +872,10 @@ class _EncoderFn(torch.autograd.Function):
                     s_dqkv, dq_uni = i32(), sc["dqkv_scale"]
                     K.weight_scales([dict(w=dqkv, row_scale=s_dqkv, stats=sc["dqkv_stats"], rows_only=True)])
                     K.bound_scales([dict(w=sc["dqkv_stats"], w_index=2, out_scale=sc["dqkv_scale"])])
-                dw(dqkv, h1, gw, gb, arith=ar, dy_scale=None if o_h1 else dq_uni, x_scale=None if o_h1 else sc["h1_scale"])
+                dw_later(dqkv, h1, gw, gb, arith=ar, dy_scale=None if o_h1 else dq_uni, x_scale=None if o_h1 else sc["h1_scale"])
                 dh1 = K.linear_bwd_input(dqkv, wqkv, **prod(i, 4, a_scale=s_dqkv, b_scale=sc["cs_qkv"]))
             else:
-                dw(dqkv, h1, gw, gb, arith=ar)
+                dw_later(dqkv, h1, gw, gb, arith=ar)
                 dh1 = K.linear_bwd_input(dqkv, wqkv, arith=ar)
             g1w, g1b = G(b + "sublayer_connections.0.norm.weight"), G(b + "sublayer_connections.0.norm.bias")
             if fuse and i > 0:      # the gradient enters layer i - 1 through ITS FFN-output dropout: made here, with its scales
@@ -836,6 +894,7 @@ class _EncoderFn(torch.autograd.Function):
                                      pending=ln_pending)
                 dy2 = s_dy2 = bs_dz1 = None
                 have_min = have_planes = False
+            dw_flush()
             done(b + "self_attn.wq.weight", b + "sublayer_connections.1.norm.bias")
             ctx.saved[i] = None
         K.layernorm_bwd_flush(ln_pending)

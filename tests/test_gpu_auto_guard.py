@@ -366,3 +366,39 @@ def test_side_stream_is_bit_identical(dev):
         for a, b in zip(grads, res[False][0][0]):
             assert torch.equal(a, b)
         assert torch.equal(flat, res[False][0][1])
+
+
+def test_weight_gradient_grouping_modes(dev):
+    """The weight-gradient products of a layer one by one, as an FFN pair + an attention pair, or all four as one group
+    (ptamd_gemm_group): different K splits, so not bit-identical - but the same gradients to fp32 summation-order accuracy,
+    each of them inside the gradient tolerance against fp64, the groups really launched, and every mode reproducible."""
+    from protein_transformer_amd import kernels as K
+    grads, calls = {}, {}
+    real = K.linear_bwd_weight_group
+    ref = None
+    for mode in ("off", "pairs", "layer", "pairs"):
+        model, batch = _setup(dev, 2, 8, 512, 2048, [512] * 8, seed=17)
+        model.dw_group = mode
+        n = []
+        K.linear_bwd_weight_group = lambda jobs, sk: (n.append((len(jobs), sk)), real(jobs, sk))[1]    # noqa: E731
+        try:
+            _one_pass(model, batch, dev)            # nothing is trusted before the first measurement: bf16x3, no groups
+            torch.cuda.synchronize()
+            assert not n
+            _, _, g = _one_pass(model, batch, dev)  # bounds measured: uniform scales, f16x2, groups
+            torch.cuda.synchronize()
+        finally:
+            K.linear_bwd_weight_group = real
+        if ref is None:
+            params = {k: v.detach().cpu().double() for k, v in model.state_dict().items()}
+            ref = fp64_reference(params, batch[0], batch[2], 8)
+        e, groups, worst = grad_errors(g, ref["grads"])
+        assert e < 1e-3 and max(groups.values()) < 1e-3, (mode, e, groups, worst)
+        flat = torch.cat([g[k].reshape(-1) for k in sorted(g)])
+        if mode in grads:                           # the second "pairs" run: bit-identical to the first
+            assert torch.equal(flat, grads[mode])
+        grads[mode], calls[mode] = flat, list(n)
+    assert calls["off"] == [] and calls["pairs"] == [(2, 4)] * 4 and calls["layer"] == [(4, 2)] * 2, calls
+    for mode in ("pairs", "layer"):
+        d = float((grads[mode] - grads["off"]).norm() / grads["off"].norm())
+        assert d < 2e-6, (mode, d)

@@ -205,6 +205,60 @@ def test_weight_gradient_product_with_uniform_scales(dev):
     assert torch.allclose(db_u, db_b, rtol=1e-5, atol=1e-3 * float(db_b.abs().max()))      # the fused bias gradient is fp32 either way
 
 
+@pytest.mark.parametrize("T,shapes,split", [(16384, [(512, 2048), (2048, 512), (512, 512), (1536, 512)], 8),
+                                            (4096, [(256, 1024), (1024, 256), (768, 256)], 3),
+                                            (2100, [(512, 2048), (36, 260)], 2)])
+def test_weight_gradient_products_as_a_group(dev, T, shapes, split):
+    """ptamd_gemm_group: the weight-gradient products of a layer in one launch (+ one reduce launch) give, bit for bit, what
+    the separate ptamd_gemm calls with the same K split give - accumulated into non-zero dW / dbias, ragged tiles and a
+    token count that is not a multiple of the stage included; members it does not take are refused before any launch."""
+    import ctypes as C
+    from protein_transformer_amd import kernels as K
+    from protein_transformer_amd._lib import GemmArgs, lib
+    g = torch.Generator().manual_seed(7)
+    jobs, sep = [], []
+    for N, Kd in shapes:
+        dy = (torch.randn(T, N, generator=g) * torch.exp(torch.randn(T, 1, generator=g))).to(dev)
+        x = torch.randn(T, Kd, generator=g).to(dev)
+        uni = torch.zeros(2, 4, dtype=torch.int32, device=dev)
+        st = torch.zeros(2, 4, device=dev)
+        K.weight_scales([dict(w=dy, stats=st[0], rows_only=True), dict(w=x, stats=st[1], rows_only=True)])
+        K.bound_scales([dict(w=st[0], w_index=2, out_scale=uni[0]), dict(w=st[1], w_index=2, post_scale=4.0, out_scale=uni[1])])
+        dw0, db0 = torch.randn(N, Kd, generator=g).to(dev), torch.randn(N, generator=g).to(dev)
+        jobs.append((dy, x, dw0.clone(), db0.clone(), uni[0], uni[1]))
+        sep.append((dy, x, dw0.clone(), db0.clone(), uni[0], uni[1]))
+    K.linear_bwd_weight_group(jobs, split)
+    for dy, x, dw, db, sy, sx in sep:
+        N, Kd = dw.shape
+        K.gemm(dy, x, dw, M=N, N=Kd, K=T, lda=N, ldb=Kd, ldc=Kd, a_kmajor=True, b_kmajor=True, flags=K.EPI_ACCUM, split_k=split,
+               colsum=db, arith=K.GEMM_F16X2, a_scale=sy, a_scale_stride=0, b_scale=sx, b_scale_stride=0)
+    torch.cuda.synchronize()
+    for (_, _, dw_g, db_g, _, _), (dy, x, dw_s, db_s, _, _) in zip(jobs, sep):
+        assert torch.equal(dw_g, dw_s) and torch.equal(db_g, db_s)
+    dy, x, dw, db, sy, sx = jobs[0]
+    # refused: bf16x3 member, a member without slabs, too many members
+    def args(**kw):
+        N, Kd = dw.shape
+        ws = torch.empty(lib().ptamd_gemm_workspace_bytes(N, Kd, split), dtype=torch.uint8, device=dev)
+        base = dict(M=N, N=Kd, K=T, A=dy.data_ptr(), lda=N, a_kmajor=1, B=x.data_ptr(), ldb=Kd, b_kmajor=1, C=dw.data_ptr(), ldc=Kd,
+                    bias=None, residual=None, ldr=0, flags=K.EPI_ACCUM, dropout_p=0.0, seed=0, stream_id=0, split_k=split,
+                    workspace=ws.data_ptr(), workspace_bytes=ws.numel(), colsum=None, gate_scale=0.0, arith=K.GEMM_F16X2,
+                    reserved_cus=0, a_scale=sy.data_ptr(), a_scale_stride=0, b_scale=sx.data_ptr(), b_scale_stride=0)
+        base.update(kw)
+        return GemmArgs(**base), ws
+    before = dw.clone()
+    for bad in (dict(arith=K.GEMM_BF16X3), dict(split_k=1), dict(flags=0), dict(a_scale=None), dict(a_kmajor=0, lda=T)):
+        a, _ws = args(**bad)
+        arr = (GemmArgs * 1)(a)
+        assert lib().ptamd_gemm_group(arr, 1, K.stream()) == -1, bad
+    a, _ws = args()
+    assert lib().ptamd_gemm_group((GemmArgs * 5)(a, a, a, a, a), 5, K.stream()) == -1
+    assert lib().ptamd_gemm_group(None, 1, K.stream()) == -1
+    torch.cuda.synchronize()
+    assert torch.equal(dw, before)
+    assert K.pick_group_split(64, 16384) == 4 and K.pick_group_split(32, 16384) == 8 and K.pick_group_split(96, 1024) == 0
+
+
 @pytest.mark.parametrize("B,L,H,dk", [(3, 300, 4, 64), (2, 130, 8, 32)])
 def test_attention_bwd_row_scales(dev, B, L, H, dk):
     """ptamd_attention_bwd (f16x2 arithmetic) leaves the f16x2 row scales of dqkv and the smallest of them behind: exactly
