@@ -19,6 +19,9 @@ KERNEL = ("_mfma_kernel", "gemm_hp_kernel", "gemm_hp3_kernel")   # gemm_bf16x3_m
 
 def stats(path, steps):
     rows = list(csv.DictReader(open(path)))
+    if str(steps) == "auto":      # steps the process ran in all (warm-up, timed, kernel-timing passes): the loss kernel runs once per step
+        steps = max(int(r["Calls"]) for r in rows if "drmsd_tri_kernel" in r["Name"])
+    steps = int(steps)
     total = sum(float(r["TotalDurationNs"]) for r in rows)
     print(f"{'kernel':70s} {'calls/step':>10s} {'avg us':>9s} {'ms/step':>9s} {'%':>6s}")
     for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:24]:
@@ -85,7 +88,7 @@ def step_traffic(fetch_csv, write_csv, steps):
 
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
-        stats(sys.argv[2], int(sys.argv[3]))
+        stats(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "traffic":
         traffic(*sys.argv[2:6])
     elif sys.argv[1] == "step_traffic":

@@ -21,7 +21,7 @@ find $out -name "*.csv" | head -20
 # summaries (the numbers bench.py and DESIGN.md quote): per-step kernel table, HBM traffic of the GEMM launches (with the
 # digest of the GEMM sources it was measured on: bench.py refuses a stale record), HBM traffic per step by kernel
 stats=$(find $out/prof -name "*kernel_stats.csv" | head -1)
-python profiles/summarize.py stats $stats 7 > $out/per_step_table.txt
+python profiles/summarize.py stats $stats auto > $out/per_step_table.txt
 if [ "$2" = "full" ]; then
   f=$(find $out/pmc_fetch -name "*counter_collection.csv" | head -1); w=$(find $out/pmc_write -name "*counter_collection.csv" | head -1)
   alg=$(python -c "import json; print(json.load(open('$out/bench_cfg4.json'))['roofline']['algorithmic_bytes_per_launch'])")
