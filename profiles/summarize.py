@@ -86,8 +86,41 @@ def step_traffic(fetch_csv, write_csv, steps):
     print(f"total {sum(tot.values()) / steps / 1e9:.3f} GB/step")
 
 
+def sq(paths):
+    """Where the wave cycles of every kernel go: SQ counters of one or more PMC passes (rocprofv3 --pmc SQ_..., separate
+    runs of the same command), summed over the launches of a kernel, as fractions of SQ_WAVE_CYCLES.  Per the guide's PMC
+    table: WAIT_ANY (parked at s_waitcnt / barrier) + WAIT_INST_ANY (issue stall) + ACTIVE_INST_ANY ~ WAVE_CYCLES; these
+    count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES and SQ_BUSY_CYCLES count cycles."""
+    import collections
+    import re
+    tot = collections.defaultdict(lambda: collections.defaultdict(float))
+    calls = collections.Counter()
+    for path in paths:
+        seen = set()
+        for r in csv.DictReader(open(path)):
+            k = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
+            k = re.sub(r"^void ", "", k).split("(")[0]
+            k = re.sub(r"^(pt\w+::)", "", k)[:58]
+            tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            key = (k, r.get("Dispatch_Id"))
+            if path == paths[0] and key not in seen:
+                seen.add(key)
+                calls[k] += 1
+    names = sorted({c for v in tot.values() for c in v})
+    cols = [c for c in names if c != "SQ_WAVE_CYCLES"]
+    print("# per kernel: launches, SQ_WAVE_CYCLES (quad-cycles, summed over waves), then each counter / SQ_WAVE_CYCLES")
+    print(f"{'kernel':58s} {'n':>5s} {'wave_cyc':>10s} " + " ".join(f"{c.replace('SQ_', '')[:14]:>14s}" for c in cols))
+    for k, v in sorted(tot.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0.0))[:16]:
+        wc = v.get("SQ_WAVE_CYCLES", 0.0)
+        if wc <= 0:
+            continue
+        print(f"{k:58s} {calls[k]:5d} {wc:10.3e} " + " ".join(f"{v.get(c, 0.0) / wc:14.3f}" for c in cols))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "sq":
+        sq(sys.argv[2:])
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "traffic":
         traffic(*sys.argv[2:6])
