@@ -71,6 +71,9 @@ def step_traffic(fetch_csv, write_csv, steps):
     import collections
     import re
     tot, calls = collections.defaultdict(float), collections.Counter()
+    if str(steps) == "auto":   # the loss kernel runs once per step, whatever passes the profiled command made
+        steps = sum(1 for r in csv.DictReader(open(fetch_csv)) if r["Counter_Name"] == "FETCH_SIZE" and "drmsd_tri_kernel" in r["Kernel_Name"])
+    steps = int(steps)
     for path, name, mult in ((fetch_csv, "FETCH_SIZE", 2.0), (write_csv, "WRITE_SIZE", 1.0)):
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] != name:
@@ -125,6 +128,6 @@ if __name__ == "__main__":
     elif sys.argv[1] == "traffic":
         traffic(*sys.argv[2:6])
     elif sys.argv[1] == "step_traffic":
-        step_traffic(sys.argv[2], sys.argv[3], int(sys.argv[4]))
+        step_traffic(sys.argv[2], sys.argv[3], sys.argv[4])
     else:
         sys.exit(__doc__)

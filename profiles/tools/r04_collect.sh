@@ -26,5 +26,5 @@ if [ "$2" = "full" ]; then
   f=$(find $out/pmc_fetch -name "*counter_collection.csv" | head -1); w=$(find $out/pmc_write -name "*counter_collection.csv" | head -1)
   alg=$(python -c "import json; print(json.load(open('$out/bench_cfg4.json'))['roofline']['algorithmic_bytes_per_launch'])")
   python profiles/summarize.py traffic $f $w $alg $out/gemm_hbm_traffic.json > /dev/null
-  python profiles/summarize.py step_traffic $f $w 3 > $out/hbm_traffic_per_step.txt
+  python profiles/summarize.py step_traffic $f $w auto > $out/hbm_traffic_per_step.txt
 fi
