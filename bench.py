@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--no-side-stream", action="store_true", help="ablation: weight-gradient products of small batches on the main stream")
     ap.add_argument("--no-hp-forward", action="store_true", help="ablation: the FFN-layer-1 forward product on ptamd_gemm instead of ptamd_gemm_hp")
     ap.add_argument("--no-hp-qkv", action="store_true", help="ablation: the QKV product on ptamd_gemm instead of ptamd_gemm_hp")
+    ap.add_argument("--no-attn-keep-bits", action="store_true", help="ablation: the fused attention backward kernel draws the dropout decisions again instead of reading the forward kernel's")
     ap.add_argument("--no-top-layer-scales", action="store_true", help="ablation: the top layer's FFN weight-gradient products in bf16x3 (no pass over its dy2)")
     ap.add_argument("--dw-group", default="auto", choices=["auto", "pairs", "layer", "off"],
                     help="grouping of the weight-gradient products of a layer (ptamd_gemm_group); off = one by one (ablation)")
@@ -295,6 +296,7 @@ def main():
         kernels.DW_SLOTS = int(os.environ["PTAMD_DW_SLOTS"])
     model.hp_forward = not a.no_hp_forward
     model.hp_qkv, model.hp_dx = not a.no_hp_qkv, bool(a.hp_dx)
+    model.keep_attn_bits = not a.no_attn_keep_bits
     model.dw_group = a.dw_group
     model.top_layer_scales = not a.no_top_layer_scales
     model.dropout_seed += 7919 * rank
@@ -504,6 +506,8 @@ def main():
         # bound for exact scales / bf16x3 because the measured slack of the bound exceeded 8 binades, and what was measured
         guard = model.auto_guard.report()
         out["auto_fallbacks_per_step"] = round(guard["fallbacks_per_step"], 3)
+        # layers x passes whose attention forward kernel handed its dropout decisions to the fused backward kernel
+        out["attn_keep_bits_layer_passes"] = int(model.__dict__.get("_attn_bits_passes", 0))
         out["auto_guard"] = guard
         out["communication"] = comm
         if world == 1 and not a.no_cpu_baseline:

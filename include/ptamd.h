@@ -332,14 +332,25 @@ int ptamd_embed_bwd(const int64_t *seq, const float *dout, int B, int L, int D, 
  *   lse [B,H,L] saves log-sum-exp per query row for the backward. dk must be 32 or 64.
  *   ptamd_attention_bwd, row_scale [T] / row_scale_min [4] (optional, both or only the first; f16x2 arithmetic with
  *   dk 32 / 64 only, PTAMD_ERR_BAD_SHAPE otherwise): the f16x2 row scales of dqkv (ptamd_gemm a_scale) and the smallest
- *   of them (4 copies: a uniform scale, stride 0), accumulated with atomicMin - preset both to 0x7F000000. */
+ *   of them (4 copies: a uniform scale, stride 0), accumulated with atomicMin - preset both to 0x7F000000.
+ *   keep_bits (optional, f16x2 arithmetic with dk 32 / 64 only, PTAMD_ERR_BAD_SHAPE otherwise; ptamd_attention_keep_bits_bytes
+ *   bytes): the dropout decisions of the probabilities, written by ptamd_attention_fwd and handed to ptamd_attention_bwd by
+ *   the caller (the library keeps nothing between calls), so that the backward kernel reads one word per key and 32
+ *   queries instead of drawing the counter hash again: word [(b, h)][q / 32][key] (keys padded to a multiple of 32),
+ *   bit q % 32 = 1 where query q keeps key.  The decisions are the generator's (csrc/attn_dropout.h) either way: a
+ *   backward call without them, or in another arithmetic, regenerates exactly the same mask. */
 int ptamd_attention_fwd(const float *qkv, const int64_t *seq, int B, int L, int H, int dk, float dropout_p,
-                        uint64_t seed, uint32_t stream_id, int arith, float *out, float *lse, void *stream);
+                        uint64_t seed, uint32_t stream_id, int arith, float *out, float *lse, uint32_t *keep_bits,
+                        void *stream);
 int ptamd_attention_bwd(const float *qkv, const int64_t *seq, const float *out, const float *dout, const float *lse,
                         int B, int L, int H, int dk, float dropout_p, uint64_t seed, uint32_t stream_id, int arith,
-                        float *dqkv, uint32_t *row_scale, uint32_t *row_scale_min, void *workspace,
-                        size_t workspace_bytes, void *stream);
+                        float *dqkv, uint32_t *row_scale, uint32_t *row_scale_min, const uint32_t *keep_bits,
+                        void *workspace, size_t workspace_bytes, void *stream);
 size_t ptamd_attention_workspace_bytes(int B, int L, int H, int dk);
+size_t ptamd_attention_keep_bits_bytes(int B, int L, int H);
+/* 1 when ptamd_attention_bwd of this shape and arithmetic would read keep_bits (the one-sweep kernel: dk = 64 and enough
+ * (protein, head) pairs to fill the chip), 0 when it would draw the decisions again - a caller saves the buffer then */
+int ptamd_attention_bwd_reads_keep_bits(int B, int L, int H, int dk, int arith);
 
 /* column sums: out[N] (+)= sum_t x[t,N]   (bias gradients) */
 size_t ptamd_colsum_workspace_bytes(int N);

@@ -109,9 +109,11 @@ SIGNATURES = {
     "ptamd_embed_fwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _u64, _p, _p]),
     "ptamd_embed_bwd_workspace_bytes": (_sz, [_i]),
     "ptamd_embed_bwd": (_i, [_p, _p, _i, _i, _i, _f, _u64, _p, _p, _sz, _p]),
-    "ptamd_attention_fwd": (_i, [_p, _p, _i, _i, _i, _i, _f, _u64, _u32, _i, _p, _p, _p]),
-    "ptamd_attention_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _u32, _i, _p, _p, _p, _p, _sz, _p]),
+    "ptamd_attention_fwd": (_i, [_p, _p, _i, _i, _i, _i, _f, _u64, _u32, _i, _p, _p, _p, _p]),
+    "ptamd_attention_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _u32, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "ptamd_attention_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "ptamd_attention_keep_bits_bytes": (_sz, [_i, _i, _i]),
+    "ptamd_attention_bwd_reads_keep_bits": (_i, [_i, _i, _i, _i, _i]),
     "ptamd_colsum_workspace_bytes": (_sz, [_i]),
     "ptamd_colsum": (_i, [_p, _i64, _i, _i, _i, _p, _p, _sz, _p]),
     "ptamd_relu_dropout_bwd": (_i, [_p, _p, _i64, _f, _p, _p]),

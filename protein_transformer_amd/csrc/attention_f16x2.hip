@@ -257,7 +257,7 @@ constexpr size_t ATTN_LDS = (size_t)2 * BUF * sizeof(unsigned short);
 template <int DK, int NW, int PARTS>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PT_ATTN_FWD_WAVES, PT_ATTN_FWD_WAVES))) void attn_fwd_f16x2_kernel(
     const float *__restrict__ qkv, const int64_t *__restrict__ seq, int L, int H, float p_drop, uint64_t seed,
-    uint32_t stream_id, float *__restrict__ out, float *__restrict__ lse) {
+    uint32_t stream_id, float *__restrict__ out, float *__restrict__ lse, uint32_t *__restrict__ keep_bits) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   __shared__ __attribute__((aligned(16))) float sBias[2][PARTS][TR];
   __shared__ __attribute__((aligned(16))) float sInvK[2][PARTS][8], sInvV[2][PARTS][8];
@@ -389,8 +389,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PT_ATTN
     const float vn = inv_pow2(v_run);
     const float4 ivh = lh ? ivb : iva;
     const float fv[4] = {ivh.x * TWO14 * vn, ivh.y * TWO14 * vn, ivh.z * TWO14 * vn, ivh.w * TWO14 * vn};  // <= 2^14
-    if (p_drop > 0.f) {
-      attn_drop_keys_in_rows(dk_, q_part, k0, lh, s);  // the 1 / (1 - p) is applied to O at the end
+    if (p_drop > 0.f) {  // the 1 / (1 - p) is applied to O at the end
+      if (keep_bits) {   // (uniform) the decisions also go out for the fused backward kernel: attn_dropout.h
+        const uint32_t word = attn_drop_keys_in_rows_export(dk_, q_part, k0, lh, s);
+        const int lk = (L + 31) & ~31;
+        if (lane < 32 && k0 + lane < lk && q0 < lk)   // (a workgroup's last wavefronts may hold no query at all)
+          keep_bits[((size_t)(b * H + h) * (lk >> 5) + (q0 >> 5)) * lk + k0 + lane] = word;
+      } else {
+        attn_drop_keys_in_rows(dk_, q_part, k0, lh, s);
+      }
     }
     // O^T[d][q] += V^T[d][key] P^T[key][q]: the accumulator rows of s are already in the k order of frag_cols
 #pragma unroll
@@ -954,7 +961,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float *__restrict
 __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_fused_f16x2_kernel(
     const float *__restrict__ qkv, const int64_t *__restrict__ seq, const float *__restrict__ d_o,
     const float *__restrict__ lse, const float *__restrict__ delta, int L, int H, float p_drop, uint64_t seed,
-    uint32_t stream_id, float *__restrict__ dqkv, uint32_t *__restrict__ row_scale, uint32_t *__restrict__ row_min) {
+    uint32_t stream_id, float *__restrict__ dqkv, uint32_t *__restrict__ row_scale, uint32_t *__restrict__ row_min,
+    const uint32_t *__restrict__ keep_bits) {
   constexpr int DK = 64, NW = 8, KS = DK / 16, NT = DK / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   __shared__ __attribute__((aligned(16))) float sLse[2][TR], sDel[2][TR];
@@ -973,6 +981,8 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   const AttnDrop dk_ = make_attn_drop(seed, stream_id, (uint32_t)(b * H + h), p_drop);
   const float ks = p_drop > 0.f ? dk_.ks : 1.f;
   const int ntiles = (L + TR - 1) / TR, nkb = (L + FK - 1) / FK;
+  const int lk = (L + 31) & ~31;
+  const bool use_bits = keep_bits != nullptr && p_drop > 0.f;   // (uniform)
   const int db = 16 * (wave & 3), qb = 16 * (wave >> 2);   // this wavefront's piece of a tile's dQ^T
   auto tile = [&](int buf) __attribute__((always_inline)) { return smem + buf * BUF; };
   uint32_t my_min = 0x7F000000u;                          // smallest f16x2 scale of the dQ rows this thread published
@@ -988,6 +998,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int key = kb * FK + wave * 32 + l31;
     const bool k_ok = key < L;
     const bool k_valid = k_ok && seq[(size_t)b * L + key] != PTAMD_PAD_ID;
+    const uint32_t *const keep_row = keep_bits + (size_t)(b * H + h) * (lk >> 5) * lk + min(key, lk - 1);
     f16x8 vf[KS][2];
     float ikl;
     {  // the scaled K rows of the block go to LDS as planes and are read from there by BOTH products that need them (S = Q K^T
@@ -1038,6 +1049,10 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         r_lse = qn < L ? lse_b[qn] * LOG2E : INFINITY;
         r_del = qn < L ? del_b[qn] : 0.f;
       }
+      // the forward kernel's dropout decisions of this lane's key against the 32 queries of the tile (bit = query), if the
+      // caller kept them: requested here, used behind the two products
+      uint32_t kword = 0xffffffffu;
+      if (use_bits) kword = keep_row[(size_t)qt * lk];
       const float4 iq4 = *reinterpret_cast<const float4 *>(&sInvQ[cur][4 * lh]);
       const float4 iga = *reinterpret_cast<const float4 *>(&sInvG[cur][0]), igb = *reinterpret_cast<const float4 *>(&sInvG[cur][4]);
       f32x16 s, dp;
@@ -1088,7 +1103,15 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         fp[j] = ig[j] * TWO14 * gn;
       }
       f32x16 pd;   // dropped probabilities (operand of dV)
-      const uint32_t keepbits = p_drop > 0.f ? attn_keep_bits_queries_in_rows_paired(dk_, (uint32_t)key, qq0, lh) : 0xffffu;
+      // bit (r & 3) + 8 (r >> 2) of `keepw` = register r (query qq0 + 4 lh + (r & 3) + 8 (r >> 2)) is kept: the stored word
+      // shifted by the lane half, or the generator's 16 bits spread to the same positions
+      uint32_t keepw;
+      if (use_bits) {
+        keepw = kword >> (4 * lh);
+      } else {
+        const uint32_t kb16 = p_drop > 0.f ? attn_keep_bits_queries_in_rows_paired(dk_, (uint32_t)key, qq0, lh) : 0xffffu;
+        keepw = (kb16 & 0xfu) | ((kb16 & 0xf0u) << 4) | ((kb16 & 0xf00u) << 8) | ((kb16 & 0xf000u) << 12);
+      }
       float wmax = 0.f;
       float gm[4] = {0.f, 0.f, 0.f, 0.f};   // max |dS / (Q group scale)| per register quadruple (= per Q group)
 #pragma unroll
@@ -1101,8 +1124,8 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const float p = __builtin_amdgcn_exp2f(k_valid ? fmaf(s[r], cu[j], -my_l) : -INFINITY);
         float g = dp[r] * ug[j], pk = p;
         if (p_drop > 0.f) {
-          g = keep_or_zero(g, keepbits, r);
-          pk = keep_or_zero(p, keepbits, r);
+          g = keep_or_zero(g, keepw, (r & 3) + 8 * (r >> 2));
+          pk = keep_or_zero(p, keepw, (r & 3) + 8 * (r >> 2));
         }
         pd[r] = pk;
         s[r] = p * (g - my_d) * wq[j];   // dS[q][key] / (Q group scale)
@@ -1285,12 +1308,12 @@ inline Shape dkv_shape(Shape sh) { return sh == W8_HALVES ? W4 : sh; }
 
 template <int DK, int NW, int PARTS>
 int launch_fwd(const float *qkv, const int64_t *seq, int B, int L, int H, float p, uint64_t seed, uint32_t sid, float *out,
-               float *lse, hipStream_t st) {
+               float *lse, uint32_t *keep_bits, hipStream_t st) {
   constexpr int QB = 32 * NW / PARTS;
   const dim3 grid((L + QB - 1) / QB, H, B);
   if (int rc = set_lds(attn_fwd_f16x2_kernel<DK, NW, PARTS>, PARTS)) return rc;  // idempotent, host-only: no state kept between calls
   hipLaunchKernelGGL((attn_fwd_f16x2_kernel<DK, NW, PARTS>), grid, dim3(64 * NW), PARTS * ATTN_LDS, st, qkv, seq, L, H, p, seed, sid,
-                     out, lse);
+                     out, lse, keep_bits);
   return pt_check_launch();
 }
 template <int DK, int NW, int PARTS>
@@ -1316,10 +1339,10 @@ int launch_dkv(const float *qkv, const int64_t *seq, const float *d_o, const flo
 }
 template <int DK>
 int fwd_by_shape(Shape sh, const float *qkv, const int64_t *seq, int B, int L, int H, float p, uint64_t seed, uint32_t sid,
-                 float *out, float *lse, hipStream_t st) {
-  if (sh == W8) return launch_fwd<DK, 8, 1>(qkv, seq, B, L, H, p, seed, sid, out, lse, st);
-  if (sh == W8_HALVES) return launch_fwd<DK, 8, 2>(qkv, seq, B, L, H, p, seed, sid, out, lse, st);
-  return launch_fwd<DK, 4, 2>(qkv, seq, B, L, H, p, seed, sid, out, lse, st);
+                 float *out, float *lse, uint32_t *keep_bits, hipStream_t st) {
+  if (sh == W8) return launch_fwd<DK, 8, 1>(qkv, seq, B, L, H, p, seed, sid, out, lse, keep_bits, st);
+  if (sh == W8_HALVES) return launch_fwd<DK, 8, 2>(qkv, seq, B, L, H, p, seed, sid, out, lse, keep_bits, st);
+  return launch_fwd<DK, 4, 2>(qkv, seq, B, L, H, p, seed, sid, out, lse, keep_bits, st);
 }
 // the fused kernel: dk = 64 and enough (protein, head) pairs that one workgroup each fills more than half of the chip
 // (PTAMD_ATTN_FUSED = 0 / 1 in the environment, read at every call: never / whenever dk = 64 - for tests, which run small
@@ -1331,7 +1354,7 @@ inline bool use_fused(int B, int L, int H, int dk) {
 }
 int launch_fused(const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse, float *delta,
                  int B, int L, int H, float p, uint64_t seed, uint32_t sid, float *dqkv, uint32_t *row_scale,
-                 uint32_t *row_min, hipStream_t st) {
+                 uint32_t *row_min, const uint32_t *keep_bits, hipStream_t st) {
   const size_t items = (size_t)B * L * H * 16;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, o_fwd, d_o, B * L, L, H, 64, delta);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_fused_f16x2_kernel),
@@ -1341,7 +1364,7 @@ int launch_fused(const float *qkv, const int64_t *seq, const float *o_fwd, const
     return PTAMD_ERR_HIP;
   }
   hipLaunchKernelGGL(attn_bwd_fused_f16x2_kernel, dim3(1, H, B), dim3(512), FUSED_LDS, st, qkv, seq, d_o, lse, delta, L, H, p,
-                     seed, sid, dqkv, row_scale, row_min);
+                     seed, sid, dqkv, row_scale, row_min, keep_bits);
   return pt_check_launch();
 }
 template <int DK>
@@ -1362,18 +1385,22 @@ int bwd_by_shape(Shape sh, const float *qkv, const int64_t *seq, const float *o_
 }  // namespace ptattn16
 
 int pt_attention_fwd_f16x2(const float *qkv, const int64_t *seq, int B, int L, int H, int dk, float p, uint64_t seed,
-                           uint32_t sid, float *out, float *lse, hipStream_t st) {
+                           uint32_t sid, float *out, float *lse, uint32_t *keep_bits, hipStream_t st) {
   using namespace ptattn16;
   const Shape sh = launch_shape(B, L, H);
-  return dk == 64 ? fwd_by_shape<64>(sh, qkv, seq, B, L, H, p, seed, sid, out, lse, st)
-                  : fwd_by_shape<32>(sh, qkv, seq, B, L, H, p, seed, sid, out, lse, st);
+  return dk == 64 ? fwd_by_shape<64>(sh, qkv, seq, B, L, H, p, seed, sid, out, lse, keep_bits, st)
+                  : fwd_by_shape<32>(sh, qkv, seq, B, L, H, p, seed, sid, out, lse, keep_bits, st);
 }
+
+bool pt_attention_bwd_f16x2_reads_keep_bits(int B, int L, int H, int dk) { return ptattn16::use_fused(B, L, H, dk); }
 
 int pt_attention_bwd_f16x2(const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse,
                            float *delta, int B, int L, int H, int dk, float p, uint64_t seed, uint32_t sid, float *dqkv,
-                           uint32_t *row_scale, uint32_t *row_min, hipStream_t st) {
+                           uint32_t *row_scale, uint32_t *row_min, const uint32_t *keep_bits, hipStream_t st) {
   using namespace ptattn16;
-  if (use_fused(B, L, H, dk)) return launch_fused(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
+  // (the forward kernel's decisions are read by the fused kernel only; the two-kernel path draws the same ones again)
+  if (use_fused(B, L, H, dk))
+    return launch_fused(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, keep_bits, st);
   const Shape sh = launch_shape(B, L, H);
   return dk == 64 ? bwd_by_shape<64>(sh, qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st)
                   : bwd_by_shape<32>(sh, qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);

@@ -61,6 +61,51 @@ __device__ __forceinline__ void attn_drop_keys_in_rows(const AttnDrop &d, uint32
     x[2 * j + 1] = (uint16_t)(w >> 16) >= t16 ? x[2 * j + 1] : 0.f;
   }
 }
+// The same, and the decisions EXPORTED for a backward kernel that keeps keys in lanes (attn_bwd_fused_f16x2_kernel reads them
+// instead of drawing the words again: the generator is 29 % of that kernel's VALU instructions).  The compare of an element
+// already leaves its 64 lane decisions in a scalar register pair - lanes 0..31: the 32 queries against the key of lane half
+// 0, lanes 32..63: against the key four rows further - so the export is two v_writelane per compare: the returned word of
+// lane i < 32 holds, in bit q, whether query (lane q) keeps key k0 + i.
+// v_writelane_b32 through the LLVM intrinsic (this clang has no builtin for it; as inline asm the compiler does not see the
+// wait states the instruction needs behind the v_cmp that wrote its scalar source - measured: two stale words per tile)
+extern "C" __device__ int pt_llvm_amdgcn_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane");
+template <int LANE>
+__device__ __forceinline__ void attn_writelane(int &word, uint32_t value) {
+  word = pt_llvm_amdgcn_writelane((int)value, LANE, word);
+}
+template <int J, typename V>
+__device__ __forceinline__ void attn_drop_export_pair(const AttnDrop &d, uint32_t q_part, uint32_t base, uint16_t t16, V &x, int &word) {
+  const uint32_t w = attn_word(q_part, base + (uint32_t)((J & 1) + 4 * (J >> 1)) * ATTN_C_K);
+  const bool ke = (uint16_t)w >= t16, ko = (uint16_t)(w >> 16) >= t16;
+  x[2 * J] = ke ? x[2 * J] : 0.f;
+  x[2 * J + 1] = ko ? x[2 * J + 1] : 0.f;
+  const uint64_t me = __builtin_amdgcn_ballot_w64(ke), mo = __builtin_amdgcn_ballot_w64(ko);
+  constexpr int OFF = 2 * (J & 1) + 8 * (J >> 1);   // row of register 2 J in lane half 0 (lane half 1: + 4)
+  attn_writelane<OFF>(word, (uint32_t)me);
+  attn_writelane<OFF + 4>(word, (uint32_t)(me >> 32));
+  attn_writelane<OFF + 1>(word, (uint32_t)mo);
+  attn_writelane<OFF + 5>(word, (uint32_t)(mo >> 32));
+}
+template <typename V>
+__device__ __forceinline__ uint32_t attn_drop_keys_in_rows_export(const AttnDrop &d, uint32_t q_part, int k0, int lh, V &x) {
+  const uint32_t base = attn_kp_part(d, (uint32_t)((k0 >> 1) + 2 * lh));
+  const uint16_t t16 = (uint16_t)d.thr16;
+  int word = 0;
+  attn_drop_export_pair<0>(d, q_part, base, t16, x, word);
+  attn_drop_export_pair<1>(d, q_part, base, t16, x, word);
+  attn_drop_export_pair<2>(d, q_part, base, t16, x, word);
+  attn_drop_export_pair<3>(d, q_part, base, t16, x, word);
+  attn_drop_export_pair<4>(d, q_part, base, t16, x, word);
+  attn_drop_export_pair<5>(d, q_part, base, t16, x, word);
+  attn_drop_export_pair<6>(d, q_part, base, t16, x, word);
+  attn_drop_export_pair<7>(d, q_part, base, t16, x, word);
+  return (uint32_t)word;
+}
+// layout of the exported decisions: word [(protein, head)][query tile of 32][key], keys padded to a multiple of 32
+__host__ __device__ inline size_t attn_keep_words(int B, int L, int H) {
+  const size_t nt = (size_t)(L + 31) / 32;
+  return (size_t)B * H * nt * (nt * 32);
+}
 // Keys in lanes, queries in rows (dK/dV kernel), q0 = first query of the 32-query block: register r holds query
 // q0 + 4 lh + (r & 3) + 8 (r >> 2); the lane's key selects the half of every word.  Returns bit r = keep.
 __device__ __forceinline__ uint32_t attn_keep_bits_queries_in_rows(const AttnDrop &d, uint32_t key, int q0, int lh) {

@@ -409,20 +409,32 @@ def embed_bwd(seq, dout, D, dropout_p, seed, demb):
                                 ws.numel(), stream()), "embed_bwd")
 
 
-def attention_fwd(qkv, seq, H, dropout_p, seed, stream_id, arith=None):
+def attention_bwd_reads_keep_bits(B, L, H, dk, arith):
+    return bool(lib().ptamd_attention_bwd_reads_keep_bits(B, L, H, dk, int(_DEFAULT_ARITH if arith is None else arith)))
+
+
+def attention_keep_bits(B, L, H, device):
+    """Buffer for the dropout decisions ptamd_attention_fwd hands to ptamd_attention_bwd (f16x2 arithmetic, dk 32 / 64)."""
+    return torch.empty(lib().ptamd_attention_keep_bits_bytes(B, L, H) // 4, dtype=torch.int32, device=device)
+
+
+def attention_fwd(qkv, seq, H, dropout_p, seed, stream_id, arith=None, keep_bits=None):
+    """keep_bits (attention_keep_bits, optional): filled with the dropout decisions when dropout_p > 0."""
     B, L = seq.shape
     D = qkv.shape[1] // 3
     out = torch.empty(B * L, D, dtype=torch.float32, device=qkv.device)
     lse = torch.empty(B, H, L, dtype=torch.float32, device=qkv.device)
     check(lib().ptamd_attention_fwd(ptr(qkv), ptr(seq), B, L, H, D // H, float(dropout_p), int(seed), int(stream_id),
-                                    int(_DEFAULT_ARITH if arith is None else arith), ptr(out), ptr(lse), stream()),
-          "attention_fwd")
+                                    int(_DEFAULT_ARITH if arith is None else arith), ptr(out), ptr(lse), ptr(keep_bits),
+                                    stream()), "attention_fwd")
     return out, lse
 
 
-def attention_bwd(qkv, seq, out, dout, lse, H, dropout_p, seed, stream_id, arith=None, row_scale=None, row_scale_min=None):
+def attention_bwd(qkv, seq, out, dout, lse, H, dropout_p, seed, stream_id, arith=None, row_scale=None, row_scale_min=None,
+                  keep_bits=None):
     """row_scale [T] / row_scale_min [4] (int32, preset to 0x7F000000): f16x2 scales of the rows of dqkv as a by-product
-    (f16x2 arithmetic and head size 32 / 64 only - `attention_row_scales_available`)."""
+    (f16x2 arithmetic and head size 32 / 64 only - `attention_row_scales_available`).  keep_bits: what attention_fwd filled
+    for the same (seed, stream_id) - the fused backward kernel reads the decisions instead of drawing them again."""
     B, L = seq.shape
     D = qkv.shape[1] // 3
     dqkv = torch.empty_like(qkv)
@@ -430,7 +442,7 @@ def attention_bwd(qkv, seq, out, dout, lse, H, dropout_p, seed, stream_id, arith
     check(lib().ptamd_attention_bwd(ptr(qkv), ptr(seq), ptr(out), ptr(dout), ptr(lse), B, L, H, D // H,
                                     float(dropout_p), int(seed), int(stream_id),
                                     int(_DEFAULT_ARITH if arith is None else arith), ptr(dqkv), ptr(row_scale),
-                                    ptr(row_scale_min), ptr(ws), ws.numel(), stream()), "attention_bwd")
+                                    ptr(row_scale_min), ptr(keep_bits), ptr(ws), ws.numel(), stream()), "attention_bwd")
     return dqkv
 
 

@@ -273,6 +273,7 @@ class _TransformerBase(nn.Module):
         self.gemm_mode = None                        # kernels.GEMM_* arithmetic of THIS model; None = kernels.get_gemm_mode()
         self.hp_forward = True                       # FFN-layer-1 forward product on ptamd_gemm_hp from LayerNorm-written planes (read every pass)
         self.hp_qkv = True                           # ... the QKV product too (three-stage kernel of round 4)
+        self.keep_attn_bits = True                   # attention dropout decisions handed from the forward to the fused backward kernel
         self.hp_dx = False                           # dX of FFN layer 2 there too (A: planes from the fused LayerNorm backward, B: W2^T planes): built and
                                                      # tested, measured +-0 in the step (profiles/r04/NOTES.md), off
         self.side_stream_dw = True                   # small batches: weight-gradient products on a side stream
@@ -642,8 +643,15 @@ class _EncoderFn(torch.autograd.Function):
                                 torch.empty(Tn, 3 * D, dtype=torch.float32, device=x.device), bias=bqkv)
             else:
                 qkv = K.linear_fwd(h1, wqkv, bqkv, **prod(i, 0, a_scale=s_h1, b_scale=sc and sc["rs_qkv"]))
-            att, lse = K.attention_fwd(qkv, seq, H, pa, seed, sid + _SITE_ATTN,
-                                        arith=attn_default if m.attn_mode is None else m.attn_mode)
+            attn_ar_f = attn_default if m.attn_mode is None else m.attn_mode
+            # the dropout decisions of the probabilities, kept for the backward kernel that reads them instead of drawing
+            # them again (8 MB per layer at 32 x 512 x 8 heads; only where that kernel will run)
+            kbits = None
+            if pa > 0.0 and m.keep_attn_bits and m.__dict__.get("_fwd_grad", False) and \
+                    K.attention_bwd_reads_keep_bits(B, L, H, D // H, attn_ar_f):
+                kbits = K.attention_keep_bits(B, L, H, x.device)
+                m.__dict__["_attn_bits_passes"] = m.__dict__.get("_attn_bits_passes", 0) + 1
+            att, lse = K.attention_fwd(qkv, seq, H, pa, seed, sid + _SITE_ATTN, arith=attn_ar_f, keep_bits=kbits)
             use_b = sc is not None and not (off is not None and off[i, 0])          # att on its bound (else: exact row scales)
             x2 = K.linear_fwd(att, W(b + "self_attn.wo.weight"), W(b + "self_attn.wo.bias"), residual=x, ldr=D,
                               dropout_p=p, seed=seed, stream_id=sid + _SITE_ATTN_OUT,
@@ -665,7 +673,7 @@ class _EncoderFn(torch.autograd.Function):
                               dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_OUT,
                               **prod(i, 3, a_scale=sc["f1_scale"] if use_b else None, a_scale_stride=0 if use_b else 1,
                                      b_scale=sc and sc["rs_2"]))
-            saved.append((x, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, f1))
+            saved.append((x, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, f1, kbits))
             if measure_fwd:
                 gs = sc["guard_stats"][i]
                 K.weight_scales([dict(w=t, stats=gs[j], rows_only=True) for j, t in ((0, att), (1, f1), (3, h1), (4, h2))])
@@ -804,7 +812,7 @@ class _EncoderFn(torch.autograd.Function):
             b = f"encoder.enc_layers.{i}."
             sid = i * 8
             sc = scales[i] if scales is not None else None
-            x, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, f1 = ctx.saved[i]
+            x, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, f1, kbits = ctx.saved[i]
             # x3 = x2 + drop(f1 W2^T + b2)
             if dy2 is None:
                 dy2 = K.dropout_bwd(dx, p, seed, sid + _SITE_FFN_OUT) if p > 0 else dx
@@ -863,7 +871,7 @@ class _EncoderFn(torch.autograd.Function):
                 s_dqkv_all = torch.full((m.nlayers, B * L), 0x7F000000, dtype=torch.int32, device=dpred.device)
             s_dqkv = s_dqkv_all[i] if attn_scales else None
             dqkv = K.attention_bwd(qkv, seq, att, datt, lse, H, pa, seed, sid + _SITE_ATTN, arith=attn_ar,
-                                    row_scale=s_dqkv, row_scale_min=sc["dqkv_min"] if attn_scales else None)
+                                    row_scale=s_dqkv, row_scale_min=sc["dqkv_min"] if attn_scales else None, keep_bits=kbits)
             gw, gb = m._qkv(gflat, i)
             wqkv, _ = m._qkv(flat, i)
             if sc is not None:

@@ -128,6 +128,123 @@ def test_fused_dropout_masks_match_the_forward_kernel(dev):
     assert_close(dqkv, ref, 1e-4, 5e-6 * max(1.0, ref.abs().max().item()), "fused attention bwd (dropout)")
 
 
+@pytest.mark.parametrize("B,L,H,lens,parts", [(2, 320, 2, [320, 283], None), (1, 700, 2, [651], None), (3, 96, 8, [96, 33, 1], None),
+                                              (32, 512, 8, None, None), (2, 130, 1, [130, 5], None)])
+def test_keep_bits_handed_from_forward_to_fused_backward(dev, B, L, H, lens, parts):
+    """ptamd_attention_fwd exports its dropout decisions (word [(b, h)][q / 32][key], bit q % 32); the fused backward kernel
+    reading them gives the SAME BITS as the fused kernel drawing the generator again, the forward output does not depend on
+    the export, and the exported words are the mask a forward pass with V = I shows."""
+    from protein_transformer_amd import kernels as K_
+    p, seed, sid, dk = 0.25, 991, 3, 64
+    D = H * dk
+    seq = _seq(B, L, lens if lens is not None else [L] * B, seed=5).to(dev)
+    qd = rnd((B * L, 3 * D), 31, 1.2).to(dev)
+    dout = rnd((B * L, D), 32).to(dev)
+    bits = K_.attention_keep_bits(B, L, H, dev)
+    bits.fill_(0x5A5A5A5A)
+    o0, lse0 = K_.attention_fwd(qd, seq, H, p, seed, sid, arith=K_.GEMM_F16X2)
+    o1, lse1 = K_.attention_fwd(qd, seq, H, p, seed, sid, arith=K_.GEMM_F16X2, keep_bits=bits)
+    assert torch.equal(o0, o1) and torch.equal(lse0, lse1)
+    with fused(True):
+        a = K_.attention_bwd(qd, seq, o1, dout, lse1, H, p, seed, sid, arith=K_.GEMM_F16X2)
+        b = K_.attention_bwd(qd, seq, o1, dout, lse1, H, p, seed, sid, arith=K_.GEMM_F16X2, keep_bits=bits)
+    assert torch.equal(a, b)
+    # a corrupted word must change the result (the kernel really reads them)
+    bad = bits.clone()
+    bad[: bad.numel() // 2] = 0
+    with fused(True):
+        c = K_.attention_bwd(qd, seq, o1, dout, lse1, H, p, seed, sid, arith=K_.GEMM_F16X2, keep_bits=bad)
+    assert not torch.equal(a, c)
+    if B * L <= 2048:   # the words against the mask a forward pass with V = I shows (first 64 keys)
+        eye = qd.clone().view(B, L, 3 * D)
+        v = torch.zeros(L, dk)
+        v[:min(dk, L)] = torch.eye(dk)[:min(dk, L)]
+        eye[:, :, 2 * D:] = v[None].repeat(B, 1, H).to(dev)
+        pd, _ = K_.attention_fwd(eye.view(B * L, 3 * D), seq, H, p, seed, sid, arith=K_.GEMM_F16X2)
+        shown = (pd.view(B, L, H, dk).permute(0, 2, 1, 3) != 0).cpu()            # [B, H, q, key < 64]: kept AND p > 0
+        nt = (L + 31) // 32
+        w = bits.view(B, H, nt, nt * 32).cpu().numpy().astype(np.uint32)
+        q = np.arange(L)
+        kept = ((w[:, :, q // 32, :] >> (q % 32)[None, None, :, None].astype(np.uint32)) & 1).astype(bool)   # [B, H, q, key]
+        valid = (seq != 20).cpu().numpy()
+        for bb in range(B):
+            n = int(valid[bb].sum())
+            kk = min(dk, n)
+            got = kept[bb, :, :n, :kk]
+            want = shown[bb, :, :n, :kk].numpy()
+            # (a kept probability that underflowed to 0 would read as dropped: none at these magnitudes)
+            assert (got == want).all(), f"protein {bb}: {int((got != want).sum())} decisions differ"
+        frac = kept[:, :, :, :L].mean()
+        assert abs(frac - (1 - p)) < 0.01
+
+
+def _attn_decisions_restated(B, L, H, p, seed, sid):
+    """numpy restatement of csrc/attn_dropout.h (pt_mix32 of common.h on (query, key pair) words, 16-bit halves against a
+    16-bit threshold) in the layout of ptamd_attention_fwd's keep_bits: word [(b, h)][q / 32][key], bit q % 32."""
+    M = np.uint64(0xFFFFFFFF)
+    u = lambda x: (x & M).astype(np.uint64)                          # noqa: E731
+    sh = lambda n: np.uint64(n)                                      # noqa: E731
+
+    def mix32(x):
+        x = u(x)
+        x = u((~x & M) + (x << sh(15)))
+        x = x ^ (x >> sh(12))
+        x = u(x + (x << sh(2)))
+        x = x ^ (x >> sh(4))
+        x = u(x + (x << sh(3)) + (x << sh(11)))
+        return u(x ^ (x >> sh(16)))
+    nt = (L + 31) // 32
+    lk = nt * 32
+    out = np.zeros((B * H, nt, lk), dtype=np.uint32)
+    thr = int(p * 65536.0 + 0.5)
+    idx = np.arange(lk, dtype=np.uint64)
+    for bh in range(B * H):
+        lo = np.uint64((seed & 0xFFFFFFFF) ^ ((bh * 0xC2B2AE35) & 0xFFFFFFFF))
+        hi = np.uint64(((seed >> 32) & 0xFFFFFFFF) ^ ((sid * 0x27D4EB2F) & 0xFFFFFFFF) ^ bh)
+        qp = u(idx * np.uint64(0x9E3779B1) + lo)
+        kp = u((idx >> sh(1)) * np.uint64(0x85EBCA77) + hi)
+        w = mix32(qp[:, None] ^ kp[None, :])                                                    # [q, key]
+        keep = ((w >> (sh(16) * (idx & sh(1)))[None, :]) & np.uint64(0xFFFF)) >= thr
+        for t in range(nt):
+            out[bh, t] = (keep[32 * t:32 * t + 32].astype(np.uint64) << np.arange(32, dtype=np.uint64)[:, None]).sum(0).astype(np.uint32)
+    return out
+
+
+@pytest.mark.parametrize("B,L,H", [(1, 64, 1), (2, 320, 2), (3, 96, 8), (2, 100, 4), (8, 512, 8)])
+def test_keep_bits_are_the_generators_decisions(dev, B, L, H):
+    """Every exported word against the numpy restatement of the generator - including the query tiles past the end of a
+    workgroup (nothing may be written outside the buffer: a guard band behind it stays untouched)."""
+    from protein_transformer_amd import kernels as K_
+    p, seed, sid = 0.25, (77 << 32) | 991, 3
+    D = 64 * H
+    qd = rnd((B * L, 3 * D), 41).to(dev)
+    seq = _seq(B, L, [L] * B).to(dev)
+    n = K_.lib().ptamd_attention_keep_bits_bytes(B, L, H) // 4
+    buf = torch.full((n + 4096,), 0x13572468, dtype=torch.int32, device=dev)
+    K_.attention_fwd(qd, seq, H, p, seed, sid, arith=K_.GEMM_F16X2, keep_bits=buf[:n])
+    nt = (L + 31) // 32
+    got = buf[:n].cpu().numpy().view(np.uint32).reshape(B * H, nt, nt * 32)
+    want = _attn_decisions_restated(B, L, H, p, seed, sid)
+    qmask = np.array([sum(1 << i for i in range(32) if 32 * t + i < L) for t in range(nt)], dtype=np.uint32)   # queries < L
+    diff = (got ^ want) & qmask[None, :, None]
+    assert not diff[:, :, :L].any(), f"{int(np.count_nonzero(diff[:, :, :L]))} words differ"
+    assert (buf[n:] == 0x13572468).all()
+
+
+def test_keep_bits_only_in_the_f16x2_arithmetic(dev):
+    from protein_transformer_amd import kernels as K_
+    B, L, H = 1, 64, 2
+    qd = rnd((B * L, 3 * 64 * H), 33).to(dev)
+    seq = _seq(B, L, [L]).to(dev)
+    bits = K_.attention_keep_bits(B, L, H, dev)
+    assert bits.numel() == B * H * 2 * 64
+    with pytest.raises(RuntimeError):
+        K_.attention_fwd(qd, seq, H, 0.1, 1, 1, arith=K_.GEMM_BF16X3, keep_bits=bits)
+    assert K_.attention_bwd_reads_keep_bits(32, 512, 8, 64, K_.GEMM_AUTO)
+    assert not K_.attention_bwd_reads_keep_bits(32, 512, 8, 64, K_.GEMM_BF16X3)
+    assert not K_.attention_bwd_reads_keep_bits(32, 512, 16, 32, K_.GEMM_AUTO)
+
+
 def test_fused_wide_row_ranges_and_degenerate_rows(dev):
     from protein_transformer_amd import kernels as K_
     B, L, H, dk = 2, 512, 8, 64
