@@ -80,10 +80,11 @@ def parse():
     ap.add_argument("--no-hp-forward", action="store_true", help="ablation: the FFN-layer-1 forward product on ptamd_gemm instead of ptamd_gemm_hp")
     ap.add_argument("--no-hp-qkv", action="store_true", help="ablation: the QKV product on ptamd_gemm instead of ptamd_gemm_hp")
     ap.add_argument("--no-attn-keep-bits", action="store_true", help="ablation: the fused attention backward kernel draws the dropout decisions again instead of reading the forward kernel's")
+    ap.add_argument("--no-ffn-gate-mask", action="store_true", help="ablation: the gated dX product of FFN layer 2 reads the fp32 activation instead of its 1-bit gate")
     ap.add_argument("--no-top-layer-scales", action="store_true", help="ablation: the top layer's FFN weight-gradient products in bf16x3 (no pass over its dy2)")
     ap.add_argument("--dw-group", default="auto", choices=["auto", "pairs", "layer", "off"],
                     help="grouping of the weight-gradient products of a layer (ptamd_gemm_group); off = one by one (ablation)")
-    ap.add_argument("--hp-dx", action="store_true", help="ablation: dX of FFN layer 2 on ptamd_gemm_hp (off by default: +-0 in the step)")
+    ap.add_argument("--no-hp-dx", action="store_true", help="ablation: dX of FFN layer 2 on the staging kernel instead of ptamd_gemm_hp")
     ap.add_argument("--attn-mode", default=None, choices=["f32", "bf16x3", "f16x2"],
                     help="arithmetic of the attention kernels alone (ablation; default: that of --gemm-mode)")
     ap.add_argument("--gemm-mode", default="auto", choices=["f32", "bf16x3", "bf16x3full", "f16x2", "auto"],
@@ -295,8 +296,9 @@ def main():
     if os.environ.get("PTAMD_DW_SLOTS"):
         kernels.DW_SLOTS = int(os.environ["PTAMD_DW_SLOTS"])
     model.hp_forward = not a.no_hp_forward
-    model.hp_qkv, model.hp_dx = not a.no_hp_qkv, bool(a.hp_dx)
+    model.hp_qkv, model.hp_dx = not a.no_hp_qkv, not a.no_hp_dx
     model.keep_attn_bits = not a.no_attn_keep_bits
+    model.ffn_gate_mask = not a.no_ffn_gate_mask
     model.dw_group = a.dw_group
     model.top_layer_scales = not a.no_top_layer_scales
     model.dropout_seed += 7919 * rank
@@ -508,6 +510,8 @@ def main():
         out["auto_fallbacks_per_step"] = round(guard["fallbacks_per_step"], 3)
         # layers x passes whose attention forward kernel handed its dropout decisions to the fused backward kernel
         out["attn_keep_bits_layer_passes"] = int(model.__dict__.get("_attn_bits_passes", 0))
+        # ... and whose FFN layer 1 left the 1-bit gate of its output for the gated dX product of layer 2
+        out["ffn_gate_mask_layer_passes"] = int(model.__dict__.get("_gate_mask_passes", 0))
         out["auto_guard"] = guard
         out["communication"] = comm
         if world == 1 and not a.no_cpu_baseline:

@@ -151,7 +151,18 @@ typedef struct {
    * the error is then relative to the largest row of the operand (norm-wise over the whole product). */
   const uint32_t *a_scale; int a_scale_stride;
   const uint32_t *b_scale; int b_scale_stride;
+  /* PTAMD_EPI_GATE from ONE BIT per element instead of the [M, N] fp32 activation (exactly one of `residual` and
+   * `gate_mask` with that flag): what ptamd_gemm_hp wrote through `gate_mask_out` when it produced the activation
+   * (ptamd_gate_mask_bytes(M, N) bytes).  F16X2 / BF16X3 arithmetic, float4 epilogue (N, ldc % 4 == 0, C 16-byte
+   * aligned), split_k <= 1 and dropout_p == 0 only - PTAMD_ERR_BAD_SHAPE otherwise.  Same result, bit for bit, as gating by the activation. */
+  const uint64_t *gate_mask;
 } ptamd_gemm_args;
+/* Layout of the 1-bit gate of an [M, N] activation: entry ((cb * ceil(M / 32) + rb) * 16 + r), one uint64 = the 64 lane
+ * decisions of accumulator register r of the 32 x 32 block (rb, cb) of v_mfma_f32_32x32x*: bit l set <=> element
+ * (row 32 rb + (r & 3) + 8 (r >> 2) + 4 (l >> 5), column 32 cb + (l & 31)) is > 0.  The producing epilogue stores the
+ * ballots of its compares, the gated epilogue reads them as scalar loads and selects with them: 4 MB instead of 134 MB per
+ * layer for the hidden layer of the feed-forward block at 32 x 512 tokens (Sublayers.py:28-34, ReLU + dropout). */
+size_t ptamd_gate_mask_bytes(int M, int N);
 size_t ptamd_gemm_workspace_bytes(int M, int N, int split_k);
 int ptamd_gemm(const ptamd_gemm_args *args, void *stream);
 
@@ -244,6 +255,9 @@ typedef struct {
   void *workspace; size_t workspace_bytes;
   float gate_scale;
   int reserved_cus;
+  const uint64_t *gate_mask;   /* PTAMD_EPI_GATE from the 1-bit gate (see ptamd_gemm_args.gate_mask) */
+  uint64_t *gate_mask_out;     /* optional: the 1-bit gate "result > 0" of THIS product's output (after bias / ReLU /
+                                  dropout), ptamd_gate_mask_bytes(M, N) bytes; float4 epilogue and split_k <= 1 only */
 } ptamd_gemm_hp_args;
 size_t ptamd_gemm_hp_workspace_bytes(int M, int N, int split_k);
 int ptamd_gemm_hp(const ptamd_gemm_hp_args *args, void *stream);

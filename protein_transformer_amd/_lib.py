@@ -34,7 +34,8 @@ class GemmArgs(C.Structure):
                 ("arith", _i),
                 ("reserved_cus", _i),
                 ("a_scale", _p), ("a_scale_stride", _i),
-                ("b_scale", _p), ("b_scale_stride", _i)]
+                ("b_scale", _p), ("b_scale_stride", _i),
+                ("gate_mask", _p)]
 
 
 class WScaleJob(C.Structure):
@@ -67,7 +68,8 @@ class GemmHpArgs(C.Structure):
                 ("split_k", _i),
                 ("workspace", _p), ("workspace_bytes", _sz),
                 ("gate_scale", _f),
-                ("reserved_cus", _i)]
+                ("reserved_cus", _i),
+                ("gate_mask", _p), ("gate_mask_out", _p)]
 
 
 # name -> (restype, argtypes); mirrors include/ptamd.h one to one
@@ -89,6 +91,7 @@ SIGNATURES = {
     "ptamd_mse_angles_fwd": (_i, [_p, _p, _i64, _p, _p, _sz, _p]),
     "ptamd_mse_angles_bwd": (_i, [_p, _p, _i64, _p, _f, _i, _p, _p]),
     "ptamd_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ptamd_gate_mask_bytes": (_sz, [_i, _i]),
     "ptamd_gemm": (_i, [C.POINTER(GemmArgs), _p]),
     "ptamd_gemm_products": (_i, [C.POINTER(GemmArgs)]),
     "ptamd_gemm_group": (_i, [C.POINTER(GemmArgs), _i, _p]),

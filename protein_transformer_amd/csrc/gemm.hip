@@ -450,7 +450,10 @@ int build_params(const ptamd_gemm_args *a, GemmParams &p, int &splits, int &mode
     while (p.colsum_share * 2 <= tiles_n && p.colsum_share < 16) p.colsum_share *= 2;
   }
   if (a->colsum && !a->a_kmajor) return PTAMD_ERR_BAD_SHAPE;
-  if ((a->flags & PTAMD_EPI_GATE) && !a->residual) return PTAMD_ERR_BAD_SHAPE;
+  if ((a->flags & PTAMD_EPI_GATE) && (a->residual == nullptr) == (a->gate_mask == nullptr)) return PTAMD_ERR_BAD_SHAPE;
+  if (a->gate_mask && !(a->flags & PTAMD_EPI_GATE)) return PTAMD_ERR_BAD_SHAPE;
+  p.gate_mask = a->gate_mask; p.gate_mask_out = nullptr;
+  p.mask_rb = (a->M + 31) / 32; p.mask_cb = (a->N + 31) / 32;
   user_c = a->C;
   if (splits > 1) {
     if (!a->workspace || a->workspace_bytes < slab_bytes(a->M, a->N, splits)) return PTAMD_ERR_WORKSPACE;
@@ -459,6 +462,9 @@ int build_params(const ptamd_gemm_args *a, GemmParams &p, int &splits, int &mode
     if (a->colsum) p.colsum = p.C + (size_t)splits * p.slab;
   }
   mode = resolve_mode(a);
+  // the 1-bit gate is read in the float4 epilogue of the split-arithmetic kernels, in unsplit products
+  if (a->gate_mask && (mode == PTAMD_GEMM_F32 || mode == PTAMD_GEMM_BF16X3_FULL || !p.vec_epilogue || splits > 1 || a->dropout_p != 0.f))
+    return PTAMD_ERR_BAD_SHAPE;
   p.scale_a = p.scale_b = nullptr;
   p.scale_a_stride = p.scale_b_stride = 1;
   if (mode == PTAMD_GEMM_F16X2) {
@@ -468,6 +474,11 @@ int build_params(const ptamd_gemm_args *a, GemmParams &p, int &splits, int &mode
   return PTAMD_OK;
 }
 }  // namespace
+
+size_t ptamd_gate_mask_bytes(int M, int N) {
+  if (M <= 0 || N <= 0) return 0;
+  return (size_t)((M + 31) / 32) * ((N + 31) / 32) * 16 * sizeof(uint64_t);
+}
 
 int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
   GemmParams p;
@@ -517,7 +528,7 @@ int ptamd_gemm_group(const ptamd_gemm_args *args, int n, void *stream) {
     // what a member has to be: a k-major x k-major product (a weight gradient) in f16x2 arithmetic with the scales of both
     // operands given, written as split-K slabs (so: split_k >= 2) and accumulated into C; a bias gradient in all or in none
     if (!a->a_kmajor || !a->b_kmajor || mode != PTAMD_GEMM_F16X2 || !a->a_scale || !a->b_scale || splits < 2 ||
-        a->flags != PTAMD_EPI_ACCUM || a->bias || a->residual || a->dropout_p != 0.f || (a->N & 3) || (a->ldc & 3) ||
+        a->flags != PTAMD_EPI_ACCUM || a->bias || a->residual || a->gate_mask || a->dropout_p != 0.f || (a->N & 3) || (a->ldc & 3) ||
         !pt_aligned16(a->C) || !pt_aligned16(a->workspace) || (a->colsum != nullptr) != (args[0].colsum != nullptr) ||
         a->reserved_cus != args[0].reserved_cus)
       return PTAMD_ERR_BAD_SHAPE;

@@ -41,7 +41,29 @@ struct GemmParams {
   int scale_a_stride, scale_b_stride; // 1: one scale per operand row; 0: ONE scale for every row (a caller-provided bound; the
                                       // array then holds four copies, because row-contiguous operands load four rows' scales at once)
   int reserved_cus;  // CUs the persistent grid leaves free (room for a concurrent collective kernel); 0 = none
+  // PTAMD_EPI_GATE from a 1-bit gate instead of the [M, N] fp32 activation (include/ptamd.h, ptamd_gate_mask_bytes): entry
+  // ((cb * mask_rb + rb) * 16 + r) = the 64 lane decisions of accumulator register r of the 32 x 32 block (rb, cb) - bit l =
+  // element (row 32 rb + (r & 3) + 8 (r >> 2) + 4 (l >> 5), column 32 cb + (l & 31)) passes.  Written by the epilogue of the
+  // product whose ReLU + dropout it gates (gate_mask_out: the ballot of "result > 0"), read as scalar loads + v_cndmask.
+  const uint64_t *gate_mask;
+  uint64_t *gate_mask_out;
+  int mask_rb, mask_cb;  // 32-row / 32-column blocks of the masked matrix
 };
+// The 16 gate masks of the 32 x 32 block (rb, cb) - 128 bytes - arrive by ONE coalesced vector load: lane l holds dword
+// l & 31 (the compiler will not use scalar loads here: the kernel stores to global memory in front of them and the pointer
+// sits in a by-value struct, so it cannot prove the words unclobbered).  Register r's 64 lane decisions are then two
+// v_readlane into a scalar pair and the select is a v_cndmask on that pair.  Blocks outside the matrix read block 0:
+// nothing of them is ever stored.
+__device__ __forceinline__ uint32_t load_gate_masks(const GemmParams &p, int rb, int cb, int lane) {
+  const int rbu = __builtin_amdgcn_readfirstlane(rb), cbu = __builtin_amdgcn_readfirstlane(cb);
+  const bool in = rbu < p.mask_rb && cbu < p.mask_cb;
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(p.gate_mask + ((size_t)(in ? cbu : 0) * p.mask_rb + (in ? rbu : 0)) * 16);
+  return src[lane & 31];
+}
+__device__ __forceinline__ bool gate_keep(uint32_t masks, int r) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)masks, 2 * r), hi = (uint32_t)__builtin_amdgcn_readlane((int)masks, 2 * r + 1);
+  return __builtin_amdgcn_inverse_ballot_w64(((uint64_t)hi << 32) | lo);
+}
 
 // ---- staging: each thread carries 4 float4 per operand per stage; global -> registers -> LDS, no transposition:
 //      the LDS image keeps the operand's own contiguity and the MFMA k-assignment adapts instead
@@ -136,6 +158,12 @@ __device__ __forceinline__ void tile_epilogue_vec(const GemmParams &p, const f32
     for (int j = 0; j < 2; ++j) {
       const int col = col0 + j * 32 + l31;
       const float bias = (EPI != EPI_PLAIN && !partial && p.bias && col < p.N) ? p.bias[col] : 0.f;
+      // (uniform) the 1-bit gate of this 32 x 32 block, in the accumulator layout: scalar loads + one select per element.
+      // Compiled into the no-dropout instantiation only - a gated product has no dropout of its own, and the full one is
+      // at 256 registers
+      const bool gated = VEC && EPI == EPI_NODROP && !partial && p.gate_mask != nullptr;
+      uint32_t gm = 0;
+      if (gated) gm = load_gate_masks(p, (row0 >> 5) + i, (col0 >> 5) + j, lane);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int rowq = row0 + i * 32 + 8 * g + 4 * lh;
@@ -146,6 +174,7 @@ __device__ __forceinline__ void tile_epilogue_vec(const GemmParams &p, const f32
             v += bias;
             if (p.flags & PTAMD_EPI_RELU) v = fmaxf(v, 0.f);
             if (EPI == EPI_FULL && p.dropout_p > 0.f) v = (keep[i] >> (j * 16 + g * 4 + e)) & 1u ? v * keep_scale : 0.f;
+            if (gated) v = gate_keep(gm, g * 4 + e) ? v * p.gate_scale : 0.f;
           }
           scratch[(8 * g + 4 * lh + e) * 64 + j * 32 + l31] = v;
         }

@@ -28,6 +28,9 @@
 #include "hp_format.h"
 #include "split_bf16.h"
 
+// v_writelane_b32 through the LLVM intrinsic (no clang builtin here; as inline asm the compiler would not see its hazards)
+extern "C" __device__ int pt_llvm_amdgcn_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane");
+
 namespace pthp {
 namespace {
 
@@ -256,6 +259,7 @@ int launch_hp(const HpParams &p, int splits, hipStream_t st) {
   // loop to keep the two 32-row blocks apart - so those launches take the full instantiation, whose dropout branch is a
   // run-time no-op at p = 0: same results, no spills)
   if (p.g.vec_epilogue && !(e && e[0] == '2')) return launch_hp3<EPI == ptgemm::EPI_NODROP ? ptgemm::EPI_FULL : EPI>(p, splits, st);
+  if (p.g.gate_mask_out) return PTAMD_ERR_BAD_SHAPE;   // only the three-stage kernel's epilogue writes the 1-bit gate
   return launch_hp_g<Geom, EPI>(p, splits, st);
 }
 
@@ -339,6 +343,13 @@ __device__ __forceinline__ void hp3_epilogue(const GemmParams &p, const f32x16 (
       const int col = col0 + j * 32 + l31;
       bias[j] = (EPI != EPI_PLAIN && !partial && p.bias && col < p.N) ? p.bias[col] : 0.f;
     }
+    int mask_lo[2] = {0, 0}, mask_hi[2] = {0, 0};
+    const bool gated = EPI != EPI_PLAIN && !partial && p.gate_mask != nullptr;   // (uniform)
+    uint32_t gmk[2] = {0u, 0u};
+    if (gated) {
+      gmk[0] = ptgemm::load_gate_masks(p, (row0 >> 5) + i, col0 >> 5, lane);
+      gmk[1] = ptgemm::load_gate_masks(p, (row0 >> 5) + i, (col0 >> 5) + 1, lane);
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
 #pragma unroll
@@ -350,6 +361,12 @@ __device__ __forceinline__ void hp3_epilogue(const GemmParams &p, const f32x16 (
             v += bias[j];
             if (p.flags & PTAMD_EPI_RELU) v = fmaxf(v, 0.f);
             if (EPI == EPI_FULL && p.dropout_p > 0.f) v = (keep[i] >> (j * 16 + g * 4 + e)) & 1u ? v * keep_scale : 0.f;
+            if (gated) v = ptgemm::gate_keep(gmk[j], g * 4 + e) ? v * p.gate_scale : 0.f;
+            if (p.gate_mask_out) {   // (uniform) the decisions "result > 0" of this register: lane g * 4 + e of the block's pair
+              const uint64_t m = __builtin_amdgcn_ballot_w64(v > 0.f);
+              mask_lo[j] = pt_llvm_amdgcn_writelane((int)(uint32_t)m, g * 4 + e, mask_lo[j]);
+              mask_hi[j] = pt_llvm_amdgcn_writelane((int)(uint32_t)(m >> 32), g * 4 + e, mask_hi[j]);
+            }
           }
           scratch[(4 * lh + e) * 64 + j * 32 + l31] = v;
         }
@@ -382,6 +399,15 @@ __device__ __forceinline__ void hp3_epilogue(const GemmParams &p, const f32x16 (
           }
           *reinterpret_cast<float4 *>(C + (size_t)row * ldc + col) = v;
         }
+      }
+    }
+    if (EPI != EPI_PLAIN && !partial && p.gate_mask_out) {
+      const int rb = __builtin_amdgcn_readfirstlane((row0 >> 5) + i);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int cb = __builtin_amdgcn_readfirstlane((col0 >> 5) + j);
+        if (lane < 16 && rb < p.mask_rb && cb < p.mask_cb)
+          p.gate_mask_out[((size_t)cb * p.mask_rb + rb) * 16 + lane] = ((uint64_t)(uint32_t)mask_hi[j] << 32) | (uint32_t)mask_lo[j];
       }
     }
   }
@@ -828,7 +854,8 @@ int ptamd_gemm_hp(const ptamd_gemm_hp_args *a, void *stream) {
   if (!a->A || !a->B || !a->A_scale || !a->B_scale || !a->C) return PTAMD_ERR_BAD_SHAPE;
   if (!pt_aligned16(a->A) || !pt_aligned16(a->B)) return PTAMD_ERR_ALIGN;
   if (a->dropout_p < 0.f || a->dropout_p >= 1.f) return PTAMD_ERR_BAD_SHAPE;
-  if ((a->flags & PTAMD_EPI_GATE) && !a->residual) return PTAMD_ERR_BAD_SHAPE;
+  if ((a->flags & PTAMD_EPI_GATE) && (a->residual == nullptr) == (a->gate_mask == nullptr)) return PTAMD_ERR_BAD_SHAPE;
+  if (a->gate_mask && !(a->flags & PTAMD_EPI_GATE)) return PTAMD_ERR_BAD_SHAPE;
   HpParams p;
   GemmParams &g = p.g;
   g.M = a->M; g.N = a->N; g.K = a->K;
@@ -837,6 +864,8 @@ int ptamd_gemm_hp(const ptamd_gemm_hp_args *a, void *stream) {
   g.dropout_p = a->dropout_p; g.seed = a->seed; g.stream_id = a->stream_id; g.gate_scale = a->gate_scale;
   g.reserved_cus = a->reserved_cus;
   g.colsum = nullptr; g.colsum_share = 1; g.scale_a = g.scale_b = nullptr; g.scale_a_stride = g.scale_b_stride = 1;
+  g.gate_mask = a->gate_mask; g.gate_mask_out = a->gate_mask_out;
+  g.mask_rb = (a->M + 31) / 32; g.mask_cb = (a->N + 31) / 32;
   constexpr int HBK = 32;
   const int Kp = round_up(a->K, 32), stages = Kp / HBK;
   int splits = a->split_k > 1 ? a->split_k : 1;
@@ -861,7 +890,10 @@ int ptamd_gemm_hp(const ptamd_gemm_hp_args *a, void *stream) {
   p.a_rb_last = (round_up(a->M, 32) / 32) - 1;
   p.b_rb_last = (round_up(a->N, 32) / 32) - 1;
   hipStream_t st = (hipStream_t)stream;
-  const bool plain = !a->bias && !a->residual && !(a->flags & (PTAMD_EPI_RELU | PTAMD_EPI_TANH | PTAMD_EPI_ACCUM)) && a->dropout_p == 0.f;
+  const bool plain = !a->bias && !a->residual && !a->gate_mask && !a->gate_mask_out &&
+                     !(a->flags & (PTAMD_EPI_RELU | PTAMD_EPI_TANH | PTAMD_EPI_ACCUM)) && a->dropout_p == 0.f;
+  // the 1-bit gate (read or written) lives in the float4 epilogue of the three-stage kernel and in unsplit products only
+  if ((a->gate_mask || a->gate_mask_out) && (!g.vec_epilogue || splits > 1)) return PTAMD_ERR_BAD_SHAPE;
   int rc;
   if (plain || splits > 1) rc = launch_hp<ptgemm::EPI_PLAIN>(p, splits, st);
   else if (a->dropout_p == 0.f) rc = launch_hp<ptgemm::EPI_NODROP>(p, splits, st);

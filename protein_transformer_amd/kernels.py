@@ -22,7 +22,7 @@ GEMM_RESERVED_CUS = 0    # CUs the persistent GEMMs leave free (dp.reserve_cus_f
 
 def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, bias=None, residual=None,
          ldr=0, flags=0, dropout_p=0.0, seed=0, stream_id=0, split_k=1, colsum=None, gate_scale=0.0, arith=None,
-         a_scale=None, a_scale_stride=1, b_scale=None, b_scale_stride=1):
+         a_scale=None, a_scale_stride=1, b_scale=None, b_scale_stride=1, gate_mask=None):
     """C[M,N] = epilogue(A (*) B); operand layouts as documented in ptamd.h.  `arith`: GEMM_* constant of this call
     (None = the host-side default, `set_gemm_mode`); the library itself keeps no mode."""
     # split-K slabs and, for the f16x2 arithmetic, the row scales of the two operands
@@ -37,7 +37,8 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False,
                     colsum=colsum.data_ptr() if colsum is not None else None, gate_scale=float(gate_scale),
                     arith=int(_DEFAULT_ARITH if arith is None else arith), reserved_cus=int(GEMM_RESERVED_CUS),
                     a_scale=a_scale.data_ptr() if a_scale is not None else None, a_scale_stride=int(a_scale_stride),
-                    b_scale=b_scale.data_ptr() if b_scale is not None else None, b_scale_stride=int(b_scale_stride))
+                    b_scale=b_scale.data_ptr() if b_scale is not None else None, b_scale_stride=int(b_scale_stride),
+                    gate_mask=gate_mask.data_ptr() if gate_mask is not None else None)
     if GEMM_TIMING is None:
         check(lib().ptamd_gemm(C.byref(args), stream()), "gemm")
     else:
@@ -107,7 +108,7 @@ def hp_split(x, transposed=False, out=None):
 
 
 def gemm_hp(a, b, C_out, *, bias=None, residual=None, ldr=0, flags=0, dropout_p=0.0, seed=0, stream_id=0, split_k=1,
-            gate_scale=0.0):
+            gate_scale=0.0, gate_mask=None, gate_mask_out=None):
     """C[M,N] = epilogue(A B^T) from pre-split operands a = hp [M,K], b = hp [N,K]."""
     assert a.K == b.K
     M, N = a.rows, b.rows
@@ -119,7 +120,9 @@ def gemm_hp(a, b, C_out, *, bias=None, residual=None, ldr=0, flags=0, dropout_p=
                       dropout_p=float(dropout_p), seed=int(seed) & (2 ** 64 - 1), stream_id=int(stream_id),
                       split_k=int(split_k), workspace=ws.data_ptr() if ws is not None else None,
                       workspace_bytes=ws.numel() if ws is not None else 0, gate_scale=float(gate_scale),
-                      reserved_cus=int(GEMM_RESERVED_CUS))
+                      reserved_cus=int(GEMM_RESERVED_CUS),
+                      gate_mask=gate_mask.data_ptr() if gate_mask is not None else None,
+                      gate_mask_out=gate_mask_out.data_ptr() if gate_mask_out is not None else None)
     if GEMM_TIMING is None:
         check(lib().ptamd_gemm_hp(C.byref(args), stream()), "gemm_hp")
     else:
@@ -169,14 +172,24 @@ def linear_fwd(x, w, b, out=None, **epi):
                 split_k=pick_split_k_rows(T, N, K), **epi)
 
 
-def linear_bwd_input(dy, w, out=None, flags=0, gate=None, gate_dropout_p=0.0, arith=None, **scales):
+def gate_mask_buffer(M, N, device):
+    """Buffer for the 1-bit gate of an [M, N] activation (ptamd_gemm_hp gate_mask_out -> ptamd_gemm gate_mask)."""
+    return torch.empty(lib().ptamd_gate_mask_bytes(M, N) // 8, dtype=torch.int64, device=device)
+
+
+def linear_bwd_input(dy, w, out=None, flags=0, gate=None, gate_dropout_p=0.0, arith=None, gate_mask=None, **scales):
     """dx[T,K] = dy[T,N] w[N,K];  with `gate` (the saved output of a ReLU + dropout layer, [T,K]) the product is passed
-    through the backward of that layer in the epilogue: dx = gate > 0 ? dx / (1 - p) : 0."""
+    through the backward of that layer in the epilogue: dx = gate > 0 ? dx / (1 - p) : 0.  `gate_mask`: the same gate as one
+    bit per element (written by the product that made `gate`): read instead of `gate` where the kernel can (same bits)."""
     T, N = dy.shape
     K = w.shape[1]
     if out is None:
         out = torch.empty(T, K, dtype=torch.float32, device=dy.device)
     sk = pick_split_k_rows(T, K, N)
+    if gate_mask is not None and sk == 1 and K % 4 == 0 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0 and \
+            int(_DEFAULT_ARITH if arith is None else arith) not in (GEMM_F32, GEMM_BF16X3_FULL) and N >= 16:
+        return gemm(dy, w, out, M=T, N=K, K=N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0), b_kmajor=True, split_k=1,
+                    flags=flags | EPI_GATE, gate_mask=gate_mask, gate_scale=1.0 / (1.0 - gate_dropout_p), arith=arith, **scales)
     if gate is not None:
         return gemm(dy, w, out, M=T, N=K, K=N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0), b_kmajor=True, split_k=sk,
                     flags=flags | EPI_GATE, residual=gate, ldr=gate.stride(0), gate_scale=1.0 / (1.0 - gate_dropout_p),

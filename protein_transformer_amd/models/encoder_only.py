@@ -274,8 +274,9 @@ class _TransformerBase(nn.Module):
         self.hp_forward = True                       # FFN-layer-1 forward product on ptamd_gemm_hp from LayerNorm-written planes (read every pass)
         self.hp_qkv = True                           # ... the QKV product too (three-stage kernel of round 4)
         self.keep_attn_bits = True                   # attention dropout decisions handed from the forward to the fused backward kernel
-        self.hp_dx = False                           # dX of FFN layer 2 there too (A: planes from the fused LayerNorm backward, B: W2^T planes): built and
-                                                     # tested, measured +-0 in the step (profiles/r04/NOTES.md), off
+        self.ffn_gate_mask = True                    # FFN layer 1 leaves `f1 > 0` as 1 bit / element for the gated dX product of layer 2
+        self.hp_dx = True                            # dX of FFN layer 2 there too (A: planes from the fused LayerNorm backward, B: W2^T planes): +-0 in
+                                                     # the step while its gate was the fp32 activation, -0.06 ms with the 1-bit gate (NOTES section 12)
         self.side_stream_dw = True                   # small batches: weight-gradient products on a side stream
         self.top_layer_scales = True                 # uniform scales of the top layer's dy2 / dz1 by a pass (backward())
         self.dw_group = "auto"                       # grouping of the weight-gradient products of a layer (backward())
@@ -660,10 +661,16 @@ class _EncoderFn(torch.autograd.Function):
             s_h2 = torch.empty(Tn, dtype=torch.int32, device=x.device) if sc else None
             h2, mean2, rstd2 = K.layernorm_fwd(x2, W(b + "sublayer_connections.1.norm.weight"),
                                                W(b + "sublayer_connections.1.norm.bias"), row_scale=s_h2, planes=hplanes)
+            fmask = None
             if use_hp and not (wide is not None and wide[i, 2]):
+                # (with a backward pass to come: the epilogue also leaves "f1 > 0" as one bit per element - what the gated dX
+                # product of layer 2 reads instead of the 134 MB of f1)
+                if m.ffn_gate_mask and m.__dict__.get("_fwd_grad", False):
+                    fmask = K.gate_mask_buffer(Tn, m.dff, x.device)
+                    m.__dict__["_gate_mask_passes"] = m.__dict__.get("_gate_mask_passes", 0) + 1
                 f1 = K.gemm_hp(K.hp_view(hplanes, s_h2, Tn, D), sc["hp_1"],
                                torch.empty(Tn, m.dff, dtype=torch.float32, device=x.device), bias=W(b + "pwff.layer1.bias"),
-                               flags=K.EPI_RELU, dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_HID)
+                               flags=K.EPI_RELU, dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_HID, gate_mask_out=fmask)
             else:
                 f1 = K.linear_fwd(h2, W(b + "pwff.layer1.weight"), W(b + "pwff.layer1.bias"), flags=K.EPI_RELU,
                                   dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_HID,
@@ -673,7 +680,7 @@ class _EncoderFn(torch.autograd.Function):
                               dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_OUT,
                               **prod(i, 3, a_scale=sc["f1_scale"] if use_b else None, a_scale_stride=0 if use_b else 1,
                                      b_scale=sc and sc["rs_2"]))
-            saved.append((x, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, f1, kbits))
+            saved.append((x, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, f1, kbits, fmask))
             if measure_fwd:
                 gs = sc["guard_stats"][i]
                 K.weight_scales([dict(w=t, stats=gs[j], rows_only=True) for j, t in ((0, att), (1, f1), (3, h1), (4, h2))])
@@ -812,7 +819,7 @@ class _EncoderFn(torch.autograd.Function):
             b = f"encoder.enc_layers.{i}."
             sid = i * 8
             sc = scales[i] if scales is not None else None
-            x, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, f1, kbits = ctx.saved[i]
+            x, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, f1, kbits, fmask = ctx.saved[i]
             # x3 = x2 + drop(f1 W2^T + b2)
             if dy2 is None:
                 dy2 = K.dropout_bwd(dx, p, seed, sid + _SITE_FFN_OUT) if p > 0 else dx
@@ -833,10 +840,11 @@ class _EncoderFn(torch.autograd.Function):
             if dy2_planes is not None and have_planes and not (wide is not None and wide[i, 7]):
                 # dy2 came from the fused LayerNorm backward of the layer above together with its planes: LDS-DMA kernel
                 dz1 = K.gemm_hp(K.hp_view(dy2_planes, s_dy2, B * L, D), sc["hp_2t"],
-                                torch.empty(B * L, m.dff, dtype=torch.float32, device=dx.device), residual=f1, ldr=f1.stride(0),
-                                flags=K.EPI_GATE, gate_scale=1.0 / (1.0 - p))
+                                torch.empty(B * L, m.dff, dtype=torch.float32, device=dx.device),
+                                residual=f1 if fmask is None else None, ldr=f1.stride(0) if fmask is None else 0,
+                                gate_mask=fmask, flags=K.EPI_GATE, gate_scale=1.0 / (1.0 - p))
             else:
-                dz1 = K.linear_bwd_input(dy2, W(b + "pwff.layer2.weight"), gate=f1, gate_dropout_p=p,
+                dz1 = K.linear_bwd_input(dy2, W(b + "pwff.layer2.weight"), gate=f1, gate_dropout_p=p, gate_mask=fmask,
                                          **prod(i, 7, a_scale=s_dy2 if sc else None, b_scale=sc and sc["cs_2"]))
             if ctx.measure:     # the true maxima of the five bound-scaled operands of this layer (AutoGuard; every 16th step)
                 gs = sc["guard_stats"][i]

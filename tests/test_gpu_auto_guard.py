@@ -358,14 +358,54 @@ def test_side_stream_is_bit_identical(dev):
         grads = []
         for _ in range(3):
             train_step(model, opt, ARGS, *data)
+            # (between steps only: the AutoGuard's first measurement travels to the host asynchronously and the NEXT forward
+            # pass trusts the bound-derived scales or not by whether it has landed - a host-timing question that has nothing
+            # to do with the stream order inside a step, which is what this test is about)
+            torch.cuda.synchronize()
             grads.append(model.flat_parameters()[1].clone())
-        torch.cuda.synchronize()
         assert (model.__dict__.get("_side_stream") is not None) == side
         res.setdefault(side, []).append((grads, model.flat_parameters()[0].clone()))
     for grads, flat in res[True]:
         for a, b in zip(grads, res[False][0][0]):
             assert torch.equal(a, b)
         assert torch.equal(flat, res[False][0][1])
+
+
+def test_stored_decisions_are_bit_identical(dev):
+    """Two by-products of forward kernels replace work of backward kernels: the attention dropout decisions (keep_bits, read
+    by the fused backward kernel instead of the generator) and the 1-bit gate of the FFN hidden layer (read by the gated dX
+    product instead of the fp32 activation).  Same decisions either way: gradients and parameters bit-identical, step after
+    step, with each of them on and off - and both really in use when on."""
+    from protein_transformer_amd.optim import FusedSGD
+    from protein_transformer_amd.train import train_step
+    import os
+    res = {}
+    old = os.environ.get("PTAMD_ATTN_FUSED")
+    os.environ["PTAMD_ATTN_FUSED"] = "1"          # (8 proteins x 8 heads would take the two-kernel path)
+    try:
+        for flags in ((True, True), (False, False), (True, False), (False, True)):
+            model, batch = _setup(dev, 2, 8, 512, 2048, [512] * 8, seed=37, dropout=0.1)
+            model.keep_attn_bits, model.ffn_gate_mask = flags
+            opt = FusedSGD(model, lr=1e-3, weight_decay=10e-3)
+            data = tuple(t.to(dev) for t in batch)
+            grads = []
+            for _ in range(2):
+                train_step(model, opt, ARGS, *data)
+                torch.cuda.synchronize()      # (the AutoGuard's measurement has landed before the next pass: see above)
+                grads.append(model.flat_parameters()[1].clone())
+            assert (model.__dict__.get("_attn_bits_passes", 0) > 0) == flags[0]
+            assert (model.__dict__.get("_gate_mask_passes", 0) > 0) == flags[1]
+            res[flags] = (grads, model.flat_parameters()[0].clone())
+    finally:
+        if old is None:
+            os.environ.pop("PTAMD_ATTN_FUSED", None)
+        else:
+            os.environ["PTAMD_ATTN_FUSED"] = old
+    ref = res[(False, False)]
+    for flags, (grads, flat) in res.items():
+        for a, b in zip(grads, ref[0]):
+            assert torch.equal(a, b), flags
+        assert torch.equal(flat, ref[1]), flags
 
 
 def test_weight_gradient_grouping_modes(dev):

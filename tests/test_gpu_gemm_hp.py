@@ -182,3 +182,82 @@ def test_backward_writers_of_the_format(dev):
     b = K_.linear_bwd_input(dropped, w, gate=f1, gate_dropout_p=p, arith=K_.GEMM_F16X2)
     assert torch.equal(a == 0, b == 0)
     assert float((a - b).abs().max()) <= 3e-6 * float(b.abs().max())
+
+
+def _gate_mask_restated(y):
+    """(y > 0) of an [M, N] matrix in the layout of ptamd_gate_mask_bytes: uint64 entry ((cb * ceil(M / 32) + rb) * 16 + r),
+    bit l = element (row 32 rb + (r & 3) + 8 (r >> 2) + 4 (l >> 5), column 32 cb + (l & 31))."""
+    M, N = y.shape
+    nrb, ncb = (M + 31) // 32, (N + 31) // 32
+    pad = np.zeros((nrb * 32, ncb * 32), dtype=bool)
+    pad[:M, :N] = y > 0
+    blk = pad.reshape(nrb, 32, ncb, 32).transpose(2, 0, 1, 3)                       # [cb][rb][row][col]
+    out = np.zeros((ncb, nrb, 16), dtype=np.uint64)
+    for r in range(16):
+        for half in (0, 1):
+            row = (r & 3) + 8 * (r >> 2) + 4 * half
+            bits = (blk[:, :, row, :].astype(np.uint64) << (np.arange(32, dtype=np.uint64) + np.uint64(32 * half))).sum(-1)
+            out[:, :, r] |= bits.astype(np.uint64)
+    return out.reshape(-1)
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 256, 64), (1000, 520, 96), (256, 128, 32), (16384, 2048, 512)])
+def test_one_bit_gate_written_by_the_product_and_read_by_the_gated_one(dev, M, N, K):
+    """ptamd_gemm_hp leaves `result > 0` of its ReLU + dropout output as one bit per element (gate_mask_out); the gated dX
+    products (ptamd_gemm in f16x2 and bf16x3 arithmetic, ptamd_gemm_hp) reading that mask give the SAME BITS as the ones
+    reading the fp32 activation; the mask is the restated layout of include/ptamd.h; padding blocks are in range."""
+    from protein_transformer_amd import kernels as K_
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w, bias = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1, torch.randn(N, generator=g) * 0.1
+    A, B = K_.hp_split(x.to(dev)), K_.hp_split(w.to(dev))
+    f1 = torch.empty(M, N, device=dev)
+    f1b = torch.empty(M, N, device=dev)
+    n64 = K_.lib().ptamd_gate_mask_bytes(M, N) // 8
+    buf = torch.full((n64 + 512,), 0x1357246813572468, dtype=torch.int64, device=dev)
+    kw = dict(bias=bias.to(dev), flags=K_.EPI_RELU, dropout_p=0.1, seed=11, stream_id=3)
+    K_.gemm_hp(A, B, f1, gate_mask_out=buf[:n64], **kw)
+    K_.gemm_hp(A, B, f1b, **kw)
+    assert torch.equal(f1, f1b)                                             # the export does not touch the product
+    assert (buf[n64:] == 0x1357246813572468).all()                           # ... nor anything behind the buffer
+    want = _gate_mask_restated(f1.cpu().numpy())
+    inside = _gate_mask_restated(np.ones((M, N), dtype=np.float32))      # (bits of rows / columns past the matrix: unspecified)
+    got = buf[:n64].cpu().numpy().view(np.uint64) & inside
+    assert np.array_equal(got, want), f"{int((got != want).sum())} of {n64} mask entries differ"
+    # the gated products: dz[M, N] = (dy[M, D] W2[D, N]) * (f1 > 0) / (1 - p)
+    D = 64
+    dy, w2 = torch.randn(M, D, generator=g).to(dev), (torch.randn(D, N, generator=g) * 0.1).to(dev)
+    mask = buf[:n64]
+    for ar in (K_.GEMM_F16X2, K_.GEMM_BF16X3):
+        a = K_.linear_bwd_input(dy, w2, gate=f1, gate_dropout_p=0.1, arith=ar)
+        if K_.pick_split_k_rows(M, N, D) == 1:
+            b = K_.gemm(dy, w2, torch.empty(M, N, device=dev), M=M, N=N, K=D, lda=D, ldb=N, ldc=N, b_kmajor=True,
+                        flags=K_.EPI_GATE, gate_mask=mask, gate_scale=1.0 / 0.9, arith=ar)
+            assert torch.equal(a, b), ar
+        c = K_.linear_bwd_input(dy, w2, gate=f1, gate_dropout_p=0.1, arith=ar, gate_mask=mask)   # (falls back where it must)
+        assert torch.equal(a, c), ar
+    ref = (dy.double() @ w2.double()) * (f1 > 0) / 0.9
+    assert ((a.double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
+    Ady, Bw2 = K_.hp_split(dy), K_.hp_split(w2, transposed=True)
+    h0 = K_.gemm_hp(Ady, Bw2, torch.empty(M, N, device=dev), residual=f1, ldr=N, flags=K_.EPI_GATE, gate_scale=1.0 / 0.9)
+    h1 = K_.gemm_hp(Ady, Bw2, torch.empty(M, N, device=dev), gate_mask=mask, flags=K_.EPI_GATE, gate_scale=1.0 / 0.9)
+    assert torch.equal(h0, h1)
+
+
+def test_one_bit_gate_argument_checks(dev):
+    from protein_transformer_amd import kernels as K_
+    M, N, D = 64, 64, 32
+    dy, w2, f1 = torch.randn(M, D).to(dev), torch.randn(D, N).to(dev), torch.randn(M, N).to(dev)
+    mask = K_.gate_mask_buffer(M, N, dev)
+    mask.zero_()
+    out = torch.empty(M, N, device=dev)
+    base = dict(M=M, N=N, K=D, lda=D, ldb=N, ldc=N, b_kmajor=True, gate_scale=1.0)
+    with pytest.raises(RuntimeError):                                        # both gates
+        K_.gemm(dy, w2, out, flags=K_.EPI_GATE, gate_mask=mask, residual=f1, ldr=N, arith=K_.GEMM_F16X2, **base)
+    with pytest.raises(RuntimeError):                                        # a mask without the flag
+        K_.gemm(dy, w2, out, flags=0, gate_mask=mask, arith=K_.GEMM_F16X2, **base)
+    with pytest.raises(RuntimeError):                                        # exact-f32 arithmetic
+        K_.gemm(dy, w2, out, flags=K_.EPI_GATE, gate_mask=mask, arith=K_.GEMM_F32, **base)
+    with pytest.raises(RuntimeError):                                        # with a dropout of its own
+        K_.gemm(dy, w2, out, flags=K_.EPI_GATE, gate_mask=mask, dropout_p=0.1, arith=K_.GEMM_F16X2, **base)
+    z = K_.gemm(dy, w2, out, flags=K_.EPI_GATE, gate_mask=mask, arith=K_.GEMM_F16X2, **base)
+    assert (z == 0).all()                                                    # an all-closed gate
