@@ -153,7 +153,7 @@ typedef struct {
   const uint32_t *b_scale; int b_scale_stride;
   /* PTAMD_EPI_GATE from ONE BIT per element instead of the [M, N] fp32 activation (exactly one of `residual` and
    * `gate_mask` with that flag): what ptamd_gemm_hp wrote through `gate_mask_out` when it produced the activation
-   * (ptamd_gate_mask_bytes(M, N) bytes).  F16X2 / BF16X3 arithmetic, float4 epilogue (N, ldc % 4 == 0, C 16-byte
+   * (ptamd_gate_mask_bytes(M, N) bytes).  F16X2 arithmetic (AUTO resolves to it for K-contiguous A), float4 epilogue (N, ldc % 4 == 0, C 16-byte
    * aligned), split_k <= 1 and dropout_p == 0 only - PTAMD_ERR_BAD_SHAPE otherwise.  Same result, bit for bit, as gating by the activation. */
   const uint64_t *gate_mask;
 } ptamd_gemm_args;

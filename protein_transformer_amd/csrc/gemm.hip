@@ -462,9 +462,8 @@ int build_params(const ptamd_gemm_args *a, GemmParams &p, int &splits, int &mode
     if (a->colsum) p.colsum = p.C + (size_t)splits * p.slab;
   }
   mode = resolve_mode(a);
-  // the 1-bit gate is read in the float4 epilogue of the split-arithmetic kernels, in unsplit products
-  if (a->gate_mask && (mode == PTAMD_GEMM_F32 || mode == PTAMD_GEMM_BF16X3_FULL || !p.vec_epilogue || splits > 1 || a->dropout_p != 0.f))
-    return PTAMD_ERR_BAD_SHAPE;
+  // the 1-bit gate is read in the float4 epilogue of the f16x2 kernels, in unsplit products
+  if (a->gate_mask && (mode != PTAMD_GEMM_F16X2 || !p.vec_epilogue || splits > 1 || a->dropout_p != 0.f)) return PTAMD_ERR_BAD_SHAPE;
   p.scale_a = p.scale_b = nullptr;
   p.scale_a_stride = p.scale_b_stride = 1;
   if (mode == PTAMD_GEMM_F16X2) {

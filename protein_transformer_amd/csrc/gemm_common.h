@@ -112,7 +112,9 @@ __device__ __forceinline__ float epilogue_value(float v, int row, int col, const
 // EPI selects how much of the epilogue is compiled in (instruction-cache footprint: the generator alone is most of the
 // code): EPI_PLAIN stores the accumulators as they are, EPI_NODROP has everything but dropout, EPI_FULL everything.
 constexpr int EPI_PLAIN = 0, EPI_NODROP = 1, EPI_FULL = 2;
-template <int TI, bool VEC = true, int EPI = EPI_FULL>
+// MASK_GATE: the 1-bit gate (GemmParams::gate_mask) is compiled in - the f16x2 no-dropout instantiation of the staging
+// kernel only (the bf16x3 one sits at 256 registers: with the mask code it spilled 200 of them and ran five times slower)
+template <int TI, bool VEC = true, int EPI = EPI_FULL, bool MASK_GATE = false>
 __device__ __forceinline__ void tile_epilogue_vec(const GemmParams &p, const f32x16 (&acc)[TI][2], float *C, int ldc,
                                                   bool partial, int row0, int col0, int lane, uint32_t thr,
                                                   float keep_scale, float *scratch) {
@@ -158,10 +160,9 @@ __device__ __forceinline__ void tile_epilogue_vec(const GemmParams &p, const f32
     for (int j = 0; j < 2; ++j) {
       const int col = col0 + j * 32 + l31;
       const float bias = (EPI != EPI_PLAIN && !partial && p.bias && col < p.N) ? p.bias[col] : 0.f;
-      // (uniform) the 1-bit gate of this 32 x 32 block, in the accumulator layout: scalar loads + one select per element.
-      // Compiled into the no-dropout instantiation only - a gated product has no dropout of its own, and the full one is
-      // at 256 registers
-      const bool gated = VEC && EPI == EPI_NODROP && !partial && p.gate_mask != nullptr;
+      // (uniform) the 1-bit gate of this 32 x 32 block, applied in the accumulator layout: one coalesced load of its 16
+      // masks, two v_readlane + one select per element
+      const bool gated = VEC && MASK_GATE && !partial && p.gate_mask != nullptr;
       uint32_t gm = 0;
       if (gated) gm = load_gate_masks(p, (row0 >> 5) + i, (col0 >> 5) + j, lane);
 #pragma unroll

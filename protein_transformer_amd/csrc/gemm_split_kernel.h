@@ -559,7 +559,7 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
                 for (int j = 0; j < 2; ++j) acc[i][j][g * 4 + e] = acc[i][j][g * 4 + e] * ia * ib[j];
               }
         }
-        if (p.vec_epilogue) tile_epilogue_vec<TI, true, EPI>(p, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 2048);
+        if (p.vec_epilogue) tile_epilogue_vec<TI, true, EPI, NPROD == 3 && EPI == EPI_NODROP>(p, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 2048);
         else tile_epilogue_vec<TI, false, EPI>(p, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 2048);
         zero_acc();
         if (colsum_on(cc.it)) {  // the producers published this item's sums before the barrier above: one row per lane

@@ -227,9 +227,9 @@ def test_one_bit_gate_written_by_the_product_and_read_by_the_gated_one(dev, M, N
     D = 64
     dy, w2 = torch.randn(M, D, generator=g).to(dev), (torch.randn(D, N, generator=g) * 0.1).to(dev)
     mask = buf[:n64]
-    for ar in (K_.GEMM_F16X2, K_.GEMM_BF16X3):
+    for ar in (K_.GEMM_F16X2, K_.GEMM_AUTO, K_.GEMM_BF16X3):
         a = K_.linear_bwd_input(dy, w2, gate=f1, gate_dropout_p=0.1, arith=ar)
-        if K_.pick_split_k_rows(M, N, D) == 1:
+        if K_.pick_split_k_rows(M, N, D) == 1 and ar != K_.GEMM_BF16X3:     # (bf16x3: the wrapper gates by f1)
             b = K_.gemm(dy, w2, torch.empty(M, N, device=dev), M=M, N=N, K=D, lda=D, ldb=N, ldc=N, b_kmajor=True,
                         flags=K_.EPI_GATE, gate_mask=mask, gate_scale=1.0 / 0.9, arith=ar)
             assert torch.equal(a, b), ar
@@ -255,8 +255,9 @@ def test_one_bit_gate_argument_checks(dev):
         K_.gemm(dy, w2, out, flags=K_.EPI_GATE, gate_mask=mask, residual=f1, ldr=N, arith=K_.GEMM_F16X2, **base)
     with pytest.raises(RuntimeError):                                        # a mask without the flag
         K_.gemm(dy, w2, out, flags=0, gate_mask=mask, arith=K_.GEMM_F16X2, **base)
-    with pytest.raises(RuntimeError):                                        # exact-f32 arithmetic
-        K_.gemm(dy, w2, out, flags=K_.EPI_GATE, gate_mask=mask, arith=K_.GEMM_F32, **base)
+    for ar in (K_.GEMM_F32, K_.GEMM_BF16X3, K_.GEMM_BF16X3_FULL):
+        with pytest.raises(RuntimeError):                                    # the f16x2 kernels only
+            K_.gemm(dy, w2, out, flags=K_.EPI_GATE, gate_mask=mask, arith=ar, **base)
     with pytest.raises(RuntimeError):                                        # with a dropout of its own
         K_.gemm(dy, w2, out, flags=K_.EPI_GATE, gate_mask=mask, dropout_p=0.1, arith=K_.GEMM_F16X2, **base)
     z = K_.gemm(dy, w2, out, flags=K_.EPI_GATE, gate_mask=mask, arith=K_.GEMM_F16X2, **base)
