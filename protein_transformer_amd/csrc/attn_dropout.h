@@ -6,7 +6,8 @@
 // query per lane hold such pairs in adjacent accumulator registers, so they evaluate the hash once per two elements.
 // The drop probability is therefore quantised to thr16 / 65536 (0.1 -> 0.100006) and the kept probabilities are
 // scaled by exactly 65536 / (65536 - thr16), so the expectation is preserved.  Masks are regenerated in the backward
-// kernels instead of being stored.
+// kernels instead of being stored - except that the f16x2 forward kernel can hand its decisions (1 bit each) to the fused
+// backward kernel, which then skips the generator (attn_drop_keys_in_rows_export below); same decisions either way.
 #pragma once
 #include "common.h"
 
