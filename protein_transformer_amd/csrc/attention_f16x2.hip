@@ -958,6 +958,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float *__restrict
   }
 }
 
+template <bool BITS>   // BITS: the dropout decisions come from the forward kernel (keep_bits) - the generator is not compiled in
 __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_fused_f16x2_kernel(
     const float *__restrict__ qkv, const int64_t *__restrict__ seq, const float *__restrict__ d_o,
     const float *__restrict__ lse, const float *__restrict__ delta, int L, int H, float p_drop, uint64_t seed,
@@ -982,7 +983,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   const float ks = p_drop > 0.f ? dk_.ks : 1.f;
   const int ntiles = (L + TR - 1) / TR, nkb = (L + FK - 1) / FK;
   const int lk = (L + 31) & ~31;
-  const bool use_bits = keep_bits != nullptr && p_drop > 0.f;   // (uniform)
+  const bool use_bits = BITS && p_drop > 0.f;   // (uniform)
   const int db = 16 * (wave & 3), qb = 16 * (wave >> 2);   // this wavefront's piece of a tile's dQ^T
   auto tile = [&](int buf) __attribute__((always_inline)) { return smem + buf * BUF; };
   uint32_t my_min = 0x7F000000u;                          // smallest f16x2 scale of the dQ rows this thread published
@@ -1106,7 +1107,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       // bit (r & 3) + 8 (r >> 2) of `keepw` = register r (query qq0 + 4 lh + (r & 3) + 8 (r >> 2)) is kept: the stored word
       // shifted by the lane half, or the generator's 16 bits spread to the same positions
       uint32_t keepw;
-      if (use_bits) {
+      if (BITS) {
         keepw = kword >> (4 * lh);
       } else {
         const uint32_t kb16 = p_drop > 0.f ? attn_keep_bits_queries_in_rows_paired(dk_, (uint32_t)key, qq0, lh) : 0xffffu;
@@ -1357,14 +1358,15 @@ int launch_fused(const float *qkv, const int64_t *seq, const float *o_fwd, const
                  uint32_t *row_min, const uint32_t *keep_bits, hipStream_t st) {
   const size_t items = (size_t)B * L * H * 16;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, o_fwd, d_o, B * L, L, H, 64, delta);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_fused_f16x2_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS);
+  const bool bits = keep_bits != nullptr && p > 0.f;
+  auto kern = bits ? attn_bwd_fused_f16x2_kernel<true> : attn_bwd_fused_f16x2_kernel<false>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS);
   if (e != hipSuccess) {
     g_pt_last_hip_error = e;
     return PTAMD_ERR_HIP;
   }
-  hipLaunchKernelGGL(attn_bwd_fused_f16x2_kernel, dim3(1, H, B), dim3(512), FUSED_LDS, st, qkv, seq, d_o, lse, delta, L, H, p,
-                     seed, sid, dqkv, row_scale, row_min, keep_bits);
+  hipLaunchKernelGGL(kern, dim3(1, H, B), dim3(512), FUSED_LDS, st, qkv, seq, d_o, lse, delta, L, H, p, seed, sid, dqkv, row_scale,
+                     row_min, keep_bits);
   return pt_check_launch();
 }
 template <int DK>
