@@ -151,7 +151,11 @@ class AutoGuard:
     def submit(self, stats, ints, minbuf, layers):
         """Called at the end of a measuring backward pass: asynchronous copies of the measured maxima and of the bound /
         weight scales into pinned memory, one event behind them."""
-        host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (stats, ints, minbuf)]
+        # (the pinned buffers are kept: a measurement is only submitted once the previous one has been read, and a pinned
+        # allocation costs a few hundred microseconds of host time inside a step)
+        host = self.__dict__.get("_host")
+        if host is None or any(h.shape != t.shape or h.dtype != t.dtype for h, t in zip(host, (stats, ints, minbuf))):
+            host = self._host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (stats, ints, minbuf)]
         for h, t in zip(host, (stats, ints, minbuf)):
             h.copy_(t, non_blocking=True)
         ev = torch.cuda.Event()
