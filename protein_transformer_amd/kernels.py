@@ -187,7 +187,8 @@ def linear_bwd_input(dy, w, out=None, flags=0, gate=None, gate_dropout_p=0.0, ar
         out = torch.empty(T, K, dtype=torch.float32, device=dy.device)
     sk = pick_split_k_rows(T, K, N)
     if gate_mask is not None and sk == 1 and K % 4 == 0 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0 and \
-            int(_DEFAULT_ARITH if arith is None else arith) in (GEMM_F16X2, GEMM_AUTO) and N >= 32:
+            int(_DEFAULT_ARITH if arith is None else arith) in (GEMM_F16X2, GEMM_AUTO) and N >= 32 and \
+            dy.shape[0] * dy.stride(0) * 4 < 2 ** 32 and w.shape[0] * w.stride(0) * 4 < 2 ** 32:   # (else ptamd_gemm runs in f32)
         return gemm(dy, w, out, M=T, N=K, K=N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0), b_kmajor=True, split_k=1,
                     flags=flags | EPI_GATE, gate_mask=gate_mask, gate_scale=1.0 / (1.0 - gate_dropout_p), arith=arith, **scales)
     if gate is not None:
