@@ -362,8 +362,8 @@ int ptamd_attention_bwd(const float *qkv, const int64_t *seq, const float *out, 
                         void *workspace, size_t workspace_bytes, void *stream);
 size_t ptamd_attention_workspace_bytes(int B, int L, int H, int dk);
 size_t ptamd_attention_keep_bits_bytes(int B, int L, int H);
-/* 1 when ptamd_attention_bwd of this shape and arithmetic would read keep_bits (the one-sweep kernel: dk = 64 and enough
- * (protein, head) pairs to fill the chip), 0 when it would draw the decisions again - a caller saves the buffer then */
+/* 1 when ptamd_attention_bwd of this shape and arithmetic would read keep_bits (f16x2 arithmetic, dk 32 / 64: the one-sweep
+ * kernel or the dK / dV kernel of the two-kernel path), 0 when it would draw every decision again - a caller saves the buffer then */
 int ptamd_attention_bwd_reads_keep_bits(int B, int L, int H, int dk, int arith);
 
 /* column sums: out[N] (+)= sum_t x[t,N]   (bias gradients) */

@@ -677,11 +677,14 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2
 // dK, dV: one workgroup = 256 keys of one (protein, head); lane column = key.  The scaled K and V rows of a lane's key
 // stay in registers as B operands; Q and dO tiles of 32 queries stream through LDS and serve both as row fragments
 // (S = Q K^T, dP = dO V^T) and as transposed fragments (dK^T += Q^T dS, dV^T += dO^T Pd).
-template <int DK, int NW, int PARTS>
+// BITS: the dropout decisions are the forward kernel's (keep_bits, one word per key and 32-query tile) - the generator is
+// not compiled in (as in attn_bwd_fused_f16x2_kernel below)
+template <int DK, int NW, int PARTS, bool BITS>
 __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv_f16x2_kernel(
     const float *__restrict__ qkv, const int64_t *__restrict__ seq, const float *__restrict__ d_o,
     const float *__restrict__ lse, const float *__restrict__ delta, int L, int H, float p_drop, uint64_t seed,
-    uint32_t stream_id, float *__restrict__ dqkv, uint32_t *__restrict__ row_scale, uint32_t *__restrict__ row_min) {
+    uint32_t stream_id, float *__restrict__ dqkv, uint32_t *__restrict__ row_scale, uint32_t *__restrict__ row_min,
+    const uint32_t *__restrict__ keep_bits) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   __shared__ __attribute__((aligned(16))) float sLse[2][PARTS][TR], sDel[2][PARTS][TR];
   __shared__ __attribute__((aligned(16))) float sInvQ[2][PARTS][8], sInvG[2][PARTS][8];
@@ -699,6 +702,7 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2
   const bool k_valid = k_ok && seq[(size_t)b * L + key] != PTAMD_PAD_ID;
   constexpr int KS = DK / 16, NT = DK / 32;
   const float scale = DK == 64 ? 0.125f : 0.17677669529663687f;
+  const int lkb = (L + 31) & ~31;   // keys (and query tiles x 32) of the keep_bits layout
   const AttnDrop dk_ = make_attn_drop(seed, stream_id, (uint32_t)(b * H + h), p_drop);
   const float ks = p_drop > 0.f ? dk_.ks : 1.f;
 
@@ -754,6 +758,9 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2
         r_del[pt] = qn < L ? del_b[qn] : 0.f;
       }
     }
+    // (BITS) this lane's key against the 32 queries of the tile, bit = query: requested here, used behind the products
+    uint32_t kword = 0xffffffffu;
+    if (BITS && qq0 < lkb) kword = keep_bits[((size_t)(b * H + h) * (lkb >> 5) + (qq0 >> 5)) * lkb + min(key, lkb - 1)];
     const float4 iq4 = *reinterpret_cast<const float4 *>(&sInvQ[cur][part][4 * lh]);
     const float4 iga = *reinterpret_cast<const float4 *>(&sInvG[cur][part][0]), igb = *reinterpret_cast<const float4 *>(&sInvG[cur][part][4]);
     f32x16 s, dp;
@@ -805,7 +812,15 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2
       fp[j] = ig[j] * TWO14 * gn;  // <= 2^14
     }
     f32x16 pd;  // dropped probabilities (operand of dV), without the 1 / (1 - p): that is applied to dV at the end
-    const uint32_t keepbits = p_drop > 0.f ? attn_keep_bits_queries_in_rows_paired(dk_, (uint32_t)key, qq0, lh) : 0xffffu;
+    // bit (r & 3) + 8 (r >> 2) of `keepw` = register r is kept: the stored word shifted by the lane half, or the generator's 16
+    // bits spread to the same positions
+    uint32_t keepw;
+    if (BITS) {
+      keepw = kword >> (4 * lh);
+    } else {
+      const uint32_t kb16 = p_drop > 0.f ? attn_keep_bits_queries_in_rows_paired(dk_, (uint32_t)key, qq0, lh) : 0xffffu;
+      keepw = (kb16 & 0xfu) | ((kb16 & 0xf0u) << 4) | ((kb16 & 0xf00u) << 8) | ((kb16 & 0xf000u) << 12);
+    }
     float wmax = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -819,8 +834,8 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(2, 2
       const float p = __builtin_amdgcn_exp2f(k_valid ? fmaf(s[r], cu[j], -my_l) : -INFINITY);
       float g = dp[r] * ug[j], pk = p;
       if (p_drop > 0.f) {
-        g = keep_or_zero(g, keepbits, r);
-        pk = keep_or_zero(p, keepbits, r);
+        g = keep_or_zero(g, keepw, (r & 3) + 8 * (r >> 2));
+        pk = keep_or_zero(p, keepw, (r & 3) + 8 * (r >> 2));
       }
       pd[r] = pk;
       s[r] = p * (g - my_d) * wq[j];  // dS[q][key] / (Q group scale)
@@ -1330,12 +1345,19 @@ int launch_dq(const float *qkv, const int64_t *seq, const float *o_fwd, const fl
 }
 template <int DK, int NW, int PARTS>
 int launch_dkv(const float *qkv, const int64_t *seq, const float *d_o, const float *lse, const float *delta, int B, int L, int H,
-               float p, uint64_t seed, uint32_t sid, float *dqkv, uint32_t *row_scale, uint32_t *row_min, hipStream_t st) {
+               float p, uint64_t seed, uint32_t sid, float *dqkv, uint32_t *row_scale, uint32_t *row_min, const uint32_t *keep_bits,
+               hipStream_t st) {
   constexpr int QB = 32 * NW / PARTS;
   const dim3 grid((L + QB - 1) / QB, H, B);
-  if (int rc = set_lds(attn_bwd_dkv_f16x2_kernel<DK, NW, PARTS>, PARTS)) return rc;
-  hipLaunchKernelGGL((attn_bwd_dkv_f16x2_kernel<DK, NW, PARTS>), grid, dim3(64 * NW), PARTS * ATTN_LDS, st, qkv, seq, d_o, lse, delta,
-                     L, H, p, seed, sid, dqkv, row_scale, row_min);
+  if (keep_bits && p > 0.f) {
+    if (int rc = set_lds(attn_bwd_dkv_f16x2_kernel<DK, NW, PARTS, true>, PARTS)) return rc;
+    hipLaunchKernelGGL((attn_bwd_dkv_f16x2_kernel<DK, NW, PARTS, true>), grid, dim3(64 * NW), PARTS * ATTN_LDS, st, qkv, seq, d_o, lse,
+                       delta, L, H, p, seed, sid, dqkv, row_scale, row_min, keep_bits);
+  } else {
+    if (int rc = set_lds(attn_bwd_dkv_f16x2_kernel<DK, NW, PARTS, false>, PARTS)) return rc;
+    hipLaunchKernelGGL((attn_bwd_dkv_f16x2_kernel<DK, NW, PARTS, false>), grid, dim3(64 * NW), PARTS * ATTN_LDS, st, qkv, seq, d_o, lse,
+                       delta, L, H, p, seed, sid, dqkv, row_scale, row_min, nullptr);
+  }
   return pt_check_launch();
 }
 template <int DK>
@@ -1372,16 +1394,16 @@ int launch_fused(const float *qkv, const int64_t *seq, const float *o_fwd, const
 template <int DK>
 int bwd_by_shape(Shape sh, const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse,
                  float *delta, int B, int L, int H, float p, uint64_t seed, uint32_t sid, float *dqkv, uint32_t *row_scale,
-                 uint32_t *row_min, hipStream_t st) {
+                 uint32_t *row_min, const uint32_t *keep_bits, hipStream_t st) {
   int rc;
   if (sh == W8) rc = launch_dq<DK, 8, 1>(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
   else if (sh == W8_HALVES) rc = launch_dq<DK, 8, 2>(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
   else rc = launch_dq<DK, 4, 2>(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
   if (rc) return rc;
   const Shape kv = dkv_shape(sh);
-  if (kv == W8) return launch_dkv<DK, 8, 1>(qkv, seq, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
-  if (kv == W4) return launch_dkv<DK, 4, 1>(qkv, seq, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
-  return launch_dkv<DK, 4, 2>(qkv, seq, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
+  if (kv == W8) return launch_dkv<DK, 8, 1>(qkv, seq, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, keep_bits, st);
+  if (kv == W4) return launch_dkv<DK, 4, 1>(qkv, seq, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, keep_bits, st);
+  return launch_dkv<DK, 4, 2>(qkv, seq, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, keep_bits, st);
 }
 }  // namespace
 }  // namespace ptattn16
@@ -1394,16 +1416,17 @@ int pt_attention_fwd_f16x2(const float *qkv, const int64_t *seq, int B, int L, i
                   : fwd_by_shape<32>(sh, qkv, seq, B, L, H, p, seed, sid, out, lse, keep_bits, st);
 }
 
-bool pt_attention_bwd_f16x2_reads_keep_bits(int B, int L, int H, int dk) { return ptattn16::use_fused(B, L, H, dk); }
+// (the one-sweep kernel and, on the two-kernel path, the dK / dV kernel - both keep keys in lanes; the dQ kernel draws them)
+bool pt_attention_bwd_f16x2_reads_keep_bits(int B, int L, int H, int dk) { return B > 0 && L > 0 && H > 0 && (dk == 64 || dk == 32); }
 
 int pt_attention_bwd_f16x2(const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse,
                            float *delta, int B, int L, int H, int dk, float p, uint64_t seed, uint32_t sid, float *dqkv,
                            uint32_t *row_scale, uint32_t *row_min, const uint32_t *keep_bits, hipStream_t st) {
   using namespace ptattn16;
-  // (the forward kernel's decisions are read by the fused kernel only; the two-kernel path draws the same ones again)
+  // (the forward kernel's decisions are read by the fused kernel and by the dK / dV kernel of the two-kernel path)
   if (use_fused(B, L, H, dk))
     return launch_fused(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, keep_bits, st);
   const Shape sh = launch_shape(B, L, H);
-  return dk == 64 ? bwd_by_shape<64>(sh, qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st)
-                  : bwd_by_shape<32>(sh, qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, st);
+  return dk == 64 ? bwd_by_shape<64>(sh, qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, keep_bits, st)
+                  : bwd_by_shape<32>(sh, qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, keep_bits, st);
 }

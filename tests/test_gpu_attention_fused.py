@@ -242,7 +242,35 @@ def test_keep_bits_only_in_the_f16x2_arithmetic(dev):
         K_.attention_fwd(qd, seq, H, 0.1, 1, 1, arith=K_.GEMM_BF16X3, keep_bits=bits)
     assert K_.attention_bwd_reads_keep_bits(32, 512, 8, 64, K_.GEMM_AUTO)
     assert not K_.attention_bwd_reads_keep_bits(32, 512, 8, 64, K_.GEMM_BF16X3)
-    assert not K_.attention_bwd_reads_keep_bits(32, 512, 16, 32, K_.GEMM_AUTO)
+    assert K_.attention_bwd_reads_keep_bits(4, 512, 16, 32, K_.GEMM_AUTO)          # the dK / dV kernel of the two-kernel path
+    assert not K_.attention_bwd_reads_keep_bits(4, 512, 64, 8, K_.GEMM_AUTO)       # (head size 8: the exact-f32 kernels)
+
+
+@pytest.mark.parametrize("B,L,H,dk,lens", [(2, 320, 2, 64, [320, 283]), (4, 512, 8, 64, None), (3, 96, 8, 64, [96, 33, 1]),
+                                           (2, 256, 8, 32, [256, 200]), (16, 256, 8, 32, None), (1, 130, 1, 32, [101]),
+                                           (8, 512, 8, 64, None)])
+def test_keep_bits_on_the_two_kernel_path(dev, B, L, H, dk, lens):
+    """Small batches take dQ and dK / dV from two kernels; the dK / dV kernel (keys in lanes, like the one-sweep kernel) reads
+    the forward kernel's decisions, the dQ kernel draws them: same bits as both drawing them, for both head sizes and every
+    workgroup shape the launcher picks."""
+    from protein_transformer_amd import kernels as K_
+    p, seed, sid = 0.2, 4711, 6
+    D = H * dk
+    seq = _seq(B, L, lens if lens is not None else [L] * B, seed=9).to(dev)
+    qd = rnd((B * L, 3 * D), 51, 1.1).to(dev)
+    dout = rnd((B * L, D), 52).to(dev)
+    bits = K_.attention_keep_bits(B, L, H, dev)
+    bits.fill_(0x0F0F0F0F)
+    o, lse = K_.attention_fwd(qd, seq, H, p, seed, sid, arith=K_.GEMM_F16X2, keep_bits=bits)
+    with fused(False):
+        a = K_.attention_bwd(qd, seq, o, dout, lse, H, p, seed, sid, arith=K_.GEMM_F16X2)
+        b = K_.attention_bwd(qd, seq, o, dout, lse, H, p, seed, sid, arith=K_.GEMM_F16X2, keep_bits=bits)
+        bad = bits.clone()
+        bad[: bad.numel() // 2] = 0
+        c = K_.attention_bwd(qd, seq, o, dout, lse, H, p, seed, sid, arith=K_.GEMM_F16X2, keep_bits=bad)
+    assert torch.equal(a, b)
+    assert not torch.equal(a, c)          # the kernel really reads them
+
 
 
 def test_fused_wide_row_ranges_and_degenerate_rows(dev):
