@@ -12,11 +12,18 @@ the global batch is 32 x N; `--global-batch B` fixes the global batch instead = 
 headline).  One step = zero_grad, forward, NeRF + dRMSD loss + backward, gradient all-reduce, clip, optimizer step
 (train.train_step = reference train.py:36-46).  Prints ONE JSON line on rank 0 with
 
-  value        - residues/s of the whole job with the batches resident in HBM when the timed region starts;
-  h2d_inclusive- the same loop with every step's batch uploaded from pinned host memory inside the step (SURVEY 8d);
-  roofline     - ptamd_gemm (the dominant kernel family), timed live with HIP events on its launch stream during the
-                 timed steps: algorithmic fp32 FLOP / measured time against the f32-equivalent ceiling of the launch
-                 mix (dense f16 / bf16 MFMA peak / matrix products per fp32 product);
+  value        - residues/s of the whole job, the MEDIAN of `--passes` (3) timed passes of K steps each, every step's batch
+                 uploaded from pinned host memory inside the step by the product's own dataset.DevicePrefetcher (side
+                 stream, one batch ahead: SURVEY 8d puts the upload in the step); `resident` = one more pass with the
+                 batches already in HBM; `passes` = every pass and the spread;
+  roofline     - the DOMINANT KERNEL (largest share of the step's GEMM time; HIP events around every GEMM call on its
+                 launch stream in a pass of its own): `achieved` = algorithmic fp32 FLOP of its launches / their measured
+                 time, `peak` = the dense peak of the matrix pipe it runs on, `frac` = achieved / peak; beside it
+                 `mfma_issue_frac` (x the matrix-pipe products the arithmetic spends per fp32 product) and
+                 `emulation_ceiling_frac` (against peak / products), the same three for the whole GEMM family, and the
+                 per-kernel table (launches per step, average microseconds) to hold against profiles/;
+  strong_scaling - SURVEY 8(e)'s partitioning (global batch 32 -> 32 / N proteins per GPU): at N > 1 the same job timed with
+                 that split; at N = 1 the per-GPU steps of N = 2, 4, 8 (16, 8, 4 proteins) and the ceiling they imply;
   arithmetic_modes - ms/step of the same workload, measured in THIS run, with every GEMM / attention in bf16x3 and in
                  the exact-f32 MFMA arithmetic (the strictly fp32-grade alternatives to the default AUTO policy);
   cpu_baseline - the CPU oracle (a port of the reference's --no_cuda path) on a bounded sample of the same workload on
@@ -57,6 +64,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--passes", type=int, default=3, help="timed passes of --steps steps each; the line reports the median one")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling block (SURVEY 8e: global batch / N per GPU)")
     ap.add_argument("--config", type=int, default=4, choices=sorted(CONFIGS), help="BASELINE.json configuration (1-based)")
     ap.add_argument("--batch", type=int, default=None, help="proteins per GPU (weak scaling)")
     ap.add_argument("--global-batch", type=int, default=None, help="proteins of the whole job (strong scaling)")
@@ -266,6 +275,7 @@ def main():
     a = parse()
     from protein_transformer_amd import dp, kernels, synthetic
     from protein_transformer_amd.optim import FusedAdam, FusedSGD
+    from protein_transformer_amd.dataset import DevicePrefetcher
     from protein_transformer_amd.train import train_step
 
     dp.init_from_env()
@@ -311,9 +321,11 @@ def main():
     def step(i):
         return train_step(model, opt, args, *resident[i % nb], n_res=res_of[i % nb])
 
-    def step_h2d(i):                                                 # the batch comes from pinned host memory inside the step
-        b = tuple(t.to(dev, non_blocking=True) for t in host_batches[i % nb])
-        return train_step(model, opt, args, *b, n_res=res_of[i % nb])
+    def max_over_ranks(dt):
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t.item())
 
     def timed(fn, first_step):
         dp.barrier()
@@ -323,11 +335,26 @@ def main():
             out = fn(first_step + i)
         dp.barrier()
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if world > 1:
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        return float(t.item()), out
+        return max_over_ranks(time.perf_counter() - t0), out
+
+    def timed_upload(first_step, batches=None, proteins=None):
+        """K steps with every batch coming from pinned host memory INSIDE the step, the way train_epoch gets them
+        (train.py: dataset.DevicePrefetcher - the next batch's copy on a side stream under this step, the residue count on
+        the host).  `proteins`: only the first so many of every batch (the per-GPU share of a strongly scaled job)."""
+        src = host_batches if batches is None else batches
+        if proteins is not None:
+            src = [(s[:proteins], g[:proteins], c[:proteins]) for s, g, c in src]
+        feed = (src[(first_step + i) % len(src)] for i in range(a.steps))
+        out, n_res = None, 0
+        dp.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for seq, ang, crd, n in DevicePrefetcher(feed, dev):
+            out = train_step(model, opt, args, seq, ang, crd, n_res=n)
+            n_res += n
+        dp.barrier()
+        torch.cuda.synchronize()
+        return max_over_ranks(time.perf_counter() - t0), out, n_res
 
     who = dp.describe()                                              # backend, RCCL version, every rank's device identity
     verified = verify_dp(a, model, args, dev) if a.verify_dp else None
@@ -345,9 +372,23 @@ def main():
             e.record()          # materialise the underlying hipEvents outside the timed region
     gc.collect()
     gc.disable()                # a generation-2 collection over the event pool costs ~60 ms when it lands in the timed steps
-    dt, losses = timed(step, a.warmup)                               # THE timed region: K steps, nothing else on the host
-    n_res_timed = sum(res_of[(a.warmup + i) % nb] for i in range(a.steps))
+    # THE timed region, `--passes` times: K steps each, nothing else on the host; the line reports the median pass
+    passes = []
+    for _ in range(max(1, a.passes)):
+        d, losses, n_res_timed = timed_upload(a.warmup)
+        passes.append(d)
+    dt = sorted(passes)[len(passes) // 2]
+    dt_res, _ = timed(step, a.warmup)                                # the batches already resident in HBM (rounds 1-4's `value`)
     comm = {k: who[k] for k in ("backend", "rccl_version", "world_size", "ranks_ok", "distinct_devices", "ranks_seen") if k in who}
+    if world > 1:
+        # one step with the hooks traced: bytes of every slice handed to the all-reduce (in the order of the backward pass:
+        # output layer, encoder layers top down, front end) and the stream each reduction was issued from
+        dp.hook_trace_start()
+        step(0)
+        torch.cuda.synchronize()
+        trace = dp.hook_trace_stop()
+        comm["allreduce_bytes_per_layer"] = [t["bytes"] for t in trace]
+        comm["hooks"] = trace
     if world > 1:
         # the same K steps with two events per step around the tail wait of the gradient all-reduce: how much of the
         # reduction the overlap with backward did NOT hide (a pass of its own, like the GEMM events below)
@@ -363,7 +404,6 @@ def main():
                         "encoder layer from the backward pass, RCCL stream) after backward had been enqueued; bytes all-reduced "
                         "(+ one 19-entry fp64 vector of loss statistics)",
                 "reserved_cus": int(kernels.GEMM_RESERVED_CUS)})
-    dt_h2d, _ = timed(step_h2d, a.warmup)
     dt_inst = None
     if timing is not None:
         # the same K steps once more with two HIP events around every ptamd_gemm call (150 event records per step cost
@@ -390,6 +430,41 @@ def main():
         d, _ = timed(step, a.warmup)
         sweep["auto, timed again after the sweep"] = {"ms_per_step": round(1e3 * d / a.steps, 3),
                                                        "residues_per_s": round(world * n_res_timed / d, 1)}
+    # the reference's only parallelism is one protein per worker of a GLOBAL batch (losses.py:144-147), i.e. the
+    # global batch of the configuration split over the GPUs.  `value` above is weak scaling (the configuration's batch on every
+    # GPU); this block times the split: at N > 1 the job itself with batch / N proteins per GPU, at N = 1 the per-GPU step of
+    # N = 2, 4, 8 - what a GPU of such a job computes, without its all-reduce: the ceiling of the strong-scaling curve.
+    strong = None
+    if not a.no_strong and not a.ragged and scaling == "weak":
+        full_ms = 1e3 * dt / a.steps
+        if world > 1 and a.batch % world == 0:
+            pb = a.batch // world
+            for i in range(a.warmup):
+                timed_upload(i, proteins=pb)
+            d, _, n = timed_upload(a.warmup, proteins=pb)
+            strong = {"scaling": "strong", "global_batch": a.batch, "proteins_per_gpu": pb, "n_gpus": world,
+                      "ms_per_step": round(1e3 * d / a.steps, 3), "value": round(world * n / d, 1), "unit": "residues/s",
+                      "what": f"the same job with the configuration's global batch of {a.batch} proteins split over the {world} GPUs "
+                              f"(SURVEY 8e), gradient all-reduce included; divide by the N = 1 line's value for the speed-up"}
+        elif world == 1:
+            per = {}
+            for n_gpu in (2, 4, 8):
+                if a.batch % n_gpu:
+                    continue
+                pb = a.batch // n_gpu
+                for i in range(a.warmup):
+                    timed_upload(i, proteins=pb)
+                d, _, n = timed_upload(a.warmup, proteins=pb)
+                per[str(n_gpu)] = {"proteins_per_gpu": pb, "ms_per_step": round(1e3 * d / a.steps, 3),
+                                   "residues_per_s_per_gpu": round(n / d, 1),
+                                   "speedup_ceiling": round(full_ms / (1e3 * d / a.steps), 3)}
+            strong = {"scaling": "strong", "global_batch": a.batch, "per_gpu_step_at_n_gpus": per,
+                      "strong_scaling_ceiling_8gpu": per.get("8", {}).get("speedup_ceiling"),
+                      "what": f"ONE GPU running the per-GPU share of the configuration's global batch of {a.batch} proteins at N = 2, 4, "
+                              f"8 (SURVEY 8e); speedup_ceiling = ms({a.batch} proteins) / ms(share): what N GPUs could reach "
+                              f"if the all-reduce of the 75.75 MB gradient were free"}
+            for i in range(a.warmup):                                  # back to the full batch for whatever follows
+                step(i)
     gc.enable()
 
     # a step whose numbers are NaN runs FASTER (the matrix pipe draws less power on constant data): a throughput measured on
@@ -425,56 +500,53 @@ def main():
                                 f"correction of the guide); not measured in this run")
     roofline = None
     if timing:
-        flops = sum(t[0] for t in timing)
+        def pipe_peak_of(products):
+            return F32_MFMA_PEAK_TFLOPS if products == 1 else BF16_MFMA_PEAK_TFLOPS
+
+        def rates(entries):
+            """algorithmic fp32 TF/s, matrix-pipe TF/s issued, the pipe's dense peak and the three fractions of a set of
+            timed launches (flop, event, event, products per fp32 product, kernel)"""
+            flop = sum(t[0] for t in entries)
+            ms_ = sum(t[1].elapsed_time(t[2]) for t in entries)
+            alg = flop / (ms_ * 1e-3) / 1e12
+            issued = sum(t[0] * t[3] for t in entries) / (ms_ * 1e-3) / 1e12
+            # (a mix of pipes - only when f32-MFMA launches sit beside split ones - is priced launch by launch)
+            pipe_time = sum(t[0] * t[3] / (pipe_peak_of(t[3]) * 1e12) for t in entries)
+            ceiling = flop / pipe_time / 1e12                 # fp32-equivalent rate with the pipe at its dense peak throughout
+            peak = pipe_peak_of(max(t[3] for t in entries))
+            return {"achieved": round(alg, 2), "peak": peak, "frac": round(alg / peak, 4),
+                    "mfma_issue_tflops": round(issued, 1), "mfma_issue_frac": round(issued / peak, 4),
+                    "emulation_ceiling_tflops": round(ceiling, 1), "emulation_ceiling_frac": round(alg / ceiling, 4),
+                    "ms_per_step": round(ms_ / a.steps, 4), "launches_per_step": round(len(entries) / a.steps, 2),
+                    "avg_launch_us": round(1e3 * ms_ / len(entries), 2), "gflop_per_launch": round(flop / len(entries) / 1e9, 3)}
+
+        by_kernel = {}
+        for t in timing:
+            by_kernel.setdefault(t[4], []).append(t)
+        table = {k: rates(v) for k, v in by_kernel.items()}
+        dominant = max(table, key=lambda k: table[k]["ms_per_step"])
+        dom, fam = table[dominant], rates(timing)
         gemm_bytes = kernels.GEMM_BYTES
         ms = sum(t[1].elapsed_time(t[2]) for t in timing)
-        achieved = flops / (ms * 1e-3) / 1e12
-        # Every launch runs one fp32 product as `products` matrix-pipe products (1: f32 MFMA; 3: two f16 terms; 6 / 9:
-        # three bf16 terms).  The f32-equivalent ceiling of the launch mix is the rate at which the mix would run with
-        # the matrix pipe at its dense peak throughout: sum(flop) / sum(flop_i * products_i / pipe peak_i).
-        pipe_time = sum(t[0] * t[3] / ((F32_MFMA_PEAK_TFLOPS if t[3] == 1 else BF16_MFMA_PEAK_TFLOPS) * 1e12) for t in timing)
-        peak = flops / pipe_time / 1e12
-        issued = sum(t[0] * t[3] for t in timing) / (ms * 1e-3) / 1e12
-        by_products = {}
-        for t in timing:
-            e = by_products.setdefault(t[3], [0, 0.0, 0.0])
-            e[0] += 1; e[1] += t[0]; e[2] += t[1].elapsed_time(t[2])
-        names = {1: "exact-f32 MFMA (v_mfma_f32_32x32x2_f32)",
-                 3: "f16x2: two row-scaled f16 terms, 3 x v_mfma_f32_32x32x16_f16 per fp32 product (time includes the operand "
-                    "preparation launches of the call)",
-                 6: "bf16x3: three bf16 terms, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product",
-                 9: "bf16x3 full: three bf16 terms, all 9 products"}
-        mix = {names[k]: {"launches_per_step": round(v[0] / a.steps, 1), "tflops_f32_equivalent": round(v[1] / (v[2] * 1e-3) / 1e12, 1),
-                          "peak_f32_equivalent": round((F32_MFMA_PEAK_TFLOPS if k == 1 else BF16_MFMA_PEAK_TFLOPS) / k, 1),
-                          "ms_per_step": round(v[2] / a.steps, 3)} for k, v in sorted(by_products.items())}
-        kern = "ptamd_gemm: " + " + ".join(f"{round(v[0] / a.steps, 1)} x NPROD={k}" for k, v in sorted(by_products.items()))
-        products = issued / achieved
-        pipe_peak = BF16_MFMA_PEAK_TFLOPS if products > 1 else F32_MFMA_PEAK_TFLOPS
-        roofline = {"bound": "mfma", "kernel": kern,
-                    "achieved": round(issued, 1), "peak": pipe_peak, "unit": "TFLOP/s",
-                    "frac": round(issued / pipe_peak, 4), "traffic": traffic, "traffic_source": traffic_note,
-                    "mfma_issue_frac": round(issued / pipe_peak, 4),
-                    "algorithmic_frac_of_f32_mfma_peak": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-                    "achieved_is": "matrix-pipe FLOP ISSUED per second of GEMM kernel time: algorithmic 2*M*N*K of every launch x the "
-                                   "matrix-pipe products its arithmetic spends per fp32 product (3: two f16 terms, 6 / 9: three bf16 "
-                                   "terms, 1: f32 MFMA), HIP events around every ptamd_gemm / ptamd_gemm_hp call",
-                    "peak_is": "dense f16 / bf16 MFMA peak of MI355X (MI355X_MICROARCH.md); 157.3 when every product runs on the f32 MFMA",
-                    "f32_equivalent": {"achieved_tflops": round(achieved, 2), "ceiling_of_the_launch_mix_tflops": round(peak, 1),
-                                       "frac": round(achieved / peak, 4),
-                                       "what": "algorithmic fp32 FLOP per second, and the rate at which the launch mix would run with "
-                                               "the matrix pipe at its dense peak throughout: sum(flop) / sum(flop_i * products_i / peak)"},
-                    "launch_mix": mix,
-                    "traffic_unit": "HBM bytes per launch",
-                    "frac_is": "mfma_issue_frac = achieved / peak (the definition of rounds 3-4); rounds 1-2 printed the algorithmic fp32 "
-                               "rate, kept in f32_equivalent (and against the f32 MFMA peak in algorithmic_frac_of_f32_mfma_peak) so "
-                               "that the series stays comparable",
-                    "algorithmic_bytes_per_launch": round(sum(b for b in gemm_bytes) / max(len(gemm_bytes), 1)),
-                    "launches_per_step": round(len(timing) / a.steps, 1), "avg_launch_us": round(1e3 * ms / len(timing), 2),
-                    "gflop_per_step": round(flops / a.steps / 1e9, 1),
-                    "share_of_step_time": round(ms / (1e3 * dt_inst), 3),
-                    "measured_in": f"a second pass of the same {a.steps} steps with HIP events around every GEMM call and the "
-                                   f"weight-gradient products on the main stream ({round(1e3 * dt_inst / a.steps, 3)} ms/step in that pass; "
-                                   f"the value of this line comes from the un-instrumented pass)"}
+        roofline = {"bound": "mfma", "kernel": dominant, "unit": "TFLOP/s",
+                    "achieved": dom["achieved"], "peak": dom["peak"], "frac": dom["frac"],
+                    "mfma_issue_frac": dom["mfma_issue_frac"], "emulation_ceiling_frac": dom["emulation_ceiling_frac"],
+                    "avg_launch_us": dom["avg_launch_us"], "launches_per_step": dom["launches_per_step"],
+                    "gflop_per_launch": dom["gflop_per_launch"],
+                    "traffic": traffic, "traffic_source": traffic_note, "traffic_unit": "HBM bytes per GEMM launch (family average)",
+                    "frac_is": "achieved / peak with achieved = ALGORITHMIC fp32 FLOP (2 M N K of the dominant kernel's launches) per "
+                               "second of its measured launch time (HIP events on the launch stream) and peak = the dense peak of the "
+                               "matrix pipe it runs on (MI355X_MICROARCH.md: 2500 TF/s f16 / bf16, 157.3 f32).  The f16x2 arithmetic "
+                               "spends 3 matrix-pipe products per fp32 product: mfma_issue_frac = 3 x frac is how busy the pipe is, "
+                               "emulation_ceiling_frac = frac against peak / 3, the most a 3-product emulation can reach.  (Rounds 3-4 "
+                               "printed mfma_issue_frac of the whole family as `frac`.)",
+                    "gemm_family": {**fam, "share_of_step_time": round(ms / (1e3 * dt_inst), 3),
+                                    "algorithmic_bytes_per_launch": round(sum(gemm_bytes) / max(len(gemm_bytes), 1)),
+                                    "gflop_per_step": round(sum(t[0] for t in timing) / a.steps / 1e9, 1)},
+                    "kernels": table,
+                    "measured_in": f"a pass of its own: the same {a.steps} steps (batches resident) with two HIP events around every GEMM "
+                                   f"call and the weight-gradient products on the main stream ({round(1e3 * dt_inst / a.steps, 3)} ms/step in "
+                                   f"that pass; `value` comes from the un-instrumented passes)"}
 
     dtype = {"f32": "f32",
              "f16x2": "f32 (GEMM and attention operands scaled by powers of two and split into 2 f16 terms on the f16 MFMA pipe, "
@@ -499,9 +571,15 @@ def main():
                        "global_batch": a.batch * world, "seq_len": a.length, "parallelism": f"dp{world}",
                        "residues_per_step": round(world * n_res_timed / a.steps, 1),
                        "last_loss": {k: float(losses[k]) for k in ("drmsd-full", "lndrmsd-full", "mse-full")}},
-            "h2d_inclusive": {"value": round(world * n_res_timed / dt_h2d, 1), "ms_per_step": round(1e3 * dt_h2d / a.steps, 3),
-                              "what": "same loop, every step's batch copied from pinned host memory inside the step"},
-            "arithmetic_modes": {a.gemm_mode: {"ms_per_step": round(1e3 * dt / a.steps, 3)}, **sweep},
+            "passes": {"ms_per_step": [round(1e3 * d / a.steps, 3) for d in passes],
+                       "spread_rel": round((max(passes) - min(passes)) / dt, 4),
+                       "what": f"{len(passes)} timed passes of {a.steps} steps each, back to back; value / ms_per_step are the median pass; "
+                               f"every step's batch is uploaded from pinned host memory inside the step (dataset.DevicePrefetcher)"},
+            "resident": {"value": round(world * n_res_timed / dt_res, 1), "ms_per_step": round(1e3 * dt_res / a.steps, 3),
+                         "what": "one more pass with the batches already resident in HBM (the `value` of rounds 1-4)"},
+            "strong_scaling": strong,
+            "arithmetic_modes": {a.gemm_mode: {"ms_per_step": round(1e3 * dt_res / a.steps, 3)}, **sweep,
+                                 "what": "the same steps with the batches resident, per arithmetic (compare with `resident`)"},
             "roofline": roofline,
         }
         # the guard of AUTO's bound-derived f16x2 scales (models/encoder_only.py AutoGuard): products per step that left their

@@ -151,11 +151,40 @@ def attach(model):
 
     def hook(offset, numel):
         g = model._flat_grad
+        if HOOK_TRACE is not None:         # (bench.py: which slice left from which stream, so a first RCCL run diagnoses itself)
+            HOOK_TRACE.append(_hook_record(offset, numel, g.device))
         model._dp_pending.append(dist.all_reduce(g[offset:offset + numel], op=dist.ReduceOp.SUM, async_op=True))
 
     model.grad_hook = hook
     reserve_cus_for_collectives()
     return model
+
+
+# Hook trace (bench.py `communication.hooks`): when HOOK_TRACE is a list every gradient hook appends what it reduced and the
+# stream it was issued from - the collective orders itself behind THAT stream, so a slice that left
+# from the wrong one is the first thing to look for when `param_checksum_spread` / `--verify-dp` are not zero.
+HOOK_TRACE = None
+
+
+def _hook_record(offset, numel, device):
+    rec = {"offset": int(offset), "bytes": 4 * int(numel)}
+    if device.type == "cuda":
+        cur = torch.cuda.current_stream(device)
+        rec["stream"] = "default" if cur == torch.cuda.default_stream(device) else hex(cur.cuda_stream)
+    else:
+        rec["stream"] = "host"
+    return rec
+
+
+def hook_trace_start():
+    global HOOK_TRACE
+    HOOK_TRACE = []
+
+
+def hook_trace_stop():
+    global HOOK_TRACE
+    rec, HOOK_TRACE = HOOK_TRACE or [], None
+    return rec
 
 
 def reserve_cus_for_collectives(n=None):

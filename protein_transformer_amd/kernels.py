@@ -48,7 +48,11 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False,
         check(lib().ptamd_gemm(C.byref(args), stream()), "gemm")
         e1.record()
         # (flops, events, matrix-pipe products per fp32 product of the arithmetic this call ran in)
-        GEMM_TIMING.append((2.0 * M * N * K, e0, e1, lib().ptamd_gemm_products(C.byref(args))))
+        # (flops, events, matrix-pipe products per fp32 product of the arithmetic this call ran in, which kernel)
+        nprod = lib().ptamd_gemm_products(C.byref(args))
+        kind = "dW" if (a_kmajor and b_kmajor) else ("dX" if b_kmajor else "fwd")
+        GEMM_TIMING.append((2.0 * M * N * K, e0, e1, nprod,
+                            f"ptamd_gemm {kind} (staging kernel, A_KMAJOR={int(bool(a_kmajor))} B_KMAJOR={int(bool(b_kmajor))} NPROD={nprod})"))
         GEMM_BYTES.append(4 * (M * K + N * K + M * N * (1 + (residual is not None) + bool(flags & EPI_ACCUM))))
     return C_out
 
@@ -130,7 +134,7 @@ def gemm_hp(a, b, C_out, *, bias=None, residual=None, ldr=0, flags=0, dropout_p=
         e0.record()
         check(lib().ptamd_gemm_hp(C.byref(args), stream()), "gemm_hp")
         e1.record()
-        GEMM_TIMING.append((2.0 * M * N * a.K, e0, e1, 3))
+        GEMM_TIMING.append((2.0 * M * N * a.K, e0, e1, 3, "ptamd_gemm_hp (LDS-DMA kernel gemm_hp3_kernel, NPROD=3)"))
         GEMM_BYTES.append(4 * (M * a.K + N * a.K + M * N * (1 + (residual is not None) + bool(flags & EPI_ACCUM))))
     return C_out
 
@@ -191,6 +195,11 @@ def linear_bwd_input(dy, w, out=None, flags=0, gate=None, gate_dropout_p=0.0, ar
             dy.shape[0] * dy.stride(0) * 4 < 2 ** 32 and w.shape[0] * w.stride(0) * 4 < 2 ** 32:   # (else ptamd_gemm runs in f32)
         return gemm(dy, w, out, M=T, N=K, K=N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0), b_kmajor=True, split_k=1,
                     flags=flags | EPI_GATE, gate_mask=gate_mask, gate_scale=1.0 / (1.0 - gate_dropout_p), arith=arith, **scales)
+    if gate_mask is not None and gate is None:
+        # the 1-bit gate is only read by the unsplit f16x2 product with a float4 epilogue: without the fp32 activation to fall
+        # back on, this call would silently return an UNGATED product
+        raise ValueError("linear_bwd_input: gate_mask given, but this product cannot read it (split-K, arithmetic, alignment "
+                         "or operand size) and no fp32 `gate` was passed to fall back on")
     if gate is not None:
         return gemm(dy, w, out, M=T, N=K, K=N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0), b_kmajor=True, split_k=sk,
                     flags=flags | EPI_GATE, residual=gate, ldr=gate.stride(0), gate_scale=1.0 / (1.0 - gate_dropout_p),
@@ -256,7 +265,7 @@ def linear_bwd_weight_group(jobs, split_k):
         e0.record()
         check(lib().ptamd_gemm_group(arr, len(jobs), stream()), "gemm_group")
         e1.record()
-        GEMM_TIMING.append((flops, e0, e1, 3))
+        GEMM_TIMING.append((flops, e0, e1, 3, "ptamd_gemm_group dW (staging kernel on a group + one split-K reduce, NPROD=3)"))
         GEMM_BYTES.append(nbytes)
 
 

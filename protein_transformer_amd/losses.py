@@ -11,6 +11,7 @@ import torch
 
 from . import _lib
 from .protein.Sequence import VOCAB
+from .protein.structure_utils import get_backbone_from_full_coords  # noqa: F401  (losses.py:12: importable from here too)
 from .protein.Structure import (NUM_PREDICTED_ANGLES, NUM_PREDICTED_COORDS, SC_ANGLES_START_POS, generate_coords,
                                 nerf_backward, nerf_forward, raise_for_status)
 
@@ -115,10 +116,19 @@ def pairwise_internal_dist(x):
     return out
 
 
+def remove_sos_eos_from_input(input_seq):
+    """A sequence of integers without a leading SOS / trailing EOS id (losses.py:39-46).  With the default vocabulary
+    (no SOS / EOS characters) both ids are the unknown id 21 (protein/Sequence.py), as in the reference."""
+    start_idx = 1 if input_seq[0] == VOCAB.sos_id else 0
+    end_idx = -1 if input_seq[-1] == VOCAB.eos_id else None
+    return input_seq[start_idx:end_idx]
+
+
 def angles_to_coords(angles, seq, remove_batch_padding=False):
-    """Torsional angles -> coordinates (losses.py:101-116)."""
+    """Torsional angles -> coordinates (losses.py:99-116)."""
     if remove_batch_padding:
         seq = seq[seq.ne(VOCAB.pad_id)]
+    seq = remove_sos_eos_from_input(seq)
     angles = angles[:seq.shape[0]]
     return generate_coords(angles, seq)
 

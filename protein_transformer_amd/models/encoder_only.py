@@ -125,7 +125,15 @@ class AutoGuard:
     three-term split, no scales).  A product whose weight-scale spread exceeds `max_spread` runs in bf16x3.  UNTIL THE FIRST
     MEASUREMENT HAS LANDED NOTHING IS TRUSTED: every site is off its bound and every product counts as wide (the first step
     of a model, or the first steps while the copy is in flight, cost what the bf16x3 arithmetic costs).
-    `fallback_products` counts the products switched, per step."""
+    `fallback_products` counts the products switched, per step.
+
+    Determinism (round 5): a measurement is honoured at a FIXED forward pass - the second one after the backward pass that
+    submitted it (the next one for a measurement taken in a forward pass) - behind `event.synchronize()`, not whenever the
+    asynchronous copy happens to have landed.  By then the event is long complete (the host has waited for the loss
+    report of the step in between), so the wait costs nothing, and the step at which the arithmetic changes no longer
+    depends on host timing: identical seeds give bit-identical trajectories and data-parallel ranks switch together.
+    `reset()` (load_state_dict, a rebuilt flat buffer, in-place weight surgery) forgets everything that was measured on
+    the old weights: nothing is trusted again until a fresh measurement has been honoured."""
     SITES = ("att", "f1", "dz1", "h1", "h2")
     # products a site switches when it falls back: (activation x weight products, weight-gradient products)
     PRODUCTS = {"att": 2, "f1": 2, "dz1": 2, "h1": 1, "h2": 1}
@@ -143,14 +151,34 @@ class AutoGuard:
         self.max_spread_seen = -np.inf
         self.violations = 0                                             # bounds found BELOW the measured maximum
         self.train_steps = self.measured_steps = self.fallback_products = 0
+        self.passes = self.eval_passes = 0                              # forward passes polled / of them without a backward pass
         self._pending = None
+        self._force = False
+
+    def reset(self):
+        """The weights were replaced (load_state_dict, a new flat buffer, edits by hand): what was measured on the old ones
+        says nothing about these.  Back to the untrusting state; the next pass measures."""
+        self.off[:] = True
+        self.wide[:] = True
+        self.slack = self.spread = None
+        self.measured_steps = 0
+        self._pending = None
+        self._force = True
 
     def want_measure(self):
-        return self.enabled and self._pending is None and self.train_steps % max(self.interval, 1) == 0
+        return self.enabled and self._pending is None and (self._force or self.train_steps % max(self.interval, 1) == 0)
 
-    def submit(self, stats, ints, minbuf, layers):
-        """Called at the end of a measuring backward pass: asynchronous copies of the measured maxima and of the bound /
-        weight scales into pinned memory, one event behind them."""
+    def want_measure_forward(self):
+        """A pass that no backward pass follows (evaluation, inference): measure the four forward operands while nothing has
+        been measured on these weights, and again every `interval`-th such pass (the inputs change even if the weights do
+        not: the slack of a bound is a property of both)."""
+        return self.enabled and self._pending is None and (self._force or self.measured_steps == 0
+                                                           or self.eval_passes % max(self.interval, 1) == 0)
+
+    def submit(self, stats, ints, minbuf, layers, forward_only=False):
+        """Called at the end of a measuring backward pass (or of a measuring evaluation pass, `forward_only`): asynchronous
+        copies of the measured maxima and of the bound / weight scales into pinned memory, one event behind them; honoured
+        by `poll` at a fixed later pass."""
         # (the pinned buffers are kept: a measurement is only submitted once the previous one has been read, and a pinned
         # allocation costs a few hundred microseconds of host time inside a step)
         host = self.__dict__.get("_host")
@@ -163,13 +191,30 @@ class AutoGuard:
         # element ranges of the scales inside `ints` (views of it, see _step_scales)
         names = ("att_scale", "f1_scale", "h1_scale", "h2_scale") + tuple(w for _, w in self.WIDE)
         where = [{k: (L[k].storage_offset() - ints.storage_offset(), L[k].numel()) for k in names} for L in layers]
-        self._pending = (ev, host, where)
+        self._force = False
+        self._pending = (ev, host, where, self.passes + (1 if forward_only else 2), bool(forward_only))
+
+    def settle(self):
+        """Honour a submitted measurement NOW (waits for its event): for callers that want the steady state at a point of
+        their choosing - tests and parity records that compare "the pass after the first measurement" - instead of at the
+        pass it is due.  Deterministic like `poll`: what is applied does not depend on when it is applied.  Returns True
+        when there was one."""
+        if self._pending is None:
+            return False
+        self._apply()
+        return True
 
     def poll(self):
-        """Called at the start of every forward pass: if a measurement has landed, update the tables."""
-        if self._pending is None or not self._pending[0].query():
+        """Called at the start of every forward pass: a submitted measurement is honoured at the pass it is DUE (see the
+        class comment), behind a wait for its event - never earlier, however soon the copy landed."""
+        self.passes += 1
+        if self._pending is None or self.passes < self._pending[3]:
             return
-        _, (stats, ints, minbuf), where = self._pending
+        self._apply()
+
+    def _apply(self):
+        ev, (stats, ints, minbuf), where, _, forward_only = self._pending
+        ev.synchronize()
         self._pending = None
         mx = stats.numpy()[:, :, 2].astype(np.float64)                  # [nlayers, 5]: max |x| of att, f1, dz1, h1, h2
         bits = ints.numpy().view(np.uint32)
@@ -177,6 +222,8 @@ class AutoGuard:
         sb = np.array([[bits[where[i]["att_scale"][0]], bits[where[i]["f1_scale"][0]], mb[i, 4], bits[where[i]["h1_scale"][0]],
                         bits[where[i]["h2_scale"][0]]] for i in range(self.nlayers)], dtype=np.uint32)
         slack = self.slack_binades(mx, sb)
+        if forward_only and self.slack is not None:
+            slack[:, 2] = self.slack[:, 2]          # dz1 exists in backward passes only: keep what the last one measured
         spread = np.array([[self.spread_binades(bits[where[i][w][0]:where[i][w][0] + where[i][w][1]]) for _, w in self.WIDE]
                            for i in range(self.nlayers)])
         self.slack, self.spread = slack, spread
@@ -367,6 +414,7 @@ class _TransformerBase(nn.Module):
             self._flat_grad = torch.zeros_like(flat)
             self.__dict__.pop("_scale_caches", None)     # they hold views of the old flat buffer (keyed by its address)
             self.__dict__["_view_cache"] = {}
+            self.auto_guard.reset()                      # ... and whatever the guard measured, it measured on other weights
         gbase = self._flat_grad.data_ptr()
         for n, (off, shape) in self._layout.items():
             p = params[n]
@@ -379,6 +427,18 @@ class _TransformerBase(nn.Module):
 
     def _invalidate_flat(self):
         self.__dict__.pop("_flat_fast", None)
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        """As nn.Module.load_state_dict (the values are copied INTO the flat buffer through the parameter views); the
+        AutoGuard's trust in the bound-derived scales was earned on the old weights and is withdrawn."""
+        out = super().load_state_dict(state_dict, *args, **kwargs)
+        self.auto_guard.reset()
+        return out
+
+    def weights_changed(self):
+        """For callers that edit parameters in place outside an optimizer step (weight surgery, function-preserving
+        rescalings in tests): what the AutoGuard measured no longer describes this model."""
+        self.auto_guard.reset()
 
     def _apply(self, fn, *a, **kw):          # .to() / .cuda() / .float(): every parameter gets a new storage
         self._invalidate_flat()
@@ -506,8 +566,12 @@ class _TransformerBase(nn.Module):
         K.weight_scales(cache["wjobs"])
         K.bound_scales(cache["bjobs"])
         if cache["hp_mats"] and hp:
-            K.hp_split_rows(cache["hp_mats"], cache["hp_outs"])
-            if self.hp_dx and F % 32 == 0:
+            # (only what this pass will read: the QKV planes with `hp_qkv`, W2^T - an operand of the backward pass - when one follows)
+            if self.hp_qkv:
+                K.hp_split_rows(cache["hp_mats"], cache["hp_outs"])
+            else:
+                K.hp_split_rows(cache["hp_mats"][0::2], cache["hp_outs"][0::2])
+            if self.hp_dx and F % 32 == 0 and self.__dict__.get("_fwd_grad", False):
                 K.hp_split_cols(cache["hpT_mats"], cache["hpT_scales"], cache["hpT_outs"])
         return cache["layers"]
 
@@ -606,9 +670,8 @@ class _EncoderFn(torch.autograd.Function):
         # (below HP_MIN_TOKENS the staging GEMM with 128-row tiles is the faster of the two: profiles/r03/r03_tile_height.txt)
         want_hp = Tn >= HP_MIN_TOKENS and bool(m.hp_forward)
         scales = m._step_scales(flat, ar, p, pa, hp=want_hp)
-        # FFN layer 1 (the product behind the second LayerNorm) runs on ptamd_gemm_hp: the LayerNorm kernel writes its
-        # output a second time as pre-split planes (one buffer, consumed at once), the weights were split above.  (QKV, the
-        # product behind the first LayerNorm, is as fast on the staging GEMM since the end of round 3 and stays there.)
+        # QKV and FFN layer 1 (the products behind the two LayerNorms) run on ptamd_gemm_hp: the LayerNorm kernel writes its
+        # output a second time as pre-split planes (one buffer, consumed at once), the weights were split above.
         use_hp = want_hp and scales is not None and "hp_1" in scales[0]
         hplanes = torch.empty(K.lib().ptamd_hp_bytes(Tn, D), dtype=torch.uint8, device=x.device) if use_hp else None
         # the guard of the bound-derived scales: sites whose measured slack is too large do not use their bound (AutoGuard)
@@ -619,10 +682,13 @@ class _EncoderFn(torch.autograd.Function):
             if train and m.__dict__.get("_fwd_grad", False):          # a training step: a backward pass will follow
                 measure = guard.want_measure()
                 guard.count_step()
-        # a model that is only ever evaluated (no backward pass to measure in) takes its first measurement from a forward pass:
-        # the four forward operands (dz1 exists in backward only), so that inference does not stay on the untrusting path
-        measure_fwd = (guard is not None and not measure and guard.measured_steps == 0 and guard._pending is None
-                       and not (train and m.__dict__.get("_fwd_grad", False)))
+        # a pass that no backward pass follows (evaluation, inference) measures in the forward pass: the four forward operands
+        # (dz1 exists in backward only) - the first such pass on these weights, so that inference does not stay on the
+        # untrusting path, and every `interval`-th one after it (other inputs, same weights: the slack is a property of both)
+        measure_fwd = False
+        if guard is not None and not (train and m.__dict__.get("_fwd_grad", False)):
+            measure_fwd = guard.want_measure_forward()
+            guard.eval_passes += 1
         off = guard.off if guard is not None else None
         wide = guard.wide if guard is not None else None
         ctx_off = None if off is None else (off.copy(), wide.copy())
@@ -694,7 +760,7 @@ class _EncoderFn(torch.autograd.Function):
         if measure_fwd:
             scales[0]["guard_stats"][:, 2].zero_()                 # dz1: not measured here (slack 0 = "as good as its bound")
             scales[0]["minbuf"].fill_(0x7F000000)                  # ... and its scale slot reads "unused"
-            guard.submit(scales[0]["guard_stats"], scales[0]["ints"], scales[0]["minbuf"], scales)
+            guard.submit(scales[0]["guard_stats"], scales[0]["ints"], scales[0]["minbuf"], scales, forward_only=True)
         ctx.model, ctx.seed, ctx.seq, ctx.flat, ctx.arith, ctx.attn_arith = m, seed, seq, flat, ar, attn_default
         ctx.p, ctx.pa = p, pa
         ctx.guard, ctx.measure, ctx.off = guard, measure, ctx_off

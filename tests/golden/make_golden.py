@@ -7,6 +7,7 @@ Vector sets:
   G1 nerf            G2 generate_coords      G3 drmsd / pairwise distances
   G4 drmsd_work      G5 compute_batch_drmsd  G6 encoder forward
   G7 one train step  G8 mse_over_angles / combine   G9 dataset / batching
+  G10 conv-enc       G11 PDB writer          G12 backbone / SOS-EOS selectors
 
     python tests/golden/make_golden.py
 """
@@ -402,6 +403,28 @@ def g11(rng):
     return out
 
 
+def g12(rng):
+    """The two host-side selectors on the drop-in surface: structure_utils.get_backbone_from_full_coords (with and
+    without a batch dimension, inverted) and losses.remove_sos_eos_from_input (default vocabulary: SOS = EOS = unknown id)."""
+    from protein_transformer.protein.structure_utils import get_backbone_from_full_coords, get_sidechain_from_full_coords
+    out = {}
+    crd2 = rng.normal(0, 5, (7 * 14, 3)).astype(np.float32)
+    crd3 = rng.normal(0, 5, (3, 5 * 14, 3)).astype(np.float32)
+    out.update(crd2=crd2, crd3=crd3)
+    out["bb2"] = get_backbone_from_full_coords(crd2)
+    out["bb3"] = get_backbone_from_full_coords(crd3)
+    out["sc2"] = get_sidechain_from_full_coords(crd2)
+    out["sc3"] = get_backbone_from_full_coords(crd3, invert=True)
+    out["bb2_torch"] = get_backbone_from_full_coords(torch.tensor(crd2)).numpy()
+    seqs = [[0, 5, 7, 19], [21, 5, 7, 19], [0, 5, 7, 21], [21, 5, 7, 21], [21, 21, 3, 21]]
+    out["sos_ids"] = np.array([VOCAB.sos_id, VOCAB.eos_id])
+    for i, s in enumerate(seqs):
+        out[f"seq{i}"] = np.array(s)
+        out[f"stripped{i}"] = ref_losses.remove_sos_eos_from_input(torch.tensor(s)).numpy()
+    out["n"] = np.array(len(seqs))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=HERE)
@@ -409,7 +432,7 @@ def main():
     torch.set_num_threads(1)
     for name, fn, seed in (("g1_nerf", g1, 1), ("g2_coords", g2, 2), ("g3_drmsd", g3, 3), ("g4_drmsd_work", g4, 4),
                            ("g567_model_step", g567, 5), ("g8_mse", g8, 8), ("g9_dataset", g9, 9), ("g10_convenc", g10, 10),
-                           ("g11_pdb", g11, 11)):
+                           ("g11_pdb", g11, 11), ("g12_selectors", g12, 12)):
         data = fn(np.random.default_rng(seed))
         path = os.path.join(ns.out, name + ".npz")
         np.savez_compressed(path, **data)

@@ -135,3 +135,35 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
 def test_product_never_imports_the_oracle():
     hits = subprocess.run(["grep", "-rIn", "-E", r"^\s*(from|import)\s+oracle", PKG], capture_output=True, text=True).stdout
     assert hits.strip() == "", hits
+
+
+def integration_stub_source():
+    """The first python block of INTEGRATION.md: the reference-side binding, as printed."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = [b for b in blocks if "def batch_drmsd_and_grad" in b]
+    assert len(stub) == 1
+    return stub[0]
+
+
+def test_integration_md_stub_matches_header(built_lib):
+    """The ctypes `argtypes` INTEGRATION.md prints for the reference-side stub, against include/ptamd.h: same entry points,
+    same number and kinds of arguments (pointer / int / int64 / size_t) - without a GPU (the stub is EXECUTED on one by
+    tests/test_gpu_loss_path.py::test_integration_md_stub_runs)."""
+    src = integration_stub_source()
+    header = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    kinds = {"_p": "ptr", "_i": "int", "_sz": "size_t", "ctypes.c_int64": "int64"}
+    seen = 0
+    for name, args in re.findall(r"_lib\.(ptamd_[a-z0-9_]+)\.argtypes = \[(.*?)\]", src):
+        got = [kinds[a.strip()] for a in args.split(",")]
+        decl = re.search(r"\b" + name + r"\s*\((.*?)\)\s*;", header, flags=re.S)
+        assert decl, name
+        want = []
+        for a in decl.group(1).split(","):
+            a = " ".join(a.split())
+            want.append("ptr" if "*" in a else "int64" if a.startswith("int64_t") else "size_t" if a.startswith("size_t") else "int")
+        assert got == want, (name, got, want)
+        seen += 1
+    assert seen == 5
+    for name in re.findall(r"_lib\.(ptamd_[a-z0-9_]+)", src):
+        assert name in built_lib.SIGNATURES, name

@@ -358,3 +358,40 @@ def test_long_ragged_sequences(dev):
         assert int(stats[b, 4]) == st64[b][4] and int(stats[b, 5]) == st64[b][5]
         assert rel_l2(dang[b], g64[b].numpy()) < 1e-3
         assert np.all(dang[b, lens[b]:] == 0)
+
+
+def test_integration_md_stub_runs(golden, dev):
+    """INTEGRATION.md's reference-side binding, EXECUTED as printed: the python block is cut out of the document, pointed at
+    the in-tree library (PTAMD_LIB) and its `batch_drmsd_and_grad` run on the inputs of golden set G4 - the per-protein
+    losses and angle gradients the REFERENCE's drmsd_work returned for them (tests/golden/make_golden.py).  The stub goes
+    through the C ABI only (its own five-entry ctypes table, raw pointers): nothing of protein_transformer_amd is used."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    stub = [b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "def batch_drmsd_and_grad" in b]
+    assert len(stub) == 1
+    old = os.environ.get("PTAMD_LIB")
+    os.environ["PTAMD_LIB"] = os.path.join(root, "protein_transformer_amd", "csrc", "libptamd.so")
+    try:
+        ns = {}
+        exec(compile(stub[0], "INTEGRATION.md", "exec"), ns)
+    finally:
+        if old is None:
+            os.environ.pop("PTAMD_LIB", None)
+        else:
+            os.environ["PTAMD_LIB"] = old
+    g = golden("g4_drmsd_work")
+    ang = torch.tensor(g["pred_ang"])                                            # [4, 16, 12] radians
+    sincos = torch.stack([torch.cos(ang), torch.sin(ang)], -1).reshape(4, 16, 24).to(dev).contiguous()
+    stats, dsc = ns["batch_drmsd_and_grad"](sincos, torch.tensor(g["true_crd"]).to(dev).contiguous(),
+                                            torch.tensor(g["seq"]).to(dev).contiguous())
+    torch.cuda.synchronize()
+    stats = stats.cpu().numpy().astype(np.float64)
+    d = dsc.cpu().view(4, 16, 12, 2)
+    dang = (-torch.sin(ang) * d[..., 0] + torch.cos(ang) * d[..., 1]).numpy()   # chain rule through (cos, sin) at unit radius
+    for b in range(4):
+        vals = g[f"vals{b}"]
+        assert stats[b, 0] == approx(vals[0], rel=1e-4) and stats[b, 1] == approx(vals[1], abs=1e-6)
+        assert stats[b, 2] == approx(vals[2], rel=1e-4) and stats[b, 3] == approx(vals[3], abs=1e-6)
+        assert rel_l2(dang[b], g[f"grad{b}"]) < 1e-3, b

@@ -9,7 +9,7 @@ and inputs through the HIP path and through the fp64 evaluation of the oracle's 
     per-protein drmsd (relative) and lndrmsd (absolute) deltas,
     relative L2 error of the parameter gradient - whole vector, per parameter group, and the worst single tensor.
 
-The record is written to gpurun_out/parity/r04_parity.json (copied to profiles/r04/r04_parity.json for the judge); the test
+The record is written to gpurun_out/parity/r05_parity.json (copied to profiles/r05/r05_parity.json for the judge); the test
 asserts the section 8(d) tolerances on what it measured, per parameter GROUP for the gradients (a whole-vector norm cannot
 see a wrong gradient in a small group: LayerNorm gains, biases).
 
@@ -18,6 +18,14 @@ in the test suite, 8 in the committed record: profiles/tools/r04_parity_seeds.sh
 arithmetic, the median and the maximum of every quantity over the draws, the per-group gradient errors, the number of
 draws in which two arithmetics took different sides of a ReLU, and the SKIP RATE of ill-conditioned draws - "which
 arithmetic is closest varies by draw" as a table instead of a sentence.
+
+Round 5: two REGIMES per configuration.  "arbitrary" (rounds 3-4): a freshly initialised model with output weights
+N(0, 0.02) predicts arbitrary angles - bond angles near 0 / pi, (cos, sin) pairs of length 0.02 - and most L = 1500 draws
+are ill-conditioned for ANY fp32 chain (skip rate 0.7).  "realistic": the regime the reference trains in
+(encoder_only.py:28-34: output weight 0, bias arctanh(angle means)) - output weights N(0, 2e-3) around the arctanh of angle
+means with rotameric chi angles, so that the predicted angles stay near the truth distribution; there SURVEY 8(d) is
+asserted AS WRITTEN (coordinates 1 unit of 1e-3 A * max(1, L / 128), angles 1e-4 rad unconditionally) and the conditioning
+filter must fire in fewer than 10 % of the draws at L = 1500.  Both tables carry pass / fail counts against both bars.
 
 Configs 3-5 are run on a 4-protein slice of their batch at full model size and full length: every quantity here is a
 per-protein quantity (losses, coordinates) or a sum over proteins (gradient), and the fp64 oracle step on the CPU is what
@@ -34,8 +42,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.environ.get("PTAMD_PARITY_OUT", os.path.join(ROOT, "gpurun_out", "parity", "r04_parity.json"))
+OUT = os.environ.get("PTAMD_PARITY_OUT", os.path.join(ROOT, "gpurun_out", "parity", "r05_parity.json"))
 N_DRAWS = int(os.environ.get("PTAMD_PARITY_SEEDS", "2"))
+N_DRAWS_REALISTIC = int(os.environ.get("PTAMD_PARITY_SEEDS_REALISTIC", "1"))
+N_CONDITIONING_PROBES = int(os.environ.get("PTAMD_PARITY_PROBES", "12"))     # draws the skip rate of the realistic regime is taken over
 
 # (BASELINE config number, model string, d_model, layers, heads, d_ff, lengths of the proteins run here, loss)
 CASES = [
@@ -62,7 +72,20 @@ def _group(name):
     return "ffn." + ("weight" if name.endswith("weight") else "bias")
 
 
-def _make_model(dev, model, dm, nl, nh, dff, L, am, seed):
+def realistic_angle_means(seed=0, n=8192):
+    """Mean (cos, sin) of the 12 angles for the REALISTIC regime: backbone as synthetic.sample_angles, chi angles rotameric
+    (wells at -60 / 180 / +60 degrees with weights 0.5 / 0.35 / 0.15, sigma 0.25 rad - what side chains do) instead of
+    uniform: a uniform chi has a mean (cos, sin) of length ~0.02, and the atan2 of a pair that short amplifies the 1e-5
+    prediction tolerance to 5e-4 rad in any fp32 chain; rotameric ones give 0.3 - 0.5, as ProteinNet's do."""
+    from protein_transformer_amd import synthetic
+    rng = np.random.default_rng(424242 + seed)
+    a = synthetic.sample_angles(rng, n).astype(np.float64)
+    wells = rng.choice(np.array([-np.pi / 3, np.pi, np.pi / 3]), size=(n, 6), p=[0.5, 0.35, 0.15])
+    a[:, 6:] = wells + rng.normal(0, 0.25, (n, 6))
+    return np.stack([np.cos(a), np.sin(a)], -1).reshape(n, 24).mean(0)
+
+
+def _make_model(dev, model, dm, nl, nh, dff, L, am, seed, out_std=0.02):
     from protein_transformer_amd.models.convolutional_encoder import ConvEncoderOnlyTransformer
     from protein_transformer_amd.models.encoder_only import EncoderOnlyTransformer
     from protein_transformer_amd.protein.Sequence import VOCAB
@@ -77,7 +100,7 @@ def _make_model(dev, model, dm, nl, nh, dff, L, am, seed):
     m = m.to(dev).train()
     with torch.no_grad():      # off the zero init of the output layer and off the trivial LayerNorm parameters
         P = dict(m.named_parameters())
-        P["output_projection.weight"].normal_(0, 0.02)
+        P["output_projection.weight"].normal_(0, out_std)
         for n, p in P.items():
             if "norm.weight" in n:
                 p.add_(0.1 * torch.randn_like(p))
@@ -91,8 +114,9 @@ def _angle_delta(a, b):
     return np.minimum(d, 2 * np.pi - d)
 
 
-def _run_draw(case, draw):
-    """One independent draw (model initialisation + batch) of one configuration -> its record (dict)."""
+def _run_draw(case, draw, regime="arbitrary", probe_only=0):
+    """One independent draw (model initialisation + batch) of one configuration -> its record (dict).  `regime`: see the
+    module docstring.  `probe_only` = n: only the conditioning filter, on n consecutive candidate draws -> (skipped, n)."""
     from oracle import batched as obat
     from oracle import encoder as oenc
     from protein_transformer_amd import kernels as K_
@@ -121,12 +145,15 @@ def _run_draw(case, draw):
     # and the oracle's fp32 chain 1 - 4e-3 A off from there to the end of the chain.)
     skipped = []
     gen = torch.Generator().manual_seed(1234 + cfg + 7919 * draw)
-    for attempt in range(32):     # (L = 1500 chains of a random-init model: most draws hold a near-straight bond angle somewhere)
-        seed = 100 + cfg + 1000 * attempt + 100000 * draw
+    realistic = regime == "realistic"
+    n_probe_skipped = 0
+    for attempt in range(max(32, probe_only)):     # (L = 1500 chains of a random-init model: most draws hold a near-straight bond angle somewhere)
+        seed = 100 + cfg + 1000 * attempt + 100000 * draw + (50000 if realistic else 0)
         batch = synthetic.make_batch(lens, L_pad=L, seed=seed, build_coords=build, frac_missing=0.02)
         seq, ang, crd = (batch[k].to(dev) for k in ("seq", "true_ang", "true_crd"))
-        model = _make_model(dev, model_s, dm, nl, nh, dff, L, synthetic.angle_means(batch["true_ang"]),
-                            seed=7 + cfg + attempt + 131 * draw)
+        am = realistic_angle_means(seed) if realistic else synthetic.angle_means(batch["true_ang"])
+        model = _make_model(dev, model_s, dm, nl, nh, dff, L, am, seed=7 + cfg + attempt + 131 * draw,
+                            out_std=2e-3 if realistic else 0.02)
         rad_probe = angles_forward(model(seq, ang).detach()).cpu().double()
         # three backbone atoms within 5e-4 rad of a straight line (angles 3..5 = N-CA-C, CA-C-N, C-N-CA): the direction of the
         # 1e-4 A component that defines the next frame is then at the mercy of the 1e-7 A rounding of the coordinates
@@ -134,11 +161,19 @@ def _run_draw(case, draw):
         sin_bond = np.array([np.abs(np.sin(rad_probe[b, :n, 3:6].numpy())).min() for b, n in enumerate(lens)])
         if sin_bond.min() < 5e-4:
             skipped.append({"seed": seed, "smallest_abs_sin_of_a_backbone_bond_angle": [float(x) for x in sin_bond]})
+            n_probe_skipped += 1
+            if probe_only and attempt + 1 == probe_only:
+                return n_probe_skipped, probe_only
             continue
         c64 = obat.generate_coords_batched(rad_probe, seq.cpu(), torch.float64).numpy()
         sign = torch.randint(0, 2, rad_probe.shape, generator=gen).double() * 2 - 1
         c64p = obat.generate_coords_batched(rad_probe + 6e-8 * sign, seq.cpu(), torch.float64).numpy()
         resp = np.array([np.abs(c64p[b, :n * 14] - c64[b, :n * 14]).max() for b, n in enumerate(lens)]) / coord_unit
+        if probe_only:
+            n_probe_skipped += int(resp.max() > 1.0)
+            if attempt + 1 == probe_only:
+                return n_probe_skipped, probe_only
+            continue
         if resp.max() <= 1.0:
             break
         skipped.append({"seed": seed, "response_to_6e-8_rad_on_every_angle_units": [float(x) for x in resp],
@@ -161,7 +196,9 @@ def _run_draw(case, draw):
 
     rec = {"config": cfg, "model": f"{model_s} d_model={dm} n_layers={nl} n_head={nh} d_ff={dff}", "lengths": lens,
            "loss": loss, "dropout": 0.0, "reference": "fp64 evaluation of the oracle (oracle.encoder + oracle.batched)",
-           "seed": seed, "draw": draw, "skipped_draws": skipped, "modes": {}}
+           "seed": seed, "draw": draw, "skipped_draws": skipped, "modes": {}, "regime": regime,
+           "output_weight_std": 2e-3 if realistic else 0.02,
+           "smallest_radius_of_a_predicted_cos_sin_pair": float(np.where(mask[:, :, None], radius64, np.inf).min())}
     old = K_.get_gemm_mode()
     # AUTO is recorded as the arithmetic the BENCH workloads of configs 2-5 run in (f16x2 with the guard): the 4-protein slices
     # here are below the tokens x d_model threshold at which AUTO leaves bf16x3 (config 1's real workload is below it too)
@@ -192,7 +229,7 @@ def _run_draw(case, draw):
                 model.auto_guard.interval = 1
                 model.zero_grad()
                 get_losses(args, model(seq, ang), ang, crd, seq)
-                torch.cuda.synchronize()
+                model.auto_guard.settle()
             model.zero_grad()
             pred = model(seq, ang)
             gates[mode] = []
@@ -288,10 +325,33 @@ def _aggregate(draws):
     return out
 
 
+def _bars(draws):
+    """Pass / fail counts of (draw, arithmetic) pairs against the two coordinate / angle bars: SURVEY 8(d) as written
+    (coordinates within ONE unit of 1e-3 A * max(1, L / 128) for every protein, angles within 1e-4 rad unconditionally) and
+    the relaxed bar of rounds 3-4 (2 units or 3 x the drift of the reference's own fp32 chain; 1e-4 rad where the predicted
+    (cos, sin) pair is >= 0.1 long)."""
+    out = {}
+    for m in MODES:
+        c_strict = c_relaxed = a_strict = a_relaxed = 0
+        for d in draws:
+            r = d["modes"][m]
+            dev_u, ref_u = r["coord_over_1e-3A_times_max(1,L/128)"], r["coord_oracle_fp32_over_same_unit"]
+            c_strict += all(u < 1.0 for u in dev_u)
+            c_relaxed += all(u < max(2.0, 3.0 * q) for u, q in zip(dev_u, ref_u))
+            a_strict += r["angle_max_abs_rad_end_to_end"] < 1e-4
+            a_relaxed += r["angle_max_abs_rad_end_to_end_where_radius_ge_0.1"] < 1e-4 and r["angle_error_times_radius_max"] < 1.5e-5
+        n = len(draws)
+        out[m] = {"draws": n, "coords_survey_8d_as_written_pass": int(c_strict), "coords_relaxed_pass": int(c_relaxed),
+                  "angles_survey_8d_as_written_pass": int(a_strict), "angles_relaxed_pass": int(a_relaxed)}
+    return out
+
+
+@pytest.mark.parametrize("regime", ["arbitrary", "realistic"])
 @pytest.mark.parametrize("case", CASES, ids=[f"config{c[0]}" for c in CASES])
-def test_parity_record(case):
+def test_parity_record(case, regime):
     cfg = case[0]
-    draws = [_run_draw(case, d) for d in range(N_DRAWS)]
+    realistic = regime == "realistic"
+    draws = [_run_draw(case, d, regime) for d in range(N_DRAWS_REALISTIC if realistic else N_DRAWS)]
     n_skipped = sum(len(d["skipped_draws"]) for d in draws)
     flip_draws = {k: sum(1 for d in draws if sum(d["relu_gate_differences_per_layer"][k]) > 0)
                   for k in draws[0]["relu_gate_differences_per_layer"]}
@@ -299,33 +359,49 @@ def test_parity_record(case):
     closest = {m: 0 for m in MODES}
     for d in draws:
         closest[min(MODES, key=lambda m: d["modes"][m]["grad_rel_l2"])] += 1
-    rec = {"config": cfg, "model": draws[0]["model"], "lengths": draws[0]["lengths"], "loss": draws[0]["loss"], "dropout": 0.0,
-           "reference": draws[0]["reference"], "draws": len(draws),
+    rec = {"config": cfg, "regime": regime, "model": draws[0]["model"], "lengths": draws[0]["lengths"], "loss": draws[0]["loss"],
+           "dropout": 0.0, "reference": draws[0]["reference"], "draws": len(draws),
            "ill_conditioned_draws_skipped": n_skipped, "skip_rate": n_skipped / (n_skipped + len(draws)),
            "summary_over_draws": _aggregate(draws), "draws_with_relu_gate_differences": flip_draws,
+           "bars": _bars(draws),
            "proteins_beyond_2_units": {m: sum(sum(1 for u in d["modes"][m]["coord_over_1e-3A_times_max(1,L/128)"] if u >= 2.0) for d in draws)
                                        for m in MODES},
            "auto_guard_per_draw": [d.get("auto_guard") for d in draws],
            "draws_in_which_the_arithmetic_is_closest_to_fp64_in_grad_rel_l2": closest, "per_draw": draws}
+    if realistic:
+        # the conditioning filter over a fixed number of candidate draws (cheap: a forward pass and two fp64 builds each): in
+        # the regime the reference trains in it must almost never fire, also at L = 1500
+        sk, n = _run_draw(case, 1000, regime, probe_only=N_CONDITIONING_PROBES)
+        rec["conditioning_probe"] = {"candidate_draws": n, "ill_conditioned": sk, "skip_rate": sk / n}
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     allrec = {}
     if os.path.exists(OUT):
         with open(OUT) as f:
             allrec = json.load(f)
-    allrec[f"config{cfg}"] = rec
+    allrec[f"config{cfg}" + ("_realistic" if realistic else "")] = rec
     with open(OUT, "w") as f:
         json.dump(allrec, f, indent=1, sort_keys=True)
     print(json.dumps(rec["summary_over_draws"]["auto"], indent=1))
+    print(json.dumps(rec["bars"]))
     for d in draws:
         _assert_draw(d)
+    if realistic:
+        assert rec["conditioning_probe"]["skip_rate"] < 0.1, rec["conditioning_probe"]
+        assert n_skipped == 0 or rec["skip_rate"] < 0.5, rec["skip_rate"]
 
 
 def _assert_draw(rec):
     flips = rec["relu_gate_differences_per_layer"]
+    realistic = rec.get("regime") == "realistic"
     # ---- SURVEY 8(d) tolerances on the measured numbers, every arithmetic
     for mode, m in rec["modes"].items():
         assert m["pred_max_abs"] < 1e-5, (mode, m["pred_max_abs"])
         assert m["angle_max_abs_rad_given_identical_encoder_output"] < 1e-6, mode
+        if realistic:
+            # the regime the reference trains in: SURVEY 8(d) AS WRITTEN - angles within 1e-4 rad whatever the length of the
+            # predicted pair, coordinates of every protein within ONE unit of 1e-3 A * max(1, L / 128) of the fp64 build
+            assert m["angle_max_abs_rad_end_to_end"] < 1e-4, (mode, m["angle_max_abs_rad_end_to_end"])
+            assert all(u < 1.0 for u in m["coord_over_1e-3A_times_max(1,L/128)"]), (mode, m["coord_over_1e-3A_times_max(1,L/128)"])
         # An angle is atan2 of a predicted (cos, sin) pair of length r: a prediction error e (tolerance 1e-5) turns the angle
         # by e / r.  1e-4 rad is asserted where r >= 0.1 (where the prediction tolerance implies it); a random-init model also
         # predicts pairs of length 0.02 - 0.03, whose angle moves by 1e-4 under the fp32 rounding of ANY chain (recorded:

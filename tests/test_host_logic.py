@@ -197,3 +197,26 @@ def test_auto_guard_slack_arithmetic():
     # spread of a weight's row scales along a contracted index: exponents 100..112 -> 12 binades; zero rows do not count
     bits = np.array([100 << 23, 112 << 23, 105 << 23, 254 << 23], dtype=np.uint32)
     assert AutoGuard.spread_binades(bits) == 12.0 and AutoGuard.spread_binades(bits[3:]) == 0.0
+
+
+def test_selectors_golden(golden):
+    """The two host-side selectors callers of the loss path import (structure_utils.py:19-41, losses.py:39-46) against what
+    the reference returns (G12); `import protein_transformer_amd as protein_transformer` must resolve both names."""
+    from protein_transformer_amd import losses
+    from protein_transformer_amd.protein.structure_utils import get_backbone_from_full_coords, get_sidechain_from_full_coords
+    g = golden("g12_selectors")
+    assert losses.get_backbone_from_full_coords is get_backbone_from_full_coords     # losses.py:12 imports it by name
+    for nd in ("2", "3"):
+        crd = g["crd" + nd]
+        assert np.array_equal(get_backbone_from_full_coords(crd), g["bb" + nd])
+        assert np.array_equal(get_sidechain_from_full_coords(crd), g["sc" + nd])
+        assert np.array_equal(get_backbone_from_full_coords(crd, invert=True), g["sc" + nd])
+        t = torch.tensor(crd)
+        assert np.array_equal(get_backbone_from_full_coords(t).numpy(), g["bb" + nd])
+        assert np.array_equal(get_sidechain_from_full_coords(t).numpy(), g["sc" + nd])
+    assert np.array_equal(g["bb2_torch"], g["bb2"])
+    assert list(g["sos_ids"]) == [VOCAB.sos_id, VOCAB.eos_id]
+    for i in range(int(g["n"])):
+        for make in (torch.tensor, np.array, list):
+            got = losses.remove_sos_eos_from_input(make(g[f"seq{i}"].tolist()))
+            assert list(np.asarray(got)) == list(g[f"stripped{i}"])
