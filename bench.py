@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--passes", type=int, default=3, help="timed passes of --steps steps each; the line reports the median one")
+    ap.add_argument("--passes", type=int, default=5, help="timed passes of --steps steps each; the line reports the median one")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling block (SURVEY 8e: global batch / N per GPU)")
     ap.add_argument("--config", type=int, default=4, choices=sorted(CONFIGS), help="BASELINE.json configuration (1-based)")
     ap.add_argument("--batch", type=int, default=None, help="proteins per GPU (weak scaling)")
@@ -93,6 +93,7 @@ def parse():
     ap.add_argument("--no-top-layer-scales", action="store_true", help="ablation: the top layer's FFN weight-gradient products in bf16x3 (no pass over its dy2)")
     ap.add_argument("--dw-group", default="auto", choices=["auto", "pairs", "layer", "off"],
                     help="grouping of the weight-gradient products of a layer (ptamd_gemm_group); off = one by one (ablation)")
+    ap.add_argument("--no-weights-prep", action="store_true", help="ablation: scales / bounds / planes of the weights by the separate launches of rounds 2-4 in front of every forward pass instead of inside the optimizer step (csrc/wprep.hip)")
     ap.add_argument("--no-hp-dx", action="store_true", help="ablation: dX of FFN layer 2 on the staging kernel instead of ptamd_gemm_hp")
     ap.add_argument("--attn-mode", default=None, choices=["f32", "bf16x3", "f16x2"],
                     help="arithmetic of the attention kernels alone (ablation; default: that of --gemm-mode)")
@@ -311,6 +312,7 @@ def main():
     model.ffn_gate_mask = not a.no_ffn_gate_mask
     model.dw_group = a.dw_group
     model.top_layer_scales = not a.no_top_layer_scales
+    model.weights_prep = not a.no_weights_prep
     model.dropout_seed += 7919 * rank
     dp.attach(model)
     opt = (FusedAdam(model, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=10e-3) if a.optimizer == "adam"
@@ -590,6 +592,9 @@ def main():
         out["attn_keep_bits_layer_passes"] = int(model.__dict__.get("_attn_bits_passes", 0))
         # ... and whose FFN layer 1 left the 1-bit gate of its output for the gated dX product of layer 2
         out["ffn_gate_mask_layer_passes"] = int(model.__dict__.get("_gate_mask_passes", 0))
+        # forward passes that had to prepare the weights' scales / bounds / planes themselves (the others found them left behind
+        # by the optimizer step: csrc/wprep.hip)
+        out["weights_prep_launches"] = int(model.__dict__.get("_prep_launches", 0))
         out["auto_guard"] = guard
         out["communication"] = comm
         if world == 1 and not a.no_cpu_baseline:

@@ -289,6 +289,71 @@ typedef struct {
 } ptamd_bound_job;
 int ptamd_bound_scales(const ptamd_bound_job *jobs_host, int njobs, void *stream);
 
+/* ------------------------------------------------------------------ the weights of a step in ONE pass (csrc/wprep.hip)
+ * ptamd_weights_prep: what ptamd_weight_scales + ptamd_bound_scales + ptamd_hp_split_rows + ptamd_hp_split_cols compute for
+ *   the weight matrices of a model (row / column f16x2 scales, statistics, weight-derived bounds, W as hp planes, W^T as hp
+ *   planes) in two launches and one read of the weights; same bits.
+ * ptamd_sgd_step_prep / ptamd_adam_step_prep: ptamd_sgd_step / ptamd_adam_step (clip + optimizer.step(), train.py:41-46,
+ *   371-381) that leave all of that behind for the NEXT forward pass, in the pass that writes the weights anyway.
+ * The description of the model is a PLAN whose tables live in DEVICE memory (built once by the caller):
+ *   segs        the listed matrices (or vectors, rows = 1) of the flat parameter buffer, K-contiguous, row stride = cols,
+ *               cols % 4 == 0 and cols <= 2048; pairwise disjoint;
+ *   blocks_a    [nblocks_a][2] int32: (segment, block of 32 rows inside it) for the first nblocks_a_matrices entries, then
+ *               (-(range + 1), block of ptamd_wprep_plain_floats_per_block() floats inside plain range `range`): the plain
+ *               ranges [nplain][2] int64 (first element, elements) cover everything that is not a segment - segments + plain
+ *               ranges partition [0, numel);
+ *   blocks_b    [nblocks_b][4] int32: (0, segment, block of 2048 columns, 0) column scales; (1, segment, block of 256 16-byte
+ *               chunks of its col_planes, 0); (2, bounds group, 0, 0);
+ *   bounds / groups [ngroups][4] int32 (first bound job, jobs, first entry of colnorm_segs, entries): a group = an encoder layer;
+ *               a bound job is ptamd_bound_job with indices instead of pointers (statistics record, entry of `scales`, entry of
+ *               `values`; -1 = none);
+ *   scales      uint32 row / column / bound scales; values: floats (bound values); colmax [2][ncolmax], stats [2][nstats][4]:
+ *               zeroed ONCE by the caller, `parity` (0 / 1) must alternate from call to call on a plan; colsq: column
+ *               sum-of-squares partials in fp64, [4 (rows + 31) / 32][cols] doubles per segment that asks for them (16-byte
+ *               aligned; colsq_index counts doubles). */
+typedef struct {
+  int64_t offset;              /* first element in the flat parameter buffer */
+  int32_t rows, cols;
+  int32_t stats_row0;          /* rows >= stats_row0 enter the statistics (a sub-matrix: W_v inside W_qkv) */
+  int32_t stats_index;         /* record of `stats` {largest row L2 norm, largest column L2 norm, largest |w|, -}, or -1 */
+  int32_t row_scale_index;     /* first entry of `scales` for the rows' scales, or -1 */
+  int32_t col_scale_index;     /* ... for the columns' scales, or -1 (then no column work at all) */
+  int32_t colmax_index;        /* first entry of this matrix's columns in a copy of `colmax` */
+  int32_t colsq_index;         /* first double of its partials in `colsq` (the column NORM is wanted: statistics [1]), or -1 */
+  uint64_t row_planes;         /* device pointer: W as hp planes (ptamd_hp_bytes(rows, cols)) split with the row scales; rows and
+                                  cols multiples of 32; 0 = none */
+  uint64_t col_planes;         /* device pointer: W^T as hp planes (ptamd_hp_bytes(cols, rows)) split with the column scales; 0 = none */
+} ptamd_wprep_seg;
+typedef struct {
+  int32_t ln_gamma_stats, ln_beta_stats, w_stats, w_stat_index, bias_stats;   /* w_stats = -1: factor 1 (the bound of the input row) */
+  float sqrt_d, post_scale;
+  int32_t out_scale, out_value;
+} ptamd_wprep_bound;
+typedef struct {
+  const ptamd_wprep_seg *segs; int32_t nsegs;
+  const int32_t *blocks_a; int32_t nblocks_a, nblocks_a_matrices;
+  const int64_t *plain; int32_t nplain;
+  const int32_t *blocks_b; int32_t nblocks_b;
+  const ptamd_wprep_bound *bounds; int32_t nbounds;
+  const int32_t *groups; int32_t ngroups;
+  const int32_t *colnorm_segs;
+  uint32_t *scales; float *values;
+  uint32_t *colmax; int32_t ncolmax;
+  void *colsq;
+  float *stats; int32_t nstats;
+  int64_t numel;               /* floats in the flat parameter buffer */
+  int32_t with_planes;         /* this call writes the row_planes / col_planes of the segments (0: scales and bounds only -
+                                  what a pass needs whose products do not run on ptamd_gemm_hp) */
+} ptamd_wprep_plan;
+int ptamd_wprep_rows_per_block(void);
+int ptamd_wprep_plain_floats_per_block(void);
+int ptamd_weights_prep(const ptamd_wprep_plan *plan_host, const float *w, int parity, void *stream);
+int ptamd_sgd_step_prep(const ptamd_wprep_plan *plan_host, int parity, float *w, const float *g, int64_t n, const float *sqnorm,
+                        float max_norm, float lr, float weight_decay, void *stream);
+int ptamd_adam_step_prep(const ptamd_wprep_plan *plan_host, int parity, float *w, const float *g, float *m, float *v, int64_t n,
+                         const float *sqnorm, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                         int step, void *stream);
+
 /* torch.nn.LayerNorm(D, eps=1e-5) (Sublayers.py:13,17): y = (x-mean)*rstd*gamma+beta; saves mean,rstd [T];
  * row_scale [T] (may be NULL): the f16x2 scale of every row of y, for the GEMM that reads y as its A operand;
  * planes (may be NULL; needs row_scale and D % 32 == 0): y once more in the pre-split hp format (ptamd_hp_bytes(T, D)

@@ -72,6 +72,32 @@ class GemmHpArgs(C.Structure):
                 ("gate_mask", _p), ("gate_mask_out", _p)]
 
 
+class WprepSeg(C.Structure):
+    _fields_ = [("offset", _i64), ("rows", C.c_int32), ("cols", C.c_int32), ("stats_row0", C.c_int32), ("stats_index", C.c_int32),
+                ("row_scale_index", C.c_int32), ("col_scale_index", C.c_int32), ("colmax_index", C.c_int32),
+                ("colsq_index", C.c_int32), ("row_planes", _u64), ("col_planes", _u64)]
+
+
+class WprepBound(C.Structure):
+    _fields_ = [("ln_gamma_stats", C.c_int32), ("ln_beta_stats", C.c_int32), ("w_stats", C.c_int32), ("w_stat_index", C.c_int32),
+                ("bias_stats", C.c_int32), ("sqrt_d", _f), ("post_scale", _f), ("out_scale", C.c_int32), ("out_value", C.c_int32)]
+
+
+class WprepPlan(C.Structure):
+    _fields_ = [("segs", _p), ("nsegs", C.c_int32),
+                ("blocks_a", _p), ("nblocks_a", C.c_int32), ("nblocks_a_matrices", C.c_int32),
+                ("plain", _p), ("nplain", C.c_int32),
+                ("blocks_b", _p), ("nblocks_b", C.c_int32),
+                ("bounds", _p), ("nbounds", C.c_int32),
+                ("groups", _p), ("ngroups", C.c_int32),
+                ("colnorm_segs", _p),
+                ("scales", _p), ("values", _p),
+                ("colmax", _p), ("ncolmax", C.c_int32),
+                ("colsq", _p),
+                ("stats", _p), ("nstats", C.c_int32),
+                ("numel", _i64), ("with_planes", C.c_int32)]
+
+
 # name -> (restype, argtypes); mirrors include/ptamd.h one to one
 SIGNATURES = {
     "ptamd_version": (C.c_char_p, []),
@@ -131,6 +157,11 @@ SIGNATURES = {
     "ptamd_posenc_add_bwd": (_i, [_p, _i64, _f, _u64, _p, _p]),
     "ptamd_grad_sqnorm_workspace_bytes": (_sz, []),
     "ptamd_grad_sqnorm": (_i, [_p, _i64, _p, _p, _sz, _p]),
+    "ptamd_wprep_rows_per_block": (_i, []),
+    "ptamd_wprep_plain_floats_per_block": (_i, []),
+    "ptamd_weights_prep": (_i, [C.POINTER(WprepPlan), _p, _i, _p]),
+    "ptamd_sgd_step_prep": (_i, [C.POINTER(WprepPlan), _i, _p, _p, _i64, _p, _f, _f, _f, _p]),
+    "ptamd_adam_step_prep": (_i, [C.POINTER(WprepPlan), _i, _p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _f, _f, _i, _p]),
     "ptamd_sgd_step": (_i, [_p, _p, _i64, _p, _f, _f, _f, _p]),
     "ptamd_adam_step": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _f, _f, _i, _p]),
 }

@@ -7,8 +7,10 @@
 // The clip coefficient min(1, max_norm / (||g|| + 1e-6)) is computed on the device from the squared norm, so the
 // step never synchronises with the host.  Weight decay is the L2 form torch.optim uses (g + wd * w).
 #include "common.h"
+#include "optim_update.h"
 
 namespace {
+using ptopt::clip_coef;
 
 constexpr int SQ_BLOCKS = 1024;
 
@@ -40,12 +42,6 @@ __global__ __launch_bounds__(256) void sqnorm_final_kernel(const double *__restr
   if (threadIdx.x == 0) out[0] = (float)((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
 }
 
-__device__ __forceinline__ float clip_coef(const float *sqnorm, float max_norm) {
-  if (max_norm <= 0.f || sqnorm == nullptr) return 1.f;
-  const float c = max_norm / (sqrtf(sqnorm[0]) + 1e-6f);
-  return c < 1.f ? c : 1.f;
-}
-
 __global__ void sgd_kernel(float *__restrict__ w, const float *__restrict__ g, int64_t n, const float *sqnorm,
                            float max_norm, float lr, float wd) {
   const float coef = clip_coef(sqnorm, max_norm);
@@ -54,14 +50,14 @@ __global__ void sgd_kernel(float *__restrict__ w, const float *__restrict__ g, i
   if (i < n4) {
     float4 p = reinterpret_cast<float4 *>(w)[i];
     const float4 d = reinterpret_cast<const float4 *>(g)[i];
-    p.x -= lr * (coef * d.x + wd * p.x);
-    p.y -= lr * (coef * d.y + wd * p.y);
-    p.z -= lr * (coef * d.z + wd * p.z);
-    p.w -= lr * (coef * d.w + wd * p.w);
+    p.x = ptopt::sgd_update(p.x, d.x, coef, lr, wd);
+    p.y = ptopt::sgd_update(p.y, d.y, coef, lr, wd);
+    p.z = ptopt::sgd_update(p.z, d.z, coef, lr, wd);
+    p.w = ptopt::sgd_update(p.w, d.w, coef, lr, wd);
     reinterpret_cast<float4 *>(w)[i] = p;
   } else if (i < n4 + (n & 3)) {
     const int64_t k = (n4 << 2) + (i - n4);
-    w[k] -= lr * (coef * g[k] + wd * w[k]);
+    w[k] = ptopt::sgd_update(w[k], g[k], coef, lr, wd);
   }
 }
 
@@ -71,13 +67,10 @@ __global__ void adam_kernel(float *__restrict__ w, const float *__restrict__ g, 
   const float coef = clip_coef(sqnorm, max_norm);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float p = w[i];
-  const float gr = coef * g[i] + wd * p;
-  const float mi = beta1 * m[i] + (1.f - beta1) * gr;
-  const float vi = beta2 * v[i] + (1.f - beta2) * gr * gr;
+  float mi = m[i], vi = v[i];
+  w[i] = ptopt::adam_update(w[i], g[i], mi, vi, coef, wd, beta1, beta2, eps, step_size, inv_sqrt_bc2);
   m[i] = mi;
   v[i] = vi;
-  w[i] = p - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
 }
 
 }  // namespace

@@ -98,13 +98,18 @@ __global__ __launch_bounds__(WS_THREADS) void wscale_kernel(const WJobs js) {
       }
     }
   } else {
-    __shared__ float4 s_m[WS_RY][17], s_q[WS_RY][17];
+    // (column sums of squares in fp64: the largest column norm is then the same fp32 number whatever the order of the sum -
+    // csrc/wprep.hip sums per 32-row block - and with it every bound derived from it)
+    __shared__ float4 s_m[WS_RY][17];
+    __shared__ double s_q[WS_RY][17][4];
     const int cb = b - js.row_blocks[j];
     const int cx = tid & 15, ry = tid >> 4, c = cb * COLS_PER_BLOCK + cx * 4;
-    float4 m = make_float4(0.f, 0.f, 0.f, 0.f), sq = m;
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+    double sq[4] = {0.0, 0.0, 0.0, 0.0};
     auto take = [&](const float4 v) __attribute__((always_inline)) {
       m.x = fmaxf(m.x, fabsf(v.x)); m.y = fmaxf(m.y, fabsf(v.y)); m.z = fmaxf(m.z, fabsf(v.z)); m.w = fmaxf(m.w, fabsf(v.w));
-      sq.x = fmaf(v.x, v.x, sq.x); sq.y = fmaf(v.y, v.y, sq.y); sq.z = fmaf(v.z, v.z, sq.z); sq.w = fmaf(v.w, v.w, sq.w);
+      sq[0] = fma((double)v.x, (double)v.x, sq[0]); sq[1] = fma((double)v.y, (double)v.y, sq[1]);
+      sq[2] = fma((double)v.z, (double)v.z, sq[2]); sq[3] = fma((double)v.w, (double)v.w, sq[3]);
     };
     if (c < jb.cols) {
       if (vec) {
@@ -118,22 +123,24 @@ __global__ __launch_bounds__(WS_THREADS) void wscale_kernel(const WJobs js) {
       }
     }
     s_m[ry][cx] = m;
-    s_q[ry][cx] = sq;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s_q[ry][cx][e] = sq[e];
     __syncthreads();
     if (ry == 0 && c < jb.cols) {   // (fixed order: deterministic)
 #pragma unroll 8
       for (int k = 1; k < WS_RY; ++k) {
-        const float4 a = s_m[k][cx], q = s_q[k][cx];
+        const float4 a = s_m[k][cx];
         m.x = fmaxf(m.x, a.x); m.y = fmaxf(m.y, a.y); m.z = fmaxf(m.z, a.z); m.w = fmaxf(m.w, a.w);
-        sq.x += q.x; sq.y += q.y; sq.z += q.z; sq.w += q.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sq[e] += s_q[k][cx][e];
       }
-      const float mm[4] = {m.x, m.y, m.z, m.w}, qq[4] = {sq.x, sq.y, sq.z, sq.w};
+      const float mm[4] = {m.x, m.y, m.z, m.w};
       float nmax = 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         if (c + e < jb.cols) {
           if (jb.col_scale) jb.col_scale[c + e] = pt_row_scale_bits(__float_as_uint(mm[e]));
-          nmax = fmaxf(nmax, sqrtf(qq[e]));
+          nmax = fmaxf(nmax, (float)sqrt(sq[e]));
         }
       if (stat_bits) atomicMax(stat_bits + 1, __float_as_uint(nmax));
     }

@@ -136,6 +136,8 @@ def broadcast_parameters(model, src=0):
     if world_size() > 1:
         flat, _ = model.flat_parameters()
         dist.broadcast(flat, src=src)
+        if hasattr(model, "weights_changed"):
+            model.weights_changed()              # (a collective wrote the flat buffer: nothing prepared for the old weights holds)
 
 
 def attach(model):

@@ -562,3 +562,133 @@ def posenc_add_bwd(dy, dropout_p, seed):
     dx = torch.empty_like(dy)
     check(lib().ptamd_posenc_add_bwd(ptr(dy), dy.numel(), float(dropout_p), int(seed), ptr(dx), stream()), "posenc_add_bwd")
     return dx
+
+
+# ----------------------------------------------------------------------------- the weights of a step in one pass (csrc/wprep.hip)
+class WeightsPrep:
+    """Plan of ptamd_weights_prep / ptamd_sgd_step_prep / ptamd_adam_step_prep for one model: the device-resident tables of
+    include/ptamd.h (`ptamd_wprep_plan`) built from a description of the flat parameter buffer.
+
+      numel    floats in the flat buffer
+      segs     list of dict(offset, rows, cols, stats_row0=0, stats=None | record index, row_scale=None | view of `ints`,
+               col_scale=None | view of `ints`, colnorm=False, row_planes=None | uint8 tensor, col_planes=None | uint8 tensor)
+               - pairwise disjoint pieces of the buffer; everything else is updated as plain parameters
+      groups   list (an encoder layer each) of lists of dict(ln_gamma, ln_beta, w, w_index, bias [statistics records or
+               None], sqrt_d, post_scale, out_scale [view of `ints`] / out_value [view of `values`])
+      ints     int32 tensor that holds every scale; values: float tensor that holds every bound value; nstats: records
+    """
+
+    def __init__(self, numel, segs, groups, ints, values, nstats):
+        import numpy as np
+        from ._lib import WprepBound, WprepPlan, WprepSeg
+        dev = ints.device
+        RB, PF = lib().ptamd_wprep_rows_per_block(), lib().ptamd_wprep_plain_floats_per_block()
+        segs = sorted(segs, key=lambda s: s["offset"])
+        idx = lambda view, base: -1 if view is None else view.storage_offset() - base.storage_offset()       # noqa: E731
+        arr = (WprepSeg * len(segs))()
+        blocks_a, blocks_b, plain, colnorm_of = [], [], [], {}
+        ncolmax = ncolsq = 0
+        pos = 0
+        for k, s in enumerate(segs):
+            rows, cols, off = int(s["rows"]), int(s["cols"]), int(s["offset"])
+            if cols % 4 or cols > 2048 or off % 4 or off < pos:
+                raise ValueError(f"ptamd_weights_prep: segment {k} (offset {off}, {rows} x {cols}) is not representable")
+            if off > pos:
+                plain.append((pos, off - pos))
+            pos = off + rows * cols
+            want_cols = s.get("col_scale") is not None
+            for name in ("row_planes", "col_planes"):
+                if s.get(name) is not None and (rows % 32 or cols % 32):
+                    raise ValueError("ptamd_weights_prep: planes need rows and cols that are multiples of 32")
+            if s.get("col_planes") is not None and not want_cols:
+                raise ValueError("ptamd_weights_prep: col_planes need col_scale")
+            arr[k] = WprepSeg(offset=off, rows=rows, cols=cols, stats_row0=int(s.get("stats_row0", 0)),
+                              stats_index=-1 if s.get("stats") is None else int(s["stats"]),
+                              row_scale_index=idx(s.get("row_scale"), ints), col_scale_index=idx(s.get("col_scale"), ints),
+                              colmax_index=ncolmax if want_cols else 0,
+                              colsq_index=ncolsq if (s.get("colnorm") and want_cols) else -1,
+                              row_planes=0 if s.get("row_planes") is None else s["row_planes"].data_ptr(),
+                              col_planes=0 if s.get("col_planes") is None else s["col_planes"].data_ptr())
+            nrb = -(-rows // RB)
+            blocks_a += [(k, b) for b in range(nrb)]
+            if want_cols:
+                blocks_b += [(0, k, b, 0) for b in range(-(-cols // 2048))]
+                if s.get("col_planes") is not None:
+                    nchunks = (cols // 32) * (-(-rows // 32) * 2) * 64           # rows of W^T = cols; 16-column blocks of its K = rows
+                    blocks_b += [(1, k, b, 0) for b in range(-(-nchunks // 256))]
+                if s.get("colnorm"):
+                    if s.get("stats") is None:
+                        raise ValueError("ptamd_weights_prep: colnorm needs a statistics record")
+                    colnorm_of[id(s)] = k
+                    ncolsq += 4 * nrb * cols
+                ncolmax += cols
+        if pos < numel:
+            plain.append((pos, numel - pos))
+        n_matrix_blocks = len(blocks_a)
+        for j, (first, n) in enumerate(plain):
+            blocks_a += [(-(j + 1), b) for b in range(-(-n // PF))]
+        # bound jobs, per group; the segments whose column norm a group needs are those flagged `colnorm` whose statistics
+        # record one of the group's jobs reads with w_index == 1
+        by_stats = {int(s["stats"]): k for k, s in enumerate(segs) if s.get("colnorm")}
+        bounds, grp_rows, cn_list = [], [], []
+        rec = lambda v: -1 if v is None else int(v)                                                         # noqa: E731
+        for g, jobs in enumerate(groups):
+            first, cn_first = len(bounds), len(cn_list)
+            for j in jobs:
+                bounds.append(WprepBound(ln_gamma_stats=rec(j.get("ln_gamma")), ln_beta_stats=rec(j.get("ln_beta")), w_stats=int(j["w"]),
+                                         w_stat_index=int(j["w_index"]), bias_stats=rec(j.get("bias")),
+                                         sqrt_d=float(j.get("sqrt_d", 0.0)), post_scale=float(j.get("post_scale", 1.0)),
+                                         out_scale=idx(j.get("out_scale"), ints), out_value=idx(j.get("out_value"), values)))
+                if int(j["w_index"]) == 1 and int(j["w"]) in by_stats and by_stats[int(j["w"])] not in cn_list[cn_first:]:
+                    cn_list.append(by_stats[int(j["w"])])
+            grp_rows.append((first, len(bounds) - first, cn_first, len(cn_list) - cn_first))
+            blocks_b.append((2, g, 0, 0))
+        if not groups:
+            raise ValueError("ptamd_weights_prep: at least one bounds group (it also resets the statistics)")
+        up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=dt))).to(dev)           # noqa: E731
+        self.t_segs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        self.t_blocks_a = up(blocks_a, np.int32).reshape(-1, 2)
+        self.t_plain = up(plain if plain else [(0, 0)], np.int64).reshape(-1, 2)
+        self.t_blocks_b = up(blocks_b, np.int32).reshape(-1, 4)
+        barr = (WprepBound * max(len(bounds), 1))(*bounds)
+        self.t_bounds = torch.frombuffer(bytearray(bytes(barr)), dtype=torch.uint8).to(dev)
+        self.t_groups = up(grp_rows, np.int32).reshape(-1, 4)
+        self.t_colnorm = up(cn_list if cn_list else [0], np.int32)
+        self.colmax = torch.zeros(2, max(ncolmax, 1), dtype=torch.int32, device=dev)
+        self.colsq = torch.zeros(max(ncolsq, 2), dtype=torch.float64, device=dev)
+        self.stats = torch.zeros(2, nstats, 4, dtype=torch.float32, device=dev)
+        self.ints, self.values = ints, values
+        self.parity = 0
+        self.numel = int(numel)
+        self.plan = WprepPlan(segs=self.t_segs.data_ptr(), nsegs=len(segs), blocks_a=self.t_blocks_a.data_ptr(),
+                              nblocks_a=len(blocks_a), nblocks_a_matrices=n_matrix_blocks, plain=self.t_plain.data_ptr(),
+                              nplain=len(plain), blocks_b=self.t_blocks_b.data_ptr(), nblocks_b=len(blocks_b),
+                              bounds=self.t_bounds.data_ptr(), nbounds=len(bounds), groups=self.t_groups.data_ptr(),
+                              ngroups=len(grp_rows), colnorm_segs=self.t_colnorm.data_ptr(), scales=ints.data_ptr(),
+                              values=values.data_ptr(), colmax=self.colmax.data_ptr(), ncolmax=max(ncolmax, 1),
+                              colsq=self.colsq.data_ptr(), stats=self.stats.data_ptr(), nstats=int(nstats), numel=int(numel),
+                              with_planes=1)
+
+    def _next(self, with_planes):
+        self.plan.with_planes = int(bool(with_planes))
+        p = self.parity
+        self.parity ^= 1
+        return p
+
+    def last_stats(self):
+        """The statistics records of the most recent call ([nstats, 4] view)."""
+        return self.stats[self.parity ^ 1]
+
+    def prepare(self, flat, with_planes=True):
+        """Scales, statistics, bounds (and planes) of the weights as they are: no update."""
+        assert flat.numel() == self.numel
+        check(lib().ptamd_weights_prep(C.byref(self.plan), ptr(flat), self._next(with_planes), stream()), "weights_prep")
+
+    def sgd_step(self, w, g, sqnorm, max_norm, lr, weight_decay, with_planes=True):
+        check(lib().ptamd_sgd_step_prep(C.byref(self.plan), self._next(with_planes), ptr(w), ptr(g), w.numel(), ptr(sqnorm),
+                                        float(max_norm or 0.0), float(lr), float(weight_decay), stream()), "sgd_step_prep")
+
+    def adam_step(self, w, g, m, v, sqnorm, max_norm, lr, beta1, beta2, eps, weight_decay, step, with_planes=True):
+        check(lib().ptamd_adam_step_prep(C.byref(self.plan), self._next(with_planes), ptr(w), ptr(g), ptr(m), ptr(v), w.numel(),
+                                         ptr(sqnorm), float(max_norm or 0.0), float(lr), float(beta1), float(beta2), float(eps),
+                                         float(weight_decay), int(step), stream()), "adam_step_prep")

@@ -331,6 +331,8 @@ class _TransformerBase(nn.Module):
         self.side_stream_dw = True                   # small batches: weight-gradient products on a side stream
         self.top_layer_scales = True                 # uniform scales of the top layer's dy2 / dz1 by a pass (backward())
         self.dw_group = "auto"                       # grouping of the weight-gradient products of a layer (backward())
+        self.weights_prep = True                     # scales / bounds / planes of the weights in one pass (csrc/wprep.hip), fused into the
+                                                     # optimizer step where one precedes the forward pass; False: the separate launches of rounds 2-4
         self.auto_guard = AutoGuard(nlayers)         # measures the slack of the bound-derived f16x2 scales, falls back per site
         self._init_parameters()
 
@@ -413,6 +415,8 @@ class _TransformerBase(nn.Module):
             self._flat = flat
             self._flat_grad = torch.zeros_like(flat)
             self.__dict__.pop("_scale_caches", None)     # they hold views of the old flat buffer (keyed by its address)
+            self.__dict__.pop("_train_cache", None)
+            self.__dict__["_param_list"] = list(params.values())
             self.__dict__["_view_cache"] = {}
             self.auto_guard.reset()                      # ... and whatever the guard measured, it measured on other weights
         gbase = self._flat_grad.data_ptr()
@@ -433,12 +437,43 @@ class _TransformerBase(nn.Module):
         AutoGuard's trust in the bound-derived scales was earned on the old weights and is withdrawn."""
         out = super().load_state_dict(state_dict, *args, **kwargs)
         self.auto_guard.reset()
+        self._forget_prepared_weights()
         return out
 
     def weights_changed(self):
-        """For callers that edit parameters in place outside an optimizer step (weight surgery, function-preserving
-        rescalings in tests): what the AutoGuard measured no longer describes this model."""
+        """For callers that change parameters behind PyTorch's back (raw-pointer writes, `.data` edits, collectives on the flat
+        buffer): what the AutoGuard measured and what the last optimizer step prepared (scales, bounds, planes of the
+        weights) no longer describe this model.  In-place torch ops on the parameters or the flat buffer are noticed without
+        this call (their version counters move: `_weights_stamp`)."""
         self.auto_guard.reset()
+        self._forget_prepared_weights()
+
+    def _forget_prepared_weights(self):
+        for c in self.__dict__.get("_scale_caches", {}).values():
+            c.pop("fresh", None)
+        self.__dict__.pop("_train_cache", None)
+
+    def _weights_stamp(self):
+        """Moves whenever a torch op writes the flat buffer or a parameter (their views do not share one version counter)."""
+        params = self.__dict__.get("_param_list")
+        if params is None:
+            params = self.__dict__["_param_list"] = list(self.parameters())
+        return self._flat._version + sum(p._version for p in params)
+
+    def prepared_step(self):
+        """For the fused optimizers (optim.py): (WeightsPrep plan, with_planes, mark_fresh) of the scale cache the last TRAINING
+        forward pass used - the optimizer step that updates the weights then leaves their scales / bounds / planes behind for
+        the next one (csrc/wprep.hip) - or None (no such pass yet, another arithmetic, feature off)."""
+        tc = self.__dict__.get("_train_cache")
+        if tc is None or not self.weights_prep:
+            return None
+        cache, with_planes = tc
+        if cache.get("prep") is None:
+            return None
+
+        def mark_fresh():
+            cache["fresh"] = (self._weights_stamp(), with_planes)
+        return cache["prep"], with_planes, mark_fresh
 
     def _apply(self, fn, *a, **kw):          # .to() / .cuda() / .float(): every parameter gets a new storage
         self._invalidate_flat()
@@ -485,6 +520,7 @@ class _TransformerBase(nn.Module):
         caches = self.__dict__.setdefault("_scale_caches", {})
         if len(caches) > 4:
             caches.clear()
+            self.__dict__.pop("_train_cache", None)
         cache = caches.get(key)
         if cache is None:
             dev = flat.device
@@ -551,8 +587,10 @@ class _TransformerBase(nn.Module):
             if D % 32 == 0 and D <= 2048:         # (built whatever `hp_forward` says now: the flag is read at use time)
                 for i, L in enumerate(layers):
                     w1 = W(f"encoder.enc_layers.{i}.pwff.layer1.weight")
-                    L["hp_1"] = K.HpOperand(F, D, dev)
-                    L["hp_qkv"] = K.HpOperand(3 * D, D, dev)
+                    # (the planes' row scales ARE the rows' f16x2 scales: one array serves the staging GEMM and ptamd_gemm_hp)
+                    L["hp_1"] = K.hp_view(torch.empty(K.lib().ptamd_hp_bytes(F, D), dtype=torch.uint8, device=dev), L["rs_1"], F, D)
+                    L["hp_qkv"] = K.hp_view(torch.empty(K.lib().ptamd_hp_bytes(3 * D, D), dtype=torch.uint8, device=dev),
+                                            L["rs_qkv"], 3 * D, D)
                     cache["hp_mats"] += [w1, self._qkv(flat, i)[0]]
                     cache["hp_outs"] += [L["hp_1"], L["hp_qkv"]]
                     # W2^T as the B operand of dX = dy2 W2 (operand rows = the F columns of W2 [D, F], contraction over D): split
@@ -563,6 +601,20 @@ class _TransformerBase(nn.Module):
                     cache["hpT_mats"] += [w2]
                     cache["hpT_scales"] += [L["cs_2"]]
                     cache["hpT_outs"] += [L["hp_2t"]]
+            cache["prep"] = self._build_prep(cache, p, pa) if (F <= 2048 and D % 4 == 0 and F % 4 == 0) else None
+        need_planes = bool(cache["hp_mats"]) and bool(hp)
+        if self.weights_prep and cache.get("prep") is not None:
+            # ONE pass over the weights (two launches) - or none at all when the optimizer step that wrote these weights left
+            # everything behind (`prepared_step`) and nothing has touched them since
+            stamp = self._weights_stamp()
+            fresh = cache.get("fresh")
+            if fresh is None or fresh[0] != stamp or (need_planes and not fresh[1]):
+                cache["prep"].prepare(self._flat, with_planes=need_planes)
+                cache["fresh"] = (stamp, need_planes)
+                self.__dict__["_prep_launches"] = self.__dict__.get("_prep_launches", 0) + 1
+            if self.training and self.__dict__.get("_fwd_grad", False):
+                self.__dict__["_train_cache"] = (cache, need_planes)
+            return cache["layers"]
         K.weight_scales(cache["wjobs"])
         K.bound_scales(cache["bjobs"])
         if cache["hp_mats"] and hp:
@@ -574,6 +626,44 @@ class _TransformerBase(nn.Module):
             if self.hp_dx and F % 32 == 0 and self.__dict__.get("_fwd_grad", False):
                 K.hp_split_cols(cache["hpT_mats"], cache["hpT_scales"], cache["hpT_outs"])
         return cache["layers"]
+
+    def _build_prep(self, cache, p, pa):
+        """The description of this model's encoder weights for csrc/wprep.hip: the matrices / vectors of `_step_scales`' job
+        lists as disjoint segments of the flat buffer (W_v's statistics are rows 2D.. of the W_qkv segment), the bound jobs per
+        layer with statistics records instead of pointers."""
+        D, F = self.dlayer, self.dff
+        layers = cache["layers"]
+        ints, factor = cache["keep"][0], cache["keep"][2]
+        off = lambda name: self._layout[name][0]                                              # noqa: E731
+        planes_ok = bool(cache["hp_mats"])
+        segs, groups = [], []
+        for i, L in enumerate(layers):
+            b = f"encoder.enc_layers.{i}."
+            r = lambda k, i=i: 9 * i + k                                                       # noqa: E731  (statistics record)
+            segs += [
+                dict(offset=off(b + "self_attn.wq.weight"), rows=3 * D, cols=D, row_scale=L["rs_qkv"], col_scale=L["cs_qkv"],
+                     stats=r(0), stats_row0=2 * D, row_planes=L["hp_qkv"].planes if planes_ok else None),
+                dict(offset=off(b + "self_attn.wq.bias") + 2 * D, rows=1, cols=D, stats=r(7)),             # b_v
+                dict(offset=off(b + "self_attn.wo.weight"), rows=D, cols=D, row_scale=L["rs_o"], col_scale=L["cs_o"]),
+                dict(offset=off(b + "pwff.layer1.weight"), rows=F, cols=D, row_scale=L["rs_1"], col_scale=L["cs_1"], stats=r(1),
+                     row_planes=L["hp_1"].planes if planes_ok else None),
+                dict(offset=off(b + "pwff.layer1.bias"), rows=1, cols=F, stats=r(8)),
+                dict(offset=off(b + "pwff.layer2.weight"), rows=D, cols=F, row_scale=L["rs_2"], col_scale=L["cs_2"], stats=r(2),
+                     colnorm=True, col_planes=L["hp_2t"].planes if (planes_ok and F % 32 == 0) else None),
+                dict(offset=off(b + "sublayer_connections.0.norm.weight"), rows=1, cols=D, stats=r(3)),
+                dict(offset=off(b + "sublayer_connections.0.norm.bias"), rows=1, cols=D, stats=r(4)),
+                dict(offset=off(b + "sublayer_connections.1.norm.weight"), rows=1, cols=D, stats=r(5)),
+                dict(offset=off(b + "sublayer_connections.1.norm.bias"), rows=1, cols=D, stats=r(6))]
+            sq = math.sqrt(D)
+            groups.append([
+                dict(ln_gamma=r(3), ln_beta=r(4), w=r(0), w_index=0, bias=r(7), sqrt_d=sq, post_scale=1.0 / (1.0 - pa),
+                     out_scale=L["att_scale"]),
+                dict(ln_gamma=r(5), ln_beta=r(6), w=r(1), w_index=0, bias=r(8), sqrt_d=sq, post_scale=1.0 / (1.0 - p),
+                     out_scale=L["f1_scale"]),
+                dict(w=r(2), w_index=1, post_scale=1.0 / (1.0 - p), out_value=L["dz1_factor"]),
+                dict(ln_gamma=r(3), ln_beta=r(4), w=-1, w_index=0, sqrt_d=sq, out_scale=L["h1_scale"]),
+                dict(ln_gamma=r(5), ln_beta=r(6), w=-1, w_index=0, sqrt_d=sq, out_scale=L["h2_scale"])])
+        return K.WeightsPrep(self._flat_numel, segs, groups, ints, factor.view(-1), 9 * self.nlayers)
 
     def _slice(self, buf, name):
         """View of parameter `name` in a flat buffer (the parameters or the gradients); the views of the two long-lived

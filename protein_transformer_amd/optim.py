@@ -34,6 +34,12 @@ class _FlatOptimizer(torch.optim.Optimizer):
         self.max_norm = float(max_norm or 0.0)
         return self._sqnorm
 
+    def _prepared(self):
+        """(plan, with_planes, mark_fresh) when the model wants the step to prepare the next forward pass's view of the weights
+        (models/encoder_only.py `prepared_step`), else None: the plain optimizer kernel."""
+        fn = getattr(self.model, "prepared_step", None)
+        return fn() if fn is not None else None
+
     def _clip_args(self):
         sq, mx = (self._sqnorm, self.max_norm) if self.max_norm > 0 else (None, 0.0)
         self.max_norm = 0.0                      # one clip arms one step, like the reference's call order
@@ -51,7 +57,13 @@ class FusedSGD(_FlatOptimizer):
         w, g = self.model.flat_parameters()
         grp = self.param_groups[0]
         sq, mx = self._clip_args()
-        K.sgd_step(w, g, sq, mx, grp["lr"], grp["weight_decay"])
+        prepared = self._prepared()
+        if prepared is None:
+            K.sgd_step(w, g, sq, mx, grp["lr"], grp["weight_decay"])
+        else:       # the same update, and the scales / bounds / planes of the NEW weights for the next forward pass (csrc/wprep.hip)
+            plan, with_planes, mark_fresh = prepared
+            plan.sgd_step(w, g, sq, mx, grp["lr"], grp["weight_decay"], with_planes=with_planes)
+            mark_fresh()
 
 
 class FusedAdam(_FlatOptimizer):
@@ -72,8 +84,15 @@ class FusedAdam(_FlatOptimizer):
         grp = self.param_groups[0]
         self._t += 1
         sq, mx = self._clip_args()
-        K.adam_step(w, g, self._m, self._v, sq, mx, grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"],
-                    grp["weight_decay"], self._t)
+        prepared = self._prepared()
+        if prepared is None:
+            K.adam_step(w, g, self._m, self._v, sq, mx, grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"],
+                        grp["weight_decay"], self._t)
+        else:
+            plan, with_planes, mark_fresh = prepared
+            plan.adam_step(w, g, self._m, self._v, sq, mx, grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"],
+                           grp["weight_decay"], self._t, with_planes=with_planes)
+            mark_fresh()
 
     def state_dict(self):
         sd = super().state_dict()

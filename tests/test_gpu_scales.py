@@ -283,3 +283,107 @@ def test_attention_bwd_row_scales(dev, B, L, H, dk):
     assert K.attention_row_scales_available(dk, K.GEMM_AUTO) and not K.attention_row_scales_available(dk, K.GEMM_BF16X3)
     with pytest.raises(RuntimeError):
         K.attention_bwd(qkv, seq, o, dout, lse, H, 0.1, 5, 2, arith=K.GEMM_BF16X3, row_scale=rs, row_scale_min=mn)
+
+
+def _prep_model(dev, nl=2, dm=512, dff=2048, seed=3):
+    from protein_transformer_amd import synthetic
+    from protein_transformer_amd.models.encoder_only import EncoderOnlyTransformer
+    from protein_transformer_amd.protein.Sequence import VOCAB
+    from protein_transformer_amd.protein.Structure import nerf_forward
+    build = lambda ang, seq: nerf_forward(ang.to(dev), seq.to(dev))[0]  # noqa: E731
+    batch = synthetic.make_batch([512] * 8, L_pad=512, seed=seed, build_coords=build)
+    torch.manual_seed(seed)
+    m = EncoderOnlyTransformer(nl, 8, dm, dff, 512, VOCAB, synthetic.angle_means(batch["true_ang"]), True, dropout=0.1).to(dev).train()
+    with torch.no_grad():
+        P = dict(m.named_parameters())
+        P["output_projection.weight"].normal_(0, 0.02)
+        for n, p in P.items():
+            if "norm.weight" in n:
+                p.add_(0.1 * torch.randn_like(p))
+            elif "norm.bias" in n or n.endswith(".bias"):
+                p.add_(0.05 * torch.randn_like(p))
+    return m, tuple(batch[k].to(dev) for k in ("seq", "true_ang", "true_crd"))
+
+
+def _snapshot(layers):
+    out = {}
+    for i, L in enumerate(layers):
+        for k in ("rs_qkv", "cs_qkv", "rs_o", "cs_o", "rs_1", "cs_1", "rs_2", "cs_2", "att_scale", "f1_scale", "h1_scale", "h2_scale"):
+            out[(i, k)] = L[k].clone()
+        out[(i, "dz1_factor")] = L["dz1_factor"].clone()
+        for k in ("hp_1", "hp_qkv", "hp_2t"):
+            out[(i, k)] = L[k].planes.clone()
+    return out
+
+
+def test_weights_prep_matches_separate_launches(dev):
+    """csrc/wprep.hip (ONE pass over the weights, two launches) against the launches it replaces (ptamd_weight_scales,
+    ptamd_bound_scales, ptamd_hp_split_rows, ptamd_hp_split_cols) on a model's weights: every row / column / bound scale
+    and every plane byte identical - also the one statistic whose summation order differs (the largest column norm of W_2: both
+    kernels sum its squares in fp64, so the fp32 results agree whatever the order).  Also with the vector segments at odd offsets (b_v inside the QKV bias) and twice in
+    a row (the two copies of the atomicMax targets alternate)."""
+    from protein_transformer_amd import kernels as K
+    m, _ = _prep_model(dev)
+    flat, _ = m.flat_parameters()
+    m.__dict__["_fwd_grad"] = True
+    m.weights_prep = False
+    ref = _snapshot(m._step_scales(flat, K.GEMM_AUTO, 0.1, 0.1, hp=True))
+    for L in m._step_scales(flat, K.GEMM_AUTO, 0.1, 0.1, hp=False):      # scribble over everything the prep pass has to write
+        for k in ("rs_qkv", "cs_qkv", "rs_o", "cs_o", "rs_1", "cs_1", "rs_2", "cs_2", "att_scale", "f1_scale", "h1_scale", "h2_scale"):
+            L[k].fill_(-7)
+        L["dz1_factor"].fill_(-1.0)
+        for k in ("hp_1", "hp_qkv", "hp_2t"):
+            L[k].planes.fill_(0x5A)
+    m.weights_prep = True
+    for rep in range(3):
+        m._forget_prepared_weights()
+        got = _snapshot(m._step_scales(flat, K.GEMM_AUTO, 0.1, 0.1, hp=True))
+        torch.cuda.synchronize()
+        for key, want in ref.items():
+            assert torch.equal(got[key], want), (rep, key, int((got[key] != want).sum()))
+    assert m.__dict__["_prep_launches"] == 3
+    # nothing has touched the weights: the next pass launches nothing; an in-place torch op on a parameter is noticed
+    m._step_scales(flat, K.GEMM_AUTO, 0.1, 0.1, hp=True)
+    assert m.__dict__["_prep_launches"] == 3
+    with torch.no_grad():
+        dict(m.named_parameters())["encoder.enc_layers.1.pwff.layer2.weight"][5, 7] = 1000.0
+    L = m._step_scales(flat, K.GEMM_AUTO, 0.1, 0.1, hp=True)
+    assert m.__dict__["_prep_launches"] == 4
+    assert as_float(L[1]["cs_2"])[7] == scale_of(np.float32(1000.0)) and as_float(L[1]["rs_2"])[5] == scale_of(np.float32(1000.0))
+
+
+@pytest.mark.parametrize("optimizer", ["sgd", "adam"])
+def test_optimizer_step_prepares_the_next_pass(dev, optimizer):
+    """ptamd_sgd_step_prep / ptamd_adam_step_prep: the optimizer step that also leaves the scales / bounds / planes of the NEW
+    weights behind.  Two identical models, one with the fused step and one with the separate launches of rounds 2-4, four
+    training steps each: parameters and gradients bit-identical after every step (same update expression, same scales), the
+    fused one launched its preparation pass ONCE (the first forward pass; afterwards the optimizer step did it), and what the
+    step left behind is what a fresh pass over the updated weights computes."""
+    import types
+    from protein_transformer_amd import kernels as K
+    from protein_transformer_amd.optim import FusedAdam, FusedSGD
+    from protein_transformer_amd.train import train_step
+    args = types.SimpleNamespace(loss="drmsd", combined_drmsd_weight=0.5, backbone_loss=False, clip=1.0)
+    runs = {}
+    for prep in (True, False):
+        m, data = _prep_model(dev, seed=5)
+        m.weights_prep = prep
+        opt = (FusedAdam(m, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=10e-3) if optimizer == "adam"
+               else FusedSGD(m, lr=1e-2, weight_decay=10e-3))
+        snaps = []
+        for _ in range(4):
+            train_step(m, opt, args, *data)
+            snaps.append((m.flat_parameters()[0].clone(), m.flat_parameters()[1].clone()))
+        runs[prep] = (m, snaps)
+    for (wa, ga), (wb, gb) in zip(runs[True][1], runs[False][1]):
+        assert torch.equal(ga, gb) and torch.equal(wa, wb)
+    m = runs[True][0]
+    assert m.__dict__.get("_prep_launches", 0) == 1
+    assert runs[False][0].__dict__.get("_prep_launches", 0) == 0
+    flat, _ = m.flat_parameters()
+    left = _snapshot(m.__dict__["_train_cache"][0]["layers"])
+    m._forget_prepared_weights()
+    m.__dict__["_fwd_grad"] = True
+    again = _snapshot(m._step_scales(flat, K.GEMM_AUTO, m.dropout, m.attn_dropout, hp=True))
+    for key, want in again.items():
+        assert torch.equal(left[key], want), key
