@@ -309,7 +309,7 @@ int ptamd_bound_scales(const ptamd_bound_job *jobs_host, int njobs, void *stream
  *               `values`; -1 = none);
  *   scales      uint32 row / column / bound scales; values: floats (bound values); colmax [2][ncolmax], stats [2][nstats][4]:
  *               zeroed ONCE by the caller, `parity` (0 / 1) must alternate from call to call on a plan; colsq: column
- *               sum-of-squares partials in fp64, [4 (rows + 31) / 32][cols] doubles per segment that asks for them (16-byte
+ *               sum-of-squares partials in fp64, [(rows + 31) / 32][cols] doubles per segment that asks for them (16-byte
  *               aligned; colsq_index counts doubles). */
 typedef struct {
   int64_t offset;              /* first element in the flat parameter buffer */

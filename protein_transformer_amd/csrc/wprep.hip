@@ -47,23 +47,38 @@ using ptopt::sgd_update;
 __device__ __forceinline__ float adam_update(float p, float g, float &m, float &v, float coef, const OptArgs &o) {
   return ptopt::adam_update(p, g, m, v, coef, o.wd, o.beta1, o.beta2, o.eps, o.step_size, o.inv_sqrt_bc2);
 }
+// the float4 of an update: loaded first (all requests of a row - or of two rows - in flight), applied and stored afterwards
+template <int KIND>
+struct Quad {
+  float4 p, d, m, v;
+  __device__ __forceinline__ void load(const float *__restrict__ w, int64_t i, const OptArgs &o) {
+    p = *reinterpret_cast<const float4 *>(w + i);
+    if (KIND >= 1) d = *reinterpret_cast<const float4 *>(o.g + i);
+    if (KIND == 2) {
+      m = *reinterpret_cast<const float4 *>(o.m + i);
+      v = *reinterpret_cast<const float4 *>(o.v + i);
+    }
+  }
+  __device__ __forceinline__ float4 apply(float *__restrict__ w, int64_t i, const OptArgs &o, float coef) {
+    if (KIND == 0) return p;
+    if (KIND == 1) {
+      p.x = sgd_update(p.x, d.x, coef, o.lr, o.wd); p.y = sgd_update(p.y, d.y, coef, o.lr, o.wd);
+      p.z = sgd_update(p.z, d.z, coef, o.lr, o.wd); p.w = sgd_update(p.w, d.w, coef, o.lr, o.wd);
+    } else {
+      p.x = adam_update(p.x, d.x, m.x, v.x, coef, o); p.y = adam_update(p.y, d.y, m.y, v.y, coef, o);
+      p.z = adam_update(p.z, d.z, m.z, v.z, coef, o); p.w = adam_update(p.w, d.w, m.w, v.w, coef, o);
+      *reinterpret_cast<float4 *>(o.m + i) = m;
+      *reinterpret_cast<float4 *>(o.v + i) = v;
+    }
+    *reinterpret_cast<float4 *>(w + i) = p;
+    return p;
+  }
+};
 template <int KIND>
 __device__ __forceinline__ float4 update4(float *__restrict__ w, int64_t i, const OptArgs &o, float coef) {
-  float4 p = *reinterpret_cast<const float4 *>(w + i);
-  if (KIND == 0) return p;
-  const float4 d = *reinterpret_cast<const float4 *>(o.g + i);
-  if (KIND == 1) {
-    p.x = sgd_update(p.x, d.x, coef, o.lr, o.wd); p.y = sgd_update(p.y, d.y, coef, o.lr, o.wd);
-    p.z = sgd_update(p.z, d.z, coef, o.lr, o.wd); p.w = sgd_update(p.w, d.w, coef, o.lr, o.wd);
-  } else {
-    float4 m = *reinterpret_cast<const float4 *>(o.m + i), v = *reinterpret_cast<const float4 *>(o.v + i);
-    p.x = adam_update(p.x, d.x, m.x, v.x, coef, o); p.y = adam_update(p.y, d.y, m.y, v.y, coef, o);
-    p.z = adam_update(p.z, d.z, m.z, v.z, coef, o); p.w = adam_update(p.w, d.w, m.w, v.w, coef, o);
-    *reinterpret_cast<float4 *>(o.m + i) = m;
-    *reinterpret_cast<float4 *>(o.v + i) = v;
-  }
-  *reinterpret_cast<float4 *>(w + i) = p;
-  return p;
+  Quad<KIND> q;
+  q.load(w, i, o);
+  return q.apply(w, i, o, coef);
 }
 
 struct PlanA {
@@ -76,6 +91,82 @@ struct PlanA {
   float *stats;              // [2][nstats][4]
   int with_planes;
 };
+
+struct RowAcc {
+  float4 cm[MAXV];      // column maxima of this wavefront's rows
+  double cs[MAXV][4];   // column sums of squares (fp64: see below)
+  float bn, bm;         // largest row norm / largest |w| of the rows that enter the statistics
+};
+// The RW rows of one wavefront.  NV float4 per lane and row (cols <= 256 NV); PIPE: the loads of row r + 1 are issued in front
+// of the arithmetic and the two wavefront reductions of row r (short rows: two 16-byte requests per lane and stream would
+// otherwise be all that is in flight - measured 3.9 TB/s for the SGD variant against 7 TB/s of the plain kernel).
+template <int KIND, int NV, bool PIPE>
+__device__ __forceinline__ void rows_loop(float *__restrict__ w, const PlanA &pl, const OptArgs &o, const ptamd_wprep_seg &sg, int row_first,
+                                          int lane, float coef, bool want_cols, bool want_sq, char *planes, RowAcc &acc) {
+  const int cols = sg.cols;
+  Quad<KIND> cur[NV], nxt[NV];
+  auto load = [&](Quad<KIND> (&q)[NV], int r) __attribute__((always_inline)) {
+    const int64_t row0 = sg.offset + (int64_t)r * cols;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < cols) q[i].load(w, row0 + c, o);
+    }
+  };
+  if (row_first < sg.rows) load(cur, row_first);
+#pragma unroll 1
+  for (int rr = 0; rr < RW; ++rr) {
+    const int r = row_first + rr;
+    if (r >= sg.rows) break;  // (wavefront-uniform)
+    if (PIPE && rr + 1 < RW && r + 1 < sg.rows) load(nxt, r + 1);
+    const int64_t row0 = sg.offset + (int64_t)r * cols;
+    float4 v[NV];
+    float m = 0.f, sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < cols) {
+        v[i] = cur[i].apply(w, row0 + c, o, coef);
+        // (row maximum and row sum of squares in the order of wscale_kernel: the statistics - and with them every bound - are
+        // bit for bit what ptamd_weight_scales gives)
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+        sq = fmaf(v[i].x, v[i].x, fmaf(v[i].y, v[i].y, fmaf(v[i].z, v[i].z, fmaf(v[i].w, v[i].w, sq))));
+        if (want_cols) {
+          acc.cm[i].x = fmaxf(acc.cm[i].x, fabsf(v[i].x)); acc.cm[i].y = fmaxf(acc.cm[i].y, fabsf(v[i].y));
+          acc.cm[i].z = fmaxf(acc.cm[i].z, fabsf(v[i].z)); acc.cm[i].w = fmaxf(acc.cm[i].w, fabsf(v[i].w));
+        }
+        if (want_sq) {
+          acc.cs[i][0] = fma((double)v[i].x, (double)v[i].x, acc.cs[i][0]); acc.cs[i][1] = fma((double)v[i].y, (double)v[i].y, acc.cs[i][1]);
+          acc.cs[i][2] = fma((double)v[i].z, (double)v[i].z, acc.cs[i][2]); acc.cs[i][3] = fma((double)v[i].w, (double)v[i].w, acc.cs[i][3]);
+        }
+      } else {
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    m = wave_max(m);
+    sq = wave_sum(sq);
+    const uint32_t sbits = pt_row_scale_bits(__float_as_uint(m));
+    if (lane == 0 && sg.row_scale_index >= 0) pl.scales[sg.row_scale_index + r] = sbits;
+    if (r >= sg.stats_row0) {
+      acc.bn = fmaxf(acc.bn, sqrtf(sq));
+      acc.bm = fmaxf(acc.bm, m);
+    }
+    if (planes) {  // (rows and cols are multiples of 32 here: the builder of the plan checks)
+      const float s = __uint_as_float(sbits);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < cols) pthp::store4_split(planes, cols >> 4, r, c, v[i], s);
+      }
+    }
+    if (PIPE) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) cur[i] = nxt[i];
+    } else if (rr + 1 < RW && r + 1 < sg.rows) {
+      load(cur, r + 1);
+    }
+  }
+}
 
 template <int KIND>
 __global__ __launch_bounds__(64 * WAVES) void wprep_rows_kernel(float *__restrict__ w, const PlanA pl, const OptArgs o) {
@@ -102,60 +193,20 @@ __global__ __launch_bounds__(64 * WAVES) void wprep_rows_kernel(float *__restric
   const bool want_cols = sg.col_scale_index >= 0, want_sq = sg.colsq_index >= 0;
   // (column sums of squares in fp64: the largest column norm is then the same fp32 number whatever the order of the sum -
   // here per wavefront and 32-row block, in wscale_kernel per 64-row stride - and with it every bound derived from it)
-  float4 cm[MAXV];
-  double cs[MAXV][4];
+  RowAcc acc;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    cm[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    cs[i][0] = cs[i][1] = cs[i][2] = cs[i][3] = 0.0;
+    acc.cm[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    acc.cs[i][0] = acc.cs[i][1] = acc.cs[i][2] = acc.cs[i][3] = 0.0;
   }
-  float bn = 0.f, bm = 0.f;
+  acc.bn = acc.bm = 0.f;
   char *planes = pl.with_planes ? reinterpret_cast<char *>(sg.row_planes) : nullptr;
-#pragma unroll 1
-  for (int rr = 0; rr < RW; ++rr) {
-    const int r = blk.y * RB + wave * RW + rr;
-    if (r >= sg.rows) break;  // (wavefront-uniform)
-    const int64_t row0 = sg.offset + (int64_t)r * cols;
-    float4 v[MAXV];
-    float m = 0.f, sq = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int c = (i * 64 + lane) * 4;
-      if (i < nv && c < cols) {
-        v[i] = update4<KIND>(w, row0 + c, o, coef);
-        // (row maximum and row sum of squares in the order of wscale_kernel: the statistics - and with them every bound - are
-        // bit for bit what ptamd_weight_scales gives)
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
-        sq = fmaf(v[i].x, v[i].x, fmaf(v[i].y, v[i].y, fmaf(v[i].z, v[i].z, fmaf(v[i].w, v[i].w, sq))));
-        if (want_cols) {
-          cm[i].x = fmaxf(cm[i].x, fabsf(v[i].x)); cm[i].y = fmaxf(cm[i].y, fabsf(v[i].y));
-          cm[i].z = fmaxf(cm[i].z, fabsf(v[i].z)); cm[i].w = fmaxf(cm[i].w, fabsf(v[i].w));
-        }
-        if (want_sq) {
-          cs[i][0] = fma((double)v[i].x, (double)v[i].x, cs[i][0]); cs[i][1] = fma((double)v[i].y, (double)v[i].y, cs[i][1]);
-          cs[i][2] = fma((double)v[i].z, (double)v[i].z, cs[i][2]); cs[i][3] = fma((double)v[i].w, (double)v[i].w, cs[i][3]);
-        }
-      } else {
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-    m = wave_max(m);
-    sq = wave_sum(sq);
-    const uint32_t sbits = pt_row_scale_bits(__float_as_uint(m));
-    if (lane == 0 && sg.row_scale_index >= 0) pl.scales[sg.row_scale_index + r] = sbits;
-    if (r >= sg.stats_row0) {
-      bn = fmaxf(bn, sqrtf(sq));
-      bm = fmaxf(bm, m);
-    }
-    if (planes) {  // (rows and cols are multiples of 32 here: checked by the entry point's caller-side builder and below)
-      const float s = __uint_as_float(sbits);
-#pragma unroll
-      for (int i = 0; i < MAXV; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        if (i < nv && c < cols) pthp::store4_split(planes, cols >> 4, r, c, v[i], s);
-      }
-    }
-  }
+  const int row_first = blk.y * RB + wave * RW;
+  if (nv <= 2) rows_loop<KIND, 2, true>(w, pl, o, sg, row_first, lane, coef, want_cols, want_sq, planes, acc);
+  else rows_loop<KIND, MAXV, false>(w, pl, o, sg, row_first, lane, coef, want_cols, want_sq, planes, acc);
+  const float bn = acc.bn, bm = acc.bm;
+  float4 (&cm)[MAXV] = acc.cm;
+  double (&cs)[MAXV][4] = acc.cs;
   if (sg.stats_index >= 0) {
     if (lane == 0) {
       s_nrm[wave] = bn;
@@ -185,15 +236,24 @@ __global__ __launch_bounds__(64 * WAVES) void wprep_rows_kernel(float *__restric
       atomicMax(pl.colmax + sg.colmax_index + c, __float_as_uint(mx));
     }
   }
-  if (want_sq) {   // one fp64 partial per (32-row block, wavefront, column), summed by kernel B in that order
-    double *dst = pl.colsq + sg.colsq_index + ((int64_t)blk.y * WAVES + wave) * cols;
+  if (want_sq) {
+    // one fp64 partial per (32-row block, column): the four wavefronts meet in LDS (the 32 KiB of s_col hold 4 x 1024 doubles:
+    // two rounds of 1024 columns), summed in wavefront order; kernel B adds the blocks in block order
+    double (*s_d)[1024] = reinterpret_cast<double (*)[1024]>(&s_col[0][0]);
+    double *dst = pl.colsq + sg.colsq_index + (int64_t)blk.y * cols;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int c = (i * 64 + lane) * 4;
-      if (i < nv && c < cols) {
-        *reinterpret_cast<double2 *>(dst + c) = make_double2(cs[i][0], cs[i][1]);
-        *reinterpret_cast<double2 *>(dst + c + 2) = make_double2(cs[i][2], cs[i][3]);
+      for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4 - 1024 * half;
+        if (i < nv && c >= 0 && c < 1024) {
+          s_d[wave][c] = cs[i][0]; s_d[wave][c + 1] = cs[i][1]; s_d[wave][c + 2] = cs[i][2]; s_d[wave][c + 3] = cs[i][3];
+        }
       }
+      __syncthreads();
+      for (int c = tid; c < 1024 && c + 1024 * half < cols; c += 64 * WAVES)
+        dst[c + 1024 * half] = ((s_d[0][c] + s_d[1][c]) + s_d[2][c]) + s_d[3][c];
     }
   }
 }
@@ -265,12 +325,23 @@ __global__ __launch_bounds__(256) void wprep_cols_kernel(const float *__restrict
   __shared__ float s_red[4];
   for (int e = 0; e < grp.w; ++e) {
     const ptamd_wprep_seg sg = pl.segs[pl.colnorm_segs[grp.z + e]];
-    const int nb = (sg.rows + RB - 1) / RB * WAVES;
+    const int nb = (sg.rows + RB - 1) / RB;
     float nmax = 0.f;
     for (int c = tid; c < sg.cols; c += 256) {
-      double s = 0.0;
-      for (int b = 0; b < nb; ++b) s += pl.colsq[sg.colsq_index + (int64_t)b * sg.cols + c];   // fixed order
-      nmax = fmaxf(nmax, (float)sqrt(s));
+      // (fixed order: four interleaved partial sums over the 32-row blocks - eight independent loads in flight per round instead of
+      // one load per addition of a single chain, which made this the slowest part of the launch)
+      const double *q = pl.colsq + sg.colsq_index + c;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int b = 0;
+      for (; b + 8 <= nb; b += 8) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = q[(int64_t)(b + u) * sg.cols];
+        s0 += t[0]; s1 += t[1]; s2 += t[2]; s3 += t[3];
+        s0 += t[4]; s1 += t[5]; s2 += t[6]; s3 += t[7];
+      }
+      for (; b < nb; ++b) s0 += q[(int64_t)b * sg.cols];
+      nmax = fmaxf(nmax, (float)sqrt((s0 + s1) + (s2 + s3)));
     }
     nmax = wave_max(nmax);
     __syncthreads();

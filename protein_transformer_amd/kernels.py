@@ -620,7 +620,7 @@ class WeightsPrep:
                     if s.get("stats") is None:
                         raise ValueError("ptamd_weights_prep: colnorm needs a statistics record")
                     colnorm_of[id(s)] = k
-                    ncolsq += 4 * nrb * cols
+                    ncolsq += nrb * cols
                 ncolmax += cols
         if pos < numel:
             plain.append((pos, numel - pos))

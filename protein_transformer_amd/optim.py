@@ -89,9 +89,13 @@ class FusedAdam(_FlatOptimizer):
             K.adam_step(w, g, self._m, self._v, sq, mx, grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"],
                         grp["weight_decay"], self._t)
         else:
+            # (ptamd_adam_step_prep - the fused form, tested in tests/test_gpu_scales.py - streams seven arrays through a kernel
+            # that holds whole rows in registers: 190 us against 84 + 61 for the plain Adam kernel followed by the preparation
+            # pass over the new weights, profiles/r05/r05_wprep_bench.txt; the SGD form breaks even and saves a launch)
             plan, with_planes, mark_fresh = prepared
-            plan.adam_step(w, g, self._m, self._v, sq, mx, grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"],
-                           grp["weight_decay"], self._t, with_planes=with_planes)
+            K.adam_step(w, g, self._m, self._v, sq, mx, grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"],
+                        grp["weight_decay"], self._t)
+            plan.prepare(w, with_planes=with_planes)
             mark_fresh()
 
     def state_dict(self):
