@@ -93,6 +93,7 @@ def parse():
     ap.add_argument("--no-top-layer-scales", action="store_true", help="ablation: the top layer's FFN weight-gradient products in bf16x3 (no pass over its dy2)")
     ap.add_argument("--dw-group", default="auto", choices=["auto", "pairs", "layer", "off"],
                     help="grouping of the weight-gradient products of a layer (ptamd_gemm_group); off = one by one (ablation)")
+    ap.add_argument("--no-kv-planes", action="store_true", help="ablation: the QKV product stores K / V as fp32 and the attention kernels scale, split and stage them themselves (rounds 2-4)")
     ap.add_argument("--no-weights-prep", action="store_true", help="ablation: scales / bounds / planes of the weights by the separate launches of rounds 2-4 in front of every forward pass instead of inside the optimizer step (csrc/wprep.hip)")
     ap.add_argument("--no-hp-dx", action="store_true", help="ablation: dX of FFN layer 2 on the staging kernel instead of ptamd_gemm_hp")
     ap.add_argument("--attn-mode", default=None, choices=["f32", "bf16x3", "f16x2"],
@@ -313,6 +314,7 @@ def main():
     model.dw_group = a.dw_group
     model.top_layer_scales = not a.no_top_layer_scales
     model.weights_prep = not a.no_weights_prep
+    model.kv_planes = not a.no_kv_planes
     model.dropout_seed += 7919 * rank
     dp.attach(model)
     opt = (FusedAdam(model, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=10e-3) if a.optimizer == "adam"
@@ -594,6 +596,7 @@ def main():
         out["ffn_gate_mask_layer_passes"] = int(model.__dict__.get("_gate_mask_passes", 0))
         # forward passes that had to prepare the weights' scales / bounds / planes themselves (the others found them left behind
         # by the optimizer step: csrc/wprep.hip)
+        out["kv_plane_layer_passes"] = int(model.__dict__.get("_kv_plane_passes", 0))
         out["weights_prep_launches"] = int(model.__dict__.get("_prep_launches", 0))
         out["auto_guard"] = guard
         out["communication"] = comm

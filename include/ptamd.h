@@ -258,6 +258,11 @@ typedef struct {
   const uint64_t *gate_mask;   /* PTAMD_EPI_GATE from the 1-bit gate (see ptamd_gemm_args.gate_mask) */
   uint64_t *gate_mask_out;     /* optional: the 1-bit gate "result > 0" of THIS product's output (after bias / ReLU /
                                   dropout), ptamd_gate_mask_bytes(M, N) bytes; float4 epilogue and split_k <= 1 only */
+  /* optional, the QKV product (Attention.py:49): columns kv_col0 .. N - 1 = K then V, kv_heads heads of 64 columns each
+   * (N == kv_col0 + 128 kv_heads), leave the epilogue as the pre-split planes the f16x2 attention kernels read
+   * (ptamd_attention_kv_bytes / _kv_inv_floats; csrc/kv_format.h) INSTEAD of fp32 - C[:, kv_col0:] is not written; columns in
+   * front (Q) are stored as usual.  M a multiple of 32, bias only (flags 0, no dropout / residual / gate), split_k <= 1. */
+  void *kv_planes; float *kv_inv; int kv_col0, kv_heads;
 } ptamd_gemm_hp_args;
 size_t ptamd_gemm_hp_workspace_bytes(int M, int N, int split_k);
 int ptamd_gemm_hp(const ptamd_gemm_hp_args *args, void *stream);
@@ -417,14 +422,25 @@ int ptamd_embed_bwd(const int64_t *seq, const float *dout, int B, int L, int D, 
  *   the caller (the library keeps nothing between calls), so that the backward kernel reads one word per key and 32
  *   queries instead of drawing the counter hash again: word [(b, h)][q / 32][key] (keys padded to a multiple of 32),
  *   bit q % 32 = 1 where query q keeps key.  The decisions are the generator's (csrc/attn_dropout.h) either way: a
- *   backward call without them, or in another arithmetic, regenerates exactly the same mask. */
+ *   backward call without them, or in another arithmetic, regenerates exactly the same mask.
+ *   kv_planes / kv_inv (optional, both or none; f16x2 arithmetic and shapes for which ptamd_attention_reads_kv_planes says 1,
+ *   PTAMD_ERR_BAD_SHAPE otherwise): K and V PRE-SPLIT, as the epilogue of the QKV product wrote them (ptamd_gemm_hp_args.kv_planes;
+ *   ptamd_attention_kv_bytes(T, H) bytes and ptamd_attention_kv_inv_floats(T, H) floats, T = B L; layout: csrc/kv_format.h).
+ *   The K | V columns of `qkv` are then NOT read (they need not have been written); Q is.  The forward result is bit for bit
+ *   that of the call without planes on the fp32 K / V the planes were made from; the backward one differs by rounding (a key
+ *   row is scaled with its group of four there instead of on its own). */
 int ptamd_attention_fwd(const float *qkv, const int64_t *seq, int B, int L, int H, int dk, float dropout_p,
                         uint64_t seed, uint32_t stream_id, int arith, float *out, float *lse, uint32_t *keep_bits,
-                        void *stream);
+                        const void *kv_planes, const float *kv_inv, void *stream);
 int ptamd_attention_bwd(const float *qkv, const int64_t *seq, const float *out, const float *dout, const float *lse,
                         int B, int L, int H, int dk, float dropout_p, uint64_t seed, uint32_t stream_id, int arith,
                         float *dqkv, uint32_t *row_scale, uint32_t *row_scale_min, const uint32_t *keep_bits,
-                        void *workspace, size_t workspace_bytes, void *stream);
+                        const void *kv_planes, const float *kv_inv, void *workspace, size_t workspace_bytes, void *stream);
+size_t ptamd_attention_kv_bytes(int T, int H);
+size_t ptamd_attention_kv_inv_floats(int T, int H);
+/* 1 when ptamd_attention_fwd / _bwd of this shape and arithmetic read pre-split K / V (head size 64, L a multiple of 32, a batch
+ * large enough for the 256-query forward kernel and the one-sweep backward kernel) */
+int ptamd_attention_reads_kv_planes(int B, int L, int H, int dk, int arith);
 size_t ptamd_attention_workspace_bytes(int B, int L, int H, int dk);
 size_t ptamd_attention_keep_bits_bytes(int B, int L, int H);
 /* 1 when ptamd_attention_bwd of this shape and arithmetic would read keep_bits (f16x2 arithmetic, dk 32 / 64: the one-sweep

@@ -69,7 +69,8 @@ class GemmHpArgs(C.Structure):
                 ("workspace", _p), ("workspace_bytes", _sz),
                 ("gate_scale", _f),
                 ("reserved_cus", _i),
-                ("gate_mask", _p), ("gate_mask_out", _p)]
+                ("gate_mask", _p), ("gate_mask_out", _p),
+                ("kv_planes", _p), ("kv_inv", _p), ("kv_col0", _i), ("kv_heads", _i)]
 
 
 class WprepSeg(C.Structure):
@@ -138,8 +139,11 @@ SIGNATURES = {
     "ptamd_embed_fwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _u64, _p, _p]),
     "ptamd_embed_bwd_workspace_bytes": (_sz, [_i]),
     "ptamd_embed_bwd": (_i, [_p, _p, _i, _i, _i, _f, _u64, _p, _p, _sz, _p]),
-    "ptamd_attention_fwd": (_i, [_p, _p, _i, _i, _i, _i, _f, _u64, _u32, _i, _p, _p, _p, _p]),
-    "ptamd_attention_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _u32, _i, _p, _p, _p, _p, _p, _sz, _p]),
+    "ptamd_attention_fwd": (_i, [_p, _p, _i, _i, _i, _i, _f, _u64, _u32, _i, _p, _p, _p, _p, _p, _p]),
+    "ptamd_attention_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _u32, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "ptamd_attention_kv_bytes": (_sz, [_i, _i]),
+    "ptamd_attention_kv_inv_floats": (_sz, [_i, _i]),
+    "ptamd_attention_reads_kv_planes": (_i, [_i, _i, _i, _i, _i]),
     "ptamd_attention_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ptamd_attention_keep_bits_bytes": (_sz, [_i, _i, _i]),
     "ptamd_attention_bwd_reads_keep_bits": (_i, [_i, _i, _i, _i, _i]),

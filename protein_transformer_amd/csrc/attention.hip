@@ -18,6 +18,7 @@
 //   * dropout masks come from a counter hash of (seed, protein*head, query, key) and are regenerated in the
 //     backward kernels instead of being stored.
 #include "attn_dropout.h"
+#include "kv_format.h"
 
 // split-bf16 variants for dk = 64 and dk = 32 (attention_split.hip), selected by the `arith` argument of the entry points
 int pt_attention_fwd_split(const float *qkv, const int64_t *seq, int B, int L, int H, int dk, float p, uint64_t seed,
@@ -27,11 +28,14 @@ int pt_attention_bwd_split(const float *qkv, const int64_t *seq, const float *o_
                            hipStream_t st);
 // two-term f16 variants (attention_f16x2.hip): arith = PTAMD_GEMM_AUTO / PTAMD_GEMM_F16X2
 int pt_attention_fwd_f16x2(const float *qkv, const int64_t *seq, int B, int L, int H, int dk, float p, uint64_t seed,
-                           uint32_t sid, float *out, float *lse, uint32_t *keep_bits, hipStream_t st);
+                           uint32_t sid, float *out, float *lse, uint32_t *keep_bits, const void *kv_planes, const float *kv_inv,
+                           hipStream_t st);
 int pt_attention_bwd_f16x2(const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse,
                            float *delta, int B, int L, int H, int dk, float p, uint64_t seed, uint32_t sid, float *dqkv,
-                           uint32_t *row_scale, uint32_t *row_min, const uint32_t *keep_bits, hipStream_t st);
+                           uint32_t *row_scale, uint32_t *row_min, const uint32_t *keep_bits, const void *kv_planes,
+                           const float *kv_inv, hipStream_t st);
 bool pt_attention_bwd_f16x2_reads_keep_bits(int B, int L, int H, int dk);
+bool pt_attention_f16x2_reads_kv_planes(int B, int L, int H, int dk);
 
 namespace {
 
@@ -501,16 +505,24 @@ int ptamd_attention_bwd_reads_keep_bits(int B, int L, int H, int dk, int arith) 
   return pt_attention_bwd_f16x2_reads_keep_bits(B, L, H, dk) ? 1 : 0;
 }
 
+size_t ptamd_attention_kv_bytes(int T, int H) { return (T <= 0 || H <= 0) ? 0 : ptkv::planes_bytes(T, H); }
+size_t ptamd_attention_kv_inv_floats(int T, int H) { return (T <= 0 || H <= 0) ? 0 : ptkv::inv_floats(T, H); }
+int ptamd_attention_reads_kv_planes(int B, int L, int H, int dk, int arith) {
+  if (B <= 0 || L <= 0 || H <= 0 || !(arith == PTAMD_GEMM_AUTO || arith == PTAMD_GEMM_F16X2)) return 0;
+  return pt_attention_f16x2_reads_kv_planes(B, L, H, dk) ? 1 : 0;
+}
+
 int ptamd_attention_fwd(const float *qkv, const int64_t *seq, int B, int L, int H, int dk, float dropout_p,
                         uint64_t seed, uint32_t stream_id, int arith, float *out, float *lse, uint32_t *keep_bits,
-                        void *stream) {
+                        const void *kv_planes, const float *kv_inv, void *stream) {
   if (B <= 0 || L <= 0 || H <= 0 || arith < PTAMD_GEMM_F32 || arith > PTAMD_GEMM_AUTO) return PTAMD_ERR_BAD_SHAPE;
   if (dropout_p < 0.f || dropout_p >= 1.f) return PTAMD_ERR_BAD_SHAPE;
   if (!pt_aligned16(qkv) || !pt_aligned16(out)) return PTAMD_ERR_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   const bool f16x2 = (dk == 64 || dk == 32) && (arith == PTAMD_GEMM_AUTO || arith == PTAMD_GEMM_F16X2);
   if (keep_bits && !f16x2) return PTAMD_ERR_BAD_SHAPE;  // the decisions are a by-product of the f16x2 kernels only
-  if (f16x2) return pt_attention_fwd_f16x2(qkv, seq, B, L, H, dk, dropout_p, seed, stream_id, out, lse, keep_bits, st);
+  if (kv_planes && !(f16x2 && kv_inv && pt_aligned16(kv_planes))) return PTAMD_ERR_BAD_SHAPE;   // ... the planes their input only
+  if (f16x2) return pt_attention_fwd_f16x2(qkv, seq, B, L, H, dk, dropout_p, seed, stream_id, out, lse, keep_bits, kv_planes, kv_inv, st);
   if ((dk == 64 || dk == 32) && arith != PTAMD_GEMM_F32)
     return pt_attention_fwd_split(qkv, seq, B, L, H, dk, dropout_p, seed, stream_id, out, lse, st);
   switch (dk) {
@@ -525,7 +537,7 @@ int ptamd_attention_fwd(const float *qkv, const int64_t *seq, int B, int L, int 
 int ptamd_attention_bwd(const float *qkv, const int64_t *seq, const float *out, const float *dout, const float *lse,
                         int B, int L, int H, int dk, float dropout_p, uint64_t seed, uint32_t stream_id, int arith,
                         float *dqkv, uint32_t *row_scale, uint32_t *row_scale_min, const uint32_t *keep_bits,
-                        void *workspace, size_t workspace_bytes, void *stream) {
+                        const void *kv_planes, const float *kv_inv, void *workspace, size_t workspace_bytes, void *stream) {
   if (B <= 0 || L <= 0 || H <= 0 || arith < PTAMD_GEMM_F32 || arith > PTAMD_GEMM_AUTO) return PTAMD_ERR_BAD_SHAPE;
   if (dropout_p < 0.f || dropout_p >= 1.f) return PTAMD_ERR_BAD_SHAPE;
   if (!workspace || workspace_bytes < ptamd_attention_workspace_bytes(B, L, H, dk)) return PTAMD_ERR_WORKSPACE;
@@ -534,8 +546,8 @@ int ptamd_attention_bwd(const float *qkv, const int64_t *seq, const float *out, 
   float *delta = static_cast<float *>(workspace);
   if ((dk == 64 || dk == 32) && (arith == PTAMD_GEMM_AUTO || arith == PTAMD_GEMM_F16X2))
     return pt_attention_bwd_f16x2(qkv, seq, out, dout, lse, delta, B, L, H, dk, dropout_p, seed, stream_id, dqkv, row_scale,
-                                  row_scale ? row_scale_min : nullptr, keep_bits, st);
-  if (row_scale || row_scale_min || keep_bits) return PTAMD_ERR_BAD_SHAPE;  // by-products of the f16x2 kernels only
+                                  row_scale ? row_scale_min : nullptr, keep_bits, kv_planes, kv_inv, st);
+  if (row_scale || row_scale_min || keep_bits || kv_planes) return PTAMD_ERR_BAD_SHAPE;  // by-products / inputs of the f16x2 kernels only
   if ((dk == 64 || dk == 32) && arith != PTAMD_GEMM_F32)
     return pt_attention_bwd_split(qkv, seq, out, dout, lse, delta, B, L, H, dk, dropout_p, seed, stream_id, dqkv, st);
   switch (dk) {

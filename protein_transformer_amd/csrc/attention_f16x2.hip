@@ -23,7 +23,10 @@
 // Decomposition, LDS format, dropout hash and prefetching are those of attention_split.hip (8 wavefronts = 256 queries
 // or keys per workgroup, 32-row tiles, scores transposed so that a soft-max row is lane-local), with two planes per
 // tile instead of three (48 KB of LDS instead of 72).
+#include <stdlib.h>
+
 #include "attn_dropout.h"
+#include "kv_format.h"
 #include "split_bf16.h"
 
 namespace ptattn16 {
@@ -121,6 +124,53 @@ struct Tile2 {
     }
   }
 };
+
+// ---- a K / V tile that arrives PRE-SPLIT (kv_format.h): [plane][32 rows][64 f16], chunk-swizzled, written into LDS by LDS-DMA
+typedef __attribute__((address_space(1))) const void *kv_gptr_t;
+typedef __attribute__((address_space(3))) void *kv_lptr_t;
+struct KvTile {
+  // 64 lanes x 16 B of global memory (g already holds the lane's + 16 lane) -> 1 KiB of LDS at l (wavefront-uniform)
+  static __device__ __forceinline__ void dma16(const char *g, char *l) {
+    __builtin_amdgcn_global_load_lds((kv_gptr_t)g, (kv_lptr_t)l, 16, 0, 0);
+  }
+  // lane l holds tile row (l & 31), d = 16 step + 8 (l >> 5) + 0..7   (Tile2::frag_rows)
+  static __device__ __forceinline__ void frag_rows(const char *__restrict__ s, int step, int lane, f16x8 (&f)[2]) {
+    const char *q = s + ptkv::plane_offset(lane & 31, 16 * step + 8 * (lane >> 5));
+#pragma unroll
+    for (int t = 0; t < 2; ++t) f[t] = *reinterpret_cast<const f16x8 *>(q + t * ptkv::PLANE_BYTES);
+  }
+  // the transposed fragment of Tile2::frag_cols: column d0 + (l & 31) of tile rows kb + 4 (l >> 5) + {0..3} and + 8
+  static __device__ __forceinline__ void frag_cols(const char *__restrict__ s, int kb, int d0, int lane, f16x8 (&f)[2]) {
+    const int q16 = lane & 15;
+    const int row = kb + 4 * (lane >> 5) + (q16 >> 2), d = d0 + (lane & 16) + 4 * (q16 & 3);
+    const char *q0 = s + ptkv::plane_offset(row, d), *q1 = s + ptkv::plane_offset(row + 8, d);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(q0 + t * ptkv::PLANE_BYTES));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(q1 + t * ptkv::PLANE_BYTES));
+      const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      f[t] = __builtin_bit_cast(f16x8, both);
+    }
+  }
+};
+// one row of the planes as the lane's B operand (load_row_scaled for pre-split K / V): lane (l31, lh) holds d = 16 s + 8 lh + 0..7
+// of token `tok`; returns the INVERSE scale of the row's group of four tokens
+template <int KS>
+__device__ __forceinline__ float load_row_planes(const char *__restrict__ planes, const float *__restrict__ inv, size_t hc_tiles,
+                                                 int tok, bool ok, int lh, f16x8 (&f)[KS][2]) {
+  const size_t tile = hc_tiles + (size_t)(tok >> 5);
+  const int r = tok & 31;
+  const char *base = planes + tile * ptkv::TILE_BYTES;
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const uint4 v = ok ? *reinterpret_cast<const uint4 *>(base + t * ptkv::PLANE_BYTES + ptkv::plane_offset(r, 16 * s + 8 * lh))
+                         : make_uint4(0u, 0u, 0u, 0u);
+      f[s][t] = __builtin_bit_cast(f16x8, v);
+    }
+  return ok ? inv[tile * 8 + ptkv::group_slot(r >> 2)] : 1.f;
+}
 
 // 32 rows x DK floats of a [*, ld] matrix: global -> registers (one float4 per thread) -> scaled f16 planes in LDS.
 // A group of four rows is held by 4 DK / 4 adjacent lanes (one wavefront for DK = 64, half of one for DK = 32); its
@@ -450,6 +500,218 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PT_ATTN
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   // soft-max normalisation, dropout scale and the common V scale in one factor
+  const float inv = (p_drop > 0.f ? dk_.ks : 1.f) * v_run * INV_TWO14 / l_tot;
+  if (q_ok) {
+    float *op = out + (size_t)(b * L + q) * D + h * DK;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = t * 32 + 8 * g + 4 * lh;
+        *reinterpret_cast<float4 *>(op + d) =
+            make_float4(o[t][4 * g] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
+      }
+    if (lh == 0) lse[((size_t)b * H + h) * L + q] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The forward kernel on PRE-SPLIT K / V (kv_format.h; dk = 64, 8 wavefronts = 256 queries per workgroup): what the QKV
+// product's epilogue wrote is byte for byte the LDS image of a tile, so a stage of K and V is filled by 1-KiB LDS-DMA pieces
+// (two per wavefront and 32-key tile) instead of two float4 loads, a group maximum, a split and two ds_write per thread and
+// tile - the staging that was a fifth of the kernel's VALU instructions (profiles/tools/isa_mix.py: 570 -> 491 per tile and
+// wavefront, all paths).  Same scaling groups, same split arithmetic, same soft-max, same dropout decisions: bit-identical to
+// attn_fwd_f16x2_kernel<64, 8, 1> on the fp32 K / V those planes were made from.
+// A stage is TPS tiles (TPS x 32 keys): THREE stage buffers, the pieces of stage s + 2 issued at the end of stage s and a
+// counted wait (this wavefront's pieces of that stage may stay in flight) in front of a raw s_barrier - HBM latency is two
+// stages of arithmetic, and there is ONE barrier per stage: with TPS = 2 half as many as the fp32 kernel, whose eight
+// wavefronts meet at every tile and so keep walking its phases (matrix products, soft-max, matrix products) in lock step.
+// Q stays an fp32 row per lane (one load per workgroup).
+template <int TPS>
+struct KvpGeo {
+  static constexpr int STAGE = TPS * 2 * ptkv::TILE_BYTES;   // per tile: K tile, V tile
+  static constexpr size_t LDS = 3 * (size_t)STAGE;
+};
+template <int TPS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(PT_ATTN_FWD_WAVES, PT_ATTN_FWD_WAVES))) void attn_fwd_kvp_f16x2_kernel(
+    const float *__restrict__ qkv, const char *__restrict__ kvp, const float *__restrict__ kv_inv, int kv_nt,
+    const int64_t *__restrict__ seq, int L, int H, float p_drop, uint64_t seed, uint32_t stream_id, float *__restrict__ out,
+    float *__restrict__ lse, uint32_t *__restrict__ keep_bits) {
+  constexpr int DK = 64, KS = DK / 16, NT = DK / 32, STAGE = KvpGeo<TPS>::STAGE;
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  __shared__ __attribute__((aligned(16))) float sBias[2][TPS][TR];
+  __shared__ __attribute__((aligned(16))) float sInvK[2][TPS][8], sInvV[2][TPS][8];
+  char *const stage0 = reinterpret_cast<char *>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 256 + wave * 32;
+  const int D = H * DK, D3 = 3 * D;
+  const float *base = qkv + (size_t)b * L * D3 + h * DK;  // Q block of this head
+  const int64_t *sq = seq + (size_t)b * L;
+  const int q = q0 + l31;
+  const bool q_ok = q < L;
+  const float scale = 0.125f;  // 1 / sqrt(dk)
+  const AttnDrop dk_ = make_attn_drop(seed, stream_id, (uint32_t)(b * H + h), p_drop);
+  const uint32_t q_part = attn_q_part(dk_, (uint32_t)q);
+  // tiles of this (protein, head): global tile gt0 + kt of K (which = 0) and V (which = 1); L is a multiple of 32 here
+  const int ntiles = L >> 5, nstages = (ntiles + TPS - 1) / TPS, gt0 = (b * L) >> 5;
+  const size_t tk = ptkv::tile_index(0, h, gt0, H, kv_nt), tv = ptkv::tile_index(1, h, gt0, H, kv_nt);
+  const char *const gk = kvp + tk * ptkv::TILE_BYTES + wave * 1024 + lane * 16;   // this wavefront's piece of a K / V tile
+  const char *const gv = kvp + tv * ptkv::TILE_BYTES + wave * 1024 + lane * 16;
+  // the pieces of stage st (2 per tile: K, V) into stage buffer buf; returns nothing - the number issued is 2 x tiles of the stage
+  auto issue = [&](int st, int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < TPS; ++u) {
+      const int kt = st * TPS + u;
+      if (kt < ntiles) {   // (uniform)
+        KvTile::dma16(gk + (size_t)kt * ptkv::TILE_BYTES, stage0 + buf * STAGE + u * 2 * ptkv::TILE_BYTES + wave * 1024);
+        KvTile::dma16(gv + (size_t)kt * ptkv::TILE_BYTES, stage0 + buf * STAGE + (u * 2 + 1) * ptkv::TILE_BYTES + wave * 1024);
+      }
+    }
+  };
+  // inverse group scales (8 + 8 floats) and the key mask of the tiles of a stage: loaded at the top of the stage before, published
+  // at its end.  (The loaded words are not touched before publish(): the wait for them then sits at the end of the stage, where
+  // the pieces of the next stage have to be in anyway - used at once, wavefront 0 would wait vmcnt(0) at the top of every stage.)
+  float r_inv = 0.f;
+  int64_t r_seq = 0;
+  auto fetch_small = [&](int st) __attribute__((always_inline)) {
+    const int u = tid >> 5, kt = st * TPS + u;               // thread tid serves tile u = tid / 32 of the stage
+    if (tid < 32 * TPS && kt < ntiles) {
+      r_seq = sq[kt * TR + (tid & 31)];
+      if ((tid & 31) < 16) r_inv = kv_inv[(((tid & 31) < 8 ? tk : tv) + kt) * 8 + (tid & 7)];
+    }
+  };
+  auto publish = [&](int slot) __attribute__((always_inline)) {
+    const int u = tid >> 5, t31 = tid & 31;
+    if (tid < 32 * TPS) {
+      if (t31 < 8) sInvK[slot][u][t31] = r_inv;
+      else if (t31 < 16) sInvV[slot][u][t31 - 8] = r_inv;
+      sBias[slot][u][t31] = r_seq != PTAMD_PAD_ID ? 0.f : -INFINITY;
+    }
+  };
+
+  issue(0, 0);
+  fetch_small(0);
+  f16x8 qf[KS][2];
+  const float iq = load_row_scaled<KS>(base, D3, min(q, L - 1), q_ok, lh, qf);
+  const float cq = scale * LOG2E * iq;
+  f32x16 o[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f, v_run = 0.f;
+  publish(0);
+  if (nstages > 1) {
+    issue(1, 1);
+    // stage 0 is in; the pieces of stage 1 (2 per tile it holds) may stay in flight
+    if (TPS == 1 || ntiles >= 2 * TPS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  int buf = 0;
+  for (int st = 0; st < nstages; ++st) {
+    const int cur = st & 1;
+    const bool more = st + 1 < nstages, more2 = st + 2 < nstages;
+    const int nbuf2 = buf >= 1 ? buf - 1 : 2;                // (buf + 2) % 3: read last in stage st - 1
+    if (more) fetch_small(st + 1);
+#pragma unroll
+    for (int u = 0; u < TPS; ++u) {
+      const int kt = st * TPS + u, k0 = kt * TR;
+      if (kt >= ntiles) break;   // (uniform; only the last stage can be short)
+      const char *sK = stage0 + buf * STAGE + u * 2 * ptkv::TILE_BYTES, *sV = sK + ptkv::TILE_BYTES;
+      const float4 ik4 = *reinterpret_cast<const float4 *>(&sInvK[cur][u][4 * lh]);
+      const float4 iva = *reinterpret_cast<const float4 *>(&sInvV[cur][u][0]), ivb = *reinterpret_cast<const float4 *>(&sInvV[cur][u][4]);
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {  // S^T[key][q] = K Q^T (scaled operands)
+        f16x8 kf[2];
+        KvTile::frag_rows(sK, k, lane, kf);
+        s = mfma3(kf, qf[k], s);
+      }
+      const float cu[4] = {cq * ik4.x, cq * ik4.y, cq * ik4.z, cq * ik4.w};
+      float mt = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 b4 = *reinterpret_cast<const float4 *>(&sBias[cur][u][8 * j + 4 * lh]);
+        const float bias[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s[4 * j + e] = fmaf(s[4 * j + e], cu[j], bias[e]);
+          mt = fmaxf(mt, s[4 * j + e]);
+        }
+      }
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float m_new = fmaxf(m_run, mt);
+      const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = __builtin_amdgcn_exp2f(s[r] - m_safe);
+        ps += s[r];
+      }
+      l_run = l_run * alpha + ps;
+      m_run = m_new;
+      const float vt = fmaxf(fmaxf(fmaxf(iva.x, iva.y), fmaxf(iva.z, iva.w)), fmaxf(fmaxf(ivb.x, ivb.y), fmaxf(ivb.z, ivb.w)));
+      float resc = alpha;
+      if (vt > v_run) {
+        resc *= v_run * inv_pow2(vt);
+        v_run = vt;
+      }
+      if (__builtin_amdgcn_ballot_w64(resc != 1.f)) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = o[t][r] * resc;
+            asm volatile("" : "+v"(v));
+            o[t][r] = v;
+          }
+      }
+      const float vn = inv_pow2(v_run);
+      const float4 ivh = lh ? ivb : iva;
+      const float fv[4] = {ivh.x * TWO14 * vn, ivh.y * TWO14 * vn, ivh.z * TWO14 * vn, ivh.w * TWO14 * vn};
+      if (p_drop > 0.f) {
+        if (keep_bits) {
+          const uint32_t word = attn_drop_keys_in_rows_export(dk_, q_part, k0, lh, s);
+          if (lane < 32 && q0 < L)
+            keep_bits[((size_t)(b * H + h) * (L >> 5) + (q0 >> 5)) * L + k0 + lane] = word;
+        } else {
+          attn_drop_keys_in_rows(dk_, q_part, k0, lh, s);
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const float x[8] = {s[8 * m], s[8 * m + 1], s[8 * m + 2], s[8 * m + 3], s[8 * m + 4], s[8 * m + 5], s[8 * m + 6], s[8 * m + 7]};
+        f16x8 pf[2];
+        split8g(x, fv[2 * m], fv[2 * m + 1], pf);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          f16x8 vf[2];
+          KvTile::frag_cols(sV, 16 * m, 32 * t, lane, vf);
+          o[t] = mfma3(vf, pf, o[t]);
+        }
+      }
+    }
+    // The pieces of stage st + 2 are this wavefront's LAST memory operations of the stage (behind the decision stores, the small
+    // loads and every LDS read): the counted wait then leaves exactly them in flight - stage st + 1, issued a stage ago, has
+    // landed; behind the barrier everybody is done with this buffer.
+    if (more) publish(cur ^ 1);
+    if (more2) issue(st + 2, nbuf2);
+    if (more2 && (TPS == 1 || (st + 3) * TPS <= ntiles)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    buf = buf == 2 ? 0 : buf + 1;
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = (p_drop > 0.f ? dk_.ks : 1.f) * v_run * INV_TWO14 / l_tot;
   if (q_ok) {
     float *op = out + (size_t)(b * L + q) * D + h * DK;
@@ -973,12 +1235,16 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float *__restrict
   }
 }
 
-template <bool BITS>   // BITS: the dropout decisions come from the forward kernel (keep_bits) - the generator is not compiled in
+// BITS: the dropout decisions come from the forward kernel (keep_bits) - the generator is not compiled in.
+// KVP: the key block's K and V rows come PRE-SPLIT (kv_format.h, written by the QKV product's epilogue) - a row's scale is
+// then that of its group of four tokens instead of its own; nothing else changes (Q and dO tiles are staged as before).
+template <bool BITS, bool KVP = false>
 __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_fused_f16x2_kernel(
     const float *__restrict__ qkv, const int64_t *__restrict__ seq, const float *__restrict__ d_o,
     const float *__restrict__ lse, const float *__restrict__ delta, int L, int H, float p_drop, uint64_t seed,
     uint32_t stream_id, float *__restrict__ dqkv, uint32_t *__restrict__ row_scale, uint32_t *__restrict__ row_min,
-    const uint32_t *__restrict__ keep_bits) {
+    const uint32_t *__restrict__ keep_bits, const char *__restrict__ kvp = nullptr, const float *__restrict__ kv_inv = nullptr,
+    int kv_nt = 0) {
   constexpr int DK = 64, NW = 8, KS = DK / 16, NT = DK / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   __shared__ __attribute__((aligned(16))) float sLse[2][TR], sDel[2][TR];
@@ -1021,14 +1287,16 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
        // as row fragments, dQ^T += K^T dS^T by transposing reads): 32 registers less than holding them (the dK/dV kernel's 256
        // are all taken).  (The previous block's readers are behind the last barrier of its loop.)
       f16x8 kf[KS][2];
-      ikl = load_row_scaled<KS>(base + D, D3, min(key, L - 1), k_ok, lh, kf);
+      if (KVP) ikl = load_row_planes<KS>(kvp, kv_inv, ptkv::tile_index(0, h, 0, H, kv_nt), b * L + min(key, L - 1), k_ok, lh, kf);
+      else ikl = load_row_scaled<KS>(base + D, D3, min(key, L - 1), k_ok, lh, kf);
       const int row = wave * 32 + l31;
 #pragma unroll
       for (int st = 0; st < KS; ++st)
 #pragma unroll
         for (int t = 0; t < 2; ++t) *reinterpret_cast<f16x8 *>(sKP + t * KP_PLANE + kp_off(row, 16 * st + 8 * lh)) = kf[st][t];
     }
-    const float ivl = load_row_scaled<KS>(base + 2 * D, D3, min(key, L - 1), k_ok, lh, vf);
+    const float ivl = KVP ? load_row_planes<KS>(kvp, kv_inv, ptkv::tile_index(1, h, 0, H, kv_nt), b * L + min(key, L - 1), k_ok, lh, vf)
+                          : load_row_scaled<KS>(base + 2 * D, D3, min(key, L - 1), k_ok, lh, vf);
     const float ck = scale * LOG2E * ikl, gk = ivl * ks;
     f32x16 dk[NT], dv[NT];
 #pragma unroll
@@ -1360,6 +1628,27 @@ int launch_dkv(const float *qkv, const int64_t *seq, const float *d_o, const flo
   }
   return pt_check_launch();
 }
+template <int TPS>
+int launch_fwd_kvp_t(const float *qkv, const char *kvp, const float *kv_inv, const int64_t *seq, int B, int L, int H, float p,
+                     uint64_t seed, uint32_t sid, float *out, float *lse, uint32_t *keep_bits, hipStream_t st) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_kvp_f16x2_kernel<TPS>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)KvpGeo<TPS>::LDS);
+  if (e != hipSuccess) {
+    g_pt_last_hip_error = e;
+    return PTAMD_ERR_HIP;
+  }
+  hipLaunchKernelGGL(attn_fwd_kvp_f16x2_kernel<TPS>, dim3((L + 255) / 256, H, B), dim3(512), KvpGeo<TPS>::LDS, st, qkv, kvp, kv_inv,
+                     (B * L) / 32, seq, L, H, p, seed, sid, out, lse, keep_bits);
+  return pt_check_launch();
+}
+// 64-key stages (one barrier per two tiles); PTAMD_ATTN_KVP_TPS = 1 in the environment (read at every call) selects 32-key
+// stages for A/B measurements - same results either way
+int launch_fwd_kvp(const float *qkv, const char *kvp, const float *kv_inv, const int64_t *seq, int B, int L, int H, float p,
+                   uint64_t seed, uint32_t sid, float *out, float *lse, uint32_t *keep_bits, hipStream_t st) {
+  const char *e = getenv("PTAMD_ATTN_KVP_TPS");
+  if (e && e[0] == '1') return launch_fwd_kvp_t<1>(qkv, kvp, kv_inv, seq, B, L, H, p, seed, sid, out, lse, keep_bits, st);
+  return launch_fwd_kvp_t<2>(qkv, kvp, kv_inv, seq, B, L, H, p, seed, sid, out, lse, keep_bits, st);
+}
 template <int DK>
 int fwd_by_shape(Shape sh, const float *qkv, const int64_t *seq, int B, int L, int H, float p, uint64_t seed, uint32_t sid,
                  float *out, float *lse, uint32_t *keep_bits, hipStream_t st) {
@@ -1377,18 +1666,19 @@ inline bool use_fused(int B, int L, int H, int dk) {
 }
 int launch_fused(const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse, float *delta,
                  int B, int L, int H, float p, uint64_t seed, uint32_t sid, float *dqkv, uint32_t *row_scale,
-                 uint32_t *row_min, const uint32_t *keep_bits, hipStream_t st) {
+                 uint32_t *row_min, const uint32_t *keep_bits, const char *kvp, const float *kv_inv, hipStream_t st) {
   const size_t items = (size_t)B * L * H * 16;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, o_fwd, d_o, B * L, L, H, 64, delta);
   const bool bits = keep_bits != nullptr && p > 0.f;
-  auto kern = bits ? attn_bwd_fused_f16x2_kernel<true> : attn_bwd_fused_f16x2_kernel<false>;
+  auto kern = kvp ? (bits ? attn_bwd_fused_f16x2_kernel<true, true> : attn_bwd_fused_f16x2_kernel<false, true>)
+                  : (bits ? attn_bwd_fused_f16x2_kernel<true, false> : attn_bwd_fused_f16x2_kernel<false, false>);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS);
   if (e != hipSuccess) {
     g_pt_last_hip_error = e;
     return PTAMD_ERR_HIP;
   }
   hipLaunchKernelGGL(kern, dim3(1, H, B), dim3(512), FUSED_LDS, st, qkv, seq, d_o, lse, delta, L, H, p, seed, sid, dqkv, row_scale,
-                     row_min, keep_bits);
+                     row_min, keep_bits, kvp, kv_inv, (B * L) / 32);
   return pt_check_launch();
 }
 template <int DK>
@@ -1408,9 +1698,21 @@ int bwd_by_shape(Shape sh, const float *qkv, const int64_t *seq, const float *o_
 }  // namespace
 }  // namespace ptattn16
 
-int pt_attention_fwd_f16x2(const float *qkv, const int64_t *seq, int B, int L, int H, int dk, float p, uint64_t seed,
-                           uint32_t sid, float *out, float *lse, uint32_t *keep_bits, hipStream_t st) {
+// pre-split K / V (kv_format.h) are read by the 256-query forward kernel and the one-sweep backward kernel: head size 64, whole
+// 32-token tiles per protein, and the batch shapes at which exactly those two kernels run
+bool pt_attention_f16x2_reads_kv_planes(int B, int L, int H, int dk) {
   using namespace ptattn16;
+  return B > 0 && L > 0 && H > 0 && dk == 64 && (L & 31) == 0 && use_fused(B, L, H, dk) && launch_shape(B, L, H) == W8;
+}
+
+int pt_attention_fwd_f16x2(const float *qkv, const int64_t *seq, int B, int L, int H, int dk, float p, uint64_t seed,
+                           uint32_t sid, float *out, float *lse, uint32_t *keep_bits, const void *kv_planes, const float *kv_inv,
+                           hipStream_t st) {
+  using namespace ptattn16;
+  if (kv_planes) {
+    if (!kv_inv || !pt_attention_f16x2_reads_kv_planes(B, L, H, dk)) return PTAMD_ERR_BAD_SHAPE;
+    return launch_fwd_kvp(qkv, static_cast<const char *>(kv_planes), kv_inv, seq, B, L, H, p, seed, sid, out, lse, keep_bits, st);
+  }
   const Shape sh = launch_shape(B, L, H);
   return dk == 64 ? fwd_by_shape<64>(sh, qkv, seq, B, L, H, p, seed, sid, out, lse, keep_bits, st)
                   : fwd_by_shape<32>(sh, qkv, seq, B, L, H, p, seed, sid, out, lse, keep_bits, st);
@@ -1421,11 +1723,14 @@ bool pt_attention_bwd_f16x2_reads_keep_bits(int B, int L, int H, int dk) { retur
 
 int pt_attention_bwd_f16x2(const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse,
                            float *delta, int B, int L, int H, int dk, float p, uint64_t seed, uint32_t sid, float *dqkv,
-                           uint32_t *row_scale, uint32_t *row_min, const uint32_t *keep_bits, hipStream_t st) {
+                           uint32_t *row_scale, uint32_t *row_min, const uint32_t *keep_bits, const void *kv_planes,
+                           const float *kv_inv, hipStream_t st) {
   using namespace ptattn16;
+  if (kv_planes && (!kv_inv || !pt_attention_f16x2_reads_kv_planes(B, L, H, dk))) return PTAMD_ERR_BAD_SHAPE;
   // (the forward kernel's decisions are read by the fused kernel and by the dK / dV kernel of the two-kernel path)
   if (use_fused(B, L, H, dk))
-    return launch_fused(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, keep_bits, st);
+    return launch_fused(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, keep_bits,
+                        static_cast<const char *>(kv_planes), kv_inv, st);
   const Shape sh = launch_shape(B, L, H);
   return dk == 64 ? bwd_by_shape<64>(sh, qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, keep_bits, st)
                   : bwd_by_shape<32>(sh, qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, keep_bits, st);

@@ -26,6 +26,7 @@
 
 #include "gemm_common.h"
 #include "hp_format.h"
+#include "kv_format.h"
 #include "split_bf16.h"
 
 // v_writelane_b32 through the LLVM intrinsic (no clang builtin here; as inline asm the compiler would not see its hazards)
@@ -46,6 +47,11 @@ struct HpParams {
   const float *a_scale, *b_scale;
   int kb16;                // 16-column blocks per block row (= Kp / 16)
   int a_rb_last, b_rb_last;  // last valid block row of each operand (tile rows beyond are clamped, never stored)
+  // the QKV product (Attention.py:49): the columns from kv_col0 on - K and V, head by head, 64 columns each - leave the epilogue
+  // as pre-split planes (kv_format.h) instead of fp32; columns in front (Q) are stored as usual
+  char *kv_planes;
+  float *kv_inv;
+  int kv_col0, kv_heads, kv_nt;
 };
 
 typedef __attribute__((address_space(1))) const void *gptr_t;
@@ -297,9 +303,28 @@ typedef Hp3G<4> Hp3;
 // the epilogue of one wavefront's 64 x 64 block (TI = 2), eight rows at a time through `scratch` (512 floats): bias / ReLU /
 // dropout in the MFMA layout, residual / gate / accumulate operands and the stores as float4 rows.  Arithmetic, order of
 // operations and dropout masks are those of ptgemm::tile_epilogue_vec (gemm_common.h).
-template <int EPI>
+// eight f32 of one row -> the two f16x8 chunks (hi, lo) of x * s, with the arithmetic of the attention kernels' own staging
+__device__ __forceinline__ void kv_split8(const float4 &a, const float4 &b, float s, uint4 &hi, uint4 &lo) {
+  uint2 h0, l0, h1, l1;
+  ptsplit::split_quad_f16(a.x, a.y, a.z, a.w, s, s, s, s, h0, l0);
+  ptsplit::split_quad_f16(b.x, b.y, b.z, b.w, s, s, s, s, h1, l1);
+  hi = make_uint4(h0.x, h0.y, h1.x, h1.y);
+  lo = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+// maximum over the 32 lanes of a wavefront half (in every lane of it): four DPP steps inside the rows of 16, one exchange
+__device__ __forceinline__ uint32_t half_umax(uint32_t v) {
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));  // row_mirror
+  v = max(v, (uint32_t)__shfl_xor((int)v, 16, 64));
+  return v;
+}
+
+template <int EPI, bool KVP = false>
 __device__ __forceinline__ void hp3_epilogue(const GemmParams &p, const f32x16 (&acc)[2][2], float *C, int ldc, bool partial,
-                                             int row0, int col0, int lane, uint32_t thr, float keep_scale, float *scratch) {
+                                             int row0, int col0, int lane, uint32_t thr, float keep_scale, float *scratch,
+                                             const HpParams *hp = nullptr) {
   using ptgemm::EPI_FULL;
   using ptgemm::EPI_PLAIN;
   typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -370,6 +395,31 @@ __device__ __forceinline__ void hp3_epilogue(const GemmParams &p, const f32x16 (
           }
           scratch[(4 * lh + e) * 64 + j * 32 + l31] = v;
         }
+      if (KVP && col0 >= hp->kv_col0) {
+        // K / V columns (one head per wavefront): the eight rows go out as planes - lane (row lane >> 3 of the eight, chunk
+        // lane & 7) holds 8 consecutive d; a group of four rows = a wavefront half, scaled by the power of two of ITS maximum
+        const int rr = lane >> 3, ch = lane & 7;
+        const float4 a = *reinterpret_cast<const float4 *>(scratch + rr * 64 + ch * 8);
+        const float4 b = *reinterpret_cast<const float4 *>(scratch + rr * 64 + ch * 8 + 4);
+        const uint32_t am = half_umax(max(max(max(__float_as_uint(a.x) & 0x7fffffffu, __float_as_uint(a.y) & 0x7fffffffu),
+                                              max(__float_as_uint(a.z) & 0x7fffffffu, __float_as_uint(a.w) & 0x7fffffffu)),
+                                          max(max(__float_as_uint(b.x) & 0x7fffffffu, __float_as_uint(b.y) & 0x7fffffffu),
+                                              max(__float_as_uint(b.z) & 0x7fffffffu, __float_as_uint(b.w) & 0x7fffffffu))));
+        const uint32_t sbits = pt_row_scale_bits(am);
+        uint4 hi, lo;
+        kv_split8(a, b, __uint_as_float(sbits), hi, lo);
+        const int hc = (col0 - hp->kv_col0) >> 6;                       // (which, head): which = hc / heads
+        const int gt = (row0 >> 5) + i, r = 8 * g + rr;
+        if (row0 + i * 32 < p.M) {   // (M is a multiple of 32 on this path: whole tiles only)
+          char *tile = hp->kv_planes + ((size_t)hc * hp->kv_nt + gt) * ptkv::TILE_BYTES;
+          char *dst = tile + r * ptkv::ROW_BYTES + ptkv::chunk_pos(r, ch) * 16;
+          *reinterpret_cast<uint4 *>(dst) = hi;
+          *reinterpret_cast<uint4 *>(dst + ptkv::PLANE_BYTES) = lo;
+          if ((lane & 31) == 0)
+            hp->kv_inv[((size_t)hc * hp->kv_nt + gt) * 8 + ptkv::group_slot(2 * g + lh)] = __uint_as_float((254u << 23) - sbits);
+        }
+        continue;
+      }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int f = lane + 64 * u, rr = f >> 4, c4 = (f & 15) * 4;   // rr: 0..7 of this group of eight rows
@@ -415,7 +465,7 @@ __device__ __forceinline__ void hp3_epilogue(const GemmParams &p, const f32x16 (
 
 #define PT_DS_READ_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 
-template <int EPI, int WM>
+template <int EPI, int WM, bool KVP = false>
 __global__ __launch_bounds__(Hp3G<WM>::THREADS, 2) void gemm_hp3_kernel(const HpParams p) {
   using G = Hp3G<WM>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -574,7 +624,7 @@ __global__ __launch_bounds__(Hp3G<WM>::THREADS, 2) void gemm_hp3_kernel(const Hp
               for (int j = 0; j < 2; ++j) acc[i][j][g * 4 + e] = acc[i][j][g * 4 + e] * ia * ib[j];
             }
       }
-      hp3_epilogue<EPI>(p.g, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 512);
+      hp3_epilogue<EPI, KVP>(p.g, acc, C, ldc, partial, row0, col0, lane, thr, keep_scale, scratch + wave * 512, &p);
       zero_acc();
     }
     if (!advance(cc)) break;
@@ -582,11 +632,11 @@ __global__ __launch_bounds__(Hp3G<WM>::THREADS, 2) void gemm_hp3_kernel(const Hp
   }
 }
 
-template <int EPI, int WM>
+template <int EPI, int WM, bool KVP = false>
 int launch_hp3_g(const HpParams &p, int splits, hipStream_t st) {
   using G = Hp3G<WM>;
   const int work = ((p.g.M + G::TILE_M - 1) / G::TILE_M) * ((p.g.N + HBN - 1) / HBN) * splits;
-  auto kern = gemm_hp3_kernel<EPI, WM>;
+  auto kern = gemm_hp3_kernel<EPI, WM, KVP>;
   PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
   const int slots = ptgemm::persistent_grid(p.g.reserved_cus) * G::WG_PER_CU;
   hipLaunchKernelGGL(kern, dim3(work < slots ? work : slots), dim3(G::THREADS), G::LDS, st, p);
@@ -889,7 +939,21 @@ int ptamd_gemm_hp(const ptamd_gemm_hp_args *a, void *stream) {
   p.kb16 = Kp / 16;
   p.a_rb_last = (round_up(a->M, 32) / 32) - 1;
   p.b_rb_last = (round_up(a->N, 32) / 32) - 1;
+  p.kv_planes = static_cast<char *>(a->kv_planes);
+  p.kv_inv = a->kv_inv;
+  p.kv_col0 = a->kv_col0;
+  p.kv_heads = a->kv_heads;
+  p.kv_nt = a->M / 32;
   hipStream_t st = (hipStream_t)stream;
+  if (a->kv_planes) {
+    // K / V leave as planes (kv_format.h): whole 32-token tiles, 64-column heads, the plain bias epilogue of an unsplit product
+    if (!a->kv_inv || a->kv_heads <= 0 || (a->M & 31) || (a->kv_col0 & 63) || a->kv_col0 < 0 ||
+        a->N != a->kv_col0 + 2 * a->kv_heads * 64 || !g.vec_epilogue || splits > 1 || a->residual || a->gate_mask ||
+        a->gate_mask_out || a->dropout_p != 0.f || a->flags != 0)
+      return PTAMD_ERR_BAD_SHAPE;
+    if (!pt_aligned16(a->kv_planes)) return PTAMD_ERR_ALIGN;
+    return launch_hp3_g<ptgemm::EPI_FULL, 4, true>(p, 1, st);
+  }
   const bool plain = !a->bias && !a->residual && !a->gate_mask && !a->gate_mask_out &&
                      !(a->flags & (PTAMD_EPI_RELU | PTAMD_EPI_TANH | PTAMD_EPI_ACCUM)) && a->dropout_p == 0.f;
   // the 1-bit gate (read or written) lives in the float4 epilogue of the three-stage kernel and in unsplit products only

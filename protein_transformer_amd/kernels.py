@@ -112,8 +112,10 @@ def hp_split(x, transposed=False, out=None):
 
 
 def gemm_hp(a, b, C_out, *, bias=None, residual=None, ldr=0, flags=0, dropout_p=0.0, seed=0, stream_id=0, split_k=1,
-            gate_scale=0.0, gate_mask=None, gate_mask_out=None):
-    """C[M,N] = epilogue(A B^T) from pre-split operands a = hp [M,K], b = hp [N,K]."""
+            gate_scale=0.0, gate_mask=None, gate_mask_out=None, kv=None, kv_col0=0, kv_heads=0):
+    """C[M,N] = epilogue(A B^T) from pre-split operands a = hp [M,K], b = hp [N,K].  `kv` = (planes, inverse scales) of
+    `attention_kv_buffers`: the columns from kv_col0 on (K | V of the QKV product, kv_heads heads of 64) leave as the pre-split
+    planes the f16x2 attention kernels read instead of fp32 (C[:, kv_col0:] is then not written)."""
     assert a.K == b.K
     M, N = a.rows, b.rows
     ws = workspace("gemm_hp", lib().ptamd_gemm_hp_workspace_bytes(M, N, split_k), C_out.device) if split_k > 1 else None
@@ -126,7 +128,9 @@ def gemm_hp(a, b, C_out, *, bias=None, residual=None, ldr=0, flags=0, dropout_p=
                       workspace_bytes=ws.numel() if ws is not None else 0, gate_scale=float(gate_scale),
                       reserved_cus=int(GEMM_RESERVED_CUS),
                       gate_mask=gate_mask.data_ptr() if gate_mask is not None else None,
-                      gate_mask_out=gate_mask_out.data_ptr() if gate_mask_out is not None else None)
+                      gate_mask_out=gate_mask_out.data_ptr() if gate_mask_out is not None else None,
+                      kv_planes=kv[0].data_ptr() if kv is not None else None, kv_inv=kv[1].data_ptr() if kv is not None else None,
+                      kv_col0=int(kv_col0), kv_heads=int(kv_heads))
     if GEMM_TIMING is None:
         check(lib().ptamd_gemm_hp(C.byref(args), stream()), "gemm_hp")
     else:
@@ -441,20 +445,33 @@ def attention_keep_bits(B, L, H, device):
     return torch.empty(lib().ptamd_attention_keep_bits_bytes(B, L, H) // 4, dtype=torch.int32, device=device)
 
 
-def attention_fwd(qkv, seq, H, dropout_p, seed, stream_id, arith=None, keep_bits=None):
-    """keep_bits (attention_keep_bits, optional): filled with the dropout decisions when dropout_p > 0."""
+def attention_reads_kv_planes(B, L, H, dk, arith):
+    """True when the attention kernels of this shape and arithmetic read K / V pre-split (written by the QKV product's epilogue)."""
+    return bool(lib().ptamd_attention_reads_kv_planes(B, L, H, dk, int(_DEFAULT_ARITH if arith is None else arith)))
+
+
+def attention_kv_buffers(T, H, device):
+    """(planes uint8, inverse group scales float32) for the pre-split K / V of T tokens and H heads of 64 (csrc/kv_format.h)."""
+    return (torch.empty(lib().ptamd_attention_kv_bytes(T, H), dtype=torch.uint8, device=device),
+            torch.empty(lib().ptamd_attention_kv_inv_floats(T, H), dtype=torch.float32, device=device))
+
+
+def attention_fwd(qkv, seq, H, dropout_p, seed, stream_id, arith=None, keep_bits=None, kv=None):
+    """keep_bits (attention_keep_bits, optional): filled with the dropout decisions when dropout_p > 0.  kv (optional):
+    `attention_kv_buffers` filled by the QKV product - K and V are read from there, only the Q columns of `qkv` are."""
     B, L = seq.shape
     D = qkv.shape[1] // 3
     out = torch.empty(B * L, D, dtype=torch.float32, device=qkv.device)
     lse = torch.empty(B, H, L, dtype=torch.float32, device=qkv.device)
     check(lib().ptamd_attention_fwd(ptr(qkv), ptr(seq), B, L, H, D // H, float(dropout_p), int(seed), int(stream_id),
                                     int(_DEFAULT_ARITH if arith is None else arith), ptr(out), ptr(lse), ptr(keep_bits),
+                                    ptr(kv[0]) if kv is not None else None, ptr(kv[1]) if kv is not None else None,
                                     stream()), "attention_fwd")
     return out, lse
 
 
 def attention_bwd(qkv, seq, out, dout, lse, H, dropout_p, seed, stream_id, arith=None, row_scale=None, row_scale_min=None,
-                  keep_bits=None):
+                  keep_bits=None, kv=None):
     """row_scale [T] / row_scale_min [4] (int32, preset to 0x7F000000): f16x2 scales of the rows of dqkv as a by-product
     (f16x2 arithmetic and head size 32 / 64 only - `attention_row_scales_available`).  keep_bits: what attention_fwd filled
     for the same (seed, stream_id) - the fused backward kernel reads the decisions instead of drawing them again."""
@@ -465,7 +482,8 @@ def attention_bwd(qkv, seq, out, dout, lse, H, dropout_p, seed, stream_id, arith
     check(lib().ptamd_attention_bwd(ptr(qkv), ptr(seq), ptr(out), ptr(dout), ptr(lse), B, L, H, D // H,
                                     float(dropout_p), int(seed), int(stream_id),
                                     int(_DEFAULT_ARITH if arith is None else arith), ptr(dqkv), ptr(row_scale),
-                                    ptr(row_scale_min), ptr(keep_bits), ptr(ws), ws.numel(), stream()), "attention_bwd")
+                                    ptr(row_scale_min), ptr(keep_bits), ptr(kv[0]) if kv is not None else None,
+                                    ptr(kv[1]) if kv is not None else None, ptr(ws), ws.numel(), stream()), "attention_bwd")
     return dqkv
 
 

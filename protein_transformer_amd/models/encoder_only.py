@@ -331,6 +331,7 @@ class _TransformerBase(nn.Module):
         self.side_stream_dw = True                   # small batches: weight-gradient products on a side stream
         self.top_layer_scales = True                 # uniform scales of the top layer's dy2 / dz1 by a pass (backward())
         self.dw_group = "auto"                       # grouping of the weight-gradient products of a layer (backward())
+        self.kv_planes = True                        # the QKV product's epilogue writes K / V pre-split for the attention kernels (csrc/kv_format.h)
         self.weights_prep = True                     # scales / bounds / planes of the weights in one pass (csrc/wprep.hip), fused into the
                                                      # optimizer step where one precedes the forward pass; False: the separate launches of rounds 2-4
         self.auto_guard = AutoGuard(nlayers)         # measures the slack of the bound-derived f16x2 scales, falls back per site
@@ -799,12 +800,18 @@ class _EncoderFn(torch.autograd.Function):
             h1, mean1, rstd1 = K.layernorm_fwd(x, W(b + "sublayer_connections.0.norm.weight"),
                                                W(b + "sublayer_connections.0.norm.bias"), row_scale=s_h1,
                                                planes=hplanes if hp_q else None)
+            attn_ar_f = attn_default if m.attn_mode is None else m.attn_mode
+            # K and V leave the QKV product as the pre-split planes the attention kernels of this batch shape read (no fp32 K / V at
+            # all: the forward kernel fills its stages by LDS-DMA, the one-sweep backward kernel loads its key rows from them)
+            kv = None
+            if hp_q and m.kv_planes and K.attention_reads_kv_planes(B, L, H, D // H, attn_ar_f):
+                kv = K.attention_kv_buffers(Tn, H, x.device)
+                m.__dict__["_kv_plane_passes"] = m.__dict__.get("_kv_plane_passes", 0) + 1
             if hp_q:
                 qkv = K.gemm_hp(K.hp_view(hplanes, s_h1, Tn, D), sc["hp_qkv"],
-                                torch.empty(Tn, 3 * D, dtype=torch.float32, device=x.device), bias=bqkv)
+                                torch.empty(Tn, 3 * D, dtype=torch.float32, device=x.device), bias=bqkv, kv=kv, kv_col0=D, kv_heads=H)
             else:
                 qkv = K.linear_fwd(h1, wqkv, bqkv, **prod(i, 0, a_scale=s_h1, b_scale=sc and sc["rs_qkv"]))
-            attn_ar_f = attn_default if m.attn_mode is None else m.attn_mode
             # the dropout decisions of the probabilities, kept for the backward kernel that reads them instead of drawing
             # them again (8 MB per layer at 32 x 512 x 8 heads; only where that kernel will run)
             kbits = None
@@ -812,7 +819,7 @@ class _EncoderFn(torch.autograd.Function):
                     K.attention_bwd_reads_keep_bits(B, L, H, D // H, attn_ar_f):
                 kbits = K.attention_keep_bits(B, L, H, x.device)
                 m.__dict__["_attn_bits_passes"] = m.__dict__.get("_attn_bits_passes", 0) + 1
-            att, lse = K.attention_fwd(qkv, seq, H, pa, seed, sid + _SITE_ATTN, arith=attn_ar_f, keep_bits=kbits)
+            att, lse = K.attention_fwd(qkv, seq, H, pa, seed, sid + _SITE_ATTN, arith=attn_ar_f, keep_bits=kbits, kv=kv)
             use_b = sc is not None and not (off is not None and off[i, 0])          # att on its bound (else: exact row scales)
             x2 = K.linear_fwd(att, W(b + "self_attn.wo.weight"), W(b + "self_attn.wo.bias"), residual=x, ldr=D,
                               dropout_p=p, seed=seed, stream_id=sid + _SITE_ATTN_OUT,
@@ -840,7 +847,7 @@ class _EncoderFn(torch.autograd.Function):
                               dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_OUT,
                               **prod(i, 3, a_scale=sc["f1_scale"] if use_b else None, a_scale_stride=0 if use_b else 1,
                                      b_scale=sc and sc["rs_2"]))
-            saved.append((x, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, f1, kbits, fmask))
+            saved.append((x, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, f1, kbits, fmask, kv))
             if measure_fwd:
                 gs = sc["guard_stats"][i]
                 K.weight_scales([dict(w=t, stats=gs[j], rows_only=True) for j, t in ((0, att), (1, f1), (3, h1), (4, h2))])
@@ -979,7 +986,7 @@ class _EncoderFn(torch.autograd.Function):
             b = f"encoder.enc_layers.{i}."
             sid = i * 8
             sc = scales[i] if scales is not None else None
-            x, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, f1, kbits, fmask = ctx.saved[i]
+            x, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, f1, kbits, fmask, kv = ctx.saved[i]
             # x3 = x2 + drop(f1 W2^T + b2)
             if dy2 is None:
                 dy2 = K.dropout_bwd(dx, p, seed, sid + _SITE_FFN_OUT) if p > 0 else dx
@@ -1039,7 +1046,8 @@ class _EncoderFn(torch.autograd.Function):
                 s_dqkv_all = torch.full((m.nlayers, B * L), 0x7F000000, dtype=torch.int32, device=dpred.device)
             s_dqkv = s_dqkv_all[i] if attn_scales else None
             dqkv = K.attention_bwd(qkv, seq, att, datt, lse, H, pa, seed, sid + _SITE_ATTN, arith=attn_ar,
-                                    row_scale=s_dqkv, row_scale_min=sc["dqkv_min"] if attn_scales else None, keep_bits=kbits)
+                                    row_scale=s_dqkv, row_scale_min=sc["dqkv_min"] if attn_scales else None, keep_bits=kbits,
+                                    kv=kv)
             gw, gb = m._qkv(gflat, i)
             wqkv, _ = m._qkv(flat, i)
             if sc is not None:

@@ -60,8 +60,8 @@ def test_host_only_entry_points(built_lib):
     assert lib.ptamd_nerf_fwd(None, None, 0, 5, None, None, None) == -1          # PTAMD_ERR_BAD_SHAPE
     assert lib.ptamd_nerf_fwd(None, None, 2, 5000, None, None, None) == -2       # PTAMD_ERR_TOO_LONG
     assert lib.ptamd_drmsd_fwd_bwd(None, None, None, 2, 8, None, None, None, 0, None) == -3   # PTAMD_ERR_WORKSPACE
-    assert lib.ptamd_attention_fwd(None, None, 1, 8, 2, 24, 0.0, 0, 0, 4, None, None, None, None) == -1      # head size 24
-    assert lib.ptamd_attention_fwd(None, None, 1, 8, 2, 32, 0.0, 0, 0, 7, None, None, None, None) == -1      # unknown arithmetic
+    assert lib.ptamd_attention_fwd(None, None, 1, 8, 2, 24, 0.0, 0, 0, 4, None, None, None, None, None, None) == -1      # head size 24
+    assert lib.ptamd_attention_fwd(None, None, 1, 8, 2, 32, 0.0, 0, 0, 7, None, None, None, None, None, None) == -1      # unknown arithmetic
     assert lib.ptamd_kabsch_rmsd(None, None, None, 0, 8, None, None) == -1
 
 
