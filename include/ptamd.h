@@ -86,9 +86,11 @@ int ptamd_nerf_bwd(const float *ang, const int64_t *seq, const float *crd, const
  *   dcrd [B,L*14,3] out or NULL: d(drmsd/n)/d(pred_crd)  (the reference always
  *   differentiates the length-normalised loss, losses.py:80,91-92).
  * Workspace: 52 B per atom slot (compacted copies: predicted coordinates, (predicted, true) interleaved per axis, index) plus
- * the fixed-order partial sums of the upper-triangle sweep, which grow as O(n^2 / 256) per protein (n = 14 L atom slots): one
- * 1 KB column partial per (4-row-tile strip, 64-atom column tile) and one 4 KB row partial per (strip, chunk of 8 column
- * tiles).  B = 32: 166 MB at L = 512, about 1.39 GB at L = 1500.  The size is a function of (B, L) only. */
+ * the fixed-order partial sums of the upper-triangle sweep - one 1 KB column partial per (4-row-tile strip, 64-atom column
+ * tile) and one 4 KB row partial per (strip, chunk of 8 column tiles): O(n^2 / 256) per protein (n = 14 L atom slots) -
+ * CAPPED at 200 MB: beyond that the strips are swept in passes over groups of strips with the same buffers (+ 32 B per atom slot
+ * of running sums), same bits as one launch.  B = 32: 159 MB at L = 512, 242 MB at L = 1500 (1.39 GB in round 4).  The size is
+ * a function of (B, L) only. */
 size_t ptamd_drmsd_workspace_bytes(int B, int L);
 int ptamd_drmsd_fwd_bwd(const float *pred_crd, const float *true_crd, const int64_t *seq, int B, int L,
                         float *stats, float *dcrd, void *workspace, size_t workspace_bytes, void *stream);

@@ -22,6 +22,8 @@
 #include <type_traits>
 #include <utility>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -194,7 +196,7 @@ template <bool WITH_GRAD>
 __global__ __launch_bounds__(RS) void drmsd_tri_kernel(const Col8 *__restrict__ col8,
                                                        const Counts *__restrict__ counts, int L,
                                                        float4 *__restrict__ rowpart, float4 *__restrict__ colpart,
-                                                       double *__restrict__ partials) {
+                                                       double *__restrict__ partials, int strip0, int spp) {
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];
   float *const s_cf = s_dyn;                                                  // [4][64][17] coefficient tiles
   float4 *const s_cs = reinterpret_cast<float4 *>(s_dyn + STRIP_TILES * TS * CF_LD);   // [2][4][64] (S, Vx, Vy, Vz) per wavefront, two column tiles
@@ -204,10 +206,12 @@ __global__ __launch_bounds__(RS) void drmsd_tri_kernel(const Col8 *__restrict__ 
   const TriLayout tl = tri_layout((int)nmax, (int)gridDim.y);
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // (told to the compiler: what depends on w only stays scalar)
-  const int strip = blockIdx.x / tl.chunks, chunk = blockIdx.x % tl.chunks;
+  // this launch covers the strips strip0 .. strip0 + spp - 1 (all of them, or one PASS of a long batch: layout()); the row /
+  // column partials are indexed by the strip's position in the pass, the loss partials by the strip itself
+  const int sl = blockIdx.x / tl.chunks, strip = strip0 + sl, chunk = blockIdx.x % tl.chunks;
   const Counts cn = counts[b];
   const int n = cn.n, nbb = cn.n_bb, nT = (n + TS - 1) / TS;
-  double *part = partials + ((size_t)b * tl.strips * tl.chunks + blockIdx.x) * 2;
+  double *part = partials + ((size_t)b * tl.strips * tl.chunks + (size_t)strip * tl.chunks + chunk) * 2;
   const int J0 = max(STRIP_TILES * strip, tl.chunk_tiles * chunk), J1 = min(nT, tl.chunk_tiles * (chunk + 1));
   if (STRIP_TILES * strip >= nT || J0 >= J1) {  // block-uniform: nothing to do (the finalize kernel skips these items too)
     if (tid == 0) part[0] = part[1] = 0.0;
@@ -359,13 +363,13 @@ __global__ __launch_bounds__(RS) void drmsd_tri_kernel(const Col8 *__restrict__ 
         const float4 a0 = slots[lane], a1 = slots[TS + lane], a2 = slots[2 * TS + lane], a3 = slots[3 * TS + lane];
         const float4 t = make_float4(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y,
                                      ((a0.z + a1.z) + a2.z) + a3.z, ((a0.w + a1.w) + a2.w) + a3.w);
-        colpart[(((size_t)b * tl.strips + strip) * tl.tiles + J) * TS + lane] = t;
+        colpart[(((size_t)b * spp + sl) * tl.tiles + J) * TS + lane] = t;
       }
     } else {
       __syncthreads();   // the next column tile is staged; this one is free
     }
   }
-  if (WITH_GRAD) rowpart[(((size_t)b * tl.strips + strip) * tl.chunks + chunk) * RS + tid] = make_float4(gx, gy, gz, 0.f);
+  if (WITH_GRAD) rowpart[(((size_t)b * spp + sl) * tl.chunks + chunk) * RS + tid] = make_float4(gx, gy, gz, 0.f);
   // loss terms: off-diagonal tiles saw every pair once, the diagonal tile twice
   double all = (double)offA + (double)offB + 0.5 * ((double)diagA + (double)diagB);
   double bbp = (double)offA + ((live && i < nbb) ? 0.5 * (double)diagA : 0.0);
@@ -388,12 +392,83 @@ __global__ __launch_bounds__(RS) void drmsd_tri_kernel(const Col8 *__restrict__ 
 }
 constexpr size_t TRI_LDS = (size_t)(STRIP_TILES * TS * CF_LD) * 4 + 2 * RS * 16;
 
-// statistics, gradient assembly and scatter back to the slot layout: grid (ceil(nmax / 256), B); dcrd was zeroed before
+// The gradient of atom j from the partial sums of ONE launch of the pair sweep over the strips strip0 .. strip0 + spp - 1:
+//   row side     the chunks of the atom's own strip that had work - a contiguous range - in chunk order (only when that strip is
+//                in the launch);
+//   column side  g += x_j S - V for every strip of the launch at or above the atom's tile, in strip order, continuing `col`.
+// Loads go out four at a time (a step of few proteins runs these kernels on a fraction of the CUs: dependent-looking loads
+// were their time).  The two sides are summed SEPARATELY (round 5) so that a long batch can be swept in passes over groups of
+// strips - the column sums of pass k continue those of pass k - 1 - and give the same bits as one launch.
+struct RowCol {
+  float rx, ry, rz, cx, cy, cz;
+};
+__device__ __forceinline__ void gather_partials(const TriLayout &tl, int b, int j, int nT, const float4 &xj,
+                                                const float4 *__restrict__ rowpart, const float4 *__restrict__ colpart,
+                                                int strip0, int spp, RowCol &g) {
+  const int J = j / TS, sJ = J / STRIP_TILES;
+  if (sJ >= strip0 && sJ < strip0 + spp) {
+    const int c0 = (STRIP_TILES * sJ) / tl.chunk_tiles, c1 = min(tl.chunks, (nT + tl.chunk_tiles - 1) / tl.chunk_tiles);
+    const float4 *rp = rowpart + (((size_t)b * spp + (sJ - strip0)) * tl.chunks) * RS + (j - sJ * RS);
+    int c = c0;
+    for (; c + 4 <= c1; c += 4) {
+      const float4 r0 = rp[(size_t)c * RS], r1 = rp[(size_t)(c + 1) * RS], r2 = rp[(size_t)(c + 2) * RS], r3 = rp[(size_t)(c + 3) * RS];
+      g.rx += r0.x; g.ry += r0.y; g.rz += r0.z;
+      g.rx += r1.x; g.ry += r1.y; g.rz += r1.z;
+      g.rx += r2.x; g.ry += r2.y; g.rz += r2.z;
+      g.rx += r3.x; g.ry += r3.y; g.rz += r3.z;
+    }
+    for (; c < c1; ++c) {
+      const float4 r = rp[(size_t)c * RS];
+      g.rx += r.x; g.ry += r.y; g.rz += r.z;
+    }
+  }
+  const int last = min(sJ, strip0 + spp - 1) - strip0;     // strips strip0 .. strip0 + last of this launch lie at or above tile J
+  if (last >= 0) {
+    const float4 *cp_ = colpart + ((size_t)b * spp * tl.tiles + J) * TS + (j & (TS - 1));
+    const size_t step = (size_t)tl.tiles * TS;
+    auto add = [&](const float4 &cp) __attribute__((always_inline)) {
+      g.cx += fmaf(xj.x, cp.x, -cp.y);
+      g.cy += fmaf(xj.y, cp.x, -cp.z);
+      g.cz += fmaf(xj.z, cp.x, -cp.w);
+    };
+    int sidx = 0;
+    for (; sidx + 4 <= last + 1; sidx += 4) {
+      const float4 q0 = cp_[sidx * step], q1 = cp_[(sidx + 1) * step], q2 = cp_[(sidx + 2) * step], q3 = cp_[(sidx + 3) * step];
+      add(q0); add(q1); add(q2); add(q3);
+    }
+    for (; sidx <= last; ++sidx) add(cp_[sidx * step]);
+  }
+}
+
+// between the passes of a long batch: the running (row sum, column sum) of every atom, grid (ceil(nmax / 256), B)
+__global__ __launch_bounds__(CB) void drmsd_accumulate_kernel(const Counts *__restrict__ counts, const float4 *__restrict__ pred4,
+                                                              const float4 *__restrict__ rowpart, const float4 *__restrict__ colpart,
+                                                              int L, int strip0, int spp, float4 *__restrict__ grow,
+                                                              float4 *__restrict__ gcol) {
+  const int b = blockIdx.y, j = blockIdx.x * CB + threadIdx.x;
+  const Counts cn = counts[b];
+  if (j >= cn.n) return;
+  const size_t nmax = (size_t)L * 14;
+  const TriLayout tl = tri_layout((int)nmax, (int)gridDim.y);
+  const size_t at = (size_t)b * nmax + j;
+  RowCol g = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (strip0 > 0) {
+    const float4 r = grow[at], c = gcol[at];
+    g = RowCol{r.x, r.y, r.z, c.x, c.y, c.z};
+  }
+  gather_partials(tl, b, j, (cn.n + TS - 1) / TS, pred4[at], rowpart, colpart, strip0, spp, g);
+  grow[at] = make_float4(g.rx, g.ry, g.rz, 0.f);
+  gcol[at] = make_float4(g.cx, g.cy, g.cz, 0.f);
+}
+
+// statistics, gradient assembly and scatter back to the slot layout: grid (ceil(nmax / 256), B); dcrd was zeroed before.
+// grow / gcol != nullptr: the sweep ran in passes and drmsd_accumulate_kernel has already summed the partials.
 __global__ __launch_bounds__(CB) void drmsd_finalize_kernel(const Counts *__restrict__ counts,
                                                             const double *__restrict__ partials,
                                                             const float4 *__restrict__ pred4,
                                                             const float4 *__restrict__ rowpart,
                                                             const float4 *__restrict__ colpart,
+                                                            const float4 *__restrict__ grow, const float4 *__restrict__ gcol,
                                                             const int *__restrict__ idx, int L,
                                                             float *__restrict__ stats, float *__restrict__ dcrd) {
   __shared__ float s_scale;
@@ -449,58 +524,40 @@ __global__ __launch_bounds__(CB) void drmsd_finalize_kernel(const Counts *__rest
   const int j = blockIdx.x * CB + tid;
   if (j >= cn.n) return;
   const float scale = s_scale;
-  const int nT = (cn.n + TS - 1) / TS, J = j / TS, sJ = J / STRIP_TILES;
-  float gx = 0.f, gy = 0.f, gz = 0.f;
-  // row side: the chunks of this atom's strip that had work - a contiguous range - added in order; the loads go out four
-  // at a time (a step of few proteins runs this kernel on a fraction of the CUs: dependent-looking loads were its time)
-  {
-    const int c0 = (STRIP_TILES * sJ) / tl.chunk_tiles, c1 = min(tl.chunks, (nT + tl.chunk_tiles - 1) / tl.chunk_tiles);
-    const float4 *rp = rowpart + (((size_t)b * tl.strips + sJ) * tl.chunks) * RS + (j - sJ * RS);
-    int c = c0;
-    for (; c + 4 <= c1; c += 4) {
-      const float4 r0 = rp[(size_t)c * RS], r1 = rp[(size_t)(c + 1) * RS], r2 = rp[(size_t)(c + 2) * RS], r3 = rp[(size_t)(c + 3) * RS];
-      gx += r0.x; gy += r0.y; gz += r0.z;
-      gx += r1.x; gy += r1.y; gz += r1.z;
-      gx += r2.x; gy += r2.y; gz += r2.z;
-      gx += r3.x; gy += r3.y; gz += r3.z;
-    }
-    for (; c < c1; ++c) {
-      const float4 r = rp[(size_t)c * RS];
-      gx += r.x; gy += r.y; gz += r.z;
-    }
+  const size_t at = (size_t)b * nmax + j;
+  RowCol g = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (grow) {
+    const float4 r = grow[at], c = gcol[at];
+    g = RowCol{r.x, r.y, r.z, c.x, c.y, c.z};
+  } else {
+    gather_partials(tl, b, j, (cn.n + TS - 1) / TS, pred4[at], rowpart, colpart, 0, tl.strips, g);
   }
-  // column side: every strip at or above this atom's tile, in order: g_j += x_j S - V
-  const float4 xj = pred4[(size_t)b * nmax + j];
-  {
-    const float4 *cp_ = colpart + ((size_t)b * tl.strips * tl.tiles + J) * TS + (j & (TS - 1));
-    const size_t step = (size_t)tl.tiles * TS;
-    auto add = [&](const float4 &cp) __attribute__((always_inline)) {
-      gx += fmaf(xj.x, cp.x, -cp.y);
-      gy += fmaf(xj.y, cp.x, -cp.z);
-      gz += fmaf(xj.z, cp.x, -cp.w);
-    };
-    int sidx = 0;
-    for (; sidx + 4 <= sJ + 1; sidx += 4) {
-      const float4 q0 = cp_[sidx * step], q1 = cp_[(sidx + 1) * step], q2 = cp_[(sidx + 2) * step], q3 = cp_[(sidx + 3) * step];
-      add(q0); add(q1); add(q2); add(q3);
-    }
-    for (; sidx <= sJ; ++sidx) add(cp_[sidx * step]);
-  }
-  const int sl = idx[(size_t)b * nmax + j];
+  const int sl = idx[at];
   float *out = dcrd + (size_t)b * nmax * 3;
-  out[sl * 3 + 0] = scale * gx;
-  out[sl * 3 + 1] = scale * gy;
-  out[sl * 3 + 2] = scale * gz;
+  out[sl * 3 + 0] = scale * (g.rx + g.cx);
+  out[sl * 3 + 1] = scale * (g.ry + g.cy);
+  out[sl * 3 + 2] = scale * (g.rz + g.cz);
 }
 
+// The fixed-order partial sums of the sweep grow as O(n^2 / 256) per protein: 166 MB at (32, 512), 1.35 GB at (32, 1500).
+// Beyond PARTIAL_BUDGET the strips are swept in PASSES of `spp` strips (one launch of the pair kernel + one of
+// drmsd_accumulate_kernel each, same buffers): the workspace stays below ~256 MB at any size, same bits.  A function of
+// (B, L) only - and of PTAMD_DRMSD_PARTIAL_MB in the environment (read at every call), which tests use to force passes.
+constexpr size_t PARTIAL_BUDGET = (size_t)200 << 20;
 struct Layout {
-  size_t pred4, col8, rowpart, colpart, idx, counts, partials, total;
+  size_t pred4, col8, rowpart, colpart, grow, gcol, idx, counts, partials, total;
+  int spp;   // strips per pass (= strips: one launch)
   TriLayout tl;
 };
 Layout layout(int B, int L) {
   Layout l;
   const size_t nmax = (size_t)L * 14, BN = (size_t)B * nmax;
   l.tl = tri_layout((int)nmax, B);
+  size_t budget = PARTIAL_BUDGET;
+  if (const char *e = getenv("PTAMD_DRMSD_PARTIAL_MB")) budget = (size_t)max(1, atoi(e)) << 20;
+  const size_t per_strip = (size_t)B * ((size_t)l.tl.chunks * RS + (size_t)l.tl.tiles * TS) * sizeof(float4);
+  l.spp = l.tl.strips;
+  if (per_strip * l.tl.strips > budget) l.spp = (int)max((size_t)1, budget / per_strip);
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o = off;
@@ -509,8 +566,11 @@ Layout layout(int B, int L) {
   };
   l.pred4 = take(BN * sizeof(float4));
   l.col8 = take(BN * sizeof(Col8));
-  l.rowpart = take((size_t)B * l.tl.strips * l.tl.chunks * RS * sizeof(float4));
-  l.colpart = take((size_t)B * l.tl.strips * l.tl.tiles * TS * sizeof(float4));
+  l.rowpart = take((size_t)B * l.spp * l.tl.chunks * RS * sizeof(float4));
+  l.colpart = take((size_t)B * l.spp * l.tl.tiles * TS * sizeof(float4));
+  const bool passes = l.spp < l.tl.strips;
+  l.grow = take(passes ? BN * sizeof(float4) : 0);
+  l.gcol = take(passes ? BN * sizeof(float4) : 0);
   l.idx = take(BN * sizeof(int));
   l.counts = take((size_t)B * sizeof(Counts));
   l.partials = take((size_t)B * l.tl.strips * l.tl.chunks * 2 * sizeof(double));
@@ -545,21 +605,26 @@ int ptamd_drmsd_fwd_bwd(const float *pred_crd, const float *true_crd, const int6
                      counts);
   int rc = pt_check_launch();
   if (rc) return rc;
-  const dim3 grid(l.tl.strips * l.tl.chunks, B);
-  if (dcrd) {
-    PT_HIP_TRY(hipMemsetAsync(dcrd, 0, (size_t)B * L * 14 * 3 * sizeof(float), st));   // slots of absent atoms stay 0
-    auto kern = drmsd_tri_kernel<true>;
-    PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRI_LDS));
-    hipLaunchKernelGGL(kern, grid, dim3(RS), TRI_LDS, st, col8, counts, L, rowpart, colpart, partials);
-  } else {
-    auto kern = drmsd_tri_kernel<false>;
-    PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRI_LDS));
-    hipLaunchKernelGGL(kern, grid, dim3(RS), TRI_LDS, st, col8, counts, L, rowpart, colpart, partials);
+  const bool passes = l.spp < l.tl.strips;
+  float4 *grow = passes ? reinterpret_cast<float4 *>(ws + l.grow) : nullptr, *gcol = passes ? reinterpret_cast<float4 *>(ws + l.gcol) : nullptr;
+  const dim3 fin_grid((unsigned)(((size_t)L * 14 + CB - 1) / CB), B);
+  if (dcrd) PT_HIP_TRY(hipMemsetAsync(dcrd, 0, (size_t)B * L * 14 * 3 * sizeof(float), st));   // slots of absent atoms stay 0
+  auto kern = dcrd ? drmsd_tri_kernel<true> : drmsd_tri_kernel<false>;
+  PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRI_LDS));
+  for (int s0 = 0; s0 < l.tl.strips; s0 += l.spp) {
+    const int ns = l.tl.strips - s0 < l.spp ? l.tl.strips - s0 : l.spp;
+    hipLaunchKernelGGL(kern, dim3(ns * l.tl.chunks, B), dim3(RS), TRI_LDS, st, col8, counts, L, rowpart, colpart, partials, s0, l.spp);
+    rc = pt_check_launch();
+    if (rc) return rc;
+    if (passes && dcrd) {
+      hipLaunchKernelGGL(drmsd_accumulate_kernel, fin_grid, dim3(CB), 0, st, counts, pred4, rowpart, colpart, L, s0, l.spp,
+                         grow, gcol);
+      rc = pt_check_launch();
+      if (rc) return rc;
+    }
   }
-  rc = pt_check_launch();
-  if (rc) return rc;
-  hipLaunchKernelGGL(drmsd_finalize_kernel, dim3((unsigned)(((size_t)L * 14 + CB - 1) / CB), B), dim3(CB), 0, st, counts,
-                     partials, pred4, rowpart, colpart, idx, L, stats, dcrd);
+  hipLaunchKernelGGL(drmsd_finalize_kernel, fin_grid, dim3(CB), 0, st, counts, partials, pred4, rowpart, colpart,
+                     dcrd ? grow : nullptr, dcrd ? gcol : nullptr, idx, L, stats, dcrd);
   return pt_check_launch();
 }
 
