@@ -50,49 +50,86 @@ __global__ void embed_fwd_kernel(const int64_t *__restrict__ seq, const float *_
   *reinterpret_cast<float4 *>(out + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
-// partial embedding-gradient tables: block (slab of 64 columns, chunk of tokens) -> part[chunk][22][D]
-constexpr int EMB_CHUNKS = 64;
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t *__restrict__ seq,
-                                                        const float *__restrict__ dout, int64_t T, int D, float p,
-                                                        uint64_t seed, float *__restrict__ part) {
-  __shared__ float tab[4][22][64];
+// partial embedding-gradient tables: block (slab of 256 columns, chunk of tokens) -> part[chunk][22][D].  A lane owns FOUR
+// consecutive columns (round 5): the two generator calls of a (token, column quadruple) serve all four of them - with a
+// column per lane, as in rounds 1-4, four lanes drew the same words (40 us for 16384 x 512, all of it the hash: now 256
+// chunks of tokens x 2 wavefronts, a quarter of the draws).
+constexpr int EMB_CHUNKS = 256, EMB_WAVES = 2;
+__global__ __launch_bounds__(64 * EMB_WAVES) void embed_bwd_kernel(const int64_t *__restrict__ seq,
+                                                                    const float *__restrict__ dout, int64_t T, int D, float p,
+                                                                    uint64_t seed, float *__restrict__ part) {
+  __shared__ float4 tab[EMB_WAVES][22][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
-  for (int v = 0; v < 22; ++v) tab[wave][v][lane] = 0.f;
+  const int c = blockIdx.x * 256 + lane * 4;
+  for (int v = 0; v < 22; ++v) tab[wave][v][lane] = make_float4(0.f, 0.f, 0.f, 0.f);
   const int64_t per = (T + EMB_CHUNKS - 1) / EMB_CHUNKS;
   const int64_t t0 = blockIdx.y * per, t1 = min(T, t0 + per);
   const float sq = sqrtf((float)D);
   const uint32_t thr = dropout_threshold(p);
   const float ks = 1.f / (1.f - p);
   if (c < D) {
-    for (int64_t t = t0 + wave; t < t1; t += 4) {
-      int64_t id = seq[t];
-      if (id < 0 || id > 21) id = 21;
-      float g = dout[t * D + c];
-      if (p > 0.f) {
-        const uint64_t i4 = (uint64_t)(t * (D >> 2) + (c >> 2));
-        const uint4 r1 = pt_rand4(seed, i4, STREAM_EMB1), r2 = pt_rand4(seed, i4, STREAM_EMB2);
-        const int k = c & 3;
-        const uint32_t w1 = k == 0 ? r1.x : k == 1 ? r1.y : k == 2 ? r1.z : r1.w;
-        const uint32_t w2 = k == 0 ? r2.x : k == 1 ? r2.y : k == 2 ? r2.z : r2.w;
-        g = w2 >= thr ? g * ks * (1.f + (w1 >= thr ? ks : 0.f)) : 0.f;
-      } else {
-        g *= 2.f;
+    // EIGHT tokens per round: their ids and gradient rows are requested first, the table updates (a dependent LDS
+    // read-modify-write chain) follow - one token per round trip to memory was the kernel's time, with or without dropout
+    constexpr int U = 8;
+    for (int64_t tb = t0 + wave; tb < t1; tb += EMB_WAVES * U) {
+      int64_t id[U];
+      float4 g[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t t = min(tb + (int64_t)u * EMB_WAVES, t1 - 1);   // (clamped: a repeated token is skipped below)
+        id[u] = seq[t];
+        g[u] = *reinterpret_cast<const float4 *>(dout + t * D + c);
       }
-      tab[wave][id][lane] += g * sq;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t t = tb + (int64_t)u * EMB_WAVES;
+        if (t >= t1) break;
+        int64_t v = id[u];
+        if (v < 0 || v > 21) v = 21;
+        float4 x = g[u];
+        if (p > 0.f) {
+          const uint64_t i4 = (uint64_t)(t * (D >> 2) + (c >> 2));
+          const uint4 r1 = pt_rand4(seed, i4, STREAM_EMB1), r2 = pt_rand4(seed, i4, STREAM_EMB2);
+          x.x = r2.x >= thr ? x.x * ks * (1.f + (r1.x >= thr ? ks : 0.f)) : 0.f;
+          x.y = r2.y >= thr ? x.y * ks * (1.f + (r1.y >= thr ? ks : 0.f)) : 0.f;
+          x.z = r2.z >= thr ? x.z * ks * (1.f + (r1.z >= thr ? ks : 0.f)) : 0.f;
+          x.w = r2.w >= thr ? x.w * ks * (1.f + (r1.w >= thr ? ks : 0.f)) : 0.f;
+        } else {
+          x.x *= 2.f; x.y *= 2.f; x.z *= 2.f; x.w *= 2.f;
+        }
+        float4 a = tab[wave][v][lane];
+        a.x += x.x * sq; a.y += x.y * sq; a.z += x.z * sq; a.w += x.w * sq;
+        tab[wave][v][lane] = a;
+      }
     }
   }
   __syncthreads();
   if (c < D)
-    for (int v = wave; v < 22; v += 4)
-      part[((size_t)blockIdx.y * 22 + v) * D + c] = tab[0][v][lane] + tab[1][v][lane] + tab[2][v][lane] + tab[3][v][lane];
+    for (int v = wave; v < 22; v += EMB_WAVES) {
+      const float4 a = tab[0][v][lane], b = tab[1][v][lane];
+      *reinterpret_cast<float4 *>(part + ((size_t)blockIdx.y * 22 + v) * D + c) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
 }
-__global__ void embed_bwd_reduce_kernel(const float *__restrict__ part, int D, float *__restrict__ demb) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 22 * D) return;
+// demb[v][c] += sum over the chunks, in a fixed order: block = (64 columns, vocabulary row v), four groups of threads take every
+// fourth chunk with eight loads in flight each (one thread walking all 256 partials was a chain of 256 dependent-looking loads)
+__global__ __launch_bounds__(256) void embed_bwd_reduce_kernel(const float *__restrict__ part, int D, float *__restrict__ demb) {
+  __shared__ float s_red[4][64];
+  const int cx = threadIdx.x & 63, cy = threadIdx.x >> 6, c = blockIdx.x * 64 + cx, v = blockIdx.y;
   float s = 0.f;
-  for (int ch = 0; ch < EMB_CHUNKS; ++ch) s += part[(size_t)ch * 22 * D + i];
-  demb[i] += s;
+  if (c < D) {
+    const float *q = part + (size_t)v * D + c;
+    const size_t step = (size_t)22 * D;
+    for (int ch = cy; ch < EMB_CHUNKS; ch += 32) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = ch + 4 * u < EMB_CHUNKS ? q[(size_t)(ch + 4 * u) * step] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += t[u];
+    }
+  }
+  s_red[cy][cx] = s;
+  __syncthreads();
+  if (cy == 0 && c < D) demb[(size_t)v * D + c] += ((s_red[0][cx] + s_red[1][cx]) + s_red[2][cx]) + s_red[3][cx];
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
@@ -541,11 +578,11 @@ int ptamd_embed_bwd(const int64_t *seq, const float *dout, int B, int L, int D, 
   if (!workspace || workspace_bytes < ptamd_embed_bwd_workspace_bytes(D)) return PTAMD_ERR_WORKSPACE;
   float *part = static_cast<float *>(workspace);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3((D + 63) / 64, EMB_CHUNKS), dim3(256), 0, st, seq, dout, (int64_t)B * L, D,
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((D + 255) / 256, EMB_CHUNKS), dim3(64 * EMB_WAVES), 0, st, seq, dout, (int64_t)B * L, D,
                      dropout_p, seed, part);
   int rc = pt_check_launch();
   if (rc) return rc;
-  hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3((22 * D + 255) / 256), dim3(256), 0, st, part, D, demb);
+  hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3((D + 63) / 64, 22), dim3(256), 0, st, part, D, demb);
   return pt_check_launch();
 }
 
