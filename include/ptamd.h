@@ -304,13 +304,13 @@ int ptamd_bound_scales(const ptamd_bound_job *jobs_host, int njobs, void *stream
  *   371-381) that leave all of that behind for the NEXT forward pass, in the pass that writes the weights anyway.
  * The description of the model is a PLAN whose tables live in DEVICE memory (built once by the caller):
  *   segs        the listed matrices (or vectors, rows = 1) of the flat parameter buffer, K-contiguous, row stride = cols,
- *               cols % 4 == 0 and cols <= 2048; pairwise disjoint;
+ *               cols % 4 == 0 and cols <= 512 (wider ones as column panels, see rowmax_index); pairwise disjoint;
  *   blocks_a    [nblocks_a][2] int32: (segment, block of 32 rows inside it) for the first nblocks_a_matrices entries, then
  *               (-(range + 1), block of ptamd_wprep_plain_floats_per_block() floats inside plain range `range`): the plain
  *               ranges [nplain][2] int64 (first element, elements) cover everything that is not a segment - segments + plain
  *               ranges partition [0, numel);
  *   blocks_b    [nblocks_b][4] int32: (0, segment, block of 2048 columns, 0) column scales; (1, segment, block of 256 16-byte
- *               chunks of its col_planes, 0); (2, bounds group, 0, 0);
+ *               chunks of its col_planes, 0); (2, bounds group, 0, 0); (3, panelled matrix, block of 256 rows, 0) row scales;
  *   bounds / groups [ngroups][4] int32 (first bound job, jobs, first entry of colnorm_segs, entries): a group = an encoder layer;
  *               a bound job is ptamd_bound_job with indices instead of pointers (statistics record, entry of `scales`, entry of
  *               `values`; -1 = none);
@@ -330,6 +330,13 @@ typedef struct {
   uint64_t row_planes;         /* device pointer: W as hp planes (ptamd_hp_bytes(rows, cols)) split with the row scales; rows and
                                   cols multiples of 32; 0 = none */
   uint64_t col_planes;         /* device pointer: W^T as hp planes (ptamd_hp_bytes(cols, rows)) split with the column scales; 0 = none */
+  int32_t ld;                  /* row stride in floats (= cols for a whole matrix) */
+  int32_t rowmax_index;        /* >= 0: this segment is a COLUMN PANEL (<= 512 columns) of a wider matrix - kernel A keeps whole rows
+                                  in registers, 512 columns at most: its row maxima go by atomicMax to colmax[rowmax_index + r] (the
+                                  pool of maxima is shared), the row scales come from a block (3, full matrix, .) of kernel B, where
+                                  the full matrix is a segment of its own that blocks_a does not list (row_scale_index, rowmax_index,
+                                  rows; col_planes with colmax_index = its first panel's); a panel has stats_row0 = -1: its
+                                  statistics are the maximum only.  -1: not a panel */
 } ptamd_wprep_seg;
 typedef struct {
   int32_t ln_gamma_stats, ln_beta_stats, w_stats, w_stat_index, bias_stats;   /* w_stats = -1: factor 1 (the bound of the input row) */

@@ -76,7 +76,7 @@ class GemmHpArgs(C.Structure):
 class WprepSeg(C.Structure):
     _fields_ = [("offset", _i64), ("rows", C.c_int32), ("cols", C.c_int32), ("stats_row0", C.c_int32), ("stats_index", C.c_int32),
                 ("row_scale_index", C.c_int32), ("col_scale_index", C.c_int32), ("colmax_index", C.c_int32),
-                ("colsq_index", C.c_int32), ("row_planes", _u64), ("col_planes", _u64)]
+                ("colsq_index", C.c_int32), ("row_planes", _u64), ("col_planes", _u64), ("ld", C.c_int32), ("rowmax_index", C.c_int32)]
 
 
 class WprepBound(C.Structure):

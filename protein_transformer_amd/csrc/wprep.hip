@@ -31,7 +31,8 @@
 
 namespace {
 
-constexpr int RB = 32, WAVES = 4, RW = RB / WAVES, MAXV = 8;   // 32 rows per workgroup, 8 per wavefront; cols <= 64 * 4 * MAXV
+constexpr int RB = 32, WAVES = 4, RW = RB / WAVES, MAXV = 2;   // 32 rows per workgroup, 8 per wavefront; cols <= 64 * 4 * MAXV = 512:
+                                                                // wider matrices come as column PANELS of 512 (ptamd_wprep_seg::ld / rowmax_index)
 constexpr int PLAIN_F4 = 4096;                                  // float4 per plain workgroup (64 KiB of parameters)
 
 struct OptArgs {
@@ -106,7 +107,7 @@ __device__ __forceinline__ void rows_loop(float *__restrict__ w, const PlanA &pl
   const int cols = sg.cols;
   Quad<KIND> cur[NV], nxt[NV];
   auto load = [&](Quad<KIND> (&q)[NV], int r) __attribute__((always_inline)) {
-    const int64_t row0 = sg.offset + (int64_t)r * cols;
+    const int64_t row0 = sg.offset + (int64_t)r * sg.ld;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
@@ -119,7 +120,7 @@ __device__ __forceinline__ void rows_loop(float *__restrict__ w, const PlanA &pl
     const int r = row_first + rr;
     if (r >= sg.rows) break;  // (wavefront-uniform)
     if (PIPE && rr + 1 < RW && r + 1 < sg.rows) load(nxt, r + 1);
-    const int64_t row0 = sg.offset + (int64_t)r * cols;
+    const int64_t row0 = sg.offset + (int64_t)r * sg.ld;
     float4 v[NV];
     float m = 0.f, sq = 0.f;
 #pragma unroll
@@ -147,7 +148,12 @@ __device__ __forceinline__ void rows_loop(float *__restrict__ w, const PlanA &pl
     sq = wave_sum(sq);
     const uint32_t sbits = pt_row_scale_bits(__float_as_uint(m));
     if (lane == 0 && sg.row_scale_index >= 0) pl.scales[sg.row_scale_index + r] = sbits;
-    if (r >= sg.stats_row0) {
+    // a column panel of a wider matrix: the row's maximum meets those of the other panels in the pool of maxima (kernel B turns
+    // it into the row scale); its statistics are the maximum only (stats_row0 < 0: a panel's norm is not the row's)
+    if (lane == 0 && sg.rowmax_index >= 0) atomicMax(pl.colmax + sg.rowmax_index + r, __float_as_uint(m));
+    if (sg.stats_row0 < 0) {
+      acc.bm = fmaxf(acc.bm, m);
+    } else if (r >= sg.stats_row0) {
       acc.bn = fmaxf(acc.bn, sqrtf(sq));
       acc.bm = fmaxf(acc.bm, m);
     }
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(64 * WAVES) void wprep_rows_kernel(float *__restric
   }
   const ptamd_wprep_seg sg = pl.segs[blk.x];
   const int cols = sg.cols, nv = (cols + 255) >> 8;
-  __shared__ __attribute__((aligned(16))) float s_col[WAVES][64 * 4 * MAXV];   // column maxima, then column sums of squares, per wavefront
+  __shared__ __attribute__((aligned(16))) float s_col[WAVES][2 * 64 * 4 * MAXV];   // column maxima (floats), then column sums of squares (doubles), per wavefront
   __shared__ float s_nrm[WAVES], s_amx[WAVES];
   const bool want_cols = sg.col_scale_index >= 0, want_sq = sg.colsq_index >= 0;
   // (column sums of squares in fp64: the largest column norm is then the same fp32 number whatever the order of the sum -
@@ -202,8 +208,7 @@ __global__ __launch_bounds__(64 * WAVES) void wprep_rows_kernel(float *__restric
   acc.bn = acc.bm = 0.f;
   char *planes = pl.with_planes ? reinterpret_cast<char *>(sg.row_planes) : nullptr;
   const int row_first = blk.y * RB + wave * RW;
-  if (nv <= 2) rows_loop<KIND, 2, true>(w, pl, o, sg, row_first, lane, coef, want_cols, want_sq, planes, acc);
-  else rows_loop<KIND, MAXV, false>(w, pl, o, sg, row_first, lane, coef, want_cols, want_sq, planes, acc);
+  rows_loop<KIND, MAXV, true>(w, pl, o, sg, row_first, lane, coef, want_cols, want_sq, planes, acc);
   const float bn = acc.bn, bm = acc.bm;
   float4 (&cm)[MAXV] = acc.cm;
   double (&cs)[MAXV][4] = acc.cs;
@@ -237,31 +242,27 @@ __global__ __launch_bounds__(64 * WAVES) void wprep_rows_kernel(float *__restric
     }
   }
   if (want_sq) {
-    // one fp64 partial per (32-row block, column): the four wavefronts meet in LDS (the 32 KiB of s_col hold 4 x 1024 doubles:
-    // two rounds of 1024 columns), summed in wavefront order; kernel B adds the blocks in block order
-    double (*s_d)[1024] = reinterpret_cast<double (*)[1024]>(&s_col[0][0]);
+    // one fp64 partial per (32-row block, column): the four wavefronts meet in LDS, summed in wavefront order; kernel B adds the
+    // blocks in block order
+    double (*s_d)[64 * 4 * MAXV] = reinterpret_cast<double (*)[64 * 4 * MAXV]>(&s_col[0][0]);
     double *dst = pl.colsq + sg.colsq_index + (int64_t)blk.y * cols;
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-      __syncthreads();
+    __syncthreads();
 #pragma unroll
-      for (int i = 0; i < MAXV; ++i) {
-        const int c = (i * 64 + lane) * 4 - 1024 * half;
-        if (i < nv && c >= 0 && c < 1024) {
-          s_d[wave][c] = cs[i][0]; s_d[wave][c + 1] = cs[i][1]; s_d[wave][c + 2] = cs[i][2]; s_d[wave][c + 3] = cs[i][3];
-        }
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (i < nv && c < cols) {
+        s_d[wave][c] = cs[i][0]; s_d[wave][c + 1] = cs[i][1]; s_d[wave][c + 2] = cs[i][2]; s_d[wave][c + 3] = cs[i][3];
       }
-      __syncthreads();
-      for (int c = tid; c < 1024 && c + 1024 * half < cols; c += 64 * WAVES)
-        dst[c + 1024 * half] = ((s_d[0][c] + s_d[1][c]) + s_d[2][c]) + s_d[3][c];
     }
+    __syncthreads();
+    for (int c = tid; c < cols; c += 64 * WAVES) dst[c] = ((s_d[0][c] + s_d[1][c]) + s_d[2][c]) + s_d[3][c];
   }
 }
 
 struct PlanB {
   const ptamd_wprep_seg *segs;
   const int4 *blocks;        // (type, index, local block, -): 0 column scales of segment `index`, 1 W^T planes of segment `index`,
-                             // 2 bounds group `index`
+                             // 2 bounds group `index`, 3 row scales of the panelled matrix `index`
   const ptamd_wprep_bound *bounds;
   const int4 *groups;        // per bounds group: (first bound job, number of jobs, first colnorm segment entry, number of entries)
   const int *colnorm_segs;   // segments whose largest column norm goes to their statistics record [1]
@@ -286,10 +287,19 @@ __global__ __launch_bounds__(256) void wprep_cols_kernel(const float *__restrict
     }
     return;
   }
+  if (blk.x == 3) {  // ---- row scales of a matrix that went through kernel A as column panels (and the reset of the other copy)
+    const ptamd_wprep_seg sg = pl.segs[blk.y];
+    const int r = blk.z * 256 + tid;
+    if (r < sg.rows) {
+      pl.scales[sg.row_scale_index + r] = pt_row_scale_bits(pl.colmax[sg.rowmax_index + r]);
+      pl.colmax_next[sg.rowmax_index + r] = 0u;
+    }
+    return;
+  }
   if (blk.x == 1) {  // ---- planes of the TRANSPOSE (operand rows = columns of the matrix), scaled by the column scales
     if (!pl.with_planes) return;
     const ptamd_wprep_seg sg = pl.segs[blk.y];
-    const int rows = sg.cols, K = sg.rows, kbv = pthp::kb16(K), ld = sg.cols;   // operand [rows = cols of W][K = rows of W]
+    const int rows = sg.cols, K = sg.rows, kbv = pthp::kb16(K), ld = sg.ld;     // operand [rows = cols of W][K = rows of W]
     const int64_t nchunks = (int64_t)(pthp::round_up(rows, 32) / 32) * kbv * 64;
     const int64_t id = (int64_t)blk.z * 256 + tid;
     if (id >= nchunks) return;
@@ -347,7 +357,8 @@ __global__ __launch_bounds__(256) void wprep_cols_kernel(const float *__restrict
     __syncthreads();
     if ((tid & 63) == 0) s_red[tid >> 6] = nmax;
     __syncthreads();
-    if (tid == 0) pl.stats[4 * sg.stats_index + 1] = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    // (several entries may share a record - the panels of one matrix: the largest of them, one after the other)
+    if (tid == 0) pl.stats[4 * sg.stats_index + 1] = fmaxf(pl.stats[4 * sg.stats_index + 1], fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3])));
   }
   __syncthreads();  // (the store above is read below by threads of this workgroup only)
   __threadfence_block();

@@ -601,16 +601,16 @@ class WeightsPrep:
         from ._lib import WprepBound, WprepPlan, WprepSeg
         dev = ints.device
         RB, PF = lib().ptamd_wprep_rows_per_block(), lib().ptamd_wprep_plain_floats_per_block()
+        PANEL = 512                     # kernel A keeps whole rows in registers: wider matrices go through it as column panels
         segs = sorted(segs, key=lambda s: s["offset"])
         idx = lambda view, base: -1 if view is None else view.storage_offset() - base.storage_offset()       # noqa: E731
-        arr = (WprepSeg * len(segs))()
-        blocks_a, blocks_b, plain, colnorm_of = [], [], [], {}
-        ncolmax = ncolsq = 0
+        table, blocks_a, blocks_b, plain = [], [], [], []
+        ncolmax = ncolsq = 0            # entries of the pool of maxima (column maxima, row maxima of panelled matrices) / of colsq
         pos = 0
-        for k, s in enumerate(segs):
+        for s in segs:
             rows, cols, off = int(s["rows"]), int(s["cols"]), int(s["offset"])
-            if cols % 4 or cols > 2048 or off % 4 or off < pos:
-                raise ValueError(f"ptamd_weights_prep: segment {k} (offset {off}, {rows} x {cols}) is not representable")
+            if cols % 4 or off % 4 or off < pos or (cols > PANEL and cols % PANEL):
+                raise ValueError(f"ptamd_weights_prep: segment (offset {off}, {rows} x {cols}) is not representable")
             if off > pos:
                 plain.append((pos, off - pos))
             pos = off + rows * cols
@@ -620,34 +620,61 @@ class WeightsPrep:
                     raise ValueError("ptamd_weights_prep: planes need rows and cols that are multiples of 32")
             if s.get("col_planes") is not None and not want_cols:
                 raise ValueError("ptamd_weights_prep: col_planes need col_scale")
-            arr[k] = WprepSeg(offset=off, rows=rows, cols=cols, stats_row0=int(s.get("stats_row0", 0)),
-                              stats_index=-1 if s.get("stats") is None else int(s["stats"]),
-                              row_scale_index=idx(s.get("row_scale"), ints), col_scale_index=idx(s.get("col_scale"), ints),
-                              colmax_index=ncolmax if want_cols else 0,
-                              colsq_index=ncolsq if (s.get("colnorm") and want_cols) else -1,
-                              row_planes=0 if s.get("row_planes") is None else s["row_planes"].data_ptr(),
-                              col_planes=0 if s.get("col_planes") is None else s["col_planes"].data_ptr())
+            if s.get("colnorm") and (s.get("stats") is None or not want_cols):
+                raise ValueError("ptamd_weights_prep: colnorm needs a statistics record and col_scale")
+            stats = -1 if s.get("stats") is None else int(s["stats"])
+            npanels = -(-cols // PANEL)
+            wide = npanels > 1
+            if wide and (s.get("row_planes") is not None or int(s.get("stats_row0", 0)) != 0):
+                raise ValueError("ptamd_weights_prep: a matrix wider than 512 columns cannot have row planes or a statistics sub-range")
+            colmax0 = ncolmax
+            ncolmax += cols if want_cols else 0
+            rowmax0 = -1
+            if wide and s.get("row_scale") is not None:
+                rowmax0 = ncolmax
+                ncolmax += rows
             nrb = -(-rows // RB)
-            blocks_a += [(k, b) for b in range(nrb)]
-            if want_cols:
-                blocks_b += [(0, k, b, 0) for b in range(-(-cols // 2048))]
+            for pnl in range(npanels):
+                pc = min(PANEL, cols - pnl * PANEL)
+                k = len(table)
+                table.append(WprepSeg(
+                    offset=off + pnl * PANEL, rows=rows, cols=pc, stats_row0=-1 if wide else int(s.get("stats_row0", 0)),
+                    stats_index=stats, row_scale_index=-1 if wide else idx(s.get("row_scale"), ints),
+                    col_scale_index=idx(s.get("col_scale"), ints) + pnl * PANEL if want_cols else -1,
+                    colmax_index=colmax0 + pnl * PANEL if want_cols else 0,
+                    colsq_index=ncolsq if s.get("colnorm") else -1,
+                    row_planes=0 if s.get("row_planes") is None else s["row_planes"].data_ptr(), col_planes=0,
+                    ld=cols, rowmax_index=rowmax0))
+                blocks_a += [(k, b) for b in range(nrb)]
+                if want_cols:
+                    blocks_b.append((0, k, 0, 0))
+                if s.get("colnorm"):
+                    ncolsq += nrb * pc
+            if wide and rowmax0 >= 0 or s.get("col_planes") is not None:
+                # the matrix as a whole, for kernel B only (not in blocks_a): row scales of a panelled matrix, planes of its transpose
+                k = len(table)
+                table.append(WprepSeg(offset=off, rows=rows, cols=cols, stats_row0=0, stats_index=-1,
+                                      row_scale_index=idx(s.get("row_scale"), ints) if wide else -1, col_scale_index=-1,
+                                      colmax_index=colmax0, colsq_index=-1, row_planes=0,
+                                      col_planes=0 if s.get("col_planes") is None else s["col_planes"].data_ptr(), ld=cols,
+                                      rowmax_index=rowmax0))
+                if rowmax0 >= 0:
+                    blocks_b += [(3, k, b, 0) for b in range(-(-rows // 256))]
                 if s.get("col_planes") is not None:
                     nchunks = (cols // 32) * (-(-rows // 32) * 2) * 64           # rows of W^T = cols; 16-column blocks of its K = rows
                     blocks_b += [(1, k, b, 0) for b in range(-(-nchunks // 256))]
-                if s.get("colnorm"):
-                    if s.get("stats") is None:
-                        raise ValueError("ptamd_weights_prep: colnorm needs a statistics record")
-                    colnorm_of[id(s)] = k
-                    ncolsq += nrb * cols
-                ncolmax += cols
         if pos < numel:
             plain.append((pos, numel - pos))
+        arr = (WprepSeg * len(table))(*table)
         n_matrix_blocks = len(blocks_a)
         for j, (first, n) in enumerate(plain):
             blocks_a += [(-(j + 1), b) for b in range(-(-n // PF))]
         # bound jobs, per group; the segments whose column norm a group needs are those flagged `colnorm` whose statistics
         # record one of the group's jobs reads with w_index == 1
-        by_stats = {int(s["stats"]): k for k, s in enumerate(segs) if s.get("colnorm")}
+        by_stats = {}
+        for k, t in enumerate(table):
+            if t.colsq_index >= 0:
+                by_stats.setdefault(int(t.stats_index), []).append(k)
         bounds, grp_rows, cn_list = [], [], []
         rec = lambda v: -1 if v is None else int(v)                                                         # noqa: E731
         for g, jobs in enumerate(groups):
@@ -657,8 +684,8 @@ class WeightsPrep:
                                          w_stat_index=int(j["w_index"]), bias_stats=rec(j.get("bias")),
                                          sqrt_d=float(j.get("sqrt_d", 0.0)), post_scale=float(j.get("post_scale", 1.0)),
                                          out_scale=idx(j.get("out_scale"), ints), out_value=idx(j.get("out_value"), values)))
-                if int(j["w_index"]) == 1 and int(j["w"]) in by_stats and by_stats[int(j["w"])] not in cn_list[cn_first:]:
-                    cn_list.append(by_stats[int(j["w"])])
+                if int(j["w_index"]) == 1 and int(j["w"]) in by_stats:
+                    cn_list += [k for k in by_stats[int(j["w"])] if k not in cn_list[cn_first:]]
             grp_rows.append((first, len(bounds) - first, cn_first, len(cn_list) - cn_first))
             blocks_b.append((2, g, 0, 0))
         if not groups:
@@ -678,7 +705,7 @@ class WeightsPrep:
         self.ints, self.values = ints, values
         self.parity = 0
         self.numel = int(numel)
-        self.plan = WprepPlan(segs=self.t_segs.data_ptr(), nsegs=len(segs), blocks_a=self.t_blocks_a.data_ptr(),
+        self.plan = WprepPlan(segs=self.t_segs.data_ptr(), nsegs=len(table), blocks_a=self.t_blocks_a.data_ptr(),
                               nblocks_a=len(blocks_a), nblocks_a_matrices=n_matrix_blocks, plain=self.t_plain.data_ptr(),
                               nplain=len(plain), blocks_b=self.t_blocks_b.data_ptr(), nblocks_b=len(blocks_b),
                               bounds=self.t_bounds.data_ptr(), nbounds=len(bounds), groups=self.t_groups.data_ptr(),
