@@ -168,6 +168,7 @@ def cpu_baseline(a, batch_cpu, params):
 def make_batches(a, rank, dev, n_batches):
     """Synthetic batches on the host (pinned); returns (list of (seq, ang, crd) CPU tensors, angle_means, first batch dict)."""
     from protein_transformer_amd import synthetic
+    from protein_transformer_amd.dataset import pack_batch
     from protein_transformer_amd.protein.Structure import nerf_forward
     build = lambda ang, seq: nerf_forward(ang.to(dev), seq.to(dev))[0]            # noqa: E731
     seed0 = synthetic.DEFAULT_SEED + 97 * rank
@@ -199,7 +200,7 @@ def make_batches(a, rank, dev, n_batches):
                 if len(batches) == n_batches:
                     break
         am = synthetic.angle_means(first["true_ang"])
-        return [tuple(t.pin_memory() for t in b) for b in batches], am, first
+        return [pack_batch(b, pin=True) for b in batches], am, first
     out, first = [], None
     for i in range(min(n_batches, 2)):
         if a.ragged == "short":                                     # configs[0]: mixed lengths in [16, L]
@@ -209,7 +210,7 @@ def make_batches(a, rank, dev, n_batches):
             lens = [a.length] * a.batch
         b = synthetic.make_batch([int(x) for x in lens], L_pad=a.length, seed=seed0 + i, build_coords=build)
         first = first or b
-        out.append(tuple(b[k].pin_memory() for k in ("seq", "true_ang", "true_crd")))
+        out.append(pack_batch(tuple(b[k] for k in ("seq", "true_ang", "true_crd")), pin=True))       # as the collate function packs them
     return out, synthetic.angle_means(first["true_ang"]), first
 
 
@@ -277,7 +278,7 @@ def main():
     a = parse()
     from protein_transformer_amd import dp, kernels, synthetic
     from protein_transformer_amd.optim import FusedAdam, FusedSGD
-    from protein_transformer_amd.dataset import DevicePrefetcher
+    from protein_transformer_amd.dataset import DevicePrefetcher, pack_batch
     from protein_transformer_amd.train import train_step
 
     dp.init_from_env()
@@ -341,13 +342,18 @@ def main():
         torch.cuda.synchronize()
         return max_over_ranks(time.perf_counter() - t0), out
 
+    shares = {}                                                      # per-GPU shares of the host batches, packed like whole ones
+
     def timed_upload(first_step, batches=None, proteins=None):
         """K steps with every batch coming from pinned host memory INSIDE the step, the way train_epoch gets them
         (train.py: dataset.DevicePrefetcher - the next batch's copy on a side stream under this step, the residue count on
         the host).  `proteins`: only the first so many of every batch (the per-GPU share of a strongly scaled job)."""
         src = host_batches if batches is None else batches
         if proteins is not None:
-            src = [(s[:proteins], g[:proteins], c[:proteins]) for s, g, c in src]
+            key = (id(src), proteins)
+            if key not in shares:
+                shares[key] = [pack_batch((s[:proteins], g[:proteins], c[:proteins]), pin=True) for s, g, c in src]
+            src = shares[key]
         feed = (src[(first_step + i) % len(src)] for i in range(a.steps))
         out, n_res = None, 0
         dp.barrier()

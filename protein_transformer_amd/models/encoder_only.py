@@ -19,6 +19,7 @@ Reference quirks reproduced on purpose: the embedding is added t
 output layer starts as weight 0 / bias arctanh(angle_means) (encoder_only.py:28-34).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -1116,7 +1117,7 @@ AUTO_F16X2_MIN_WORK = 1 << 20
 # host-side launches and the stream joins add to them
 SIDE_STREAM_MAX_WORK = 1 << 23
 # tokens from which the products behind a LayerNorm run on ptamd_gemm_hp (below: ptamd_gemm, 128-row tiles)
-HP_MIN_TOKENS = 4096
+HP_MIN_TOKENS = int(os.environ.get("PTAMD_HP_MIN_TOKENS", 4096))     # (the environment variable: for measurements)
 
 
 class EncoderOnlyTransformer(_TransformerBase):

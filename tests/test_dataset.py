@@ -33,6 +33,10 @@ def test_collate_golden(golden):
     assert np.array_equal(a.numpy(), g["collate_ang"]) and np.array_equal(c.numpy(), g["collate_crd"])
     assert int(s[2, 5]) == VOCAB.pad_id                      # shortest sequence is padded with id 20
     # truncation to max_seq_len residues / 14x atoms
+    # the batch is packed: three views of one buffer (one upload, dataset.DevicePrefetcher), the plain tensors on request
+    assert D.packed_base((s, a, c)) is not None and s.dtype == torch.int64 and a.dtype == c.dtype == torch.float32
+    plain = D.make_paired_collate_fn(D.MAX_SEQ_LEN, packed=False)([ds[i] for i in (1, 3, 0)])
+    assert D.packed_base(plain) is None and all(torch.equal(x, y) for x, y in zip(plain, (s, a, c)))
     s2, a2, c2 = D.make_paired_collate_fn(8)([ds[i] for i in (1, 3, 0)])
     assert s2.shape == (3, 8) and a2.shape == (3, 8, 24) and c2.shape == (3, 8 * 14, 3)
 

@@ -340,3 +340,14 @@ def test_device_prefetcher(dev):
         assert s.is_cuda and torch.equal(s.cpu(), seq) and torch.equal(a.cpu(), ang) and torch.equal(c.cpu(), crd)
         assert n_res == int((seq != 20).sum())
     assert list(DevicePrefetcher([], dev)) == []
+    # packed batches (dataset.pack_batch: what the collate function returns): ONE copy per batch, the same tensors on the
+    # device - views of one buffer -, pinned by the prefetcher when the loader did not; slices of a packed batch too
+    from protein_transformer_amd.dataset import pack_batch, packed_base
+    for pin in (False, True):
+        packed = [pack_batch(b, pin=pin) for b in batches] + [tuple(t[:2] for t in pack_batch(batches[2], pin=pin))]
+        assert all(packed_base(b) is not None for b in packed) and packed_base(batches[0]) is None
+        got = list(DevicePrefetcher(packed, dev))
+        for (seq, ang, crd), (s, a, c, n_res) in zip(batches + [tuple(t[:2] for t in batches[2])], got):
+            assert s.is_cuda and s.dtype == torch.int64 and torch.equal(s.cpu(), seq) and torch.equal(a.cpu(), ang) and torch.equal(c.cpu(), crd)
+            assert s.untyped_storage().data_ptr() == a.untyped_storage().data_ptr() == c.untyped_storage().data_ptr()
+            assert n_res == int((seq != 20).sum())
