@@ -1475,6 +1475,12 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       __syncthreads();  // every wavefront's dS tile (and the next staged tiles) is in LDS; nobody reads the current tiles any more
       // ---- dQ^T[db .. db + 16][qb .. qb + 16] of this query tile over the 256 keys of the block
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      // lane (i16, g16): query qq0 + qb + i16, d = db + 4 g16 + 0..3; what the earlier key blocks left there is requested
+      // here and added behind the products (it was a dependent load in front of the tile's last barrier)
+      const int dq_q = qq0 + qb + i16;
+      float *const dq_p = dqkv + (size_t)(b * L + min(dq_q, L - 1)) * D3 + h * DK + db + 4 * g16;
+      float4 dq_old = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kb > 0) dq_old = *reinterpret_cast<const float4 *>(dq_p);
 #pragma unroll 2
       for (int st = 0; st < NW; ++st) {   // keys 32 st .. 32 st + 31 = the rows wavefront st wrote; offsets: see ka0 / da0
         f16x8 a[2], bq[2];
@@ -1496,13 +1502,12 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = fmaf(c[e], ic, acc[e]);
       }
-      {  // lane (i16, g16): query qq0 + qb + i16, d = db + 4 g16 + 0..3
-        const int q = qq0 + qb + i16;
-        float *op = dqkv + (size_t)(b * L + min(q, L - 1)) * D3 + h * DK + db + 4 * g16;
+      {
+        const int q = dq_q;
+        float *op = dq_p;
         float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
         if (kb > 0 && q < L) {
-          const float4 old = *reinterpret_cast<const float4 *>(op);
-          v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+          v.x += dq_old.x; v.y += dq_old.y; v.z += dq_old.z; v.w += dq_old.w;
         }
         if (q < L) *reinterpret_cast<float4 *>(op) = v;
         if (row_scale && kb == nkb - 1) {   // the row's f16x2 scale: the four lane groups hold 16 d of the row's 64
