@@ -205,6 +205,9 @@ class SimilarLengthBatchSampler(torch.utils.data.Sampler):
             yield np.random.choice(ds.bin_map[b], size=size)
 
 
+_SIDE_STREAMS = {}
+
+
 class DevicePrefetcher:
     """Host -> device hand-over of the batches of a loader, one batch ahead: while the step of batch i runs on the
     compute stream, batch i + 1 is collated by the loader's worker, counted (non-pad residues, on the host) and copied
@@ -221,7 +224,9 @@ class DevicePrefetcher:
 
     def __iter__(self):
         dev = self.device
-        side = torch.cuda.Stream(dev)
+        side = _SIDE_STREAMS.get(dev)        # one upload stream per device for the life of the process (not one per epoch)
+        if side is None:
+            side = _SIDE_STREAMS[dev] = torch.cuda.Stream(dev)
         it = iter(self.loader)
 
         def fetch():
