@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Soak: N training steps of the headline configuration through the product's own data path (DevicePrefetcher, packed batches),
+reporting every N / 10 steps the step time, the loss, the allocator's reserved / allocated bytes and the guard's state - memory
+must be flat, the loss finite and falling, no site off its bound.  python profiles/tools/r05_soak.py [--steps 3000]"""
+import os
+import sys
+import time
+import types
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench  # noqa: E402
+
+
+def main():
+    a = bench.parse()
+    from protein_transformer_amd import dp, kernels, synthetic
+    from protein_transformer_amd.dataset import DevicePrefetcher
+    from protein_transformer_amd.optim import FusedSGD
+    from protein_transformer_amd.train import train_step
+    dp.init_from_env()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    host, angle_means, _ = bench.make_batches(a, 0, dev, 2)
+    torch.manual_seed(synthetic.DEFAULT_SEED)
+    model = bench.make_model(a, angle_means, dev)
+    model.gemm_mode = kernels.GEMM_AUTO
+    dp.attach(model)
+    opt = FusedSGD(model, lr=1e-4, weight_decay=10e-3)
+    args = types.SimpleNamespace(loss=a.loss, combined_drmsd_weight=0.5, backbone_loss=False, clip=1.0)
+    N = a.steps
+    chunk = max(1, N // 10)
+    done = 0
+    while done < N:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for seq, ang, crd, n in DevicePrefetcher((host[i % 2] for i in range(chunk)), dev):
+            out = train_step(model, opt, args, seq, ang, crd, n_res=n)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / chunk * 1e3
+        done += chunk
+        flat, g = model.flat_parameters()
+        g_ = model.auto_guard
+        print(f"step {done:6d}  {dt:7.3f} ms/step  loss {float(out['loss']):.5f}  finite {bool(torch.isfinite(flat).all())}  "
+              f"allocated {torch.cuda.memory_allocated() / 2**20:8.1f} MiB  reserved {torch.cuda.memory_reserved() / 2**20:8.1f} MiB  "
+              f"guard: measured {g_.measured_steps} off {int(g_.off.sum())} wide {int(g_.wide.sum())}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
