@@ -26,6 +26,9 @@ headline).  One step = zero_grad, forward, NeRF + dRMSD loss + backward, gradien
                  that split; at N = 1 the per-GPU steps of N = 2, 4, 8 (16, 8, 4 proteins) and the ceiling they imply;
   arithmetic_modes - ms/step of the same workload, measured in THIS run, with every GEMM / attention in bf16x3 and in
                  the exact-f32 MFMA arithmetic (the strictly fp32-grade alternatives to the default AUTO policy);
+  parity       - the metric's second half, "dRMSD-loss delta vs ref", at the size of the line (N = 1): one dropout-0 train_step
+                 of the HIP path in its steady-state arithmetic against the oracle step `cpu_baseline` has just timed, same
+                 proteins and weights: drmsd_rel, lndrmsd_abs, gradnorm_rel, grad_rel_l2, update_rel_l2;
   cpu_baseline - the CPU oracle (a port of the reference's --no_cuda path) on a bounded sample of the same workload on
                  the host cores of this box, run the way the reference runs: torch.set_num_threads(1) in the main
                  process + a spawn Pool of loss workers (train.py:344,360-365; losses.py:144-147), plus the
@@ -110,7 +113,7 @@ def parse():
 
 
 # ----------------------------------------------------------------------------- CPU baseline (the checker, timed)
-def _cpu_leg(a, batch_cpu, params, n, pool):
+def _cpu_leg(a, batch_cpu, params, n, pool, keep=False):
     """One timed oracle step on n proteins of the batch.  The oracle keeps the reference's assertion on the bond angle
     (Structure.py:42, theta in [-pi, pi] against the DOUBLE pi): a float32 angle within 9e-8 below pi rounds to
     float32(pi) > pi and trips it - about once in 1e7 angles, on the reference as on the oracle.  Such a sample says
@@ -124,7 +127,8 @@ def _cpu_leg(a, batch_cpu, params, n, pool):
                                    lr=1e-4, clip=1.0, pool=pool)
         seq, ang, crd = (batch_cpu[k][idx] for k in ("seq", "true_ang", "true_crd"))
         try:
-            return ostep.time_cpu_steps(trainer, (seq, ang, crd), n_steps=1)
+            rate, dt = ostep.time_cpu_steps(trainer, (seq, ang, crd), n_steps=1, keep_grads=keep)
+            return rate, dt, (trainer, idx)
         except AssertionError as e:                      # the reference's own input assertion, see above
             last = e
     raise last
@@ -151,10 +155,11 @@ def cpu_baseline(a, batch_cpu, params):
     with mp.get_context("spawn").Pool(workers, initializer=torch.set_num_threads, initargs=(1,)) as pool:
         pool.map(abs, range(workers))                    # workers up (imports done) before the clock starts
         t_spawn = time.perf_counter() - t0
-        rate_pool, dt_pool = _cpu_leg(a, batch_cpu, params, n_pool, pool)
+        # (keep=True: the step's losses and gradients stay behind for the `parity` block - a 76 MB clone inside a ~30 s step)
+        rate_pool, dt_pool, oracle_step = _cpu_leg(a, batch_cpu, params, n_pool, pool, keep=True)
     n_seq = 1 if heavy else min(avail, 4)
-    rate_seq, dt_seq = _cpu_leg(a, batch_cpu, params, n_seq, None)
-    return {"value": round(rate_pool, 2), "unit": "residues/s", "cores": workers, "kind": "port",
+    rate_seq, dt_seq, _ = _cpu_leg(a, batch_cpu, params, n_seq, None)
+    return oracle_step, {"value": round(rate_pool, 2), "unit": "residues/s", "cores": workers, "kind": "port",
             "host_cores": host_cores,
             "sample": f"1 step of oracle.step.CpuTrainer on {n_pool} of the {avail} proteins of a batch (L={L}, same "
                       f"model, dropout 0, torch threads = 1 in the main process and in every worker, loss in a spawn Pool of {workers} "
@@ -162,6 +167,63 @@ def cpu_baseline(a, batch_cpu, params):
                       f"{dt_pool:.1f} s (+ {t_spawn:.1f} s pool start-up)",
             "sequential": {"value": round(rate_seq, 2), "unit": "residues/s", "cores": 1,
                            "sample": f"1 step on {n_seq} protein(s), --sequential_drmsd_loss: {dt_seq:.1f} s"}}
+
+
+def parity_block(a, model, opt, args, batch_cpu, params, oracle_step, dev):
+    """The second half of BASELINE.json's metric, "dRMSD-loss delta vs ref", at the size of the line it is printed in: ONE
+    dropout-0 `train_step` of the HIP path - the model as the timed steps left it, AUTO arithmetic in its steady state (guard
+    trusted), same batch, same weights - against the step the CPU oracle has just been timed on (`cpu_baseline`'s pool leg:
+    the reference's arithmetic, fp32 on the host).  Reference quantities: compute_batch_drmsd's returned means over the
+    proteins (losses.py:153-172), the gradient clip_grad_norm_ sees and the parameter update of train.py:41-46."""
+    from protein_transformer_amd.train import train_step
+    trainer, idx = oracle_step
+    seq, ang, crd = (batch_cpu[k][idx].to(dev) for k in ("seq", "true_ang", "true_crd"))
+    p, pa = model.dropout, model.attn_dropout
+    fuse = getattr(opt, "zero_grad_in_step", False)
+    model.set_dropout(0.0)
+    opt.zero_grad_in_step = False                       # (the gradient must survive the step to be compared)
+    try:
+        flat, grad = model.flat_parameters()
+        w0 = flat.detach().clone()
+        losses = train_step(model, opt, args, seq, ang, crd, n_res=int((seq != 20).sum()))
+        torch.cuda.synchronize()
+        g, w1 = grad.detach().double().cpu(), flat.detach().clone()
+    finally:
+        model.set_dropout(p, pa)
+        opt.zero_grad_in_step = fuse
+    # the oracle's tensors in the order of the flat buffer
+    def flatten(named, like):
+        out = torch.zeros(model._flat_numel, dtype=torch.float64)
+        for name, (off, shape) in model._layout.items():
+            t = named.get(name)
+            if t is not None:
+                out[off:off + t.numel()] = t.detach().double().reshape(-1)
+        return out
+    g_ref = flatten(trainer.last_grads, None)
+    dw_ref = flatten({k: v.detach() - params[k] for k, v in trainer.params.items()}, None)
+    dw = (w1.double() - w0.double()).cpu()
+    ref = {k: float(trainer.last_losses[k]) for k in ("drmsd-full", "lndrmsd-full", "drmsd-bb", "mse-full")}
+    hip = {k: float(losses[k]) for k in ref}
+    rel = lambda x, y: abs(x - y) / max(abs(y), 1e-300)                                     # noqa: E731
+    gn, gn_ref = float(g.norm()), float(trainer.last_grad_norm)
+    guard = model.auto_guard
+    out = {"drmsd_rel": rel(hip["drmsd-full"], ref["drmsd-full"]),
+           "lndrmsd_abs": abs(hip["lndrmsd-full"] - ref["lndrmsd-full"]),
+           "drmsd_bb_rel": rel(hip["drmsd-bb"], ref["drmsd-bb"]), "mse_rel": rel(hip["mse-full"], ref["mse-full"]),
+           "gradnorm_rel": rel(gn, gn_ref), "grad_rel_l2": float((g - g_ref).norm()) / max(gn_ref, 1e-300),
+           "update_rel_l2": float((dw - dw_ref).norm()) / max(float(dw_ref.norm()), 1e-300),
+           "hip": {**hip, "grad_norm": gn}, "oracle": {**ref, "grad_norm": gn_ref},
+           "n_proteins": int(seq.shape[0]), "seq_len": int(seq.shape[1]),
+           "arithmetic": ("auto steady state" if not (guard.off.any() or guard.wide.any()) and guard.measured_steps > 0 else
+                          f"auto, {int(guard.off.sum())} sites off their bounds / {int(guard.wide.sum())} products in bf16x3")
+                         if (model.gemm_mode in (None, 4)) else f"gemm mode {model.gemm_mode}",
+           "tolerance": {"drmsd_rel": 1e-4, "lndrmsd_abs": 1e-6, "grad_rel_l2": 1e-3},
+           "what": "one dropout-0 train_step of the HIP path (the model as the timed steps left it) against the CPU oracle's step "
+                   "on the same proteins and weights (cpu_baseline's pool leg; the reference's fp32 arithmetic): batch means of "
+                   "drmsd / lndrmsd / backbone drmsd (losses.py:153-172), the MSE over angles, the gradient before the clip "
+                   "(norm and rel-L2 of the whole vector) and the parameter update (train.py:41-46)"}
+    out["ok"] = bool(out["drmsd_rel"] < 1e-4 and out["lndrmsd_abs"] < 1e-6 and out["grad_rel_l2"] < 1e-3)
+    return {k: (float(f"{v:.4g}") if isinstance(v, float) else v) for k, v in out.items()}
 
 
 # ----------------------------------------------------------------------------- workloads
@@ -320,6 +382,7 @@ def main():
     dp.attach(model)
     opt = (FusedAdam(model, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=10e-3) if a.optimizer == "adam"
            else FusedSGD(model, lr=1e-4, weight_decay=10e-3))
+    opt.zero_grad_in_step = True            # as train.setup_model_optimizer_scheduler sets it for the product's loop (optim.py)
     args = types.SimpleNamespace(loss=a.loss, combined_drmsd_weight=0.5, backbone_loss=False, clip=1.0)
     nb = len(resident)
 
@@ -611,13 +674,23 @@ def main():
             pick = min(range(nb), key=lambda i: abs(host_batches[i][0].shape[1] - 200)) if a.ragged == "binned" else 0
             cpu_batch = dict(zip(keys, (t.clone() for t in host_batches[pick])))
             params = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}   # the same model, reference keys
+            oracle_step = None
             try:
-                out["cpu_baseline"] = cpu_baseline(a, cpu_batch, params)
+                oracle_step, out["cpu_baseline"] = cpu_baseline(a, cpu_batch, params)
             except Exception as e:                       # the bench line must not depend on the checker's health
                 out["cpu_baseline"] = {"value": None, "unit": "residues/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
+            # "dRMSD-loss delta vs ref" (the metric's second half): the HIP step against the oracle step that was just timed
+            if oracle_step is not None and a.optimizer == "sgd":
+                try:
+                    out["parity"] = parity_block(a, model, opt, args, cpu_batch, params, oracle_step, dev)
+                except Exception as e:
+                    out["parity"] = {"ok": False, "failed": f"{type(e).__name__}: {e}"}
+            else:
+                out["parity"] = None
         else:
             out["cpu_baseline"] = None
+            out["parity"] = None
         print(json.dumps(out), flush=True)
     dp.shutdown()
 

@@ -90,10 +90,16 @@ int ptamd_nerf_bwd(const float *ang, const int64_t *seq, const float *crd, const
  * tile) and one 4 KB row partial per (strip, chunk of 8 column tiles): O(n^2 / 256) per protein (n = 14 L atom slots) -
  * CAPPED at 200 MB: beyond that the strips are swept in passes over groups of strips with the same buffers (+ 32 B per atom slot
  * of running sums), same bits as one launch.  B = 32: 159 MB at L = 512, 242 MB at L = 1500 (1.39 GB in round 4).  The size is
- * a function of (B, L) only. */
+ * a function of (B, L) only - nothing is read from the process environment.  The *_budget forms take the cap on the partial
+ * sums as an argument (bytes; 0 = the built-in 200 MB): for callers short of memory and for the test that forces passes on a
+ * small batch; the same budget must be given to both calls. */
 size_t ptamd_drmsd_workspace_bytes(int B, int L);
 int ptamd_drmsd_fwd_bwd(const float *pred_crd, const float *true_crd, const int64_t *seq, int B, int L,
                         float *stats, float *dcrd, void *workspace, size_t workspace_bytes, void *stream);
+size_t ptamd_drmsd_workspace_bytes_budget(int B, int L, size_t partial_budget_bytes);
+int ptamd_drmsd_fwd_bwd_budget(const float *pred_crd, const float *true_crd, const int64_t *seq, int B, int L,
+                               float *stats, float *dcrd, void *workspace, size_t workspace_bytes,
+                               size_t partial_budget_bytes, void *stream);
 
 /* rmsd (losses.py:281-286, ProDy calcTransformation + calcRMSD) for a whole batch: RMSD of the predicted atoms after optimal
  * rigid superposition (Kabsch) onto the true ones, over the atoms whose truth is present (NaN = absent), residues with
@@ -295,6 +301,10 @@ typedef struct {
   uint32_t *out_scale; float *out_value;
 } ptamd_bound_job;
 int ptamd_bound_scales(const ptamd_bound_job *jobs_host, int njobs, void *stream);
+/* Presets of up to 8 small device buffers in ONE launch (dst[0..n) = value): the atomicMin targets of a backward pass (the
+ * uniform scales of dy2 / dz1 / dyo / dqkv and the row scales of dqkv start at 0x7F000000, the largest finite power of two). */
+typedef struct { uint32_t *dst; int64_t n; uint32_t value; } ptamd_fill_job;
+int ptamd_fill_u32(const ptamd_fill_job *jobs_host, int njobs, void *stream);
 
 /* ------------------------------------------------------------------ the weights of a step in ONE pass (csrc/wprep.hip)
  * ptamd_weights_prep: what ptamd_weight_scales + ptamd_bound_scales + ptamd_hp_split_rows + ptamd_hp_split_cols compute for
@@ -362,11 +372,13 @@ typedef struct {
 int ptamd_wprep_rows_per_block(void);
 int ptamd_wprep_plain_floats_per_block(void);
 int ptamd_weights_prep(const ptamd_wprep_plan *plan_host, const float *w, int parity, void *stream);
-int ptamd_sgd_step_prep(const ptamd_wprep_plan *plan_host, int parity, float *w, const float *g, int64_t n, const float *sqnorm,
-                        float max_norm, float lr, float weight_decay, void *stream);
-int ptamd_adam_step_prep(const ptamd_wprep_plan *plan_host, int parity, float *w, const float *g, float *m, float *v, int64_t n,
+/* zero_grad != 0 (here and in ptamd_sgd_step / ptamd_adam_step): g is zeroed behind its last read - the `optimizer.zero_grad()`
+ * of the NEXT step (train.py:37) in the pass that streams g anyway instead of a 76 MB fill of its own. */
+int ptamd_sgd_step_prep(const ptamd_wprep_plan *plan_host, int parity, float *w, float *g, int64_t n, const float *sqnorm,
+                        float max_norm, float lr, float weight_decay, int zero_grad, void *stream);
+int ptamd_adam_step_prep(const ptamd_wprep_plan *plan_host, int parity, float *w, float *g, float *m, float *v, int64_t n,
                          const float *sqnorm, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
-                         int step, void *stream);
+                         int step, int zero_grad, void *stream);
 
 /* torch.nn.LayerNorm(D, eps=1e-5) (Sublayers.py:13,17): y = (x-mean)*rstd*gamma+beta; saves mean,rstd [T];
  * row_scale [T] (may be NULL): the f16x2 scale of every row of y, for the GEMM that reads y as its A operand;
@@ -495,10 +507,10 @@ size_t ptamd_grad_sqnorm_workspace_bytes(void);
 int ptamd_grad_sqnorm(const float *g, int64_t n, float *out, void *workspace, size_t workspace_bytes, void *stream);
 /* clip coefficient = min(1, max_norm / (sqrt(*sqnorm) + 1e-6)) computed on device from sqnorm[0];
  * max_norm <= 0 disables clipping */
-int ptamd_sgd_step(float *w, const float *g, int64_t n, const float *sqnorm, float max_norm, float lr,
-                   float weight_decay, void *stream);
-int ptamd_adam_step(float *w, const float *g, float *m, float *v, int64_t n, const float *sqnorm, float max_norm,
-                    float lr, float beta1, float beta2, float eps, float weight_decay, int step, void *stream);
+int ptamd_sgd_step(float *w, float *g, int64_t n, const float *sqnorm, float max_norm, float lr,
+                   float weight_decay, int zero_grad, void *stream);
+int ptamd_adam_step(float *w, float *g, float *m, float *v, int64_t n, const float *sqnorm, float max_norm,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, int step, int zero_grad, void *stream);
 
 #ifdef __cplusplus
 }

@@ -78,22 +78,29 @@ class CpuTrainer:
     def forward(self, src_seq):
         return enc.encoder_forward(self.all_tensors(), src_seq, self.nhead)
 
-    def step(self, src_seq, tgt_ang, tgt_crds):
+    def step(self, src_seq, tgt_ang, tgt_crds, keep_grads=False):
+        """`keep_grads`: leave the step's losses, its gradients (as back-propagated, before the clip) and their global norm
+        behind as `last_losses` / `last_grads` / `last_grad_norm` - what bench.py's parity block and the full-size parity test
+        compare the HIP step with."""
         self.opt.zero_grad()
         pred = self.forward(src_seq)
         losses = get_losses(self.loss, pred, tgt_ang, tgt_crds, src_seq, pool=self.pool)
+        if keep_grads:
+            self.last_losses = losses
+            self.last_grads = {k: p.grad.detach().clone() for k, p in self.params.items() if p.grad is not None}
+            self.last_grad_norm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in self.last_grads.values())))
         if self.clip:
             torch.nn.utils.clip_grad_norm_(list(self.params.values()), self.clip)
         self.opt.step()
         return losses
 
 
-def time_cpu_steps(trainer, batch, n_steps=1):
+def time_cpu_steps(trainer, batch, n_steps=1, keep_grads=False):
     """Wall-clock residues/s of the CPU path, the metric of log.py:422-430."""
     src_seq = batch[0]
     n_res = int((src_seq != enc.PAD_ID).sum())
     t0 = time.perf_counter()
     for _ in range(n_steps):
-        trainer.step(*batch)
+        trainer.step(*batch, keep_grads=keep_grads)
     dt = (time.perf_counter() - t0) / n_steps
     return n_res / dt, dt

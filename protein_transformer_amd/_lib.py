@@ -52,6 +52,10 @@ class LnReduceJob(C.Structure):
     _fields_ = [("partials", _p), ("D", _i), ("dgamma", _p), ("dbeta", _p)]
 
 
+class FillJob(C.Structure):
+    _fields_ = [("dst", _p), ("n", _i64), ("value", _u32)]
+
+
 class HpSplitJob(C.Structure):
     _fields_ = [("x", _p), ("ld", _i), ("rows", _i), ("K", _i), ("planes", _p), ("scale", _p)]
 
@@ -113,6 +117,8 @@ SIGNATURES = {
     "ptamd_nerf_bwd": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _sz, _p]),
     "ptamd_drmsd_workspace_bytes": (_sz, [_i, _i]),
     "ptamd_drmsd_fwd_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _sz, _p]),
+    "ptamd_drmsd_workspace_bytes_budget": (_sz, [_i, _i, _sz]),
+    "ptamd_drmsd_fwd_bwd_budget": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _sz, _sz, _p]),
     "ptamd_kabsch_rmsd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "ptamd_mse_angles_workspace_bytes": (_sz, []),
     "ptamd_mse_angles_fwd": (_i, [_p, _p, _i64, _p, _p, _sz, _p]),
@@ -164,10 +170,11 @@ SIGNATURES = {
     "ptamd_wprep_rows_per_block": (_i, []),
     "ptamd_wprep_plain_floats_per_block": (_i, []),
     "ptamd_weights_prep": (_i, [C.POINTER(WprepPlan), _p, _i, _p]),
-    "ptamd_sgd_step_prep": (_i, [C.POINTER(WprepPlan), _i, _p, _p, _i64, _p, _f, _f, _f, _p]),
-    "ptamd_adam_step_prep": (_i, [C.POINTER(WprepPlan), _i, _p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _f, _f, _i, _p]),
-    "ptamd_sgd_step": (_i, [_p, _p, _i64, _p, _f, _f, _f, _p]),
-    "ptamd_adam_step": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _f, _f, _i, _p]),
+    "ptamd_sgd_step_prep": (_i, [C.POINTER(WprepPlan), _i, _p, _p, _i64, _p, _f, _f, _f, _i, _p]),
+    "ptamd_adam_step_prep": (_i, [C.POINTER(WprepPlan), _i, _p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _f, _f, _i, _i, _p]),
+    "ptamd_sgd_step": (_i, [_p, _p, _i64, _p, _f, _f, _f, _i, _p]),
+    "ptamd_adam_step": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _f, _f, _i, _i, _p]),
+    "ptamd_fill_u32": (_i, [C.POINTER(FillJob), _i, _p]),
 }
 
 _lib = None

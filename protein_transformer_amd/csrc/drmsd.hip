@@ -542,19 +542,19 @@ __global__ __launch_bounds__(CB) void drmsd_finalize_kernel(const Counts *__rest
 // The fixed-order partial sums of the sweep grow as O(n^2 / 256) per protein: 166 MB at (32, 512), 1.35 GB at (32, 1500).
 // Beyond PARTIAL_BUDGET the strips are swept in PASSES of `spp` strips (one launch of the pair kernel + one of
 // drmsd_accumulate_kernel each, same buffers): the workspace stays below ~256 MB at any size, same bits.  A function of
-// (B, L) only - and of PTAMD_DRMSD_PARTIAL_MB in the environment (read at every call), which tests use to force passes.
+// (B, L) and of the budget alone: the plain entry points use PARTIAL_BUDGET, the *_budget ones take it as an ARGUMENT (tests
+// force passes on a small batch with it) - nothing is read from the process environment.
 constexpr size_t PARTIAL_BUDGET = (size_t)200 << 20;
 struct Layout {
   size_t pred4, col8, rowpart, colpart, grow, gcol, idx, counts, partials, total;
   int spp;   // strips per pass (= strips: one launch)
   TriLayout tl;
 };
-Layout layout(int B, int L) {
+Layout layout(int B, int L, size_t budget) {
   Layout l;
   const size_t nmax = (size_t)L * 14, BN = (size_t)B * nmax;
   l.tl = tri_layout((int)nmax, B);
-  size_t budget = PARTIAL_BUDGET;
-  if (const char *e = getenv("PTAMD_DRMSD_PARTIAL_MB")) budget = (size_t)max(1, atoi(e)) << 20;
+  if (budget == 0) budget = PARTIAL_BUDGET;
   const size_t per_strip = (size_t)B * ((size_t)l.tl.chunks * RS + (size_t)l.tl.tiles * TS) * sizeof(float4);
   l.spp = l.tl.strips;
   if (per_strip * l.tl.strips > budget) l.spp = (int)max((size_t)1, budget / per_strip);
@@ -582,15 +582,21 @@ Layout layout(int B, int L) {
 
 extern "C" {
 
-size_t ptamd_drmsd_workspace_bytes(int B, int L) {
+size_t ptamd_drmsd_workspace_bytes_budget(int B, int L, size_t partial_budget_bytes) {
   if (B <= 0 || L <= 0) return 0;
-  return layout(B, L).total;
+  return layout(B, L, partial_budget_bytes).total;
 }
+size_t ptamd_drmsd_workspace_bytes(int B, int L) { return ptamd_drmsd_workspace_bytes_budget(B, L, 0); }
 
 int ptamd_drmsd_fwd_bwd(const float *pred_crd, const float *true_crd, const int64_t *seq, int B, int L, float *stats,
                         float *dcrd, void *workspace, size_t workspace_bytes, void *stream) {
+  return ptamd_drmsd_fwd_bwd_budget(pred_crd, true_crd, seq, B, L, stats, dcrd, workspace, workspace_bytes, 0, stream);
+}
+
+int ptamd_drmsd_fwd_bwd_budget(const float *pred_crd, const float *true_crd, const int64_t *seq, int B, int L, float *stats,
+                               float *dcrd, void *workspace, size_t workspace_bytes, size_t partial_budget_bytes, void *stream) {
   if (B <= 0 || L <= 0) return PTAMD_ERR_BAD_SHAPE;
-  const Layout l = layout(B, L);
+  const Layout l = layout(B, L, partial_budget_bytes);
   if (!workspace || workspace_bytes < l.total) return PTAMD_ERR_WORKSPACE;
   if (!pt_aligned16(workspace)) return PTAMD_ERR_ALIGN;
   char *ws = static_cast<char *>(workspace);

@@ -42,7 +42,10 @@ __global__ __launch_bounds__(256) void sqnorm_final_kernel(const double *__restr
   if (threadIdx.x == 0) out[0] = (float)((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
 }
 
-__global__ void sgd_kernel(float *__restrict__ w, const float *__restrict__ g, int64_t n, const float *sqnorm,
+// ZERO: the gradient is zeroed behind its last read - the `optimizer.zero_grad()` of the NEXT step (train.py:37) folded into
+// the pass that streams g anyway (a 76 MB fill of its own otherwise)
+template <bool ZERO>
+__global__ void sgd_kernel(float *__restrict__ w, float *__restrict__ g, int64_t n, const float *sqnorm,
                            float max_norm, float lr, float wd) {
   const float coef = clip_coef(sqnorm, max_norm);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -55,13 +58,16 @@ __global__ void sgd_kernel(float *__restrict__ w, const float *__restrict__ g, i
     p.z = ptopt::sgd_update(p.z, d.z, coef, lr, wd);
     p.w = ptopt::sgd_update(p.w, d.w, coef, lr, wd);
     reinterpret_cast<float4 *>(w)[i] = p;
+    if (ZERO) reinterpret_cast<float4 *>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   } else if (i < n4 + (n & 3)) {
     const int64_t k = (n4 << 2) + (i - n4);
     w[k] = ptopt::sgd_update(w[k], g[k], coef, lr, wd);
+    if (ZERO) g[k] = 0.f;
   }
 }
 
-__global__ void adam_kernel(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m,
+template <bool ZERO>
+__global__ void adam_kernel(float *__restrict__ w, float *__restrict__ g, float *__restrict__ m,
                             float *__restrict__ v, int64_t n, const float *sqnorm, float max_norm, float step_size,
                             float beta1, float beta2, float eps, float wd, float inv_sqrt_bc2) {
   const float coef = clip_coef(sqnorm, max_norm);
@@ -71,6 +77,7 @@ __global__ void adam_kernel(float *__restrict__ w, const float *__restrict__ g, 
   w[i] = ptopt::adam_update(w[i], g[i], mi, vi, coef, wd, beta1, beta2, eps, step_size, inv_sqrt_bc2);
   m[i] = mi;
   v[i] = vi;
+  if (ZERO) g[i] = 0.f;
 }
 
 }  // namespace
@@ -92,22 +99,25 @@ int ptamd_grad_sqnorm(const float *g, int64_t n, float *out, void *workspace, si
   return pt_check_launch();
 }
 
-int ptamd_sgd_step(float *w, const float *g, int64_t n, const float *sqnorm, float max_norm, float lr,
-                   float weight_decay, void *stream) {
+int ptamd_sgd_step(float *w, float *g, int64_t n, const float *sqnorm, float max_norm, float lr,
+                   float weight_decay, int zero_grad, void *stream) {
   if (n <= 0) return PTAMD_ERR_BAD_SHAPE;
   if (!pt_aligned16(w) || !pt_aligned16(g)) return PTAMD_ERR_ALIGN;
   const int64_t items = (n >> 2) + (n & 3);
-  hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, g, n,
-                     sqnorm, max_norm, lr, weight_decay);
+  const dim3 grid((unsigned)((items + 255) / 256));
+  if (zero_grad) hipLaunchKernelGGL(sgd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, w, g, n, sqnorm, max_norm, lr, weight_decay);
+  else hipLaunchKernelGGL(sgd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, w, g, n, sqnorm, max_norm, lr, weight_decay);
   return pt_check_launch();
 }
 
-int ptamd_adam_step(float *w, const float *g, float *m, float *v, int64_t n, const float *sqnorm, float max_norm,
-                    float lr, float beta1, float beta2, float eps, float weight_decay, int step, void *stream) {
+int ptamd_adam_step(float *w, float *g, float *m, float *v, int64_t n, const float *sqnorm, float max_norm,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, int step, int zero_grad, void *stream) {
   if (n <= 0 || step <= 0) return PTAMD_ERR_BAD_SHAPE;
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, g, m, v, n,
-                     sqnorm, max_norm, (float)(lr / bc1), beta1, beta2, eps, weight_decay, (float)(1.0 / sqrt(bc2)));
+  const dim3 grid((unsigned)((n + 255) / 256));
+  const float ss = (float)(lr / bc1), ib = (float)(1.0 / sqrt(bc2));
+  if (zero_grad) hipLaunchKernelGGL(adam_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, w, g, m, v, n, sqnorm, max_norm, ss, beta1, beta2, eps, weight_decay, ib);
+  else hipLaunchKernelGGL(adam_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, w, g, m, v, n, sqnorm, max_norm, ss, beta1, beta2, eps, weight_decay, ib);
   return pt_check_launch();
 }
 

@@ -164,9 +164,45 @@ __global__ void bound_kernel(const BJobs js) {
   if (b.out_value) *b.out_value = v;
 }
 
+// presets of small device words (atomicMin targets, flags) of up to 8 buffers in one launch
+constexpr int MAX_FILLS = 8, FILL_THREADS = 256;
+struct FJobs {
+  ptamd_fill_job job[MAX_FILLS];
+  int first_block[MAX_FILLS + 1];
+  int n;
+};
+__global__ __launch_bounds__(FILL_THREADS) void fill_u32_kernel(const FJobs js) {
+  int j = 0;
+#pragma unroll
+  for (int k = 1; k < MAX_FILLS; ++k) j += (k < js.n && (int)blockIdx.x >= js.first_block[k]) ? 1 : 0;
+  const ptamd_fill_job f = js.job[j];
+  const int64_t i = ((int64_t)(blockIdx.x - js.first_block[j]) * FILL_THREADS + threadIdx.x) * 4;
+  if (i + 4 <= f.n && (reinterpret_cast<uintptr_t>(f.dst) & 15) == 0) {
+    *reinterpret_cast<uint4 *>(f.dst + i) = make_uint4(f.value, f.value, f.value, f.value);
+  } else {
+    for (int64_t k = i; k < f.n && k < i + 4; ++k) f.dst[k] = f.value;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int ptamd_fill_u32(const ptamd_fill_job *jobs, int njobs, void *stream) {
+  if (!jobs || njobs <= 0 || njobs > MAX_FILLS) return PTAMD_ERR_BAD_SHAPE;
+  FJobs js;
+  js.n = njobs;
+  int blocks = 0;
+  for (int j = 0; j < njobs; ++j) {
+    if (!jobs[j].dst || jobs[j].n <= 0) return PTAMD_ERR_BAD_SHAPE;
+    js.job[j] = jobs[j];
+    js.first_block[j] = blocks;
+    blocks += (int)((jobs[j].n + 4 * FILL_THREADS - 1) / (4 * FILL_THREADS));
+  }
+  js.first_block[njobs] = blocks;
+  hipLaunchKernelGGL(fill_u32_kernel, dim3(blocks), dim3(FILL_THREADS), 0, (hipStream_t)stream, js);
+  return pt_check_launch();
+}
 
 int ptamd_weight_scales(const ptamd_wscale_job *jobs, int njobs, void *stream) {
   if (!jobs || njobs <= 0 || njobs > MAX_JOBS) return PTAMD_ERR_BAD_SHAPE;

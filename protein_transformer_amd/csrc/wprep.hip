@@ -37,7 +37,8 @@ constexpr int PLAIN_F4 = 4096;                                  // float4 per pl
 
 struct OptArgs {
   int kind;                // 0: no update, 1: SGD, 2: Adam
-  const float *g;
+  int zero_g;              // the gradient is zeroed behind its read (the next step's zero_grad, folded in)
+  float *g;
   float *m, *v;
   const float *sqnorm;
   float max_norm, lr, wd, beta1, beta2, eps, step_size, inv_sqrt_bc2;
@@ -72,6 +73,7 @@ struct Quad {
       *reinterpret_cast<float4 *>(o.v + i) = v;
     }
     *reinterpret_cast<float4 *>(w + i) = p;
+    if (o.zero_g) *reinterpret_cast<float4 *>(o.g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
     return p;
   }
 };
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(64 * WAVES) void wprep_rows_kernel(float *__restric
       const int64_t k = first + (n4 << 2) + tid;
       if (KIND == 1) w[k] = sgd_update(w[k], o.g[k], coef, o.lr, o.wd);
       else w[k] = adam_update(w[k], o.g[k], o.m[k], o.v[k], coef, o);
+      if (o.zero_g) o.g[k] = 0.f;
     }
     return;
   }
@@ -432,21 +435,21 @@ int ptamd_weights_prep(const ptamd_wprep_plan *plan, const float *w, int parity,
   return run(plan, const_cast<float *>(w), parity, o, (hipStream_t)stream);
 }
 
-int ptamd_sgd_step_prep(const ptamd_wprep_plan *plan, int parity, float *w, const float *g, int64_t n, const float *sqnorm,
-                        float max_norm, float lr, float weight_decay, void *stream) {
+int ptamd_sgd_step_prep(const ptamd_wprep_plan *plan, int parity, float *w, float *g, int64_t n, const float *sqnorm,
+                        float max_norm, float lr, float weight_decay, int zero_grad, void *stream) {
   if (!plan || n != plan->numel || !g) return PTAMD_ERR_BAD_SHAPE;
   OptArgs o = {};
-  o.kind = 1; o.g = g; o.sqnorm = sqnorm; o.max_norm = max_norm; o.lr = lr; o.wd = weight_decay;
+  o.kind = 1; o.g = g; o.zero_g = zero_grad != 0; o.sqnorm = sqnorm; o.max_norm = max_norm; o.lr = lr; o.wd = weight_decay;
   return run(plan, w, parity, o, (hipStream_t)stream);
 }
 
-int ptamd_adam_step_prep(const ptamd_wprep_plan *plan, int parity, float *w, const float *g, float *m, float *v, int64_t n,
+int ptamd_adam_step_prep(const ptamd_wprep_plan *plan, int parity, float *w, float *g, float *m, float *v, int64_t n,
                          const float *sqnorm, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
-                         int step, void *stream) {
+                         int step, int zero_grad, void *stream) {
   if (!plan || n != plan->numel || !g || !m || !v || step <= 0) return PTAMD_ERR_BAD_SHAPE;
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   OptArgs o = {};
-  o.kind = 2; o.g = g; o.m = m; o.v = v; o.sqnorm = sqnorm; o.max_norm = max_norm; o.wd = weight_decay;
+  o.kind = 2; o.g = g; o.zero_g = zero_grad != 0; o.m = m; o.v = v; o.sqnorm = sqnorm; o.max_norm = max_norm; o.wd = weight_decay;
   o.beta1 = beta1; o.beta2 = beta2; o.eps = eps; o.step_size = (float)(lr / bc1); o.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   return run(plan, w, parity, o, (hipStream_t)stream);
 }

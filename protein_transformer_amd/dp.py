@@ -229,6 +229,7 @@ def all_reduce_gradients(model, empty=False):
     the step (its gradient buffer is zero and no backward ran): it issues the same reductions, in the same order."""
     if world_size() == 1:
         return
+    model.__dict__["_grad_dirty"] = True     # (a rank with an empty shard ran no backward pass, yet its buffer receives the sum)
     meter = COMM_METER is not None and torch.cuda.is_available()
     if meter:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

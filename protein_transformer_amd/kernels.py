@@ -518,15 +518,29 @@ def grad_sqnorm(g, out):
     return out
 
 
-def sgd_step(w, g, sqnorm, max_norm, lr, weight_decay):
+def sgd_step(w, g, sqnorm, max_norm, lr, weight_decay, zero_grad=False):
+    """`zero_grad`: g is zeroed behind its read (the next step's `optimizer.zero_grad()` folded into this pass)."""
     check(lib().ptamd_sgd_step(ptr(w), ptr(g), w.numel(), ptr(sqnorm), float(max_norm or 0.0), float(lr),
-                               float(weight_decay), stream()), "sgd_step")
+                               float(weight_decay), int(bool(zero_grad)), stream()), "sgd_step")
 
 
-def adam_step(w, g, m, v, sqnorm, max_norm, lr, beta1, beta2, eps, weight_decay, step):
+def adam_step(w, g, m, v, sqnorm, max_norm, lr, beta1, beta2, eps, weight_decay, step, zero_grad=False):
     check(lib().ptamd_adam_step(ptr(w), ptr(g), ptr(m), ptr(v), w.numel(), ptr(sqnorm), float(max_norm or 0.0),
                                 float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
-                                stream()), "adam_step")
+                                int(bool(zero_grad)), stream()), "adam_step")
+
+
+def fill_u32(jobs):
+    """jobs: list of (int32 / uint32 / float32 tensor, value) -> every element of each tensor = value (its bit pattern), ONE
+    launch for up to 8 contiguous tensors (ptamd_fill_u32)."""
+    from ._lib import FillJob
+    for i in range(0, len(jobs), 8):
+        chunk = jobs[i:i + 8]
+        arr = (FillJob * len(chunk))()
+        for k, (t, value) in enumerate(chunk):
+            assert t.is_contiguous() and t.element_size() == 4
+            arr[k] = FillJob(dst=t.data_ptr(), n=t.numel(), value=int(value) & 0xFFFFFFFF)
+        check(lib().ptamd_fill_u32(arr, len(chunk), stream()), "fill_u32")
 
 
 # ----------------------------------------------------------------------------- conv-enc front end
@@ -714,11 +728,13 @@ class WeightsPrep:
                               colsq=self.colsq.data_ptr(), stats=self.stats.data_ptr(), nstats=int(nstats), numel=int(numel),
                               with_planes=1)
 
-    def _next(self, with_planes):
+    def _call(self, what, fn, with_planes, *args):
+        """One library call on the copy of the double-buffered maxima / statistics that is due; the parity moves only once the
+        call has been accepted (a refused call - bad argument, launch error - must not leave the next one accumulating into
+        the copy that was never reset)."""
         self.plan.with_planes = int(bool(with_planes))
-        p = self.parity
+        check(fn(C.byref(self.plan), *[self.parity if a is _PARITY else a for a in args]), what)
         self.parity ^= 1
-        return p
 
     def last_stats(self):
         """The statistics records of the most recent call ([nstats, 4] view)."""
@@ -727,13 +743,17 @@ class WeightsPrep:
     def prepare(self, flat, with_planes=True):
         """Scales, statistics, bounds (and planes) of the weights as they are: no update."""
         assert flat.numel() == self.numel
-        check(lib().ptamd_weights_prep(C.byref(self.plan), ptr(flat), self._next(with_planes), stream()), "weights_prep")
+        self._call("weights_prep", lib().ptamd_weights_prep, with_planes, ptr(flat), _PARITY, stream())
 
-    def sgd_step(self, w, g, sqnorm, max_norm, lr, weight_decay, with_planes=True):
-        check(lib().ptamd_sgd_step_prep(C.byref(self.plan), self._next(with_planes), ptr(w), ptr(g), w.numel(), ptr(sqnorm),
-                                        float(max_norm or 0.0), float(lr), float(weight_decay), stream()), "sgd_step_prep")
+    def sgd_step(self, w, g, sqnorm, max_norm, lr, weight_decay, with_planes=True, zero_grad=False):
+        self._call("sgd_step_prep", lib().ptamd_sgd_step_prep, with_planes, _PARITY, ptr(w), ptr(g), w.numel(), ptr(sqnorm),
+                   float(max_norm or 0.0), float(lr), float(weight_decay), int(bool(zero_grad)), stream())
 
-    def adam_step(self, w, g, m, v, sqnorm, max_norm, lr, beta1, beta2, eps, weight_decay, step, with_planes=True):
-        check(lib().ptamd_adam_step_prep(C.byref(self.plan), self._next(with_planes), ptr(w), ptr(g), ptr(m), ptr(v), w.numel(),
-                                         ptr(sqnorm), float(max_norm or 0.0), float(lr), float(beta1), float(beta2), float(eps),
-                                         float(weight_decay), int(step), stream()), "adam_step_prep")
+    def adam_step(self, w, g, m, v, sqnorm, max_norm, lr, beta1, beta2, eps, weight_decay, step, with_planes=True,
+                  zero_grad=False):
+        self._call("adam_step_prep", lib().ptamd_adam_step_prep, with_planes, _PARITY, ptr(w), ptr(g), ptr(m), ptr(v), w.numel(),
+                   ptr(sqnorm), float(max_norm or 0.0), float(lr), float(beta1), float(beta2), float(eps),
+                   float(weight_decay), int(step), int(bool(zero_grad)), stream())
+
+
+_PARITY = object()       # placeholder of WeightsPrep._call: "the copy that is due"

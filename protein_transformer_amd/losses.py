@@ -60,17 +60,19 @@ def inverse_trig_transform(t):
 
 
 # ----------------------------------------------------------------------------- dRMSD
-def drmsd_forward_backward(pred_crd, true_crd, seq, need_grad=True):
-    """Batched loss kernel. Returns stats [B,8] (device) and d(drmsd/n)/d(pred_crd) or None."""
+def drmsd_forward_backward(pred_crd, true_crd, seq, need_grad=True, partial_budget_bytes=0):
+    """Batched loss kernel. Returns stats [B,8] (device) and d(drmsd/n)/d(pred_crd) or None.  `partial_budget_bytes`: cap on the
+    fixed-order partial sums of the pair sweep (0 = the library's 200 MB; smaller = the sweep runs in passes, same bits)."""
     _lib.require_gpu(pred_crd, true_crd, seq)
     B, L = seq.shape
     pred_crd, true_crd, seq = pred_crd.contiguous(), true_crd.contiguous(), seq.contiguous()
     stats = torch.empty(B, 8, dtype=torch.float32, device=seq.device)
     dcrd = torch.empty_like(pred_crd) if need_grad else None
-    nbytes = _lib.lib().ptamd_drmsd_workspace_bytes(B, L)
+    budget = int(partial_budget_bytes)
+    nbytes = _lib.lib().ptamd_drmsd_workspace_bytes_budget(B, L, budget)
     ws = _lib.workspace("drmsd", nbytes, seq.device)
-    rc = _lib.lib().ptamd_drmsd_fwd_bwd(_lib.ptr(pred_crd), _lib.ptr(true_crd), _lib.ptr(seq), B, L, _lib.ptr(stats),
-                                        _lib.ptr(dcrd), _lib.ptr(ws), ws.numel(), _lib.stream())
+    rc = _lib.lib().ptamd_drmsd_fwd_bwd_budget(_lib.ptr(pred_crd), _lib.ptr(true_crd), _lib.ptr(seq), B, L, _lib.ptr(stats),
+                                               _lib.ptr(dcrd), _lib.ptr(ws), ws.numel(), budget, _lib.stream())
     _lib.check(rc, "drmsd_fwd_bwd")
     return stats, dcrd
 

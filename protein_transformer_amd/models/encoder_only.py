@@ -448,7 +448,16 @@ class _TransformerBase(nn.Module):
         weights) no longer describe this model.  In-place torch ops on the parameters or the flat buffer are noticed without
         this call (their version counters move: `_weights_stamp`)."""
         self.auto_guard.reset()
+        self.weights_written()
         self._forget_prepared_weights()
+
+    def weights_written(self):
+        """The flat buffer was written through a raw pointer (the fused optimizer kernels, csrc/optim.hip / wprep.hip): no
+        torch version counter saw it.  Moves `_weights_stamp`, so that EVERY scale cache - the evaluation pass's (dropout 0)
+        beside the training pass's - prepares the weights again before its next use; the optimizer then marks the one cache
+        its step prepared as fresh (`prepared_step`).  (Round 5: the stamp only knew torch's counters, and validation after
+        the first epoch ran on the scales / bounds / planes of the weights of the FIRST validation.)"""
+        self.__dict__["_weights_generation"] = self.__dict__.get("_weights_generation", 0) + 1
 
     def _forget_prepared_weights(self):
         for c in self.__dict__.get("_scale_caches", {}).values():
@@ -456,11 +465,12 @@ class _TransformerBase(nn.Module):
         self.__dict__.pop("_train_cache", None)
 
     def _weights_stamp(self):
-        """Moves whenever a torch op writes the flat buffer or a parameter (their views do not share one version counter)."""
+        """Moves whenever a torch op writes the flat buffer or a parameter (their views do not share one version counter) and
+        whenever a fused optimizer kernel does (`weights_written`)."""
         params = self.__dict__.get("_param_list")
         if params is None:
             params = self.__dict__["_param_list"] = list(self.parameters())
-        return self._flat._version + sum(p._version for p in params)
+        return (self._flat._version + sum(p._version for p in params), self.__dict__.get("_weights_generation", 0))
 
     def prepared_step(self):
         """For the fused optimizers (optim.py): (WeightsPrep plan, with_planes, mark_fresh) of the scale cache the last TRAINING
@@ -603,7 +613,10 @@ class _TransformerBase(nn.Module):
                     cache["hpT_mats"] += [w2]
                     cache["hpT_scales"] += [L["cs_2"]]
                     cache["hpT_outs"] += [L["hp_2t"]]
-            cache["prep"] = self._build_prep(cache, p, pa) if (F <= 2048 and D % 4 == 0 and F % 4 == 0) else None
+            # (csrc/wprep.hip keeps whole rows of <= 512 columns in registers and walks wider matrices as 512-column panels:
+            # widths above 512 that are not multiples of 512 - d_model 768, d_ff 1000 - take the separate launches below)
+            panels_ok = all(c <= 512 or c % 512 == 0 for c in (D, F))
+            cache["prep"] = self._build_prep(cache, p, pa) if (F <= 2048 and D % 4 == 0 and F % 4 == 0 and panels_ok) else None
         need_planes = bool(cache["hp_mats"]) and bool(hp)
         if self.weights_prep and cache.get("prep") is not None:
             # ONE pass over the weights (two launches) - or none at all when the optimizer step that wrote these weights left
@@ -857,7 +870,7 @@ class _EncoderFn(torch.autograd.Function):
                             flags=K.EPI_TANH if m.use_tanh_out else 0, arith=ar)
         if measure_fwd:
             scales[0]["guard_stats"][:, 2].zero_()                 # dz1: not measured here (slack 0 = "as good as its bound")
-            scales[0]["minbuf"].fill_(0x7F000000)                  # ... and its scale slot reads "unused"
+            K.fill_u32([(scales[0]["minbuf"], 0x7F000000)])        # ... and its scale slot reads "unused"
             guard.submit(scales[0]["guard_stats"], scales[0]["ints"], scales[0]["minbuf"], scales, forward_only=True)
         ctx.model, ctx.seed, ctx.seq, ctx.flat, ctx.arith, ctx.attn_arith = m, seed, seq, flat, ar, attn_default
         ctx.p, ctx.pa = p, pa
@@ -874,6 +887,7 @@ class _EncoderFn(torch.autograd.Function):
         B, L = seq.shape
         D, H = m.dlayer, m.nhead
         gflat = m._flat_grad
+        m.__dict__["_grad_dirty"] = True          # raw-pointer writes into the flat gradient buffer from here on (optim.py: zero_grad)
         W = lambda name: m._slice(flat, name)                                      # noqa: E731
         G = lambda name: m._slice(gflat, name)                                     # noqa: E731
 
@@ -887,13 +901,19 @@ class _EncoderFn(torch.autograd.Function):
             if side is None or side.device != dpred.device:
                 side = m.__dict__["_side_stream"] = torch.cuda.Stream(device=dpred.device)
 
+        # Operands the side stream reads were allocated on the main stream.  They are kept ALIVE here until the main stream has
+        # waited for the side stream (`join`, the end of the pass) instead of being handed to `record_stream`: blocks parked
+        # behind a side-stream event return to the allocator whenever the host happens to notice - the free lists of one step
+        # differed from the next one's and reserved memory crept (9.3 -> 9.9 GiB over 4,000 steps, profiles/r05/r05_soak.txt);
+        # with plain lifetimes every step allocates and frees in the same order.  (~3 GB more at the peak of 32 x 512.)
+        side_keep = []
+
         def dw(*tensors_then_kwargs, **kw):
             """K.linear_bwd_weight(dy, x, dw, db, ...) - on the side stream when there is one."""
             if side is None:
                 return K.linear_bwd_weight(*tensors_then_kwargs, **kw)
             side.wait_stream(main)                       # the operands were produced on the main stream
-            for t in tensors_then_kwargs[:2]:
-                t.record_stream(side)                    # allocated on the main stream, read on the side stream
+            side_keep.extend(tensors_then_kwargs[:2])    # allocated on the main stream, read on the side stream
             with torch.cuda.stream(side):
                 return K.linear_bwd_weight(*tensors_then_kwargs, **kw)
 
@@ -935,14 +955,14 @@ class _EncoderFn(torch.autograd.Function):
                 return K.linear_bwd_weight_group(group, sk)
             side.wait_stream(main)
             for dy, x, *_ in ok:
-                dy.record_stream(side)
-                x.record_stream(side)
+                side_keep.extend((dy, x))
             with torch.cuda.stream(side):
                 K.linear_bwd_weight_group(group, sk)
 
         def join():
             if side is not None:
                 main.wait_stream(side)
+                side_keep.clear()                # (whatever is freed from here on is reused behind the side stream's work)
 
         def done(first, last):
             if m.grad_hook is not None:
@@ -978,7 +998,13 @@ class _EncoderFn(torch.autograd.Function):
         s_dqkv_all = None
         have_min = False                                   # ... together with the uniform scales of dy2 / dz1 for the dW products
         if scales is not None:
-            scales[0]["minbuf"].fill_(0x7F000000)          # atomicMin targets of this backward pass (largest scale)
+            # atomicMin targets of this backward pass (largest scale): the uniform scales of every layer and, where the f16x2
+            # attention kernels leave the row scales of dqkv behind, those - one launch (ptamd_fill_u32) for both presets
+            presets = [(scales[0]["minbuf"], 0x7F000000)]
+            if m.attn_row_scales and K.attention_row_scales_available(D // H, attn_ar):
+                s_dqkv_all = torch.empty((m.nlayers, B * L), dtype=torch.int32, device=dpred.device)
+                presets.append((s_dqkv_all, 0x7F000000))
+            K.fill_u32(presets)
         # dX of FFN layer 2 on ptamd_gemm_hp: the fused LayerNorm backward that makes dy2 writes it a second time as planes
         dy2_planes, have_planes = None, False
         if ctx.use_hp and m.hp_dx and fuse and scales is not None and "hp_2t" in scales[0] and m.dff % 32 == 0:
@@ -1043,8 +1069,6 @@ class _EncoderFn(torch.autograd.Function):
             # the f16x2 attention kernels leave the row scales of dqkv (A of the dX product) and the smallest of them (the
             # uniform scale of dqkv as operand of the dW product) behind; other arithmetics: one pass over dqkv
             attn_scales = sc is not None and m.attn_row_scales and K.attention_row_scales_available(D // H, attn_ar)
-            if attn_scales and s_dqkv_all is None:
-                s_dqkv_all = torch.full((m.nlayers, B * L), 0x7F000000, dtype=torch.int32, device=dpred.device)
             s_dqkv = s_dqkv_all[i] if attn_scales else None
             dqkv = K.attention_bwd(qkv, seq, att, datt, lse, H, pa, seed, sid + _SITE_ATTN, arith=attn_ar,
                                     row_scale=s_dqkv, row_scale_min=sc["dqkv_min"] if attn_scales else None, keep_bits=kbits,

@@ -18,10 +18,28 @@ class _FlatOptimizer(torch.optim.Optimizer):
         super().__init__(list(model.parameters()), defaults)
         self._sqnorm = None
         self.max_norm = 0.0
+        # True: `step()` zeroes the gradient buffer behind its last read and the `zero_grad()` that opens the next step
+        # (train.py:37) finds nothing to do - the loop of train.train_step / the reference's train_epoch, where nobody looks
+        # at the gradients between `optimizer.step()` and the next `zero_grad()`.  False (the default of the classes: torch's
+        # semantics, `p.grad` survives the step); train.setup_model_optimizer_scheduler switches it on.
+        self.zero_grad_in_step = False
+        self._zeroed = None                      # (address, version) of the gradient buffer as the last step left it: all zero
 
     def zero_grad(self, set_to_none=False):
         _, g = self.model.flat_parameters()
+        # nothing to do when the last step zeroed this very buffer and nothing has written it since: no backward pass of the
+        # model (raw-pointer writes: `_grad_dirty`), no torch op on it or on a `p.grad` view (their shared version counter)
+        if (self._zeroed == (g.data_ptr(), g._version) and not self.model.__dict__.get("_grad_dirty", True)):
+            return
         g.zero_()
+        self._zeroed = None
+
+    def _after_step(self, g, zeroed):
+        if zeroed:
+            self.model.__dict__["_grad_dirty"] = False
+            self._zeroed = (g.data_ptr(), g._version)
+        else:
+            self._zeroed = None
 
     def clip_grad_norm_(self, max_norm):
         """Device-side `clip_grad_norm_`: launches the squared-norm reduction and arms the next `step()`
@@ -39,6 +57,13 @@ class _FlatOptimizer(torch.optim.Optimizer):
         (models/encoder_only.py `prepared_step`), else None: the plain optimizer kernel."""
         fn = getattr(self.model, "prepared_step", None)
         return fn() if fn is not None else None
+
+    def _written(self):
+        """The step wrote the flat buffer through a raw pointer: every cached view of the weights (scales, bounds, planes - of
+        the training pass AND of the evaluation pass) is stale from here on (models/encoder_only.py `weights_written`)."""
+        fn = getattr(self.model, "weights_written", None)
+        if fn is not None:
+            fn()
 
     def _clip_args(self):
         sq, mx = (self._sqnorm, self.max_norm) if self.max_norm > 0 else (None, 0.0)
@@ -58,12 +83,16 @@ class FusedSGD(_FlatOptimizer):
         grp = self.param_groups[0]
         sq, mx = self._clip_args()
         prepared = self._prepared()
+        zero = bool(self.zero_grad_in_step)
         if prepared is None:
-            K.sgd_step(w, g, sq, mx, grp["lr"], grp["weight_decay"])
+            K.sgd_step(w, g, sq, mx, grp["lr"], grp["weight_decay"], zero_grad=zero)
+            self._written()
         else:       # the same update, and the scales / bounds / planes of the NEW weights for the next forward pass (csrc/wprep.hip)
             plan, with_planes, mark_fresh = prepared
-            plan.sgd_step(w, g, sq, mx, grp["lr"], grp["weight_decay"], with_planes=with_planes)
-            mark_fresh()
+            plan.sgd_step(w, g, sq, mx, grp["lr"], grp["weight_decay"], with_planes=with_planes, zero_grad=zero)
+            self._written()
+            mark_fresh()        # (after the bump: only the cache this step prepared carries the new stamp)
+        self._after_step(g, zero)
 
 
 class FusedAdam(_FlatOptimizer):
@@ -85,18 +114,22 @@ class FusedAdam(_FlatOptimizer):
         self._t += 1
         sq, mx = self._clip_args()
         prepared = self._prepared()
+        zero = bool(self.zero_grad_in_step)
         if prepared is None:
             K.adam_step(w, g, self._m, self._v, sq, mx, grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"],
-                        grp["weight_decay"], self._t)
+                        grp["weight_decay"], self._t, zero_grad=zero)
+            self._written()
         else:
             # (ptamd_adam_step_prep - the fused form, tested in tests/test_gpu_scales.py - streams seven arrays through a kernel
             # that holds whole rows in registers: 190 us against 84 + 61 for the plain Adam kernel followed by the preparation
             # pass over the new weights, profiles/r05/r05_wprep_bench.txt; the SGD form breaks even and saves a launch)
             plan, with_planes, mark_fresh = prepared
             K.adam_step(w, g, self._m, self._v, sq, mx, grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"],
-                        grp["weight_decay"], self._t)
+                        grp["weight_decay"], self._t, zero_grad=zero)
+            self._written()
             plan.prepare(w, with_planes=with_planes)
             mark_fresh()
+        self._after_step(g, zero)
 
     def state_dict(self):
         sd = super().state_dict()
@@ -150,6 +183,14 @@ class ScheduledOptim():
     @property
     def param_groups(self):
         return self._optimizer.param_groups
+
+    @property
+    def zero_grad_in_step(self):
+        return self._optimizer.zero_grad_in_step
+
+    @zero_grad_in_step.setter
+    def zero_grad_in_step(self, value):
+        self._optimizer.zero_grad_in_step = bool(value)
 
     def state_dict(self):
         return (self._optimizer.state_dict(), self.n_warmup_steps, self.n_current_steps, self.init_lr)

@@ -27,6 +27,20 @@ def raise_for_status(word, theta_is_error=True):
         raise AssertionError("theta must be in radians and in [-pi, pi] (Structure.py:42)")
 
 
+_STATUS_POOL = {}
+
+
+def _status_word(device):
+    """A zeroed int32 word for the status bits of one NeRF launch, cut from a block that is zeroed ONCE per 1024 launches (a
+    `torch.zeros(1)` per training step was one fill kernel per step); blocks stay alive through the words handed out."""
+    key = (device.type, device.index)
+    blk, used = _STATUS_POOL.get(key, (None, 0))
+    if blk is None or used >= blk.numel():
+        blk, used = torch.zeros(1024, dtype=torch.int32, device=device), 0
+    _STATUS_POOL[key] = (blk, used + 1)
+    return blk[used:used + 1]
+
+
 def nerf_forward(ang, seq, status=None):
     """ang [B,L,12] fp32 cuda (radians), seq [B,L] int64 cuda -> crd [B,L*14,3]; no sync."""
     _lib.require_gpu(ang, seq)
@@ -35,7 +49,7 @@ def nerf_forward(ang, seq, status=None):
     seq = seq.contiguous()
     crd = torch.empty(B, L * NUM_PREDICTED_COORDS, 3, dtype=torch.float32, device=ang.device)
     if status is None:
-        status = torch.zeros(1, dtype=torch.int32, device=ang.device)
+        status = _status_word(ang.device)
     rc = _lib.lib().ptamd_nerf_fwd(_lib.ptr(ang), _lib.ptr(seq), B, L, _lib.ptr(crd), _lib.ptr(status), _lib.stream())
     _lib.check(rc, "nerf_fwd")
     return crd, status

@@ -314,6 +314,9 @@ def setup_model_optimizer_scheduler(args, device, angle_means):
         optimizer = FusedAdam(model, betas=(0.9, 0.98), eps=1e-09, lr=args.learning_rate, weight_decay=wd)
     elif args.optimizer == "sgd":
         optimizer = FusedSGD(model, lr=args.learning_rate, weight_decay=wd)
+    # this module's loop is zero_grad -> forward -> backward -> clip -> step (train_step = train.py:36-46) and nothing reads the
+    # gradients behind the step: the step zeroes them itself and the next zero_grad finds nothing to do (optim.py)
+    optimizer.zero_grad_in_step = True
     if args.lr_scheduling == "noam":
         optimizer = ScheduledOptim(optimizer, args.d_model, args.n_warmup_steps)
         scheduler = None
@@ -321,6 +324,112 @@ def setup_model_optimizer_scheduler(args, device, angle_means):
         scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, patience=args.patience,
                                                                threshold=args.early_stopping_threshold)
     return model, optimizer, scheduler
+
+
+def determine_largest_batch_size(args, data, device, angle_means, fraction_to_keep=0.8, headroom=0.9, max_probe_s=300.0):
+    """`-adbs / --automatically_determine_batch_size` (train.py:532-551 + scripts/determine_largest_batchsize.py:19-110): the
+    largest `-b` whose training batches - drawn from the LARGEST length bin with the residue budget b x max_seq_len, as the
+    reference's probe draws them (`use_largest_bin=True`) - train on this GPU, times `fraction_to_keep`.
+
+    The reference doubles b in a fresh subprocess per attempt until CUDA runs out of memory (the subprocess exists because
+    a crashed CUDA context keeps its cache).  Here the probe stays in the process and never drives the device out of memory:
+    two `train_step`s per candidate on a scratch model, the peak of the caching allocator measured around them, and the
+    doubling stops when the NEXT candidate's extrapolated peak (linear in the batch's tokens, fitted to the two most recent
+    probes) would exceed `headroom` x the memory that is free (`torch.cuda.mem_get_info`) - or when a candidate does raise
+    an out-of-memory error (then the last b that trained stands, as in the reference), when the budget covers the whole
+    training set, or after `max_probe_s` seconds.  Under data parallelism every rank probes its own share of the batches and
+    the ranks agree on the smallest answer."""
+    from math import ceil
+    from .dataset import BinnedProteinDataset, SimilarLengthBatchSampler, make_paired_collate_fn
+    t_start = time.time()
+    world = dp.world_size()
+    max_seq_len = getattr(args, "max_seq_len", MAX_SEQ_LEN)
+    ds = BinnedProteinDataset(seqs=data['train']['seq'], crds=data['train']['crd'], angs=data['train']['ang'],
+                              add_sos_eos=args.add_sos_eos, skip_missing_residues=args.skip_missing_res_train,
+                              bins=args.bins, max_seq_len=max_seq_len)
+    collate = make_paired_collate_fn(max_seq_len)
+    total_tokens = int(sum(min(int(n), max_seq_len) for n in ds.lens))
+    b_cap = max(1, ceil(total_tokens / max_seq_len))            # a budget beyond the whole training set changes nothing
+    if dp.is_main():
+        print("Determining maximum batch size.")
+
+    def probe(b):
+        """Two training steps on a largest-bin batch with the budget of `b`; (tokens of this rank's share, allocator peak)."""
+        smp = SimilarLengthBatchSampler(ds, b, dynamic_batch=b * max_seq_len, optimize_batch_for_cpus=False,
+                                        use_largest_bin=True)
+        idx = next(iter(smp))
+        idx = list(idx)[dp.rank()::world] if world > 1 else list(idx)
+        seq, ang, crd = collate([ds[int(i)] for i in idx]) if idx else (torch.zeros(0, 1, dtype=torch.long),) * 3
+        model = optimizer = None
+        torch.cuda.synchronize(device)
+        torch.cuda.reset_peak_memory_stats(device)
+        try:
+            model, optimizer, _ = setup_model_optimizer_scheduler(args, device, angle_means)
+            seq, ang, crd = seq.to(device), ang.to(device), crd.to(device)
+            for _ in range(2):
+                if idx:
+                    with dp.single_process(model):          # (no collective inside the probe: the ranks may stop at different b)
+                        train_step(model, optimizer, args, seq, ang, crd, n_res=int((seq != VOCAB.pad_id).sum()))
+            torch.cuda.synchronize(device)
+            peak = torch.cuda.max_memory_allocated(device)
+        finally:
+            del model, optimizer, seq, ang, crd
+            from . import _lib
+            _lib._workspaces.clear()
+            torch.cuda.empty_cache()
+        return int(len(idx) * (max(min(int(ds.lens[int(i)]), max_seq_len) for i in idx) if idx else 0)), int(peak)
+
+    np_state, torch_state = np.random.get_state(), torch.get_rng_state()      # the probe must not move the run's RNG streams
+    b, best, history, why = 1, 0, [], "budget covers the training set"
+    try:
+        while True:
+            try:
+                tokens, peak = probe(b)
+            except (torch.cuda.OutOfMemoryError, RuntimeError) as e:
+                if "out of memory" not in str(e).lower() and not isinstance(e, torch.cuda.OutOfMemoryError):
+                    raise
+                torch.cuda.empty_cache()
+                why = f"b = {b} ran out of memory"
+                break
+            best = b
+            history.append((b, tokens, peak))
+            if dp.is_main():
+                print(f"Testing batch size {b: >4}: {tokens} tokens on this GPU, peak {peak / 2 ** 30:.2f} GiB - success.")
+            if b >= b_cap:
+                break
+            if time.time() - t_start > max_probe_s:
+                why = f"probe time limit ({max_probe_s:.0f} s)"
+                break
+            nxt = min(2 * b, b_cap)
+            free, _total = torch.cuda.mem_get_info(device)
+            if len(history) >= 2 and history[-1][1] > history[-2][1]:
+                (b0, t0, p0), (b1, t1, p1) = history[-2], history[-1]
+                per_token = max(0.0, (p1 - p0) / (t1 - t0))
+                predicted = p1 + per_token * (t1 * nxt / b1 - t1)
+                if predicted > headroom * (free + p1):     # (free excludes what the probe itself held and has returned)
+                    # the largest b the fit allows, tried once more if it is a real step beyond the last success
+                    fit = int(b1 + (headroom * (free + p1) - p1) / max(per_token * t1 / b1, 1.0))
+                    if fit >= b1 + max(1, b1 // 10) and fit < nxt:
+                        nxt = fit
+                    else:
+                        why = f"b = {nxt} would need {predicted / 2 ** 30:.1f} GiB of the {free / 2 ** 30:.1f} GiB free"
+                        break
+            b = nxt
+    finally:
+        np.random.set_state(np_state)
+        torch.set_rng_state(torch_state)
+    best = max(1, best)
+    if world > 1:
+        t = torch.tensor([best], dtype=torch.int64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+        best = int(t.item())
+    # train.py:545-548: the reference keeps b itself when the CPU loss workers bound it and 80 % of it otherwise; there are
+    # no CPU workers here, so it is always the memory that speaks
+    max_batch_size = max(1, ceil(best * fraction_to_keep))
+    if dp.is_main():
+        print(f"Maximum batch size found to be {best} ({why}). Will proceed with {max_batch_size}. "
+              f"{int((time.time() - t_start) // 60)} min elapsed.")
+    return max_batch_size
 
 
 def create_parser():
@@ -441,6 +550,9 @@ def main():
         data = torch.load(args.data, weights_only=False)
     args.max_len = data["settings"]["max_len"]
     angle_means = data["settings"]["angle_means"]
+    if args.automatically_determine_batch_size:                   # train.py:586-587
+        args.batch_size = determine_largest_batch_size(args, data, device, angle_means)
+        seed_rngs(args)                                           # the run starts from the seeds it would have had without the probe
 
     model, optimizer, scheduler = setup_model_optimizer_scheduler(args, device, angle_means)
     args.name = args.name or time.strftime("run%y%m%d-%H%M%S")

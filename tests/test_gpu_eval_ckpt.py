@@ -281,6 +281,55 @@ def test_train_cli_writes_log_and_resumes(dev, tmp_path, monkeypatch):
     monkeypatch.setattr(TR, "START_EPOCH", 0)
 
 
+def test_adbs_probe_finds_a_batch_size_and_stops_at_the_memory_it_is_given(dev, tmp_path, monkeypatch):
+    """`-adbs / --automatically_determine_batch_size` (train.py:532-551,586-587; scripts/determine_largest_batchsize.py): the
+    probe doubles the batch size on largest-bin batches, measures the allocator peak of two training steps per candidate and
+    stops where the next candidate would not fit.  (i) plenty of memory: the budget that covers the whole training set, times
+    0.8; (ii) a pretended free memory just above the first probes' peak: the doubling stops early; (iii) the run's RNG
+    streams are where they were; (iv) the flag is honoured by the CLI (round 5 parsed and ignored it)."""
+    import sys
+    from math import ceil
+    from protein_transformer_amd import train as TR
+    from protein_transformer_amd.synthetic_data import make_synthetic_dataset
+    parser = TR.create_parser()
+    args = parser.parse_args(["--synthetic", "8,48,4", "-dm", "64", "-nl", "1", "-nh", "4", "-dih", "128", "-l", "drmsd",
+                              "-b", "2", "--max_seq_len", "48"])
+    args.add_sos_eos, args.bins = False, "auto"
+    data = make_synthetic_dataset(args.synthetic, args.seed, dev)
+    am = data["settings"]["angle_means"]
+    np.random.seed(5)
+    torch.manual_seed(5)
+    st_np, st_t = np.random.get_state()[1].copy(), torch.get_rng_state().clone()
+    b_cap = ceil(32 * 48 / 48)
+    got = TR.determine_largest_batch_size(args, data, dev, am)
+    assert got == ceil(0.8 * b_cap)
+    assert (np.random.get_state()[1] == st_np).all() and torch.equal(torch.get_rng_state(), st_t)
+    # pretend the device has hardly any memory left beyond what two tiny probes need: the fit must stop the doubling
+    seen = []
+    real = torch.cuda.max_memory_allocated
+
+    def peak(device=None):
+        v = real(device)
+        seen.append(v)
+        return v
+    monkeypatch.setattr(torch.cuda, "max_memory_allocated", peak)
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda device=None: (int(0.02 * max(seen)) if seen else 1 << 40, 1 << 40))
+    small = TR.determine_largest_batch_size(args, data, dev, am)
+    assert 1 <= small < got
+    monkeypatch.undo()
+    # ... and through the command line
+    monkeypatch.setattr(TR, "START_EPOCH", 0)
+    monkeypatch.setattr(sys, "argv", ["train", "--synthetic", "8,48,2", "--name", "adbs", "-dm", "64", "-nl", "1", "-nh", "4",
+                                      "-dih", "128", "-l", "drmsd", "-b", "1", "--max_seq_len", "48", "--train_only", "-e", "1",
+                                      "-adbs", "True", "--log_dir", str(tmp_path / "logs"), "--chkpt_dir", str(tmp_path / "ck")])
+    calls = []
+    orig = TR.determine_largest_batch_size
+    monkeypatch.setattr(TR, "determine_largest_batch_size", lambda *a, **k: calls.append(orig(*a, **k)) or calls[-1])
+    TR.main()
+    assert calls and calls[0] == ceil(0.8 * ceil(16 * 48 / 48))
+    monkeypatch.setattr(TR, "START_EPOCH", 0)
+
+
 # ------------------------------------------------------------------------------------------------ no global state
 def test_two_models_two_streams_two_arithmetics(dev):
     """SURVEY.md section 8(b) 'no hidden global state, re-entrant': a model in the exact-f32 arithmetic and one in the

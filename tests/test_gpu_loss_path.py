@@ -9,6 +9,8 @@ that: the reference itself is 8e-4 A (L=128) / 5.9e-3 A (L=512) away from an fp6
 formulas); per-protein drmsd rel 1e-4; lndrmsd abs 1e-6; angle gradients
 rel-L2 1e-3.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -401,35 +403,32 @@ def test_drmsd_in_passes_is_bit_identical(dev):
     """The fixed-order partial sums of the pair sweep grow as O(n^2 / 256) per protein (1.35 GB at 32 x 1500 in round 4).  Beyond a
     budget the strips are swept in passes over groups of strips with the same buffers (csrc/drmsd.hip `layout`): the workspace of
     (32, 1500) is below 256 MB, and the result - losses and gradient - is bit for bit that of one launch.  Forced here on a
-    small batch by PTAMD_DRMSD_PARTIAL_MB (read at every call)."""
-    import os
+    small batch through the *_budget entry points (the budget is an ARGUMENT: the library reads no environment)."""
     from protein_transformer_amd import _lib, synthetic
     from protein_transformer_amd.losses import drmsd_forward_backward
     from protein_transformer_amd.protein.Structure import nerf_forward
-    assert _lib.lib().ptamd_drmsd_workspace_bytes(32, 1500) <= 256 << 20
-    assert _lib.lib().ptamd_drmsd_workspace_bytes(32, 512) <= 200 << 20
+    lib = _lib.lib()
+    assert lib.ptamd_drmsd_workspace_bytes(32, 1500) <= 256 << 20
+    assert lib.ptamd_drmsd_workspace_bytes(32, 512) <= 200 << 20
     lens = [700, 512, 333, 64, 2]
     build = lambda ang, seq: nerf_forward(ang.to(dev), seq.to(dev))[0]  # noqa: E731
     batch = synthetic.make_batch(lens, L_pad=700, seed=77, build_coords=build, frac_missing=0.05)
     seq, true = batch["seq"].to(dev), batch["true_crd"].to(dev)
     pred = nerf_forward(batch["start_ang_rad"].to(dev), seq)[0]
-    old = os.environ.get("PTAMD_DRMSD_PARTIAL_MB")
+    one = lib.ptamd_drmsd_workspace_bytes(len(lens), 700)
+    assert lib.ptamd_drmsd_workspace_bytes_budget(len(lens), 700, 0) == one
+    os.environ["PTAMD_DRMSD_PARTIAL_MB"] = "1"            # (round 5 read this at every call: it must be ignored now)
     try:
-        os.environ.pop("PTAMD_DRMSD_PARTIAL_MB", None)
-        one = _lib.lib().ptamd_drmsd_workspace_bytes(len(lens), 700)
-        s1, g1 = drmsd_forward_backward(pred, true, seq)
-        s1, g1 = s1.clone(), g1.clone()
-        for mb in ("4", "1"):
-            os.environ["PTAMD_DRMSD_PARTIAL_MB"] = mb
-            assert _lib.lib().ptamd_drmsd_workspace_bytes(len(lens), 700) < one
-            s2, g2 = drmsd_forward_backward(pred, true, seq)
-            torch.cuda.synchronize()
-            assert torch.equal(s1, s2) and torch.equal(g1, g2), mb
-            s3, _ = drmsd_forward_backward(pred, true, seq, need_grad=False)
-            assert torch.equal(s1, s3)
+        assert lib.ptamd_drmsd_workspace_bytes(len(lens), 700) == one
     finally:
-        if old is None:
-            os.environ.pop("PTAMD_DRMSD_PARTIAL_MB", None)
-        else:
-            os.environ["PTAMD_DRMSD_PARTIAL_MB"] = old
+        os.environ.pop("PTAMD_DRMSD_PARTIAL_MB", None)
+    s1, g1 = drmsd_forward_backward(pred, true, seq)
+    s1, g1 = s1.clone(), g1.clone()
+    for mb in (4, 1):
+        assert lib.ptamd_drmsd_workspace_bytes_budget(len(lens), 700, mb << 20) < one
+        s2, g2 = drmsd_forward_backward(pred, true, seq, partial_budget_bytes=mb << 20)
+        torch.cuda.synchronize()
+        assert torch.equal(s1, s2) and torch.equal(g1, g2), mb
+        s3, _ = drmsd_forward_backward(pred, true, seq, need_grad=False, partial_budget_bytes=mb << 20)
+        assert torch.equal(s1, s3)
     assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0

@@ -387,3 +387,149 @@ def test_optimizer_step_prepares_the_next_pass(dev, optimizer):
     again = _snapshot(m._step_scales(flat, K.GEMM_AUTO, m.dropout, m.attn_dropout, hp=True))
     for key, want in again.items():
         assert torch.equal(left[key], want), key
+
+
+@pytest.mark.parametrize("optimizer", ["sgd", "adam"])
+def test_eval_between_training_steps_sees_the_current_weights(dev, optimizer):
+    """Round-5 advisor finding (high): the fused optimizer kernels write the flat buffer through a raw pointer, so torch's
+    version counters - all that `_weights_stamp` looked at - never moved during training, and the EVALUATION pass's scale cache
+    (dropout 0: another cache entry than the training pass's) kept the scales / bounds / planes of the weights of the first
+    validation.  train -> eval -> train -> eval with the fused step against the same sequence with `weights_prep = False`
+    (every forward pass derives everything from the weights as they are): evaluation outputs bit-identical at every stage,
+    and the second evaluation differs from the first (the weights moved)."""
+    import types
+    from protein_transformer_amd.optim import FusedAdam, FusedSGD
+    from protein_transformer_amd.train import train_step
+    args = types.SimpleNamespace(loss="drmsd", combined_drmsd_weight=0.5, backbone_loss=False, clip=1.0)
+    outs = {}
+    for prep in (True, False):
+        m, data = _prep_model(dev, seed=11)
+        m.weights_prep = prep
+        opt = (FusedAdam(m, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, weight_decay=10e-3) if optimizer == "adam"
+               else FusedSGD(m, lr=5e-2, weight_decay=10e-3))
+        got = []
+        for _ in range(3):
+            train_step(m, opt, args, *data)
+            train_step(m, opt, args, *data)
+            m.eval()
+            with torch.no_grad():
+                got.append(m(data[0]).clone())
+            m.train()
+        outs[prep] = got
+        if prep:
+            # the evaluation cache prepared the weights again after every pair of steps (its stamp moved with the steps);
+            # the training cache only for the model's first pass
+            assert m.__dict__.get("_prep_launches", 0) == 1 + 3
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    assert not torch.equal(outs[True][0], outs[True][1]) and not torch.equal(outs[True][1], outs[True][2])
+
+
+def test_set_dropout_and_plain_steps_invalidate_prepared_weights(dev):
+    """... the same staleness behind `set_dropout` (another cache key) and behind the PLAIN optimizer kernel (a step taken
+    while `prepared_step` has nothing to offer - here: `weights_prep` switched off for one step): the pass after it must
+    not find a cache 'fresh' that was prepared on older weights."""
+    import types
+    from protein_transformer_amd.optim import FusedSGD
+    from protein_transformer_amd.train import train_step
+    args = types.SimpleNamespace(loss="drmsd", combined_drmsd_weight=0.5, backbone_loss=False, clip=1.0)
+    res = {}
+    for prep in (True, False):
+        m, data = _prep_model(dev, seed=12)
+        m.weights_prep = prep
+        opt = FusedSGD(m, lr=5e-2, weight_decay=10e-3)
+        m.set_dropout(0.0)
+        train_step(m, opt, args, *data)          # cache (0, 0): prepared by the pass, then by the step
+        m.set_dropout(0.1, 0.1)
+        train_step(m, opt, args, *data)          # cache (0.1, 0.1): first use
+        m.set_dropout(0.0)
+        train_step(m, opt, args, *data)          # cache (0, 0) again: what it holds is one step old
+        m.weights_prep = False
+        train_step(m, opt, args, *data)          # the plain kernel writes the weights
+        m.weights_prep = prep
+        train_step(m, opt, args, *data)          # ... and the cache that was fresh two steps ago is not
+        res[prep] = (m.flat_parameters()[0].clone(), m.flat_parameters()[1].clone())
+    assert torch.isfinite(res[True][0]).all()
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+
+
+@pytest.mark.parametrize("dm,dff", [(768, 2048), (512, 1000), (256, 768)])
+def test_widths_the_one_pass_preparation_cannot_panel(dev, dm, dff):
+    """Round-5 advisor finding (medium): csrc/wprep.hip walks matrices wider than 512 columns as 512-column panels; a width
+    above 512 that is not a multiple of 512 (`-dm 768`, d_ff 1000) raised ValueError in the first forward pass although
+    `weights_prep = True` is the default.  Such models take the separate launches (`prep` is None) and train."""
+    import types
+    from protein_transformer_amd import synthetic
+    from protein_transformer_amd.models.encoder_only import EncoderOnlyTransformer
+    from protein_transformer_amd.optim import FusedSGD
+    from protein_transformer_amd.protein.Sequence import VOCAB
+    from protein_transformer_amd.protein.Structure import nerf_forward
+    from protein_transformer_amd.train import train_step
+    build = lambda ang, seq: nerf_forward(ang.to(dev), seq.to(dev))[0]  # noqa: E731
+    batch = synthetic.make_batch([512] * 8, L_pad=512, seed=4, build_coords=build)
+    data = tuple(batch[k].to(dev) for k in ("seq", "true_ang", "true_crd"))
+    torch.manual_seed(4)
+    args = types.SimpleNamespace(loss="drmsd", combined_drmsd_weight=0.5, backbone_loss=False, clip=1.0)
+    flats = []
+    for prep in (True, False):
+        torch.manual_seed(4)
+        m = EncoderOnlyTransformer(2, 8, dm, dff, 512, VOCAB, synthetic.angle_means(batch["true_ang"]), True, dropout=0.1).to(dev).train()
+        m.weights_prep = prep
+        opt = FusedSGD(m, lr=1e-2, weight_decay=10e-3)
+        for _ in range(2):
+            losses = train_step(m, opt, args, *data)
+        assert np.isfinite(float(losses["drmsd-full"]))
+        caches = m.__dict__.get("_scale_caches", {})
+        if prep and caches:
+            narrow = all(c <= 512 or c % 512 == 0 for c in (dm, dff))
+            assert all((c["prep"] is not None) == narrow for c in caches.values())
+        flats.append(m.flat_parameters()[0].clone())
+    assert torch.isfinite(flats[0]).all() and torch.equal(flats[0], flats[1])
+
+
+@pytest.mark.parametrize("optimizer", ["sgd", "adam"])
+def test_step_zeroes_the_gradient_for_the_next_step(dev, optimizer):
+    """`zero_grad_in_step` (optim.py; ptamd_*_step*'s `zero_grad` argument): the optimizer step writes the zeros the next
+    step's `optimizer.zero_grad()` would write, and that call then finds nothing to do.  Same trajectory bit for bit as with
+    the fill; the buffer IS zero behind the step; a backward pass (raw-pointer writes) or a torch op on a `p.grad` between the
+    step and the next `zero_grad()` makes that call fill again."""
+    import types
+    from protein_transformer_amd.optim import FusedAdam, FusedSGD
+    from protein_transformer_amd.train import get_losses, train_step
+    args = types.SimpleNamespace(loss="drmsd", combined_drmsd_weight=0.5, backbone_loss=False, clip=1.0)
+    runs = {}
+    for fused in (True, False):
+        m, data = _prep_model(dev, seed=21)
+        opt = (FusedAdam(m, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, weight_decay=10e-3) if optimizer == "adam"
+               else FusedSGD(m, lr=1e-2, weight_decay=10e-3))
+        assert opt.zero_grad_in_step is False                # torch's semantics unless the training loop asks
+        opt.zero_grad_in_step = fused
+        snaps = []
+        for k in range(4):
+            train_step(m, opt, args, *data)
+            _, g = m.flat_parameters()
+            if fused:
+                assert not bool(g.any())
+            else:
+                assert bool(g.any())
+            if k == 1:
+                # a backward pass outside the loop (no zero_grad in front of it, like a gradient probe): the next step's
+                # zero_grad must clear what it left
+                get_losses(args, m(data[0], data[1]), data[1], data[2], data[0])
+                assert bool(g.any())
+            if k == 2:
+                next(m.parameters()).grad.add_(1.0)          # ... and a torch op on a gradient view
+            snaps.append(m.flat_parameters()[0].clone())
+        runs[fused] = snaps
+    for a, b in zip(runs[True], runs[False]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_fill_u32(dev):
+    from protein_transformer_amd import kernels as K
+    a = torch.zeros(6, 16, dtype=torch.int32, device=dev)
+    b = torch.zeros(3, 1001, dtype=torch.int32, device=dev)
+    c = torch.zeros(7, dtype=torch.float32, device=dev)[1:]      # unaligned start
+    K.fill_u32([(a, 0x7F000000), (b, 5), (c, 0x3F800000)])
+    torch.cuda.synchronize()
+    assert bool((a == 0x7F000000).all()) and bool((b == 5).all()) and bool((c == 1.0).all())
