@@ -9,6 +9,38 @@
 import numpy as np
 import torch
 
+_POOL = None
+
+
+def cpu_pool():
+    """A spawn pool for the CPU side of the parity tests (round 6: the fp64 NeRF builds of the parity record - Python loops
+    over chains of up to 1500 residues - ran one after the other and were 260 s of the GPU suite); one per test process."""
+    global _POOL
+    if _POOL is None:
+        import atexit
+        import multiprocessing as mp
+        import os
+        n = max(1, min(16, (os.cpu_count() or 2) // 2))
+        _POOL = mp.get_context("spawn").Pool(n, initializer=torch.set_num_threads, initargs=(1,))
+        atexit.register(_POOL.terminate)
+    return _POOL
+
+
+def _build_coords_job(job):
+    from oracle import batched as obat
+    rad, seq, dtype_name = job
+    dt = getattr(torch, dtype_name)
+    return obat.generate_coords_batched(torch.from_numpy(rad).to(dt), torch.from_numpy(seq), dt).double().numpy()
+
+
+def build_coords_many(jobs):
+    """jobs: list of (angles [B, L, 12] tensor, sequences [B, L] tensor, torch dtype) -> list of fp64 numpy coordinates, built by
+    oracle.batched.generate_coords_batched in the pool (in order)."""
+    packed = [(r.detach().cpu().double().numpy(), q.detach().cpu().numpy(), str(dt).split(".")[-1]) for r, q, dt in jobs]
+    if len(packed) == 1:
+        return [_build_coords_job(packed[0])]
+    return cpu_pool().map(_build_coords_job, packed)
+
 
 def group_of(name):
     if "input_embedding" in name:

@@ -220,7 +220,11 @@ def test_adversarial_ranges(dev, what):
         assert not guard.off.any() and not guard.wide.any()
 
 
-@pytest.mark.parametrize("optimizer,lr,default_steps", [("adam", 1e-4, 200), ("sgd", 1e-2, 60)])
+# (round 6: the 200 / 60-step forms took 387 s of a 976-s suite whose limit is 1200 s; the suite runs 40 / 20 steps - every
+# assertion below, the control horizon included, at a quarter of the oracle steps - and the long forms are `slow`)
+@pytest.mark.parametrize("optimizer,lr,default_steps", [
+    ("adam", 1e-4, 40), ("sgd", 1e-2, 20),
+    pytest.param("adam", 1e-4, 200, marks=pytest.mark.slow), pytest.param("sgd", 1e-2, 60, marks=pytest.mark.slow)])
 def test_moved_weights_trajectory(dev, optimizer, lr, default_steps):
     """BASELINE config-2 model (d256, 4 layers, 8 heads, dff 2048); 8 proteins x L <= 64 so that the fp64 oracle - a Python
     loop over the NeRF chain - makes `PTAMD_TRAJ_STEPS` (default 200 Adam / 60 SGD) steps in minutes.  AUTO resolves to
@@ -316,14 +320,16 @@ def test_moved_weights_trajectory(dev, optimizer, lr, default_steps):
         rec["auto_guard"] = guard
     finally:
         EO.AUTO_F16X2_MIN_WORK = old_min
-    update_record(OUT, f"trajectory_{optimizer}", rec)
+    long_form = steps >= (200 if optimizer == "adam" else 60)
+    update_record(OUT, f"trajectory_{optimizer}" + ("" if long_form else f"_{steps}_steps"), rec)
     A, F32 = rec["runs"]["auto"], rec["runs"]["f32"]
     assert guard["bound_violations"] == 0 and guard["sites_off_bounds_now"] == 0 and guard["measured_steps"] >= steps // 16 - 1
     assert max(guard["max_slack_binades_seen"].values()) <= 8                      # (e)
     assert max(A["loss_curve_rel_first_3_steps"][:1]) < 1e-5                       # (a) the first step: the single-step tolerance
     for name, _ in modes:
         r = rec["runs"][name]
-        assert r["drmsd_first_last"][1] < 0.9 * r["drmsd_first_last"][0], name    # (c) it trains, in every arithmetic
+        # (c) it trains, in every arithmetic (by a tenth over the long forms; the short forms of the suite: it goes down)
+        assert r["drmsd_first_last"][1] < (0.9 if long_form else 1.0) * r["drmsd_first_last"][0], name
     end = rec["at_the_weights_auto_arrived_at"]                                   # (d)
     e, strict = end["errors_by_arithmetic_on_the_same_weights"]["auto"], [end["errors_by_arithmetic_on_the_same_weights"][m] for m in ("bf16x3", "f32")]
     worst = {k: max(x[k] for x in strict) for k in ("pred_max_abs", "drmsd_rel_max", "lndrmsd_abs_max", "grad_rel_l2")}
