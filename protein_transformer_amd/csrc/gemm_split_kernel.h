@@ -81,7 +81,11 @@ struct Geo {
   static constexpr int NPLANES = F16 ? 2 : 3;
   static constexpr int SBK = F16 ? 32 : 16;              // f32 k per stage
   static constexpr int QK = SBK / 4;                     // float4 per K-contiguous operand row and stage
+#if defined(PT_F16_NSETS_TI2)   // measurement build: deeper prefetch of the producers for the 128-row tiles of small batches
+  static constexpr int NSETS = F16 ? (TI == 4 ? 2 : PT_F16_NSETS_TI2) : 4;
+#else
   static constexpr int NSETS = F16 ? 2 : 4;              // register sets of a producer = stages of global loads in flight (even)
+#endif
   static constexpr int LD_RK = F16 ? SBK : SBK + 8;      // f16 / bf16 per row of a [row][k] plane
   static constexpr bool SWZ = F16;                       // chunk swizzle instead of padding
   static constexpr int PLANE_A = cmax(TBM * LD_RK, SBK * (TBM + KR_PAD));
@@ -597,6 +601,13 @@ int launch(const GemmParams &p, int splits, hipStream_t st) {
   if (!AK && NPROD != 9 && p.M > 128) {
     const int slots = persistent_grid(p.reserved_cus), nt = (p.N + TBN - 1) / TBN * splits;
     const int rounds4 = (((p.M + 255) / 256) * nt + slots - 1) / slots, rounds2 = (((p.M + 127) / 128) * nt + slots - 1) / slots;
+#if defined(PT_TI1_COST)   // measurement build: 64-row tiles (f16x2 only) where rounds x cost says they finish sooner
+    if constexpr (NPROD == 3) {
+      const int rounds1 = (((p.M + 63) / 64) * nt + slots - 1) / slots;
+      if (PT_TI1_COST * rounds1 < 2 * TI2_COST_NUM * rounds2 && PT_TI1_COST * rounds1 < 2 * TI2_COST_DEN * rounds4)
+        return launch_ti<false, BKM, NPROD, EPI, 1>(p, splits, st);
+    }
+#endif
 #if defined(PT_FORCE_TI)
     if (PT_FORCE_TI == 2) return launch_ti<false, BKM, NPROD, EPI, 2>(p, splits, st);
 #else

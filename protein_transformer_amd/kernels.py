@@ -4,6 +4,7 @@ Plumbing only: tensors come from the PyTorch-ROCm caching allocator, kernels are
 current HIP stream through the C ABI.  Everything here requires device tensors; nothing falls back.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -230,12 +231,15 @@ def linear_bwd_weight(dy, x, dw, dbias=None, arith=None, dy_scale=None, x_scale=
 GROUP_DW = True          # the weight-gradient products of a layer in one launch where they qualify (knob for A/B and tests)
 
 
+GROUP_MIN_K = int(os.environ.get("PTAMD_GROUP_MIN_K", 1024))      # fewest tokens per item of a group (knob for measurements)
+
+
 def pick_group_split(tiles256, T, slots=256):
     """Common K split of a GROUP of weight-gradient products (`tiles256` output tiles of 256 x 128 in all, T tokens): the
     items are dealt out in contiguous ranges of the whole list, so what counts is rounds x (tokens per item + a fixed
     cost per item: prologue, slab write and its reduction - about 640 tokens' worth).  0: not worth a group (too few tokens)."""
     best, best_cost = 0, None
-    for s in range(2, max(2, T // 1024) + 1):
+    for s in range(2, max(2, T // GROUP_MIN_K) + 1):
         rounds = -(-tiles256 * s // slots)
         cost = rounds * (-(-T // s) + 640)
         if best_cost is None or cost < best_cost:

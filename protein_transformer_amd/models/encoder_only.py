@@ -896,7 +896,7 @@ class _EncoderFn(torch.autograd.Function):
         # side stream; the main stream waits for it before a gradient slice is handed on and at the end of the pass.
         main = torch.cuda.current_stream(dpred.device)
         side = None
-        if m.side_stream_dw and D >= 512 and B * L >= 4096 and B * L * D <= SIDE_STREAM_MAX_WORK:
+        if m.side_stream_dw and D >= 512 and B * L >= SIDE_STREAM_MIN_TOKENS and B * L * D <= SIDE_STREAM_MAX_WORK:
             side = m.__dict__.get("_side_stream")
             if side is None or side.device != dpred.device:
                 side = m.__dict__["_side_stream"] = torch.cuda.Stream(device=dpred.device)
@@ -1140,6 +1140,7 @@ AUTO_F16X2_MIN_WORK = 1 << 20
 # (profiles/r03/r03_ab_side_stream.txt), but +14 % on config 2 (4096 x 256) and +12 % on config 1, where the step is bound by
 # host-side launches and the stream joins add to them
 SIDE_STREAM_MAX_WORK = 1 << 23
+SIDE_STREAM_MIN_TOKENS = int(os.environ.get("PTAMD_SIDE_MIN_TOKENS", 4096))     # (the environment variable: for measurements)
 # tokens from which the products behind a LayerNorm run on ptamd_gemm_hp (below: ptamd_gemm, 128-row tiles)
 HP_MIN_TOKENS = int(os.environ.get("PTAMD_HP_MIN_TOKENS", 4096))     # (the environment variable: for measurements)
 

@@ -220,11 +220,11 @@ def test_adversarial_ranges(dev, what):
         assert not guard.off.any() and not guard.wide.any()
 
 
-# (round 6: the 200 / 60-step forms took 387 s of a 976-s suite whose limit is 1200 s; the suite runs 40 / 20 steps - every
-# assertion below, the control horizon included, at a quarter of the oracle steps - and the long forms are `slow`)
-@pytest.mark.parametrize("optimizer,lr,default_steps", [
-    ("adam", 1e-4, 40), ("sgd", 1e-2, 20),
-    pytest.param("adam", 1e-4, 200, marks=pytest.mark.slow), pytest.param("sgd", 1e-2, 60, marks=pytest.mark.slow)])
+# (round 6: these trajectories are `slow` - out of the default `-m gpu` run, whose limit on the driver's box is 1200 s: they
+# took 387 s of a 976-s suite on one box and, at a fifth of the steps, still 270 s on a box with slower host cores; run them
+# with --runslow / PTAMD_RUN_SLOW=1, record under profiles/.  Every single-step oracle comparison stays in the default run.)
+@pytest.mark.slow
+@pytest.mark.parametrize("optimizer,lr,default_steps", [("adam", 1e-4, 200), ("sgd", 1e-2, 60), ("adam", 1e-4, 40), ("sgd", 1e-2, 20)])
 def test_moved_weights_trajectory(dev, optimizer, lr, default_steps):
     """BASELINE config-2 model (d256, 4 layers, 8 heads, dff 2048); 8 proteins x L <= 64 so that the fp64 oracle - a Python
     loop over the NeRF chain - makes `PTAMD_TRAJ_STEPS` (default 200 Adam / 60 SGD) steps in minutes.  AUTO resolves to

@@ -199,22 +199,38 @@ def test_config4_full_size_auto_steady_state(dev):
         assert la == pytest.approx(lb, rel=2e-5)
     # (iv) ... and the ORACLE on the whole batch (round 5 held the headline's arithmetic against the library itself only):
     # the CPU restatement of the reference's step, fp32 like the reference, the per-protein loss in a spawn pool as the
-    # reference runs it (losses.py:144-147) - the comparison bench.py prints as `parity` in the headline line
+    # reference runs it (losses.py:144-147) - the comparison bench.py prints as `parity` in the headline line.  Two fp32
+    # chains are compared here, so the model is in the regime the reference trains in (output weights N(0, 2e-3) around the
+    # arctanh of realistic angle means, as the parity record's "realistic" draws): on the arbitrary angles of the model above
+    # some protein always holds a near-straight bond angle, and there ANY two fp32 chains differ by tens of per cent in the
+    # gradient (measured: 0.58 for AUTO and for the exact three-term arithmetic alike).
     import multiprocessing as mp
     import os
     from oracle import step as ostep
+    from test_gpu_parity_record import realistic_angle_means
+    model = _model(dev, 6, 8, 512, 2048, L, realistic_angle_means(19), seed=7)
+    with torch.no_grad():
+        dict(model.named_parameters())["output_projection.weight"].normal_(0, 2e-3)
+    guard = model.auto_guard
+    run(K_.GEMM_AUTO)
+    assert guard.settle()
+    torch.cuda.synchronize()
+    assert not guard.off.any() and not guard.wide.any(), (guard.slack, guard.spread)
+    g_auto, l_auto = run(K_.GEMM_AUTO)                   # steady state, as above
+    g_b3, _ = run(K_.GEMM_BF16X3)
+    model.gemm_mode = None
     params = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     workers = max(1, min(32, os.cpu_count() or 1))
     with mp.get_context("spawn").Pool(workers, initializer=torch.set_num_threads, initargs=(1,)) as pool:
         ref = ostep.CpuTrainer(params, 8, loss="drmsd", optimizer="sgd", lr=1e-4, clip=None, pool=pool)
         ref.step(seq.cpu(), ang.cpu(), crd.cpu(), keep_grads=True)
     d_ref, ln_ref = float(ref.last_losses["drmsd-full"]), float(ref.last_losses["lndrmsd-full"])
-    assert l_auto[0] == pytest.approx(d_ref, rel=1e-4) and abs(l_auto[1] - ln_ref) < 1e-6, (l_auto, d_ref, ln_ref)
     e_orc, t_orc = per_group({n: g.cpu() for n, g in g_auto.items()}, ref.last_grads)
     e_orc3, t_orc3 = per_group({n: g.cpu() for n, g in g_b3.items()}, ref.last_grads)
     print("config 4, 32 x 512, against the fp32 CPU oracle: drmsd rel", abs(l_auto[0] - d_ref) / d_ref, "lndrmsd abs",
           abs(l_auto[1] - ln_ref), "gradient rel-L2 AUTO steady state", t_orc, "bf16x3", t_orc3)
     print("  per group (auto / bf16x3 vs oracle):", {k: (round(e_orc[k], 7), round(e_orc3[k], 7)) for k in e_orc})
+    assert l_auto[0] == pytest.approx(d_ref, rel=1e-4) and abs(l_auto[1] - ln_ref) < 1e-6, (l_auto, d_ref, ln_ref)
     assert t_orc < 1e-3, t_orc
     for k in e_orc:          # (the oracle's own fp32 rounding is in these numbers: AUTO may not be worse than 3 x the exact arithmetic)
         assert e_orc[k] < max(2e-3, 3 * e_orc3[k]), (k, e_orc[k], e_orc3[k])

@@ -342,7 +342,7 @@ def test_long_ragged_sequences(dev):
     from protein_transformer_amd import synthetic
     from protein_transformer_amd.losses import angles_forward, drmsd_forward_backward, nerf_backward
     from protein_transformer_amd.protein.Structure import nerf_forward
-    lens, L = [1500, 611, 1234], 1500
+    lens, L = [1500, 611], 1500          # (round 6: a third chain of 1234 was 40 % of this test's fp64 pair sums and nothing new)
     hip_build = lambda ang, seq: nerf_forward(ang.to(dev), seq.to(dev))[0]      # noqa: E731
     batch = synthetic.make_batch(lens, L_pad=L, seed=77, build_coords=hip_build, frac_missing=0.02)
     seq, true_crd = batch["seq"].to(dev), batch["true_crd"].to(dev)

@@ -9,7 +9,7 @@ and inputs through the HIP path and through the fp64 evaluation of the oracle's 
     per-protein drmsd (relative) and lndrmsd (absolute) deltas,
     relative L2 error of the parameter gradient - whole vector, per parameter group, and the worst single tensor.
 
-The record is written to gpurun_out/parity/r05_parity.json (copied to profiles/r05/r05_parity.json for the judge); the test
+The record is written to gpurun_out/parity/r06_parity.json (copied to profiles/r06/r06_parity.json for the judge); the test
 asserts the section 8(d) tolerances on what it measured, per parameter GROUP for the gradients (a whole-vector norm cannot
 see a wrong gradient in a small group: LayerNorm gains, biases).
 
@@ -42,7 +42,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.environ.get("PTAMD_PARITY_OUT", os.path.join(ROOT, "gpurun_out", "parity", "r05_parity.json"))
+OUT = os.environ.get("PTAMD_PARITY_OUT", os.path.join(ROOT, "gpurun_out", "parity", "r06_parity.json"))
 N_DRAWS = int(os.environ.get("PTAMD_PARITY_SEEDS", "2"))
 N_DRAWS_REALISTIC = int(os.environ.get("PTAMD_PARITY_SEEDS_REALISTIC", "1"))
 N_CONDITIONING_PROBES = int(os.environ.get("PTAMD_PARITY_PROBES", "12"))     # draws the skip rate of the realistic regime is taken over
@@ -372,7 +372,11 @@ def _bars(draws):
 def test_parity_record(case, regime):
     cfg = case[0]
     realistic = regime == "realistic"
-    draws = [_run_draw(case, d, regime) for d in range(N_DRAWS_REALISTIC if realistic else N_DRAWS)]
+    # (config 5 - fp64 pair sums over 21 000 atom slots, Python loops over 1500-residue chains - is a third of the suite's time
+    # on a box with slow host cores: one arbitrary draw and half the conditioning probes there unless the environment asks for
+    # more; the committed record is made with 8 / 4 draws and 12 probes, profiles/tools/parity_seeds.sh)
+    n_arbitrary = N_DRAWS if (cfg < 5 or "PTAMD_PARITY_SEEDS" in os.environ) else 1
+    draws = [_run_draw(case, d, regime) for d in range(N_DRAWS_REALISTIC if realistic else n_arbitrary)]
     n_skipped = sum(len(d["skipped_draws"]) for d in draws)
     flip_draws = {k: sum(1 for d in draws if sum(d["relu_gate_differences_per_layer"][k]) > 0)
                   for k in draws[0]["relu_gate_differences_per_layer"]}
@@ -392,7 +396,8 @@ def test_parity_record(case, regime):
     if realistic:
         # the conditioning filter over a fixed number of candidate draws (cheap: a forward pass and two fp64 builds each): in
         # the regime the reference trains in it must almost never fire, also at L = 1500
-        sk, n = _run_draw(case, 1000, regime, probe_only=N_CONDITIONING_PROBES)
+        probes = N_CONDITIONING_PROBES if (cfg < 5 or "PTAMD_PARITY_PROBES" in os.environ) else max(4, N_CONDITIONING_PROBES // 2)
+        sk, n = _run_draw(case, 1000, regime, probe_only=probes)
         rec["conditioning_probe"] = {"candidate_draws": n, "ill_conditioned": sk, "skip_rate": sk / n}
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     allrec = {}
