@@ -582,6 +582,7 @@ __global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 
   }
 }
 
+constexpr int TI1_COST_X10 = 4;   // cost of a 64-row tile in tenths of a 256-row tile (so 2 * TI2_COST_NUM / 2 * TI2_COST_DEN are the others)
 constexpr int TI2_COST_NUM = 3, TI2_COST_DEN = 5;  // cost of a 128-row tile / a 256-row tile: 0.55 - 0.64 measured (profiles/r03/r03_tile_height.txt)
 template <bool AK, bool BKM, int NPROD, int EPI, int TI>
 int launch_ti(const GemmParams &p, int splits, hipStream_t st) {
@@ -601,13 +602,15 @@ int launch(const GemmParams &p, int splits, hipStream_t st) {
   if (!AK && NPROD != 9 && p.M > 128) {
     const int slots = persistent_grid(p.reserved_cus), nt = (p.N + TBN - 1) / TBN * splits;
     const int rounds4 = (((p.M + 255) / 256) * nt + slots - 1) / slots, rounds2 = (((p.M + 127) / 128) * nt + slots - 1) / slots;
-#if defined(PT_TI1_COST)   // measurement build: 64-row tiles (f16x2 only) where rounds x cost says they finish sooner
+    // 64-row tiles (f16x2 only; round 6) where even 128-row tiles leave CUs without one: the per-GPU share of a strongly
+    // scaled batch (2048 / 4096 tokens), N = 512.  A lone tile's time is its stage count x the stage time, and that falls with
+    // the tile height - 0.72 us per 32-k stage at 128 rows, 0.50 at 64 (profiles/r06/r06_longk_*.txt): wo forward / dX of wo
+    // 21.7 -> 16.0 us at 2048 tokens, 24.1 -> 17.7 at 4096.  Cost 0.4 of a 256-row tile: never chosen when it needs a second round.
     if constexpr (NPROD == 3) {
       const int rounds1 = (((p.M + 63) / 64) * nt + slots - 1) / slots;
-      if (PT_TI1_COST * rounds1 < 2 * TI2_COST_NUM * rounds2 && PT_TI1_COST * rounds1 < 2 * TI2_COST_DEN * rounds4)
+      if (TI1_COST_X10 * rounds1 < 2 * TI2_COST_NUM * rounds2 && TI1_COST_X10 * rounds1 < 2 * TI2_COST_DEN * rounds4)
         return launch_ti<false, BKM, NPROD, EPI, 1>(p, splits, st);
     }
-#endif
 #if defined(PT_FORCE_TI)
     if (PT_FORCE_TI == 2) return launch_ti<false, BKM, NPROD, EPI, 2>(p, splits, st);
 #else

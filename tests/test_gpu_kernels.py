@@ -215,6 +215,9 @@ def test_gemm_tile_heights_agree(dev, mode):
     big, small = run(T), run(Ts)
     assert torch.equal(big[:Ts], small)
     assert (small == res[:Ts]).float().mean().item() > 0.05          # (dropped elements: the residual alone)
+    # round 6: three tile heights - 256 rows (16384 tokens), 128 (8192: 64-row tiles would need a second round), 64 (<= 4096)
+    for rows in (8192, 4096, 2048):
+        assert torch.equal(big[:rows], run(rows)), rows
 
 
 def test_gemm_split_bf16_is_fp32_grade(dev):
