@@ -462,6 +462,12 @@ size_t ptamd_attention_kv_inv_floats(int T, int H);
 /* 1 when ptamd_attention_fwd / _bwd of this shape and arithmetic read pre-split K / V (head size 64, L a multiple of 32, a batch
  * large enough for the 256-query forward kernel and the one-sweep backward kernel) */
 int ptamd_attention_reads_kv_planes(int B, int L, int H, int dk, int arith);
+/* Workspace of ptamd_attention_bwd: delta [B, H, L] and, behind it, the slabs of the SPLIT one-sweep backward kernel where this
+ * shape takes it (round 6; head size 64 and at most half as many (protein, head) pairs as CUs - the per-GPU share of a strongly
+ * scaled batch): the sweep runs as one workgroup per (pair, 256-key block) and, while that leaves CUs without one, per range of
+ * query tiles as well; a key block's contribution to dQ goes to slab [key block][B L][D], a query range's dK | dV to slab
+ * [range][B L][2 D], one more launch sums them in a fixed order (dQ: the bits of the unsplit sweep) and finishes the row
+ * scales.  32 x 512 x 8 heads: 0.5 MB (delta alone); 16 / 8 / 4 proteins: + 33.5 / 50.3 / 41.9 MB. */
 size_t ptamd_attention_workspace_bytes(int B, int L, int H, int dk);
 size_t ptamd_attention_keep_bits_bytes(int B, int L, int H);
 /* 1 when ptamd_attention_bwd of this shape and arithmetic would read keep_bits (f16x2 arithmetic, dk 32 / 64: the one-sweep

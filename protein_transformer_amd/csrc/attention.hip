@@ -33,7 +33,8 @@ int pt_attention_fwd_f16x2(const float *qkv, const int64_t *seq, int B, int L, i
 int pt_attention_bwd_f16x2(const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse,
                            float *delta, int B, int L, int H, int dk, float p, uint64_t seed, uint32_t sid, float *dqkv,
                            uint32_t *row_scale, uint32_t *row_min, const uint32_t *keep_bits, const void *kv_planes,
-                           const float *kv_inv, hipStream_t st);
+                           const float *kv_inv, float *slabs, size_t slab_floats, hipStream_t st);
+size_t pt_attention_bwd_f16x2_slab_floats(int B, int L, int H, int dk);
 bool pt_attention_bwd_f16x2_reads_keep_bits(int B, int L, int H, int dk);
 bool pt_attention_f16x2_reads_kv_planes(int B, int L, int H, int dk);
 
@@ -489,10 +490,14 @@ int launch_bwd(const float *qkv, const int64_t *seq, const float *o_fwd, const f
 
 extern "C" {
 
+namespace {
+size_t delta_floats(int B, int L, int H) { return ((size_t)B * H * L + 3) & ~(size_t)3; }   // (what follows stays 16-byte aligned)
+}
 size_t ptamd_attention_workspace_bytes(int B, int L, int H, int dk) {
-  (void)dk;
   if (B <= 0 || L <= 0 || H <= 0) return 0;
-  return (size_t)B * H * L * sizeof(float);
+  // delta [B, H, L]; behind it the slabs of the split one-sweep backward kernel where this shape takes it (head size 64, few
+  // (protein, head) pairs: csrc/attention_f16x2.hip fused_split)
+  return (delta_floats(B, L, H) + pt_attention_bwd_f16x2_slab_floats(B, L, H, dk)) * sizeof(float);
 }
 
 size_t ptamd_attention_keep_bits_bytes(int B, int L, int H) {
@@ -546,7 +551,8 @@ int ptamd_attention_bwd(const float *qkv, const int64_t *seq, const float *out, 
   float *delta = static_cast<float *>(workspace);
   if ((dk == 64 || dk == 32) && (arith == PTAMD_GEMM_AUTO || arith == PTAMD_GEMM_F16X2))
     return pt_attention_bwd_f16x2(qkv, seq, out, dout, lse, delta, B, L, H, dk, dropout_p, seed, stream_id, dqkv, row_scale,
-                                  row_scale ? row_scale_min : nullptr, keep_bits, kv_planes, kv_inv, st);
+                                  row_scale ? row_scale_min : nullptr, keep_bits, kv_planes, kv_inv, delta + delta_floats(B, L, H),
+                                  workspace_bytes / sizeof(float) - delta_floats(B, L, H), st);
   if (row_scale || row_scale_min || keep_bits || kv_planes) return PTAMD_ERR_BAD_SHAPE;  // by-products / inputs of the f16x2 kernels only
   if ((dk == 64 || dk == 32) && arith != PTAMD_GEMM_F32)
     return pt_attention_bwd_split(qkv, seq, out, dout, lse, delta, B, L, H, dk, dropout_p, seed, stream_id, dqkv, st);

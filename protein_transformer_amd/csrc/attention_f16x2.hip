@@ -1238,13 +1238,19 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float *__restrict
 // BITS: the dropout decisions come from the forward kernel (keep_bits) - the generator is not compiled in.
 // KVP: the key block's K and V rows come PRE-SPLIT (kv_format.h, written by the QKV product's epilogue) - a row's scale is
 // then that of its group of four tokens instead of its own; nothing else changes (Q and dO tiles are staged as before).
-template <bool BITS, bool KVP = false>
+// SPLIT (round 6: few (protein, head) pairs - the per-GPU share of a strongly scaled batch): the same sweep cut into MORE
+// workgroups.  1: one workgroup per (pair, 256-key block) - dK / dV of the block are complete as before, the block's
+// contribution to dQ goes to slab `kb` of `dq_part` ([key blocks][tokens][D]) instead of read-add-store.  2: the query tiles
+// of a key block are cut into `qs` ranges as well, one workgroup each - its dK / dV (of its query range) go to slab `qsx` of
+// `dkv_part` ([ranges][tokens][2 D]).  attn_bwd_split_reduce_kernel sums the slabs in a fixed order (dQ: key-block order, the
+// bits of the unsplit sweep), writes dqkv and takes over the row scales of what it sums.
+template <bool BITS, bool KVP = false, int SPLIT = 0>
 __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_fused_f16x2_kernel(
     const float *__restrict__ qkv, const int64_t *__restrict__ seq, const float *__restrict__ d_o,
     const float *__restrict__ lse, const float *__restrict__ delta, int L, int H, float p_drop, uint64_t seed,
     uint32_t stream_id, float *__restrict__ dqkv, uint32_t *__restrict__ row_scale, uint32_t *__restrict__ row_min,
     const uint32_t *__restrict__ keep_bits, const char *__restrict__ kvp = nullptr, const float *__restrict__ kv_inv = nullptr,
-    int kv_nt = 0) {
+    int kv_nt = 0, float *__restrict__ dq_part = nullptr, float *__restrict__ dkv_part = nullptr, int qs = 1) {
   constexpr int DK = 64, NW = 8, KS = DK / 16, NT = DK / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   __shared__ __attribute__((aligned(16))) float sLse[2][TR], sDel[2][TR];
@@ -1264,6 +1270,19 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   const float ks = p_drop > 0.f ? dk_.ks : 1.f;
   const int ntiles = (L + TR - 1) / TR, nkb = (L + FK - 1) / FK;
   const int lk = (L + 31) & ~31;
+  // the key blocks and query tiles of THIS workgroup (everything unless SPLIT)
+  int kb_first = 0, kb_last = nkb, qt_first = 0, qt_last = ntiles, qsx = 0;
+  if (SPLIT) {
+    kb_first = (int)blockIdx.x / qs;
+    kb_last = kb_first + 1;
+    if (SPLIT == 2) {
+      const int per = (ntiles + qs - 1) / qs;
+      qsx = (int)blockIdx.x % qs;
+      qt_first = qsx * per;
+      qt_last = min(ntiles, qt_first + per);
+    }
+  }
+  const size_t T_all = (size_t)gridDim.z * L;   // tokens of the batch (slab stride)
   const bool use_bits = BITS && p_drop > 0.f;   // (uniform)
   const int db = 16 * (wave & 3), qb = 16 * (wave >> 2);   // this wavefront's piece of a tile's dQ^T
   auto tile = [&](int buf) __attribute__((always_inline)) { return smem + buf * BUF; };
@@ -1276,7 +1295,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   const unsigned short *const ka0 = sKP + kp_off(4 * g16 + (i16 >> 2), db + 4 * (i16 & 3));
   const unsigned short *const da0 = sDS + ds_off(4 * g16 + (i16 >> 2), qb + 4 * (i16 & 3));
 
-  for (int kb = 0; kb < nkb; ++kb) {
+  for (int kb = kb_first; kb < kb_last; ++kb) {
     const int key = kb * FK + wave * 32 + l31;
     const bool k_ok = key < L;
     const bool k_valid = k_ok && seq[(size_t)b * L + key] != PTAMD_PAD_ID;
@@ -1308,23 +1327,24 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     Stage<DK, NW> stQ, stG, nxQ, nxG;
     TileRows<DK, NW> rows_q, rows_g;
     float r_lse = 0.f, r_del = 0.f;
-    rows_q.init(D3, L, tid, 0);
-    rows_g.init(D, L, tid, 0);
+    rows_q.init(D3, L, tid, qt_first * TR);
+    rows_g.init(D, L, tid, qt_first * TR);
     stQ.load(base, rows_q.next());
     stG.load(gbase, rows_g.next());
-    stQ.store(tile(0), sInvQ[0], 0, L, tid);
-    stG.store(tile(0) + Tile2::ELEMS, sInvG[0], 0, L, tid);
+    stQ.store(tile(0), sInvQ[0], qt_first * TR, L, tid);
+    stG.store(tile(0) + Tile2::ELEMS, sInvG[0], qt_first * TR, L, tid);
     if (tid < TR) {
-      sLse[0][tid] = tid < L ? lse_b[tid] * LOG2E : INFINITY;
-      sDel[0][tid] = tid < L ? del_b[tid] : 0.f;
+      const int q0 = qt_first * TR + tid;
+      sLse[0][tid] = q0 < L ? lse_b[q0] * LOG2E : INFINITY;
+      sDel[0][tid] = q0 < L ? del_b[q0] : 0.f;
     }
     stQ.load(base, rows_q.next());
     stG.load(gbase, rows_g.next());
     __syncthreads();
 
-    for (int qt = 0; qt < ntiles; ++qt) {
-      const int qq0 = qt * TR, cur = qt & 1;
-      const bool more = qt + 1 < ntiles;
+    for (int qt = qt_first; qt < qt_last; ++qt) {
+      const int qq0 = qt * TR, cur = (qt - qt_first) & 1;
+      const bool more = qt + 1 < qt_last;
       const unsigned short *sQ = tile(cur), *sG = sQ + Tile2::ELEMS;
       nxQ.load(base, rows_q.next());
       nxG.load(gbase, rows_g.next());
@@ -1480,7 +1500,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       const int dq_q = qq0 + qb + i16;
       float *const dq_p = dqkv + (size_t)(b * L + min(dq_q, L - 1)) * D3 + h * DK + db + 4 * g16;
       float4 dq_old = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kb > 0) dq_old = *reinterpret_cast<const float4 *>(dq_p);
+      if (!SPLIT && kb > 0) dq_old = *reinterpret_cast<const float4 *>(dq_p);
 #pragma unroll 2
       for (int st = 0; st < NW; ++st) {   // keys 32 st .. 32 st + 31 = the rows wavefront st wrote; offsets: see ka0 / da0
         f16x8 a[2], bq[2];
@@ -1505,12 +1525,14 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       {
         const int q = dq_q;
         float *op = dq_p;
+        if (SPLIT)   // this key block's contribution: slab kb, [token][D] (summed by attn_bwd_split_reduce_kernel)
+          op = dq_part + ((size_t)kb * T_all + (size_t)b * L + min(q, L - 1)) * D + h * DK + db + 4 * g16;
         float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        if (kb > 0 && q < L) {
+        if (!SPLIT && kb > 0 && q < L) {
           v.x += dq_old.x; v.y += dq_old.y; v.z += dq_old.z; v.w += dq_old.w;
         }
         if (q < L) *reinterpret_cast<float4 *>(op) = v;
-        if (row_scale && kb == nkb - 1) {   // the row's f16x2 scale: the four lane groups hold 16 d of the row's 64
+        if (!SPLIT && row_scale && kb == nkb - 1) {   // the row's f16x2 scale: the four lane groups hold 16 d of the row's 64
           uint32_t am = q < L ? umax4(v) : 0u;
           am = max(am, (uint32_t)__shfl_xor((int)am, 16, 64));
           am = max(am, (uint32_t)__shfl_xor((int)am, 32, 64));
@@ -1523,7 +1545,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
     // ---- dK, dV of this key block
     const float uk = inv_pow2(bscale), uv = ks * g_run * INV_TWO14;
-    if (row_scale) {
+    if (row_scale && SPLIT != 2) {
       float ak = 0.f, av = 0.f;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -1540,6 +1562,10 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
     if (k_ok) {
       float *okp = dqkv + (size_t)(b * L + key) * D3 + D + h * DK, *ovp = okp + D;
+      if (SPLIT == 2) {   // the share of this workgroup's query range: slab qsx, [token][2 D]
+        okp = dkv_part + ((size_t)qsx * T_all + (size_t)b * L + key) * (2 * D) + h * DK;
+        ovp = okp + D;
+      }
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -1552,7 +1578,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
     }
   }
-  if (row_scale && row_min) {  // the smallest scale of all rows this workgroup wrote: one global atomic per copy
+  if (row_scale && row_min && SPLIT != 2) {  // the smallest scale of all rows this workgroup wrote: one global atomic per copy
     if (tid == 0) sMin = 0x7F000000u;
     __syncthreads();
 #pragma unroll
@@ -1560,6 +1586,56 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     if (lane == 0) atomicMin(&sMin, my_min);
     __syncthreads();
     if (tid < 4) atomicMin(row_min + tid, sMin);
+  }
+}
+
+// The slabs of the split sweep -> dqkv, one wavefront per token: dQ = the key blocks' contributions in block order (the bits
+// of the unsplit sweep's read-add-store), and with DKV the query ranges' dK | dV in range order; the f16x2 scale of what was
+// summed joins the row's scale (atomicMin: with SPLIT = 1 the sweep itself contributed the K / V columns) and the batch minimum.
+template <bool DKV>
+__global__ __launch_bounds__(256) void attn_bwd_split_reduce_kernel(const float *__restrict__ dq_part, int nkb,
+                                                                  const float *__restrict__ dkv_part, int qs, size_t T, int D,
+                                                                  float *__restrict__ dqkv, uint32_t *__restrict__ row_scale,
+                                                                  uint32_t *__restrict__ row_min) {
+  __shared__ unsigned int sMin;
+  const int lane = threadIdx.x & 63;
+  const size_t t = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (threadIdx.x == 0) sMin = 0x7F000000u;
+  __syncthreads();
+  uint32_t sb = 0x7F000000u;
+  if (t < T) {
+    uint32_t am = 0u;
+    float *out = dqkv + t * (size_t)(3 * D);
+    for (int c = lane * 4; c < D; c += 256) {
+      float4 v = *reinterpret_cast<const float4 *>(dq_part + t * D + c);
+      for (int k = 1; k < nkb; ++k) {
+        const float4 o = *reinterpret_cast<const float4 *>(dq_part + ((size_t)k * T + t) * D + c);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+      }
+      *reinterpret_cast<float4 *>(out + c) = v;
+      am = max(am, umax4(v));
+    }
+    if (DKV) {
+      for (int c = lane * 4; c < 2 * D; c += 256) {
+        float4 v = *reinterpret_cast<const float4 *>(dkv_part + t * (size_t)(2 * D) + c);
+        for (int k = 1; k < qs; ++k) {
+          const float4 o = *reinterpret_cast<const float4 *>(dkv_part + ((size_t)k * T + t) * (2 * D) + c);
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        *reinterpret_cast<float4 *>(out + D + c) = v;
+        am = max(am, umax4(v));
+      }
+    }
+    if (row_scale) {
+      am = group_umax<64>(am);
+      sb = pt_row_scale_bits(am);
+      if (lane == 0) atomicMin(row_scale + t, sb);
+    }
+  }
+  if (row_scale && row_min) {
+    if (lane == 0) atomicMin(&sMin, sb);
+    __syncthreads();
+    if (threadIdx.x < 4) atomicMin(row_min + threadIdx.x, sMin);
   }
 }
 
@@ -1664,10 +1740,70 @@ int fwd_by_shape(Shape sh, const float *qkv, const int64_t *seq, int B, int L, i
 // the fused kernel: dk = 64 and enough (protein, head) pairs that one workgroup each fills more than half of the chip
 // (PTAMD_ATTN_FUSED = 0 / 1 in the environment, read at every call: never / whenever dk = 64 - for tests, which run small
 // batches, and for A/B measurements; the choice changes the summation order of dQ, nothing else)
-inline bool use_fused(int B, int L, int H, int dk) {
+// PTAMD_ATTN_FUSED in the environment (read at every call; for tests, which run small batches, and for A/B measurements):
+// 0 = never (the two-kernel path), 1 = the unsplit sweep whatever the batch, 2 = the split sweep whatever the batch.  The
+// choice changes the summation order of dQ (two-kernel path) / of dK and dV (split ranges), nothing else.
+inline bool use_fused(int B, int L, int H, int dk) {   // the UNSPLIT one-sweep kernel: one workgroup per (protein, head)
   if (dk != 64) return false;
   if (const char *e = getenv("PTAMD_ATTN_FUSED")) return e[0] == '1';
   return (size_t)B * H * 2 > (size_t)ptgemm::persistent_grid(0);
+}
+// The split sweep (round 6): head size 64 and too few (protein, head) pairs for one workgroup each to fill the chip - the
+// per-GPU share of a strongly scaled batch (4 / 8 / 16 proteins x 512: 92 / ~135 / ~205 us of dQ + dK/dV kernels per layer).
+// split = 1: a workgroup per (pair, 256-key block); 2: the query tiles cut into `qs` ranges too, so that about one
+// workgroup per CU comes out.
+struct FusedSplit {
+  int split, nkb, qs;
+};
+inline FusedSplit fused_split(int B, int L, int H, int dk) {
+  FusedSplit f = {0, (L + FK - 1) / FK, 1};
+  if (dk != 64) return f;
+  if (const char *e = getenv("PTAMD_ATTN_FUSED")) {
+    if (e[0] != '2') return f;
+  } else if (use_fused(B, L, H, dk)) {
+    return f;
+  }
+  const size_t cus = (size_t)ptgemm::persistent_grid(0), wg = (size_t)B * H * f.nkb;
+  const int ntiles = (L + TR - 1) / TR;
+  int qs = 1;
+  while ((size_t)(2 * qs) * wg <= cus && 2 * qs <= ntiles) qs *= 2;
+  const int per = (ntiles + qs - 1) / qs;
+  f.qs = (ntiles + per - 1) / per;      // ranges that are not empty
+  f.split = f.qs > 1 ? 2 : 1;
+  return f;
+}
+inline size_t fused_split_floats(int B, int L, int H, const FusedSplit &f) {   // slabs behind delta in the workspace
+  if (!f.split) return 0;
+  const size_t T = (size_t)B * L, D = (size_t)H * 64;
+  return (size_t)f.nkb * T * D + (f.split == 2 ? (size_t)f.qs * T * 2 * D : 0);
+}
+int launch_fused_split(const FusedSplit &f, const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o,
+                       const float *lse, float *delta, float *slabs, int B, int L, int H, float p, uint64_t seed, uint32_t sid,
+                       float *dqkv, uint32_t *row_scale, uint32_t *row_min, const uint32_t *keep_bits, hipStream_t st) {
+  const size_t items = (size_t)B * L * H * 16, T = (size_t)B * L;
+  const int D = H * 64;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, o_fwd, d_o, B * L, L, H, 64, delta);
+  const bool bits = keep_bits != nullptr && p > 0.f;
+  float *dq_part = slabs, *dkv_part = slabs + (size_t)f.nkb * T * D;
+  auto kern = f.split == 2 ? (bits ? attn_bwd_fused_f16x2_kernel<true, false, 2> : attn_bwd_fused_f16x2_kernel<false, false, 2>)
+                           : (bits ? attn_bwd_fused_f16x2_kernel<true, false, 1> : attn_bwd_fused_f16x2_kernel<false, false, 1>);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS);
+  if (e != hipSuccess) {
+    g_pt_last_hip_error = e;
+    return PTAMD_ERR_HIP;
+  }
+  hipLaunchKernelGGL(kern, dim3(f.nkb * f.qs, H, B), dim3(512), FUSED_LDS, st, qkv, seq, d_o, lse, delta, L, H, p, seed, sid, dqkv,
+                     row_scale, row_min, keep_bits, (const char *)nullptr, (const float *)nullptr, 0, dq_part, dkv_part, f.qs);
+  int rc = pt_check_launch();
+  if (rc) return rc;
+  const dim3 rgrid((unsigned)((T + 3) / 4));
+  if (f.split == 2)
+    hipLaunchKernelGGL(attn_bwd_split_reduce_kernel<true>, rgrid, dim3(256), 0, st, dq_part, f.nkb, dkv_part, f.qs, T, D, dqkv,
+                       row_scale, row_min);
+  else
+    hipLaunchKernelGGL(attn_bwd_split_reduce_kernel<false>, rgrid, dim3(256), 0, st, dq_part, f.nkb, dkv_part, f.qs, T, D, dqkv,
+                       row_scale, row_min);
+  return pt_check_launch();
 }
 int launch_fused(const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse, float *delta,
                  int B, int L, int H, float p, uint64_t seed, uint32_t sid, float *dqkv, uint32_t *row_scale,
@@ -1683,7 +1819,7 @@ int launch_fused(const float *qkv, const int64_t *seq, const float *o_fwd, const
     return PTAMD_ERR_HIP;
   }
   hipLaunchKernelGGL(kern, dim3(1, H, B), dim3(512), FUSED_LDS, st, qkv, seq, d_o, lse, delta, L, H, p, seed, sid, dqkv, row_scale,
-                     row_min, keep_bits, kvp, kv_inv, (B * L) / 32);
+                     row_min, keep_bits, kvp, kv_inv, (B * L) / 32, (float *)nullptr, (float *)nullptr, 1);
   return pt_check_launch();
 }
 template <int DK>
@@ -1726,16 +1862,28 @@ int pt_attention_fwd_f16x2(const float *qkv, const int64_t *seq, int B, int L, i
 // (the one-sweep kernel and, on the two-kernel path, the dK / dV kernel - both keep keys in lanes; the dQ kernel draws them)
 bool pt_attention_bwd_f16x2_reads_keep_bits(int B, int L, int H, int dk) { return B > 0 && L > 0 && H > 0 && (dk == 64 || dk == 32); }
 
+// floats of workspace the f16x2 backward pass of this shape wants BEHIND delta (the slabs of the split sweep; 0 otherwise)
+size_t pt_attention_bwd_f16x2_slab_floats(int B, int L, int H, int dk) {
+  using namespace ptattn16;
+  if (B <= 0 || L <= 0 || H <= 0) return 0;
+  return fused_split_floats(B, L, H, fused_split(B, L, H, dk));
+}
+
 int pt_attention_bwd_f16x2(const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o, const float *lse,
                            float *delta, int B, int L, int H, int dk, float p, uint64_t seed, uint32_t sid, float *dqkv,
                            uint32_t *row_scale, uint32_t *row_min, const uint32_t *keep_bits, const void *kv_planes,
-                           const float *kv_inv, hipStream_t st) {
+                           const float *kv_inv, float *slabs, size_t slab_floats, hipStream_t st) {
   using namespace ptattn16;
   if (kv_planes && (!kv_inv || !pt_attention_f16x2_reads_kv_planes(B, L, H, dk))) return PTAMD_ERR_BAD_SHAPE;
   // (the forward kernel's decisions are read by the fused kernel and by the dK / dV kernel of the two-kernel path)
   if (use_fused(B, L, H, dk))
     return launch_fused(qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, keep_bits,
                         static_cast<const char *>(kv_planes), kv_inv, st);
+  const FusedSplit fs = fused_split(B, L, H, dk);
+  if (fs.split) {
+    if (kv_planes || !slabs || slab_floats < fused_split_floats(B, L, H, fs)) return PTAMD_ERR_WORKSPACE;
+    return launch_fused_split(fs, qkv, seq, o_fwd, d_o, lse, delta, slabs, B, L, H, p, seed, sid, dqkv, row_scale, row_min, keep_bits, st);
+  }
   const Shape sh = launch_shape(B, L, H);
   return dk == 64 ? bwd_by_shape<64>(sh, qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, keep_bits, st)
                   : bwd_by_shape<32>(sh, qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, keep_bits, st);

@@ -24,12 +24,15 @@ def dev():
 
 
 class fused:
+    """PTAMD_ATTN_FUSED for the calls inside: True / 1 = the unsplit one-sweep kernel, False / 0 = the two-kernel path, 2 = the
+    split sweep (round 6: a workgroup per (pair, key block[, query range]) + the slab reduction)."""
+
     def __init__(self, on):
         self.on = on
 
     def __enter__(self):
         self.old = os.environ.get("PTAMD_ATTN_FUSED")
-        os.environ["PTAMD_ATTN_FUSED"] = "1" if self.on else "0"
+        os.environ["PTAMD_ATTN_FUSED"] = "2" if self.on == 2 else ("1" if self.on else "0")
 
     def __exit__(self, *a):
         if self.old is None:
@@ -72,6 +75,80 @@ def test_fused_backward_vs_fp64(dev, B, L, H, lens, arith):
     for i, name in enumerate(("dQ", "dK", "dV")):
         a, r = dqkv.view(B * L, 3, D)[:, i].double().cpu(), ref.view(B * L, 3, D)[:, i]
         assert ((a - r).norm() / r.norm()).item() < 2e-6, name
+
+
+@pytest.mark.parametrize("B,L,H,lens", [(2, 512, 8, [512, 300]), (4, 512, 8, [512, 411, 77, 512]), (8, 512, 8, [512] * 8),
+                                        (16, 512, 8, [512] * 15 + [129]), (1, 130, 2, [130]), (3, 700, 2, [700, 513, 31]),
+                                        (2, 256, 4, [256, 1]), (1, 257, 1, [257]), (2, 33, 2, [33, 7]), (2, 1500, 8, [1500, 611])])
+@pytest.mark.parametrize("p", [0.0, 0.25])
+def test_split_sweep(dev, B, L, H, lens, p):
+    """Round 6: the one-sweep kernel cut into a workgroup per (pair, 256-key block) and, where that still leaves CUs without
+    one, per query range as well (the per-GPU share of a strongly scaled batch: 4 / 8 / 16 proteins x 512) + the reduction of
+    its slabs.  Against the UNSPLIT sweep on the same inputs: dQ the same bits (the key blocks' contributions are summed in
+    block order, as read-add-store did), dK / dV to rounding (query ranges are summed instead of accumulated in one chain),
+    the row scales and their minimum those of the values that were written; reproducible; with and without dropout (the
+    forward kernel's decisions read, or drawn again).  Against fp64 without dropout."""
+    from protein_transformer_amd import kernels as K_
+    D, T = 64 * H, B * L
+    seq = _seq(B, L, lens, seed=11).to(dev)
+    qd = rnd((T, 3 * D), 30, 1.5).to(dev)
+    g = rnd((T, D), 31).to(dev)
+    ar = K_.GEMM_F16X2
+    res = {}
+    for mode, bits in ((1, True), (2, True), (2, False)):
+        kb = K_.attention_keep_bits(B, L, H, dev) if (bits and p > 0) else None
+        o, lse = K_.attention_fwd(qd, seq, H, p, 77, 3, arith=ar, keep_bits=kb)
+        with fused(mode):
+            outs = []
+            for _ in range(2):
+                rs = torch.full((T,), 0x7F000000, dtype=torch.int32, device=dev)
+                rm = torch.full((4,), 0x7F000000, dtype=torch.int32, device=dev)
+                d = K_.attention_bwd(qd, seq, o, g, lse, H, p, 77, 3, arith=ar, row_scale=rs, row_scale_min=rm, keep_bits=kb)
+                outs.append((d.clone(), rs.clone(), rm.clone()))
+            torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(*outs)), (mode, bits)          # reproducible
+        res[(mode, bits)] = outs[0]
+    one, split, drawn = res[(1, True)], res[(2, True)], res[(2, False)]
+    assert torch.equal(split[0], drawn[0])                                           # decisions read = decisions drawn
+    dq1, dq2 = one[0].view(T, 3, D)[:, 0], split[0].view(T, 3, D)[:, 0]
+    assert torch.equal(dq1, dq2)
+    for i in (1, 2):
+        a, b = one[0].view(T, 3, D)[:, i].double(), split[0].view(T, 3, D)[:, i].double()
+        assert ((a - b).norm() / b.norm()).item() < 1e-6, i          # (measured 2.6e-7: another summation order, fp32)
+    # row scales: the power of two that takes the largest |x| of the WRITTEN row into [2^14, 2^15); their minimum over the rows
+    amax = split[0].abs().amax(1).contiguous().view(torch.int32)
+    want = (torch.clamp(268 - (amax >> 23), max=254) << 23).to(torch.int32)
+    assert torch.equal(split[1], want)
+    assert bool((split[2] == want.min()).all())
+    if p == 0.0:
+        q64 = qd.double().cpu().view(B, L, 3 * D).requires_grad_()
+        out, _ = ref_attention(q64, seq.cpu() != 20, H)
+        out.backward(g.double().cpu().view(B, L, D))
+        ref = q64.grad.view(T, 3 * D)
+        assert_close(split[0], ref, 1e-4, 2e-6 * max(1.0, ref.abs().max().item()), "split sweep")
+
+
+def test_split_sweep_is_the_default_for_few_pairs(dev):
+    """Without PTAMD_ATTN_FUSED in the environment: head size 64 and at most half as many (protein, head) pairs as CUs take the
+    split sweep (its workspace is asked for and its result is what PTAMD_ATTN_FUSED=2 gives), more pairs the unsplit one."""
+    from protein_transformer_amd import _lib
+    from protein_transformer_amd import kernels as K_
+    assert "PTAMD_ATTN_FUSED" not in os.environ
+    lib = _lib.lib()
+    delta = lambda B, L, H: 4 * ((B * H * L + 3) // 4 * 4)                                           # noqa: E731
+    assert lib.ptamd_attention_workspace_bytes(32, 512, 8, 64) == delta(32, 512, 8)                   # 256 pairs: unsplit
+    assert lib.ptamd_attention_workspace_bytes(16, 512, 8, 64) == delta(16, 512, 8) + 4 * 2 * 8192 * 512            # key blocks only
+    assert lib.ptamd_attention_workspace_bytes(4, 512, 8, 64) == delta(4, 512, 8) + 4 * (2 + 4 * 2) * 2048 * 512    # + 4 query ranges
+    assert lib.ptamd_attention_workspace_bytes(4, 512, 8, 32) == delta(4, 512, 8)                     # head size 32: two kernels
+    B, L, H = 4, 512, 8
+    D, T = 64 * H, B * L
+    seq = _seq(B, L, [512, 300, 512, 77], seed=2).to(dev)
+    qd, g = rnd((T, 3 * D), 40, 1.5).to(dev), rnd((T, D), 41).to(dev)
+    o, lse = K_.attention_fwd(qd, seq, H, 0.0, 0, 0, arith=K_.GEMM_AUTO)
+    d_default = K_.attention_bwd(qd, seq, o, g, lse, H, 0.0, 0, 0, arith=K_.GEMM_AUTO)
+    with fused(2):
+        d_split = K_.attention_bwd(qd, seq, o, g, lse, H, 0.0, 0, 0, arith=K_.GEMM_AUTO)
+    assert torch.equal(d_default, d_split)
 
 
 def test_fused_randomised(dev):
