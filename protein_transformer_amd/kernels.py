@@ -144,7 +144,7 @@ def gemm_hp(a, b, C_out, *, bias=None, residual=None, ldr=0, flags=0, dropout_p=
     return C_out
 
 
-DW_SLOTS = 512           # knob of pick_split_k (profiles/tools/r03_ab_dw_slots.sh)
+DW_SLOTS = 512           # knob of pick_split_k (A/B of round 3: profiles/r03, script in git history 160951b)
 
 
 def pick_split_k(M, N, K, slots=None):

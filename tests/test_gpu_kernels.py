@@ -464,7 +464,7 @@ def test_attention_f16x2_wide_row_ranges(dev, B, L, H, dk):
     """The two-term f16 kernels scale K / V / Q / dO per row (lanes) or per group of four rows (LDS tiles) and adapt the
     common power of two of the probability / dS operands on line: rows whose magnitudes span five decades (V 1e-3..10,
     K 1e-2..3, dO 1e-8..1e-4) must come out as accurately as with the exact three-term bf16 kernels (norm-wise, against
-    dense fp64 attention; measured 3..6e-7 in every arithmetic - profiles/tools/r02_attn_accuracy.py)."""
+    dense fp64 attention; measured 3..6e-7 in every arithmetic - a round-2 probe, git history 160951b)."""
     from protein_transformer_amd import kernels as K_
     g = torch.Generator().manual_seed(11)
     D = H * dk
