@@ -1597,43 +1597,59 @@ __global__ __launch_bounds__(256) void attn_bwd_split_reduce_kernel(const float 
                                                                   const float *__restrict__ dkv_part, int qs, size_t T, int D,
                                                                   float *__restrict__ dqkv, uint32_t *__restrict__ row_scale,
                                                                   uint32_t *__restrict__ row_min) {
+  // two token rows per wavefront, their loads interleaved (one row's few dependent 16-byte loads per lane left the memory
+  // system idle: 29.6 us for 50 MB at 16 proteins)
   __shared__ unsigned int sMin;
   const int lane = threadIdx.x & 63;
-  const size_t t = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const size_t t0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
   if (threadIdx.x == 0) sMin = 0x7F000000u;
   __syncthreads();
-  uint32_t sb = 0x7F000000u;
-  if (t < T) {
-    uint32_t am = 0u;
-    float *out = dqkv + t * (size_t)(3 * D);
+  uint32_t sb_min = 0x7F000000u;
+  if (t0 < T) {
+    const bool two = t0 + 1 < T;
+    const size_t t1 = two ? t0 + 1 : t0;
+    uint32_t am0 = 0u, am1 = 0u;
+    float *out0 = dqkv + t0 * (size_t)(3 * D), *out1 = dqkv + t1 * (size_t)(3 * D);
     for (int c = lane * 4; c < D; c += 256) {
-      float4 v = *reinterpret_cast<const float4 *>(dq_part + t * D + c);
+      float4 v = *reinterpret_cast<const float4 *>(dq_part + t0 * D + c), w = *reinterpret_cast<const float4 *>(dq_part + t1 * D + c);
       for (int k = 1; k < nkb; ++k) {
-        const float4 o = *reinterpret_cast<const float4 *>(dq_part + ((size_t)k * T + t) * D + c);
+        const float4 o = *reinterpret_cast<const float4 *>(dq_part + ((size_t)k * T + t0) * D + c);
+        const float4 q = *reinterpret_cast<const float4 *>(dq_part + ((size_t)k * T + t1) * D + c);
         v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        w.x += q.x; w.y += q.y; w.z += q.z; w.w += q.w;
       }
-      *reinterpret_cast<float4 *>(out + c) = v;
-      am = max(am, umax4(v));
+      *reinterpret_cast<float4 *>(out0 + c) = v;
+      if (two) *reinterpret_cast<float4 *>(out1 + c) = w;
+      am0 = max(am0, umax4(v));
+      am1 = max(am1, umax4(w));
     }
     if (DKV) {
       for (int c = lane * 4; c < 2 * D; c += 256) {
-        float4 v = *reinterpret_cast<const float4 *>(dkv_part + t * (size_t)(2 * D) + c);
+        float4 v = *reinterpret_cast<const float4 *>(dkv_part + t0 * (size_t)(2 * D) + c);
+        float4 w = *reinterpret_cast<const float4 *>(dkv_part + t1 * (size_t)(2 * D) + c);
         for (int k = 1; k < qs; ++k) {
-          const float4 o = *reinterpret_cast<const float4 *>(dkv_part + ((size_t)k * T + t) * (2 * D) + c);
+          const float4 o = *reinterpret_cast<const float4 *>(dkv_part + ((size_t)k * T + t0) * (2 * D) + c);
+          const float4 q = *reinterpret_cast<const float4 *>(dkv_part + ((size_t)k * T + t1) * (2 * D) + c);
           v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          w.x += q.x; w.y += q.y; w.z += q.z; w.w += q.w;
         }
-        *reinterpret_cast<float4 *>(out + D + c) = v;
-        am = max(am, umax4(v));
+        *reinterpret_cast<float4 *>(out0 + D + c) = v;
+        if (two) *reinterpret_cast<float4 *>(out1 + D + c) = w;
+        am0 = max(am0, umax4(v));
+        am1 = max(am1, umax4(w));
       }
     }
     if (row_scale) {
-      am = group_umax<64>(am);
-      sb = pt_row_scale_bits(am);
-      if (lane == 0) atomicMin(row_scale + t, sb);
+      const uint32_t s0 = pt_row_scale_bits(group_umax<64>(am0)), s1 = pt_row_scale_bits(group_umax<64>(am1));
+      if (lane == 0) {
+        atomicMin(row_scale + t0, s0);
+        if (two) atomicMin(row_scale + t1, s1);
+      }
+      sb_min = two ? min(s0, s1) : s0;
     }
   }
   if (row_scale && row_min) {
-    if (lane == 0) atomicMin(&sMin, sb);
+    if (lane == 0) atomicMin(&sMin, sb_min);
     __syncthreads();
     if (threadIdx.x < 4) atomicMin(row_min + threadIdx.x, sMin);
   }
@@ -1796,7 +1812,7 @@ int launch_fused_split(const FusedSplit &f, const float *qkv, const int64_t *seq
                      row_scale, row_min, keep_bits, (const char *)nullptr, (const float *)nullptr, 0, dq_part, dkv_part, f.qs);
   int rc = pt_check_launch();
   if (rc) return rc;
-  const dim3 rgrid((unsigned)((T + 3) / 4));
+  const dim3 rgrid((unsigned)((T + 7) / 8));
   if (f.split == 2)
     hipLaunchKernelGGL(attn_bwd_split_reduce_kernel<true>, rgrid, dim3(256), 0, st, dq_part, f.nkb, dkv_part, f.qs, T, D, dqkv,
                        row_scale, row_min);
