@@ -50,7 +50,7 @@ sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0        # same table: dense bf16 / f16 matrix peak (the marketing figure includes 2:1 sparsity)
-TRAFFIC_RECORD = "r05/r05_gemm_hbm_traffic.json"     # under profiles/: PMC traffic of the GEMM launches of the default command
+TRAFFIC_RECORD = "r06/r06_gemm_hbm_traffic.json"     # under profiles/: PMC traffic of the GEMM launches of the default command
 
 CONFIGS = {   # BASELINE.json configs[i-1]
     # (-dih is not named by BASELINE configs[0]: the reference's default 2048, train.py:479 - 565,272 parameters)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak: N training steps of the headline configuration through the product's own data path (DevicePrefetcher, packed batches),
 reporting every N / 10 steps the step time, the loss, the allocator's reserved / allocated bytes and the guard's state - memory
-must be flat, the loss finite and falling, no site off its bound.  python profiles/tools/r05_soak.py [--steps 3000]"""
+must be flat, the loss finite and falling, no site off its bound.  python profiles/tools/soak.py [--steps 3000]"""
 import os
 import sys
 import time
@@ -28,6 +28,7 @@ def main():
     model.gemm_mode = kernels.GEMM_AUTO
     dp.attach(model)
     opt = FusedSGD(model, lr=1e-4, weight_decay=10e-3)
+    opt.zero_grad_in_step = True          # as train.setup_model_optimizer_scheduler sets it for the product's loop
     args = types.SimpleNamespace(loss=a.loss, combined_drmsd_weight=0.5, backbone_loss=False, clip=1.0)
     N = a.steps
     chunk = max(1, N // 10)
@@ -42,8 +43,10 @@ def main():
         done += chunk
         flat, g = model.flat_parameters()
         g_ = model.auto_guard
+        st = torch.cuda.memory_stats()
         print(f"step {done:6d}  {dt:7.3f} ms/step  loss {float(out['loss']):.5f}  finite {bool(torch.isfinite(flat).all())}  "
               f"allocated {torch.cuda.memory_allocated() / 2**20:8.1f} MiB  reserved {torch.cuda.memory_reserved() / 2**20:8.1f} MiB  "
+              f"segments {st.get('segment.all.current', 0)} allocs/retries {st.get('num_alloc_retries', 0)}  "
               f"guard: measured {g_.measured_steps} off {int(g_.off.sum())} wide {int(g_.wide.sum())}", flush=True)
 
 
