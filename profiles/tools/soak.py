@@ -33,11 +33,19 @@ def main():
     N = a.steps
     chunk = max(1, N // 10)
     done = 0
+    gc_every = int(os.environ.get("SOAK_GC_EVERY", "0"))      # experiment: a full collection every so many steps
+    if os.environ.get("SOAK_GC_OFF"):
+        import gc
+        gc.disable()
     while done < N:
         torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
         t0 = time.perf_counter()
-        for seq, ang, crd, n in DevicePrefetcher((host[i % 2] for i in range(chunk)), dev):
+        for k, (seq, ang, crd, n) in enumerate(DevicePrefetcher((host[i % 2] for i in range(chunk)), dev)):
             out = train_step(model, opt, args, seq, ang, crd, n_res=n)
+            if gc_every and (k + 1) % gc_every == 0:
+                import gc
+                gc.collect()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / chunk * 1e3
         done += chunk
@@ -45,7 +53,7 @@ def main():
         g_ = model.auto_guard
         st = torch.cuda.memory_stats()
         print(f"step {done:6d}  {dt:7.3f} ms/step  loss {float(out['loss']):.5f}  finite {bool(torch.isfinite(flat).all())}  "
-              f"allocated {torch.cuda.memory_allocated() / 2**20:8.1f} MiB  reserved {torch.cuda.memory_reserved() / 2**20:8.1f} MiB  "
+              f"allocated {torch.cuda.memory_allocated() / 2**20:8.1f} MiB (peak {torch.cuda.max_memory_allocated() / 2**20:8.1f})  reserved {torch.cuda.memory_reserved() / 2**20:8.1f} MiB  "
               f"segments {st.get('segment.all.current', 0)} allocs/retries {st.get('num_alloc_retries', 0)}  "
               f"guard: measured {g_.measured_steps} off {int(g_.off.sum())} wide {int(g_.wide.sum())}", flush=True)
 

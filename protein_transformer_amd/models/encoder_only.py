@@ -877,7 +877,10 @@ class _EncoderFn(torch.autograd.Function):
         ctx.guard, ctx.measure, ctx.off = guard, measure, ctx_off
         ctx.use_hp = use_hp
         ctx.saved, ctx.conv_saved, ctx.scales = saved, conv_saved, scales
-        ctx.x_last, ctx.pred = x, pred
+        # (NOT `ctx.pred = pred`: the output's grad_fn is this node, the node would hold the output - a reference cycle only the
+        # cyclic collector frees, at a time of its choosing, with everything else the node still holds.  A detached alias of the
+        # same storage carries no grad_fn.)
+        ctx.x_last, ctx.pred = x, pred.detach()
         return pred
 
     @staticmethod
@@ -1126,6 +1129,7 @@ class _EncoderFn(torch.autograd.Function):
         if m.use_embedding:
             K.embed_bwd(seq, dx, m.dmodel, p, seed, G("encoder.input_embedding.emb.weight"))
             done("encoder.input_embedding.emb.weight", "encoder.input_embedding.emb.weight")
+        ctx.saved = ctx.conv_saved = ctx.x_last = ctx.pred = ctx.scales = None      # (whatever still refers to this node holds no activations)
         return None, None, None, None
 
 
