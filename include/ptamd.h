@@ -467,7 +467,11 @@ int ptamd_attention_reads_kv_planes(int B, int L, int H, int dk, int arith);
  * scaled batch): the sweep runs as one workgroup per (pair, 256-key block) and, while that leaves CUs without one, per range of
  * query tiles as well; a key block's contribution to dQ goes to slab [key block][B L][D], a query range's dK | dV to slab
  * [range][B L][2 D], one more launch sums them in a fixed order (dQ: the bits of the unsplit sweep) and finishes the row
- * scales.  32 x 512 x 8 heads: 0.5 MB (delta alone); 16 / 8 / 4 proteins: + 33.5 / 50.3 / 41.9 MB. */
+ * scales.  32 x 512 x 8 heads: 0.5 MB (delta alone); 16 / 8 / 4 proteins: + 33.5 / 50.3 / 41.9 MB.
+ * The size is a function of (B, L, H, dk), the CU count of the current device and - for head size 64 - of the measurement knob
+ * PTAMD_ATTN_FUSED in the process environment (read at every call: 0 = never a one-sweep kernel, 1 = the unsplit one, 2 = the split
+ * one, unset = by the number of pairs): the size query and the call must see the same value; a call that finds its workspace too
+ * small for the kernel it would take returns PTAMD_ERR_WORKSPACE and launches nothing. */
 size_t ptamd_attention_workspace_bytes(int B, int L, int H, int dk);
 size_t ptamd_attention_keep_bits_bytes(int B, int L, int H);
 /* 1 when ptamd_attention_bwd of this shape and arithmetic would read keep_bits (f16x2 arithmetic, dk 32 / 64: the one-sweep

@@ -1795,21 +1795,25 @@ inline size_t fused_split_floats(int B, int L, int H, const FusedSplit &f) {   /
 }
 int launch_fused_split(const FusedSplit &f, const float *qkv, const int64_t *seq, const float *o_fwd, const float *d_o,
                        const float *lse, float *delta, float *slabs, int B, int L, int H, float p, uint64_t seed, uint32_t sid,
-                       float *dqkv, uint32_t *row_scale, uint32_t *row_min, const uint32_t *keep_bits, hipStream_t st) {
+                       float *dqkv, uint32_t *row_scale, uint32_t *row_min, const uint32_t *keep_bits, const char *kvp,
+                       const float *kv_inv, hipStream_t st) {
   const size_t items = (size_t)B * L * H * 16, T = (size_t)B * L;
   const int D = H * 64;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, o_fwd, d_o, B * L, L, H, 64, delta);
   const bool bits = keep_bits != nullptr && p > 0.f;
   float *dq_part = slabs, *dkv_part = slabs + (size_t)f.nkb * T * D;
+  // (pre-split K / V only where the 256-query forward kernel reads them too: one workgroup per key block, no query ranges)
   auto kern = f.split == 2 ? (bits ? attn_bwd_fused_f16x2_kernel<true, false, 2> : attn_bwd_fused_f16x2_kernel<false, false, 2>)
+              : kvp        ? (bits ? attn_bwd_fused_f16x2_kernel<true, true, 1> : attn_bwd_fused_f16x2_kernel<false, true, 1>)
                            : (bits ? attn_bwd_fused_f16x2_kernel<true, false, 1> : attn_bwd_fused_f16x2_kernel<false, false, 1>);
+  if (kvp && f.split == 2) return PTAMD_ERR_BAD_SHAPE;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS);
   if (e != hipSuccess) {
     g_pt_last_hip_error = e;
     return PTAMD_ERR_HIP;
   }
   hipLaunchKernelGGL(kern, dim3(f.nkb * f.qs, H, B), dim3(512), FUSED_LDS, st, qkv, seq, d_o, lse, delta, L, H, p, seed, sid, dqkv,
-                     row_scale, row_min, keep_bits, (const char *)nullptr, (const float *)nullptr, 0, dq_part, dkv_part, f.qs);
+                     row_scale, row_min, keep_bits, kvp, kv_inv, (B * L) / 32, dq_part, dkv_part, f.qs);
   int rc = pt_check_launch();
   if (rc) return rc;
   const dim3 rgrid((unsigned)((T + 7) / 8));
@@ -1859,7 +1863,10 @@ int bwd_by_shape(Shape sh, const float *qkv, const int64_t *seq, const float *o_
 // 32-token tiles per protein, and the batch shapes at which exactly those two kernels run
 bool pt_attention_f16x2_reads_kv_planes(int B, int L, int H, int dk) {
   using namespace ptattn16;
-  return B > 0 && L > 0 && H > 0 && dk == 64 && (L & 31) == 0 && use_fused(B, L, H, dk) && launch_shape(B, L, H) == W8;
+  // (round 6: also the split sweep with one workgroup per key block - 16 proteins x 8 heads x 512 - whose forward pass is the
+  // 256-query kernel as well)
+  if (!(B > 0 && L > 0 && H > 0 && dk == 64 && (L & 31) == 0 && launch_shape(B, L, H) == W8)) return false;
+  return use_fused(B, L, H, dk) || fused_split(B, L, H, dk).split == 1;
 }
 
 int pt_attention_fwd_f16x2(const float *qkv, const int64_t *seq, int B, int L, int H, int dk, float p, uint64_t seed,
@@ -1897,8 +1904,9 @@ int pt_attention_bwd_f16x2(const float *qkv, const int64_t *seq, const float *o_
                         static_cast<const char *>(kv_planes), kv_inv, st);
   const FusedSplit fs = fused_split(B, L, H, dk);
   if (fs.split) {
-    if (kv_planes || !slabs || slab_floats < fused_split_floats(B, L, H, fs)) return PTAMD_ERR_WORKSPACE;
-    return launch_fused_split(fs, qkv, seq, o_fwd, d_o, lse, delta, slabs, B, L, H, p, seed, sid, dqkv, row_scale, row_min, keep_bits, st);
+    if (!slabs || slab_floats < fused_split_floats(B, L, H, fs)) return PTAMD_ERR_WORKSPACE;
+    return launch_fused_split(fs, qkv, seq, o_fwd, d_o, lse, delta, slabs, B, L, H, p, seed, sid, dqkv, row_scale, row_min, keep_bits,
+                              static_cast<const char *>(kv_planes), kv_inv, st);
   }
   const Shape sh = launch_shape(B, L, H);
   return dk == 64 ? bwd_by_shape<64>(sh, qkv, seq, o_fwd, d_o, lse, delta, B, L, H, p, seed, sid, dqkv, row_scale, row_min, keep_bits, st)

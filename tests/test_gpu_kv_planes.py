@@ -181,3 +181,38 @@ def test_model_step_with_and_without_planes(dev):
     assert torch.equal(res[True][0], res[False][0]) and res[True][2] == res[False][2]
     ga, gb = res[True][1], res[False][1]
     assert ((ga - gb).norm() / gb.norm()).item() < 1e-5
+
+
+def test_planes_under_the_key_block_split_sweep(dev):
+    """Round 6: 16 proteins x 8 heads x 512 - 128 (protein, head) pairs, the per-GPU share at two GPUs - run the 256-query forward
+    kernel and the one-sweep backward kernel split per 256-key block: both read pre-split K / V there too.  Forward the same bits
+    as on fp32 K / V, backward equal to rounding and reproducible; 8 proteins (query ranges as well) keep fp32 K / V."""
+    from protein_transformer_amd import kernels as K
+    B2, L2 = 16, 512
+    T2 = B2 * L2
+    assert K.attention_reads_kv_planes(B2, L2, H, DK, K.GEMM_AUTO)
+    assert not K.attention_reads_kv_planes(8, L2, H, DK, K.GEMM_AUTO) and not K.attention_reads_kv_planes(4, L2, H, DK, K.GEMM_AUTO)
+    g = torch.Generator().manual_seed(12)
+    x = (torch.randn(T2, D, generator=g) * torch.exp(0.25 * torch.randn(T2, 1, generator=g))).to(dev)
+    w = (torch.randn(3 * D, D, generator=g) / np.sqrt(D) * 1.1).to(dev)
+    bias = (torch.randn(3 * D, generator=g) * 0.3).to(dev)
+    a, bop = K.hp_split(x), K.hp_split(w)
+    ref = K.gemm_hp(a, bop, torch.empty(T2, 3 * D, device=dev), bias=bias)
+    kv = K.attention_kv_buffers(T2, H, dev)
+    got = K.gemm_hp(a, bop, torch.full((T2, 3 * D), float("nan"), device=dev), bias=bias, kv=kv, kv_col0=D, kv_heads=H)
+    seq = torch.full((B2, L2), 20, dtype=torch.int64)
+    for b, n in enumerate([L2] * 12 + [300, 97, 512, 33]):
+        seq[b, :n] = torch.randint(0, 20, (n,), generator=torch.Generator().manual_seed(b))
+    seq = seq.to(dev)
+    p, seed, sid = 0.1, 31, 2
+    bits_a, bits_b = K.attention_keep_bits(B2, L2, H, dev), K.attention_keep_bits(B2, L2, H, dev)
+    o_ref, lse_ref = K.attention_fwd(ref, seq, H, p, seed, sid, arith=K.GEMM_AUTO, keep_bits=bits_a)
+    o_kv, lse_kv = K.attention_fwd(got, seq, H, p, seed, sid, arith=K.GEMM_AUTO, keep_bits=bits_b, kv=kv)
+    assert torch.equal(o_kv, o_ref) and torch.equal(lse_kv, lse_ref) and torch.equal(bits_a, bits_b)
+    dout = torch.randn(T2, D, generator=g).to(dev)
+    d_ref = K.attention_bwd(ref, seq, o_ref, dout, lse_ref, H, p, seed, sid, arith=K.GEMM_AUTO, keep_bits=bits_a)
+    d_kv = K.attention_bwd(got, seq, o_kv, dout, lse_kv, H, p, seed, sid, arith=K.GEMM_AUTO, keep_bits=bits_b, kv=kv)
+    again = K.attention_bwd(got, seq, o_kv, dout, lse_kv, H, p, seed, sid, arith=K.GEMM_AUTO, keep_bits=bits_b, kv=kv)
+    torch.cuda.synchronize()
+    assert torch.isfinite(d_kv).all() and torch.equal(d_kv, again)
+    assert ((d_kv - d_ref).norm() / d_ref.norm()).item() < 1e-6
