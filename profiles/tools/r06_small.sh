@@ -8,7 +8,8 @@ for rep in 1 2; do
 for v in "$@"; do
   name=${v%%:*}; envs=""; [ "$v" != "$name" ] && envs=$(echo ${v#*:} | tr ',' ' ')
   for b in ${BATCHES:-4 8 16}; do
-    env $envs python bench.py --batch $b $quiet 2>$out/err_$name.log | python -c "
+    extra=""; case " $envs " in *" BENCH_ARGS="*) extra=$(echo "$envs" | tr ' ' '\n' | grep '^BENCH_ARGS=' | cut -d= -f2- | tr '+' ' ');; esac
+    env $envs python bench.py --batch $b $quiet $extra 2>$out/err_$name.log | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('$name', 'b=$b', d['ms_per_step'], d['passes']['ms_per_step'], 'resident', d['resident']['ms_per_step'], flush=True)" | tee -a $out/small.txt

@@ -412,8 +412,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dropout_kernel(
       }
     }
     };
-    // part `half` of the group's eight rows: rows half (8 / HALVES) .. of its row order (HALVES = 8, round 6: one row per
-    // wavefront - 2048 tokens, the per-GPU share of an 8-GPU strong-scaling run, leave a wavefront per row)
+    // part `half` of the group's eight rows: rows half (8 / HALVES) .. of its row order
 #define PT_LN_PART(h)                                                                     \
   case h:                                                                                 \
     if constexpr ((h) < HALVES) rows_from(std::integral_constant<int, (h) * (8 / HALVES)>{}); \
@@ -646,11 +645,13 @@ int ptamd_layernorm_bwd_dropout(const float *dy, const float *x, const float *ga
   hipStream_t st = (hipStream_t)stream;
   // two or four wavefronts per 8-row group while that still leaves every part of a group a wavefront of its own
   const int64_t ngroups = ((T + 31) / 32) * 4, nwaves = (int64_t)LN_BWD_BLOCKS * 4;
-  const int halves = ngroups * 8 <= nwaves ? 8 : ngroups * 4 <= nwaves ? 4 : ngroups * 2 <= nwaves ? 2 : 1;
+  // (one row per wavefront - eight wavefronts per group - measured SLOWER at 2048 tokens: 16.1 against 13.7 us, every
+  // wavefront draws the group's words and nothing is prefetched: round 6)
+  const int halves = ngroups * 4 <= nwaves ? 4 : ngroups * 2 <= nwaves ? 2 : 1;
 #define PT_LN_FUSED(NV, HV)                                                                                                   \
   hipLaunchKernelGGL((layernorm_bwd_dropout_kernel<NV, HV>), grid, block, 0, st, dy, x, gamma, mean, rstd, dres, T, D, dx, part, \
                      dropout_p, seed, stream_id, dropped, row_scale, bound_factor, bound_scale, row_scale_min, bound_scale_min, planes)
-#define PT_LN_FUSED_BY_T(NV) do { if (halves == 8) PT_LN_FUSED(NV, 8); else if (halves == 4) PT_LN_FUSED(NV, 4); else if (halves == 2) PT_LN_FUSED(NV, 2); else PT_LN_FUSED(NV, 1); } while (0)
+#define PT_LN_FUSED_BY_T(NV) do { if (halves == 4) PT_LN_FUSED(NV, 4); else if (halves == 2) PT_LN_FUSED(NV, 2); else PT_LN_FUSED(NV, 1); } while (0)
   if (D <= 256) PT_LN_FUSED_BY_T(1);
   else if (D <= 512) PT_LN_FUSED_BY_T(2);
   else PT_LN_FUSED_BY_T(4);
