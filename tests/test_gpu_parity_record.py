@@ -367,8 +367,19 @@ def _bars(draws):
     return out
 
 
-@pytest.mark.parametrize("regime", ["arbitrary", "realistic"])
-@pytest.mark.parametrize("case", CASES, ids=[f"config{c[0]}" for c in CASES])
+def _cases_by_regime():
+    """(case, regime) pairs; config 5 in the ARBITRARY regime is `slow` (round 6): 72 % of its L = 1500 draws are ill-conditioned for
+    any fp32 chain and skipped - the test spends its time filtering (74 s on a fast host, 270 s on a slow one) - while the realistic
+    regime, asserted as SURVEY 8(d) is written, stays in the default run; the committed record (parity_seeds.sh) has both."""
+    out = []
+    for c in CASES:
+        for regime in ("arbitrary", "realistic"):
+            marks = [pytest.mark.slow] if (c[0] == 5 and regime == "arbitrary" and "PTAMD_PARITY_SEEDS" not in os.environ) else []
+            out.append(pytest.param(c, regime, id=f"{regime}-config{c[0]}", marks=marks))
+    return out
+
+
+@pytest.mark.parametrize("case,regime", _cases_by_regime())
 def test_parity_record(case, regime):
     cfg = case[0]
     realistic = regime == "realistic"
