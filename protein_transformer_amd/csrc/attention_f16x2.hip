@@ -125,6 +125,41 @@ struct Tile2 {
   }
 };
 
+// ---- the same tile UNPADDED (round 6): [plane][32 rows][64 f16] = 4 KiB per plane with the chunk swizzle of kv_format.h
+// (conflict-free for row fragments and both transposing reads) instead of 96-element rows: 16 KB per {K, V} buffer pair instead
+// of 24, so that FOUR key quarters of a workgroup fit LDS (attn_fwd_f16x2_kernel<64, 8, 4, Tile2U>: 128 KB)
+struct Tile2U {
+  static constexpr int PLANE = TR * 64;
+  static constexpr int ELEMS = 2 * PLANE;
+  static __device__ __forceinline__ int offset(int row, int d) { return ptkv::plane_offset(row, d) >> 1; }
+  static __device__ __forceinline__ void store4(unsigned short *__restrict__ s, int row, int d, const float4 &v, float sc) {
+    uint2 t1, t2;
+    split_quad_f16(v.x, v.y, v.z, v.w, sc, sc, sc, sc, t1, t2);
+    const int off = offset(row, d);
+    *reinterpret_cast<uint2 *>(s + off) = t1;
+    *reinterpret_cast<uint2 *>(s + PLANE + off) = t2;
+  }
+  static __device__ __forceinline__ void frag_rows(const unsigned short *__restrict__ s, int step, int lane, f16x8 (&f)[2]) {
+    const unsigned short *q = s + offset(lane & 31, 16 * step + 8 * (lane >> 5));
+#pragma unroll
+    for (int t = 0; t < 2; ++t) f[t] = *reinterpret_cast<const f16x8 *>(q + t * PLANE);
+  }
+  static __device__ __forceinline__ void frag_cols(const unsigned short *__restrict__ s, int kb, int d0, int lane,
+                                                   f16x8 (&f)[2]) {
+    const int q16 = lane & 15;
+    const int row = kb + 4 * (lane >> 5) + (q16 >> 2);
+    const unsigned short *q0 = s + offset(row, d0 + (lane & 16) + 4 * (q16 & 3));
+    const unsigned short *q1 = s + offset(row + 8, d0 + (lane & 16) + 4 * (q16 & 3));
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(q0 + t * PLANE));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(q1 + t * PLANE));
+      const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      f[t] = __builtin_bit_cast(f16x8, both);
+    }
+  }
+};
+
 // ---- a K / V tile that arrives PRE-SPLIT (kv_format.h): [plane][32 rows][64 f16], chunk-swizzled, written into LDS by LDS-DMA
 typedef __attribute__((address_space(1))) const void *kv_gptr_t;
 typedef __attribute__((address_space(3))) void *kv_lptr_t;
@@ -186,7 +221,7 @@ template <int NI>
 struct TileOff {
   uint32_t o[NI];
 };
-template <int DK, int NW>
+template <int DK, int NW, typename TILE = Tile2>
 struct Stage {
   using G = StageGeo<DK, NW>;
   static constexpr int CPR = G::CPR, NI = G::NI;
@@ -205,7 +240,7 @@ struct Stage {
       const uint32_t amax = group_umax<4 * CPR>(umax4(x));
       const uint32_t sbits = pt_row_scale_bits(amax);
       if (row < TR) {  // (wavefront-uniform)
-        Tile2::store4(s, row, (tid % CPR) * 4, x, __uint_as_float(sbits));
+        TILE::store4(s, row, (tid % CPR) * 4, x, __uint_as_float(sbits));
         if ((tid % (4 * CPR)) == 0) {
           const int g = row >> 2;
           inv[(g & 1) * 4 + (g >> 1)] = __uint_as_float((254u << 23) - sbits);
@@ -304,7 +339,8 @@ constexpr size_t ATTN_LDS = (size_t)2 * BUF * sizeof(unsigned short);
 #ifndef PT_ATTN_FWD_WAVES
 #define PT_ATTN_FWD_WAVES 2   // wavefronts per SIMD the forward kernel is compiled for (4 = 128 VGPRs: 27 spilled, measured in round 4)
 #endif
-template <int DK, int NW, int PARTS>
+// TILE: the LDS image of a staged tile - Tile2 (padded rows) or Tile2U (unpadded, swizzled: what lets PARTS = 4 fit)
+template <int DK, int NW, int PARTS, typename TILE = Tile2>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PT_ATTN_FWD_WAVES, PT_ATTN_FWD_WAVES))) void attn_fwd_f16x2_kernel(
     const float *__restrict__ qkv, const int64_t *__restrict__ seq, int L, int H, float p_drop, uint64_t seed,
     uint32_t stream_id, float *__restrict__ out, float *__restrict__ lse, uint32_t *__restrict__ keep_bits) {
@@ -337,9 +373,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PT_ATTN
   float m_run = -INFINITY, l_run = 0.f;  // running maximum in log2 units
   float v_run = 0.f;                     // largest inverse V group scale so far (a power of two; wavefront-uniform)
 
-  Stage<DK, NW> stK[PARTS], stV[PARTS];
+  constexpr int TBUF = 2 * TILE::ELEMS;  // f16 elements of one {K, V} tile buffer
+  Stage<DK, NW, TILE> stK[PARTS], stV[PARTS];
   const int ntiles = ((L + TR - 1) / TR + PARTS - 1) / PARTS;  // tiles of one part: part p walks tiles p ntiles ..
-  auto tile = [&](int buf, int pt) __attribute__((always_inline)) { return smem + (buf * PARTS + pt) * BUF; };
+  auto tile = [&](int buf, int pt) __attribute__((always_inline)) { return smem + (buf * PARTS + pt) * TBUF; };
   // key mask of a tile as an ADDITIVE term of the soft-max argument (0 or -inf per key), read back one float4 per register
   // quadruple: no bit extraction and no select per element
   auto publish_mask = [&](int k0, int buf, int pt) __attribute__((always_inline)) {
@@ -349,7 +386,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PT_ATTN
     }
   };
   TileRows<DK, NW> rows[PARTS];
-  Stage<DK, NW> nxK[PARTS], nxV[PARTS];  // loads run two tiles ahead of the arithmetic (attention_split.hip)
+  Stage<DK, NW, TILE> nxK[PARTS], nxV[PARTS];  // loads run two tiles ahead of the arithmetic (attention_split.hip)
 #pragma unroll
   for (int pt = 0; pt < PARTS; ++pt) {
     rows[pt].init(D3, L, tid, pt * ntiles * TR);
@@ -357,7 +394,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PT_ATTN
     stK[pt].load(base + D, toff);
     stV[pt].load(base + 2 * D, toff);
     stK[pt].store(tile(0, pt), sInvK[0][pt], pt * ntiles * TR, L, tid);
-    stV[pt].store(tile(0, pt) + Tile2::ELEMS, sInvV[0][pt], pt * ntiles * TR, L, tid);
+    stV[pt].store(tile(0, pt) + TILE::ELEMS, sInvV[0][pt], pt * ntiles * TR, L, tid);
     publish_mask(pt * ntiles * TR, 0, pt);
     const auto toff2 = rows[pt].next();
     stK[pt].load(base + D, toff2);
@@ -368,7 +405,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PT_ATTN
   for (int kt = 0; kt < ntiles; ++kt) {
     const int k0 = (part * ntiles + kt) * TR, cur = kt & 1;
     const bool more = kt + 1 < ntiles;
-    const unsigned short *sK = tile(cur, part), *sV = sK + Tile2::ELEMS;
+    const unsigned short *sK = tile(cur, part), *sV = sK + TILE::ELEMS;
 #pragma unroll
     for (int pt = 0; pt < PARTS; ++pt) {
       const auto toff = rows[pt].next();
@@ -383,7 +420,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PT_ATTN
 #pragma unroll
     for (int st = 0; st < KS; ++st) {  // S^T[key][q] = K Q^T (scaled operands)
       f16x8 kf[2];
-      Tile2::frag_rows(sK, st, lane, kf);
+      TILE::frag_rows(sK, st, lane, kf);
       s = mfma3(kf, qf[st], s);
     }
     if (more) {  // scale + split + store the next tile(s) into the other buffer while the soft-max runs
@@ -391,7 +428,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PT_ATTN
       for (int pt = 0; pt < PARTS; ++pt) {
         const int kn = (pt * ntiles + kt + 1) * TR;
         stK[pt].store(tile(cur ^ 1, pt), sInvK[cur ^ 1][pt], kn, L, tid);
-        stV[pt].store(tile(cur ^ 1, pt) + Tile2::ELEMS, sInvV[cur ^ 1][pt], kn, L, tid);
+        stV[pt].store(tile(cur ^ 1, pt) + TILE::ELEMS, sInvV[cur ^ 1][pt], kn, L, tid);
         publish_mask(kn, cur ^ 1, pt);
       }
     }
@@ -458,7 +495,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PT_ATTN
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         f16x8 vf[2];
-        Tile2::frag_cols(sV, 16 * m, 32 * t, lane, vf);
+        TILE::frag_cols(sV, 16 * m, 32 * t, lane, vf);
         o[t] = mfma3(vf, pf, o[t]);
       }
     }
@@ -470,11 +507,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PT_ATTN
     __syncthreads();  // the other buffer is complete; nobody reads this one any more
   }
 
-  if (PARTS == 2) {
-    // the second key half hands its soft-max state (running maximum, row sum of its lane half, V scale) and its
-    // accumulators to the wavefront of the same queries that walked the first half: [slot][lane] floats in the tile area
-    float *xch = reinterpret_cast<float *>(smem) + grp * (NT * 16 + 3) * 64 + lane;
-    if (part == 1) {
+  if (PARTS > 1) {
+    // the later key ranges hand their soft-max state (running maximum, row sum of the lane half, V scale) and their accumulators
+    // to the wavefront of the same queries that walked the first range: [part - 1][group][slot][lane] floats in the tile area;
+    // it takes them in part order (fixed: deterministic)
+    constexpr int XCH = (NT * 16 + 3) * 64;
+    float *xch = reinterpret_cast<float *>(smem) + ((part > 0 ? part - 1 : 0) * NG + grp) * XCH + lane;
+    if (part > 0) {
       xch[0] = m_run;
       xch[64] = l_run;
       xch[128] = v_run;
@@ -484,19 +523,23 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PT_ATTN
         for (int r = 0; r < 16; ++r) xch[(3 + t * 16 + r) * 64] = o[t][r];
     }
     __syncthreads();
-    if (part == 1) return;
-    const float m1 = xch[0], l1 = xch[64], v1 = xch[128];
-    const float m = fmaxf(m_run, m1), ms = m == -INFINITY ? 0.f : m;
-    const float a0 = __builtin_amdgcn_exp2f(m_run - ms), a1 = __builtin_amdgcn_exp2f(m1 - ms);
-    const float vm = fmaxf(v_run, v1), ivm = inv_pow2(vm);  // common V scale (powers of two; 0 only if both are)
-    const float f0 = a0 * (v_run * ivm), f1 = a1 * (v1 * ivm);
+    if (part > 0) return;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int k = 0; k < PARTS - 1; ++k) {
+      const float *x = xch + (size_t)k * NG * XCH;
+      const float m1 = x[0], l1 = x[64], v1 = x[128];
+      const float m = fmaxf(m_run, m1), ms = m == -INFINITY ? 0.f : m;
+      const float a0 = __builtin_amdgcn_exp2f(m_run - ms), a1 = __builtin_amdgcn_exp2f(m1 - ms);
+      const float vm = fmaxf(v_run, v1), ivm = inv_pow2(vm);  // common V scale (powers of two; 0 only if both are)
+      const float f0 = a0 * (v_run * ivm), f1 = a1 * (v1 * ivm);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[t][r] = o[t][r] * f0 + xch[(3 + t * 16 + r) * 64] * f1;
-    l_run = l_run * a0 + l1 * a1;
-    m_run = m;
-    v_run = vm;
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = o[t][r] * f0 + x[(3 + t * 16 + r) * 64] * f1;
+      l_run = l_run * a0 + l1 * a1;
+      m_run = m;
+      v_run = vm;
+    }
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   // soft-max normalisation, dropout scale and the common V scale in one factor
@@ -1687,6 +1730,12 @@ inline Shape launch_shape(int B, int L, int H) {
 // pair at 8: 256 VGPRs already; built with 11 spilled registers it measured 0.5 % of a step).
 inline Shape dkv_shape(Shape sh) { return sh == W8_HALVES ? W4 : sh; }
 
+// the 2 x 4 forward shape instead of 2 x 2 where the key range has a tile for every quarter (PTAMD_ATTN_FWD_QUARTERS = 0 in the
+// environment, read at every call: never - for A/B measurements)
+inline bool fwd_quarters(int L) {
+  if (const char *e = getenv("PTAMD_ATTN_FWD_QUARTERS")) return e[0] != '0' && L > 3 * TR;
+  return L > 3 * TR;
+}
 template <int DK, int NW, int PARTS>
 int launch_fwd(const float *qkv, const int64_t *seq, int B, int L, int H, float p, uint64_t seed, uint32_t sid, float *out,
                float *lse, uint32_t *keep_bits, hipStream_t st) {
@@ -1695,6 +1744,21 @@ int launch_fwd(const float *qkv, const int64_t *seq, int B, int L, int H, float 
   if (int rc = set_lds(attn_fwd_f16x2_kernel<DK, NW, PARTS>, PARTS)) return rc;  // idempotent, host-only: no state kept between calls
   hipLaunchKernelGGL((attn_fwd_f16x2_kernel<DK, NW, PARTS>), grid, dim3(64 * NW), PARTS * ATTN_LDS, st, qkv, seq, L, H, p, seed, sid,
                      out, lse, keep_bits);
+  return pt_check_launch();
+}
+// 8 wavefronts as 2 query groups x 4 key quarters on unpadded tiles (round 6; head size 64): as many workgroups as 4 x (2 x 2)
+// - 64 queries each - with HALF the tile loop per wavefront and TWO wavefronts per SIMD (one wavefront per SIMD runs a tile in
+// 3.3 us, two in 1.5 each: the forward pass of the 4-protein share)
+int launch_fwd_quarters(const float *qkv, const int64_t *seq, int B, int L, int H, float p, uint64_t seed, uint32_t sid, float *out,
+                        float *lse, uint32_t *keep_bits, hipStream_t st) {
+  constexpr size_t LDS = (size_t)4 * 2 * (2 * Tile2U::ELEMS) * sizeof(unsigned short);
+  auto kern = attn_fwd_f16x2_kernel<64, 8, 4, Tile2U>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+  if (e != hipSuccess) {
+    g_pt_last_hip_error = e;
+    return PTAMD_ERR_HIP;
+  }
+  hipLaunchKernelGGL(kern, dim3((L + 63) / 64, H, B), dim3(512), LDS, st, qkv, seq, L, H, p, seed, sid, out, lse, keep_bits);
   return pt_check_launch();
 }
 template <int DK, int NW, int PARTS>
@@ -1751,6 +1815,7 @@ int fwd_by_shape(Shape sh, const float *qkv, const int64_t *seq, int B, int L, i
                  float *out, float *lse, uint32_t *keep_bits, hipStream_t st) {
   if (sh == W8) return launch_fwd<DK, 8, 1>(qkv, seq, B, L, H, p, seed, sid, out, lse, keep_bits, st);
   if (sh == W8_HALVES) return launch_fwd<DK, 8, 2>(qkv, seq, B, L, H, p, seed, sid, out, lse, keep_bits, st);
+  if (DK == 64 && fwd_quarters(L)) return launch_fwd_quarters(qkv, seq, B, L, H, p, seed, sid, out, lse, keep_bits, st);
   return launch_fwd<DK, 4, 2>(qkv, seq, B, L, H, p, seed, sid, out, lse, keep_bits, st);
 }
 // the fused kernel: dk = 64 and enough (protein, head) pairs that one workgroup each fills more than half of the chip
