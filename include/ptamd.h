@@ -131,6 +131,10 @@ int ptamd_mse_angles_bwd(const float *pred, const float *truth, int64_t T, const
 #define PTAMD_EPI_RELU 1
 #define PTAMD_EPI_TANH 2
 #define PTAMD_EPI_ACCUM 4 /* C += result (used for split reductions) */
+#define PTAMD_EPI_SLABS 16 /* split_k > 1 only, plain epilogue only (no bias / residual / activation / dropout / colsum): the K
+                            * slices' partial products stay in `workspace` as [splits][M][N] fp32 and NO reduction is launched -
+                            * the caller sums them in slab order in the kernel that reads the product next
+                            * (ptamd_layernorm_bwd_dropout: dy_slabs); C is not written.  Ignored when the effective split is 1. */
 #define PTAMD_EPI_GATE 8  /* result = residual[m,n] > 0 ? result * gate_scale : 0 - the backward of ReLU + dropout through
                             the saved activation (Sublayers.py:34), instead of adding `residual` */
 typedef struct {
@@ -407,13 +411,17 @@ int ptamd_layernorm_bwd(const float *dy, const float *x, const float *gamma, con
  * rows, i.e. the scale of the largest row - atomicMin into four copies that the caller preset to 0x7F000000; the uniform
  * scale of `dropped` / `dropped W` as an operand of a weight-gradient product.  dropped_planes (may be NULL; needs row_scale,
  * D % 32 == 0): `dropped` a second time in the pre-split hp format (ptamd_hp_bytes(T, D) bytes) with the scales of
- * row_scale - the A operand of ptamd_gemm_hp for the dX product behind it.  Any of the outputs may be NULL.  D <= 1024. */
+ * row_scale - the A operand of ptamd_gemm_hp for the dX product behind it.  Any of the outputs may be NULL.  D <= 1024.
+ * dy_slabs (1 ... 4; round 6): dy is the SUM of that many [T, D] slabs, dy_slab_stride floats apart - the K slices of a split
+ * product left unreduced (PTAMD_EPI_SLABS) - added in slab order while the rows are read: the bits of the reduction launch it
+ * replaces, at a fraction of that launch's cost for the few tokens at which products are split (D <= 512 for dy_slabs > 1). */
 int ptamd_layernorm_bwd_dropout(const float *dy, const float *x, const float *gamma, const float *mean, const float *rstd,
                                 const float *dres, int64_t T, int D, float dropout_p, uint64_t seed, uint32_t stream_id,
                                 float *dx, float *dropped, uint32_t *row_scale, const float *bound_factor,
                                 uint32_t *bound_scale, uint32_t *row_scale_min, uint32_t *bound_scale_min,
                                 void *dropped_planes, float *dgamma,
-                                float *dbeta, void *workspace, size_t workspace_bytes, void *stream);
+                                float *dbeta, int dy_slabs, int64_t dy_slab_stride, void *workspace, size_t workspace_bytes,
+                                void *stream);
 
 /* Embeddings * sqrt(D) and the doubled positional add of Encoder.py:30 + Sublayers.py:59-62,72:
  *   x0 = emb[seq]*sqrt(D); out = drop2(x0 + drop1(x0 + pe[pos]))      (eval: 2*x0 + pe) */

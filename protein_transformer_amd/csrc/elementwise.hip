@@ -288,13 +288,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
 // consecutive rows of the group's row order each - which all draw the group's words: a half (quarter) of the serial row
 // chain per wavefront, which is what a launch with idle wavefronts is bound by (2048 tokens: 21.6 us with one wavefront
 // per group, 16.3 with two).
-template <int NV, int HALVES>
+// NS > 1 (round 6): dy = the sum of NS slabs `slab` floats apart (the unreduced K slices of the split product that made it),
+// added in slab order behind their loads: (((s0 + s1) + s2) + s3), the bits of gemm_splitk_reduce_plain_kernel.
+template <int NV, int HALVES, int NS = 1>
 __global__ __launch_bounds__(256) void layernorm_bwd_dropout_kernel(
     const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ mean,
     const float *__restrict__ rstd, const float *__restrict__ dres, int64_t T, int D, float *__restrict__ dx,
     float *__restrict__ part, float p, uint64_t seed, uint32_t stream_id, float *__restrict__ dropped,
     uint32_t *__restrict__ row_scale, const float *__restrict__ bound_factor, uint32_t *__restrict__ bound_scale,
-    uint32_t *__restrict__ row_scale_min, uint32_t *__restrict__ bound_scale_min, char *__restrict__ planes) {
+    uint32_t *__restrict__ row_scale_min, uint32_t *__restrict__ bound_scale_min, char *__restrict__ planes, int64_t slab = 0) {
   const int lane = threadIdx.x & 63, wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   uint32_t rmin = 0x7F000000u, bmin = 0x7F000000u;  // smallest scale = largest row seen by this wavefront
   float4 g[NV], dg[NV], db[NV];
@@ -329,6 +331,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dropout_kernel(
     // Written with predicated loads the compiler turned every `if` into a branch, issued the loads two at a time and
     // waited for each pair: four dependent memory round trips per row, 3.3 TB/s (profiles/r03).
     float4 xa[2][NV], da[2][NV], ra[2][NV];
+    float4 ds[2][NS > 1 ? NS - 1 : 1][NV];   // the later slabs of dy (NS > 1)
     float mua[2], rsa[2];
     auto fetch = [&](int f, int set) __attribute__((always_inline)) {
       const int64_t row = min(r0 + 8 * (f >> 2) + (f & 3), T - 1);
@@ -340,6 +343,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dropout_kernel(
         xa[set][j] = *reinterpret_cast<const float4 *>(x + row * D + c);
         da[set][j] = *reinterpret_cast<const float4 *>(dy + row * D + c);
         ra[set][j] = *reinterpret_cast<const float4 *>(rsrc + row * D + c);
+#pragma unroll
+        for (int k = 1; k < NS; ++k) ds[set][k - 1][j] = *reinterpret_cast<const float4 *>(dy + (int64_t)k * slab + row * D + c);
       }
     };
     auto rows_from = [&](auto first) __attribute__((always_inline)) {
@@ -358,7 +363,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dropout_kernel(
         const int c = (j * 64 + lane) * 4;
         const float live = c < D ? 1.f : 0.f;   // lanes beyond D hold a clamped copy of the last columns: weight 0
         const float4 xv = xa[f & 1][j];
-        const float4 d = make_float4(da[f & 1][j].x * live, da[f & 1][j].y * live, da[f & 1][j].z * live, da[f & 1][j].w * live);
+        float4 dsum = da[f & 1][j];
+#pragma unroll
+        for (int k = 1; k < NS; ++k) {   // slab order: the reduction launch's sum
+          const float4 o = ds[f & 1][k - 1][j];
+          dsum.x += o.x; dsum.y += o.y; dsum.z += o.z; dsum.w += o.w;
+        }
+        const float4 d = make_float4(dsum.x * live, dsum.y * live, dsum.z * live, dsum.w * live);
         xh[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
         gy[j] = make_float4(d.x * g[j].x, d.y * g[j].y, d.z * g[j].z, d.w * g[j].w);
         s1 += (gy[j].x + gy[j].y) + (gy[j].z + gy[j].w);
@@ -633,8 +644,11 @@ int ptamd_layernorm_bwd_dropout(const float *dy, const float *x, const float *ga
                                 float *dx, float *dropped, uint32_t *row_scale, const float *bound_factor,
                                 uint32_t *bound_scale, uint32_t *row_scale_min, uint32_t *bound_scale_min,
                                 void *dropped_planes, float *dgamma,
-                                float *dbeta, void *workspace, size_t workspace_bytes, void *stream) {
+                                float *dbeta, int dy_slabs, int64_t dy_slab_stride, void *workspace, size_t workspace_bytes,
+                                void *stream) {
   if (T <= 0 || D <= 0 || (D & 3) || D > 1024) return PTAMD_ERR_BAD_SHAPE;  // 4 D / 256 generator words per lane stay in registers
+  if (dy_slabs < 1) dy_slabs = 1;
+  if (dy_slabs > 4 || (dy_slabs > 1 && (D > 512 || dy_slab_stride < T * (int64_t)D || (dy_slab_stride & 3)))) return PTAMD_ERR_BAD_SHAPE;
   if (dropped_planes && ((D & 31) || !pt_aligned16(dropped_planes))) return PTAMD_ERR_BAD_SHAPE;
   char *planes = static_cast<char *>(dropped_planes);
   if (dropout_p < 0.f || dropout_p >= 1.f || (dropout_p > 0.f && !dropped)) return PTAMD_ERR_BAD_SHAPE;
@@ -648,15 +662,24 @@ int ptamd_layernorm_bwd_dropout(const float *dy, const float *x, const float *ga
   // (one row per wavefront - eight wavefronts per group - measured SLOWER at 2048 tokens: 16.1 against 13.7 us, every
   // wavefront draws the group's words and nothing is prefetched: round 6)
   const int halves = ngroups * 4 <= nwaves ? 4 : ngroups * 2 <= nwaves ? 2 : 1;
-#define PT_LN_FUSED(NV, HV)                                                                                                   \
-  hipLaunchKernelGGL((layernorm_bwd_dropout_kernel<NV, HV>), grid, block, 0, st, dy, x, gamma, mean, rstd, dres, T, D, dx, part, \
-                     dropout_p, seed, stream_id, dropped, row_scale, bound_factor, bound_scale, row_scale_min, bound_scale_min, planes)
+#define PT_LN_FUSED_NS(NV, HV, NS)                                                                                                  \
+  hipLaunchKernelGGL((layernorm_bwd_dropout_kernel<NV, HV, NS>), grid, block, 0, st, dy, x, gamma, mean, rstd, dres, T, D, dx, part, \
+                     dropout_p, seed, stream_id, dropped, row_scale, bound_factor, bound_scale, row_scale_min, bound_scale_min, planes, \
+                     dy_slab_stride)
+#define PT_LN_FUSED(NV, HV)                                                        \
+  do {                                                                             \
+    if (dy_slabs == 1) PT_LN_FUSED_NS(NV, HV, 1);                                   \
+    else if (NV <= 2 && dy_slabs == 2) PT_LN_FUSED_NS((NV <= 2 ? NV : 1), HV, 2);   \
+    else if (NV <= 2 && dy_slabs == 3) PT_LN_FUSED_NS((NV <= 2 ? NV : 1), HV, 3);   \
+    else if (NV <= 2) PT_LN_FUSED_NS((NV <= 2 ? NV : 1), HV, 4);                    \
+  } while (0)
 #define PT_LN_FUSED_BY_T(NV) do { if (halves == 4) PT_LN_FUSED(NV, 4); else if (halves == 2) PT_LN_FUSED(NV, 2); else PT_LN_FUSED(NV, 1); } while (0)
   if (D <= 256) PT_LN_FUSED_BY_T(1);
   else if (D <= 512) PT_LN_FUSED_BY_T(2);
   else PT_LN_FUSED_BY_T(4);
 #undef PT_LN_FUSED_BY_T
 #undef PT_LN_FUSED
+#undef PT_LN_FUSED_NS
   int rc = pt_check_launch();
   if (rc || (!dgamma && !dbeta)) return rc;
   if (!dgamma || !dbeta) return PTAMD_ERR_BAD_SHAPE;

@@ -433,7 +433,11 @@ int build_params(const ptamd_gemm_args *a, GemmParams &p, int &splits, int &mode
   if (splits > kblocks) splits = kblocks;
   p.M = a->M; p.N = a->N; p.K = a->K;
   p.A = a->A; p.lda = a->lda; p.B = a->B; p.ldb = a->ldb; p.C = a->C; p.ldc = a->ldc;
-  p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr; p.flags = a->flags;
+  p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr; p.flags = a->flags & ~PTAMD_EPI_SLABS;
+  // slabs left to the caller: nothing of an epilogue may hang on the product
+  if ((a->flags & PTAMD_EPI_SLABS) && (a->bias || a->residual || a->colsum || a->gate_mask || a->dropout_p != 0.f ||
+                                      (a->flags & (PTAMD_EPI_RELU | PTAMD_EPI_TANH | PTAMD_EPI_ACCUM | PTAMD_EPI_GATE))))
+    return PTAMD_ERR_BAD_SHAPE;
   p.dropout_p = a->dropout_p; p.seed = a->seed; p.stream_id = a->stream_id; p.gate_scale = a->gate_scale;
   p.reserved_cus = a->reserved_cus;
   p.k_per_split = ((kblocks + splits - 1) / splits) * BK;
@@ -505,7 +509,7 @@ int ptamd_gemm(const ptamd_gemm_args *a, void *stream) {
   const int products = mode == PTAMD_GEMM_BF16X3_FULL ? 9 : mode == PTAMD_GEMM_F16X2 ? 3 : 6;
   const int rc = mode == PTAMD_GEMM_F32 ? launch_f32(p, a->a_kmajor != 0, a->b_kmajor != 0, splits, st)
                                         : launch_split(p, a->a_kmajor != 0, a->b_kmajor != 0, splits, products, st);
-  if (rc || splits == 1) return rc;
+  if (rc || splits == 1 || (a->flags & PTAMD_EPI_SLABS)) return rc;   // (PTAMD_EPI_SLABS: the caller sums [splits][M][N] in `workspace`)
   const float *slabs = p.C;
   p.C = user_c;
   const float *cs_slabs = a->colsum ? slabs + (size_t)splits * p.slab : nullptr;

@@ -11,7 +11,7 @@ import torch
 from . import _lib
 from ._lib import GemmArgs, GemmHpArgs, check, lib, ptr, stream, workspace
 
-EPI_RELU, EPI_TANH, EPI_ACCUM, EPI_GATE = 1, 2, 4, 8
+EPI_RELU, EPI_TANH, EPI_ACCUM, EPI_GATE, EPI_SLABS = 1, 2, 4, 8, 16
 
 # bench.py sets this to a list to time every GEMM launch with HIP events recorded on the launch stream:
 # entries are (flops, start_event, end_event).  None (the default) adds no work to the hot path.
@@ -23,13 +23,15 @@ GEMM_RESERVED_CUS = 0    # CUs the persistent GEMMs leave free (dp.reserve_cus_f
 
 def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, bias=None, residual=None,
          ldr=0, flags=0, dropout_p=0.0, seed=0, stream_id=0, split_k=1, colsum=None, gate_scale=0.0, arith=None,
-         a_scale=None, a_scale_stride=1, b_scale=None, b_scale_stride=1, gate_mask=None):
+         a_scale=None, a_scale_stride=1, b_scale=None, b_scale_stride=1, gate_mask=None, ws=None):
     """C[M,N] = epilogue(A (*) B); operand layouts as documented in ptamd.h.  `arith`: GEMM_* constant of this call
-    (None = the host-side default, `set_gemm_mode`); the library itself keeps no mode."""
+    (None = the host-side default, `set_gemm_mode`); the library itself keeps no mode.  `ws`: the caller's own workspace
+    (EPI_SLABS: the K slices stay in it; C_out may then be None)."""
     # split-K slabs and, for the f16x2 arithmetic, the row scales of the two operands
-    ws = workspace("gemm", lib().ptamd_gemm_workspace_bytes(M, N, split_k), C_out.device)
+    if ws is None:
+        ws = workspace("gemm", lib().ptamd_gemm_workspace_bytes(M, N, split_k), A.device)
     args = GemmArgs(M=M, N=N, K=K, A=A.data_ptr(), lda=lda, a_kmajor=int(a_kmajor), B=B.data_ptr(), ldb=ldb,
-                    b_kmajor=int(b_kmajor), C=C_out.data_ptr(), ldc=ldc,
+                    b_kmajor=int(b_kmajor), C=C_out.data_ptr() if C_out is not None else ws.data_ptr(), ldc=ldc,
                     bias=bias.data_ptr() if bias is not None else None,
                     residual=residual.data_ptr() if residual is not None else None, ldr=ldr, flags=flags,
                     dropout_p=float(dropout_p), seed=int(seed) & (2 ** 64 - 1), stream_id=int(stream_id),
@@ -186,15 +188,59 @@ def gate_mask_buffer(M, N, device):
     return torch.empty(lib().ptamd_gate_mask_bytes(M, N) // 8, dtype=torch.int64, device=device)
 
 
-def linear_bwd_input(dy, w, out=None, flags=0, gate=None, gate_dropout_p=0.0, arith=None, gate_mask=None, **scales):
+class Slabs:
+    """The K slices of a split product left unreduced (EPI_SLABS): `n` [T, D] fp32 slabs `stride` floats apart in `buf`;
+    their sum in slab order is the product.  Read by layernorm_bwd_dropout (dy)."""
+    __slots__ = ("buf", "n", "stride", "shape")
+
+    def __init__(self, buf, n, stride, shape):
+        self.buf, self.n, self.stride, self.shape = buf, n, stride, shape
+
+    def data_ptr(self):
+        return self.buf.data_ptr()
+
+    def sum(self):     # (tests: the reduction launch's order)
+        T, D = self.shape
+        v = self.buf[:self.n * self.stride * 4].view(torch.float32).view(self.n, self.stride)[:, :T * D]
+        out = v[0].clone()
+        for k in range(1, self.n):
+            out += v[k]
+        return out.view(T, D)
+
+
+DEFER_REDUCE = os.environ.get("PTAMD_DEFER_REDUCE", "1") != "0"      # knob for A/B and tests
+
+
+def effective_splits(K, split_k):
+    """The K slices ptamd_gemm makes of a reduction of length K asked to split `split_k` ways (whole 32-blocks each)."""
+    kblocks = -(-K // 32)
+    splits = max(1, min(int(split_k), kblocks))
+    per = -(-kblocks // splits) * 32
+    return -(-K // per)
+
+
+def linear_bwd_input(dy, w, out=None, flags=0, gate=None, gate_dropout_p=0.0, arith=None, gate_mask=None, defer_reduce=False,
+                     **scales):
     """dx[T,K] = dy[T,N] w[N,K];  with `gate` (the saved output of a ReLU + dropout layer, [T,K]) the product is passed
     through the backward of that layer in the epilogue: dx = gate > 0 ? dx / (1 - p) : 0.  `gate_mask`: the same gate as one
-    bit per element (written by the product that made `gate`): read instead of `gate` where the kernel can (same bits)."""
+    bit per element (written by the product that made `gate`): read instead of `gate` where the kernel can (same bits).
+    `defer_reduce`: where the product is split over K (few tokens) and the split is one layernorm_bwd_dropout can sum, the
+    K slices are returned unreduced (a `Slabs`; no reduction launch) for that kernel to add as it reads them - same bits."""
     T, N = dy.shape
     K = w.shape[1]
+    sk = pick_split_k_rows(T, K, N)
+    if defer_reduce and DEFER_REDUCE and sk > 1 and out is None and gate is None and gate_mask is None and flags == 0 and \
+            K % 4 == 0 and K <= 512 and int(_DEFAULT_ARITH if arith is None else arith) != GEMM_F32:
+        n = effective_splits(N, sk)
+        if 2 <= n <= 4:
+            # the slabs' own workspace (the shared one is the next product's); the kernel that sums them is enqueued on
+            # this stream before the next product of this kind writes it
+            ws = workspace("gemm_slabs", lib().ptamd_gemm_workspace_bytes(T, K, sk), dy.device)
+            gemm(dy, w, None, M=T, N=K, K=N, lda=dy.stride(0), ldb=w.stride(0), ldc=K, b_kmajor=True, split_k=sk,
+                 flags=EPI_SLABS, arith=arith, ws=ws, **scales)
+            return Slabs(ws, n, T * K, (T, K))
     if out is None:
         out = torch.empty(T, K, dtype=torch.float32, device=dy.device)
-    sk = pick_split_k_rows(T, K, N)
     if gate_mask is not None and sk == 1 and K % 4 == 0 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0 and \
             int(_DEFAULT_ARITH if arith is None else arith) in (GEMM_F16X2, GEMM_AUTO) and N >= 32 and \
             dy.shape[0] * dy.stride(0) * 4 < 2 ** 32 and w.shape[0] * w.stride(0) * 4 < 2 ** 32:   # (else ptamd_gemm runs in f32)
@@ -364,10 +410,12 @@ def layernorm_bwd_dropout(dy, x, gamma, mean, rstd, dgamma, dbeta, dres, dropout
         layernorm_bwd_flush(pending)
     ws = _ln_workspace(D, x.device, pending)
     defer = pending is not None
+    slabs, slab_stride = (dy.n, dy.stride) if isinstance(dy, Slabs) else (1, 0)    # (linear_bwd_input: defer_reduce)
     check(lib().ptamd_layernorm_bwd_dropout(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), T, D, float(dropout_p),
                                             int(seed), int(stream_id), ptr(dx), ptr(dropped), ptr(row_scale),
                                             ptr(bound_factor), ptr(bound_scale), ptr(row_scale_min), ptr(bound_scale_min),
-                                            ptr(planes), None if defer else ptr(dgamma), None if defer else ptr(dbeta), ptr(ws), ws.numel(),
+                                            ptr(planes), None if defer else ptr(dgamma), None if defer else ptr(dbeta),
+                                            slabs, slab_stride, ptr(ws), ws.numel(),
                                             stream()), "layernorm_bwd_dropout")
     if defer:
         pending.append((ws, D, dgamma, dbeta))

@@ -1051,7 +1051,8 @@ class _EncoderFn(torch.autograd.Function):
                                 dy_scale=sc["dz1_min"] if uni1 else None, x_scale=sc["h2_scale"] if uni1 else None)
             if dw_group != "layer":
                 dw_flush()                                    # the two FFN products now, the two attention products at the end
-            dh2 = K.linear_bwd_input(dz1, W(b + "pwff.layer1.weight"),
+            # (few tokens: the K slices of dh2 / dh1 go to the fused LayerNorm backward unreduced - kernels.Slabs)
+            dh2 = K.linear_bwd_input(dz1, W(b + "pwff.layer1.weight"), defer_reduce=fuse,
                                      **prod(i, 6, a_scale=bs_dz1 if sc and not o_dz1 else None, b_scale=sc and sc["cs_1"]))
             # x2 = x + drop(att Wo^T + bo)
             g2w, g2b = G(b + "sublayer_connections.1.norm.weight"), G(b + "sublayer_connections.1.norm.bias")
@@ -1085,10 +1086,11 @@ class _EncoderFn(torch.autograd.Function):
                     K.weight_scales([dict(w=dqkv, row_scale=s_dqkv, stats=sc["dqkv_stats"], rows_only=True)])
                     K.bound_scales([dict(w=sc["dqkv_stats"], w_index=2, out_scale=sc["dqkv_scale"])])
                 dw_later(dqkv, h1, gw, gb, arith=ar, dy_scale=None if o_h1 else dq_uni, x_scale=None if o_h1 else sc["h1_scale"])
-                dh1 = K.linear_bwd_input(dqkv, wqkv, **prod(i, 4, a_scale=s_dqkv, b_scale=sc["cs_qkv"]))
+                dh1 = K.linear_bwd_input(dqkv, wqkv, defer_reduce=fuse and i > 0,
+                                         **prod(i, 4, a_scale=s_dqkv, b_scale=sc["cs_qkv"]))
             else:
                 dw_later(dqkv, h1, gw, gb, arith=ar)
-                dh1 = K.linear_bwd_input(dqkv, wqkv, arith=ar)
+                dh1 = K.linear_bwd_input(dqkv, wqkv, arith=ar, defer_reduce=fuse and i > 0)
             g1w, g1b = G(b + "sublayer_connections.0.norm.weight"), G(b + "sublayer_connections.0.norm.bias")
             if fuse and i > 0:      # the gradient enters layer i - 1 through ITS FFN-output dropout: made here, with its scales
                 s_dy2, bs_dz1 = (i32(), i32()) if scales is not None else (None, None)

@@ -285,13 +285,13 @@ def test_attention_bwd_row_scales(dev, B, L, H, dk):
         K.attention_bwd(qkv, seq, o, dout, lse, H, 0.1, 5, 2, arith=K.GEMM_BF16X3, row_scale=rs, row_scale_min=mn)
 
 
-def _prep_model(dev, nl=2, dm=512, dff=2048, seed=3):
+def _prep_model(dev, nl=2, dm=512, dff=2048, seed=3, nprot=8):
     from protein_transformer_amd import synthetic
     from protein_transformer_amd.models.encoder_only import EncoderOnlyTransformer
     from protein_transformer_amd.protein.Sequence import VOCAB
     from protein_transformer_amd.protein.Structure import nerf_forward
     build = lambda ang, seq: nerf_forward(ang.to(dev), seq.to(dev))[0]  # noqa: E731
-    batch = synthetic.make_batch([512] * 8, L_pad=512, seed=seed, build_coords=build)
+    batch = synthetic.make_batch([512] * nprot, L_pad=512, seed=seed, build_coords=build)
     torch.manual_seed(seed)
     m = EncoderOnlyTransformer(nl, 8, dm, dff, 512, VOCAB, synthetic.angle_means(batch["true_ang"]), True, dropout=0.1).to(dev).train()
     with torch.no_grad():
@@ -533,3 +533,70 @@ def test_fill_u32(dev):
     K.fill_u32([(a, 0x7F000000), (b, 5), (c, 0x3F800000)])
     torch.cuda.synchronize()
     assert bool((a == 0x7F000000).all()) and bool((b == 5).all()) and bool((c == 1.0).all())
+
+
+@pytest.mark.parametrize("T,D,N,want", [(2048, 512, 2048, 4), (2048, 512, 1536, 3), (4096, 512, 2048, 2), (1900, 256, 2048, 4),
+                                        (16384, 512, 2048, 0)])
+def test_unreduced_k_slices_into_the_layernorm_backward(dev, T, D, N, want):
+    """Round 6 (PTAMD_EPI_SLABS, ptamd_layernorm_bwd_dropout: dy_slabs): at few tokens the dX product in front of a fused
+    LayerNorm backward leaves its K slices unreduced and that kernel adds them in slab order as it reads the rows - the bits
+    of the reduction launch it replaces, in the product and in everything the LayerNorm backward writes."""
+    from protein_transformer_amd import kernels as K
+    g = torch.Generator().manual_seed(T + N)
+    dy = (torch.randn(T, N, generator=g) * torch.exp(torch.randn(T, 1, generator=g))).to(dev)
+    w = (torch.randn(N, D, generator=g) * 0.05).to(dev)
+    x, dres = (torch.randn(T, D, generator=g).to(dev) for _ in range(2))
+    gam = (torch.rand(D, generator=g) + 0.5).to(dev)
+    _, mean, rstd = K.layernorm_fwd(x, gam, torch.zeros(D, device=dev))
+    ref = K.linear_bwd_input(dy, w, arith=K.GEMM_AUTO)
+    got = K.linear_bwd_input(dy, w, arith=K.GEMM_AUTO, defer_reduce=True)
+    if want == 0:                                     # enough tokens: the product is not split, nothing to defer
+        assert torch.is_tensor(got) and torch.equal(got, ref)
+        return
+    assert isinstance(got, K.Slabs) and got.n == want and got.shape == (T, D)
+    assert torch.equal(got.sum(), ref)
+    outs = []
+    for d in (ref, got):
+        dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+        rs, bs = torch.zeros(T, dtype=torch.int32, device=dev), torch.zeros(T, dtype=torch.int32, device=dev)
+        mins = torch.full((2,), 0x7F000000, dtype=torch.int32, device=dev)
+        planes = torch.zeros(K.lib().ptamd_hp_bytes(T, D), dtype=torch.uint8, device=dev)    # (zeros: the row padding is not written)
+        dx, dr = K.layernorm_bwd_dropout(d, x, gam, mean, rstd, dg, db, dres, 0.1, 99, 5, row_scale=rs,
+                                         bound_factor=torch.tensor([2.5], device=dev), bound_scale=bs, row_scale_min=mins[0:1],
+                                         bound_scale_min=mins[1:2], planes=planes)
+        outs.append((dx, dr, dg, db, rs, bs, mins, planes))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert torch.isfinite(outs[0][0]).all()
+    with pytest.raises(RuntimeError):                 # slabs with anything of an epilogue on them are refused
+        K.gemm(dy, w, None, M=T, N=D, K=N, lda=N, ldb=D, ldc=D, b_kmajor=True, split_k=want, flags=K.EPI_SLABS | K.EPI_RELU,
+               ws=torch.empty(K.lib().ptamd_gemm_workspace_bytes(T, D, want), dtype=torch.uint8, device=dev))
+
+
+@pytest.mark.parametrize("nprot", [4, 8])
+def test_deferred_reduction_leaves_the_step_unchanged(dev, nprot, monkeypatch):
+    """... and a training step with the K slices deferred == the step with the reduction launches, bit for bit (4 proteins:
+    4 / 3 slices of dh2 / dh1; 8 proteins: 2 / 2)."""
+    import types
+    from protein_transformer_amd import kernels as K
+    from protein_transformer_amd.optim import FusedSGD
+    from protein_transformer_amd.train import train_step
+    args = types.SimpleNamespace(loss="drmsd", combined_drmsd_weight=0.5, backbone_loss=False, clip=1.0)
+    flats, seen = [], []
+    real = K.layernorm_bwd_dropout
+
+    def spy(dy, *a, **kw):
+        seen.append(dy.n if isinstance(dy, K.Slabs) else 1)
+        return real(dy, *a, **kw)
+    monkeypatch.setattr(K, "layernorm_bwd_dropout", spy)
+    for defer in (True, False):
+        monkeypatch.setattr(K, "DEFER_REDUCE", defer)
+        del seen[:]
+        m, data = _prep_model(dev, nl=3, seed=17, nprot=nprot)
+        opt = FusedSGD(m, lr=1e-2, weight_decay=10e-3)
+        for _ in range(2):
+            train_step(m, opt, args, *data)
+        flats.append(m.flat_parameters()[0].clone())
+        want = ([4, 3] if nprot == 4 else [2, 2]) if defer else [1, 1]
+        assert seen == [want[0], want[1], want[0], want[1], want[0]] * 2, seen   # (layer 0's dh1 goes to the unfused kernel)
+    assert torch.isfinite(flats[0]).all() and torch.equal(flats[0], flats[1])
