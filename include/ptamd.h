@@ -390,6 +390,15 @@ int ptamd_adam_step_prep(const ptamd_wprep_plan *plan_host, int parity, float *w
  * bytes), scaled by row_scale - the A operand of ptamd_gemm_hp for the product behind the LayerNorm (QKV, FFN layer 1) */
 int ptamd_layernorm_fwd(const float *x, const float *gamma, const float *beta, int64_t T, int D, float *y,
                         float *mean, float *rstd, uint32_t *row_scale, void *planes, void *stream);
+/* Round 6: the same LayerNorm behind a split product whose K slices were left unreduced (PTAMD_EPI_SLABS; FFN layer 2 at few
+ * tokens): the rows are first made here - x_out = residual + dropout(sum of the n_slabs (2 ... 4) [T, D] slabs, slab_stride
+ * floats apart, in slab order + bias) with the decisions of the product's own epilogue (dropout_p, seed, stream_id as
+ * ptamd_gemm_args; Sublayers.py:16-17) - and normalised from registers: the bits of the reduction launch + ptamd_layernorm_fwd,
+ * one launch fewer.  residual / x_out [T, D] dense, D <= 512. */
+int ptamd_layernorm_fwd_sum(const float *slabs, int n_slabs, int64_t slab_stride, const float *bias, const float *residual,
+                            float dropout_p, uint64_t seed, uint32_t stream_id, float *x_out, const float *gamma,
+                            const float *beta, int64_t T, int D, float *y, float *mean, float *rstd, uint32_t *row_scale,
+                            void *planes, void *stream);
 /* dx [T,D] = LN'(dy) + dres (dres: gradient of the residual branch, may be NULL; dx may alias dres);
  * dgamma, dbeta [D] accumulated (+=) through fixed-order partials in workspace */
 size_t ptamd_layernorm_bwd_workspace_bytes(int D);

@@ -138,6 +138,7 @@ SIGNATURES = {
     "ptamd_weight_scales": (_i, [C.POINTER(WScaleJob), _i, _p]),
     "ptamd_bound_scales": (_i, [C.POINTER(BoundJob), _i, _p]),
     "ptamd_layernorm_fwd": (_i, [_p, _p, _p, _i64, _i, _p, _p, _p, _p, _p, _p]),
+    "ptamd_layernorm_fwd_sum": (_i, [_p, _i, _i64, _p, _p, _f, _u64, _u32, _p, _p, _p, _i64, _i, _p, _p, _p, _p, _p, _p]),
     "ptamd_layernorm_bwd_dropout": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _u64, _u32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _p, _sz, _p]),
     "ptamd_layernorm_bwd_workspace_bytes": (_sz, [_i]),
     "ptamd_layernorm_bwd_reduce": (_i, [C.POINTER(LnReduceJob), _i, _p]),

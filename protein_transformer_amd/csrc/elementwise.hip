@@ -133,25 +133,15 @@ __global__ __launch_bounds__(256) void embed_bwd_reduce_kernel(const float *__re
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
-// one wavefront per row, NV float4 per lane kept in registers
+// one wavefront per row, NV float4 per lane kept in registers: everything behind the loads of the row
 template <int NV>
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
-                                                            const float *__restrict__ beta, int64_t T, int D,
-                                                            float *__restrict__ y, float *__restrict__ mean_out,
-                                                            float *__restrict__ rstd_out, uint32_t *__restrict__ row_scale,
-                                                            char *__restrict__ planes) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= T) return;
-  const float *xr = x + row * D;
-  float4 v[NV];
+__device__ __forceinline__ void layernorm_fwd_row(float4 (&v)[NV], int64_t row, int lane, int D, const float *__restrict__ gamma,
+                                                  const float *__restrict__ beta, float *__restrict__ y,
+                                                  float *__restrict__ mean_out, float *__restrict__ rstd_out,
+                                                  uint32_t *__restrict__ row_scale, char *__restrict__ planes) {
   float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < NV; ++j) {
-    const int c = (j * 64 + lane) * 4;
-    v[j] = c < D ? *reinterpret_cast<const float4 *>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-  }
+  for (int j = 0; j < NV; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
   const float mean = wave_sum(s) / (float)D;
   float q = 0.f;
 #pragma unroll
@@ -192,6 +182,86 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restr
     rstd_out[row] = rstd;
     if (row_scale) row_scale[row] = sbits;
   }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, int64_t T, int D,
+                                                            float *__restrict__ y, float *__restrict__ mean_out,
+                                                            float *__restrict__ rstd_out, uint32_t *__restrict__ row_scale,
+                                                            char *__restrict__ planes) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= T) return;
+  const float *xr = x + row * D;
+  float4 v[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    v[j] = c < D ? *reinterpret_cast<const float4 *>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  layernorm_fwd_row<NV>(v, row, lane, D, gamma, beta, y, mean_out, rstd_out, row_scale, planes);
+}
+
+// Round 6: the LayerNorm behind a split product that was left unreduced (PTAMD_EPI_SLABS) - the rows are first MADE here,
+// x = residual + dropout(sum of the NS K slices + bias), in the order and with the decisions of gemm_splitk_reduce_kernel
+// (same bits), written to x_out, and normalised from registers.  The four rows of a workgroup (4 k ... 4 k + 3) take
+// their dropout decisions from the SAME generator calls (drop_call_index: fields e = row & 3 of one call per column): the
+// words are drawn once per workgroup - columns t and t + 256 by thread t - and shared through LDS.  D <= 512.
+template <int NV, int NS>
+__global__ __launch_bounds__(256) void layernorm_fwd_sum_kernel(
+    const float *__restrict__ slabs, int64_t slab, const float *__restrict__ bias, const float *__restrict__ residual,
+    float p, uint64_t seed, uint32_t stream_id, float *__restrict__ x_out, const float *__restrict__ gamma,
+    const float *__restrict__ beta, int64_t T, int D, float *__restrict__ y, float *__restrict__ mean_out,
+    float *__restrict__ rstd_out, uint32_t *__restrict__ row_scale, char *__restrict__ planes) {
+  __shared__ uint2 words[NV * 256];   // per column: the two words of the call that hold the fields of rows row0 ... row0 + 3
+  const int lane = threadIdx.x & 63, e_row = threadIdx.x >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * 4, row = row0 + e_row;
+  if (p > 0.f) {
+    const bool upper = (row0 >> 3) & 1;   // drop_field: fields 4 ... 7 (words z, w) for rows 8 ... 15 of every 16
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int col = k * 256 + threadIdx.x;
+      if (col < D) {
+        const uint4 r = pt_rand4(seed, drop_call_index(row0, col, D), stream_id);
+        words[col] = upper ? make_uint2(r.z, r.w) : make_uint2(r.x, r.y);
+      }
+    }
+    __syncthreads();
+  }
+  if (row >= T) return;
+  const uint32_t thr16 = dropout_threshold(p) >> 16;
+  const float keep_scale = 1.f / (1.f - p);
+  float4 v[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < D) {
+      float4 part[NS];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) part[k] = *reinterpret_cast<const float4 *>(slabs + (int64_t)k * slab + row * D + c);
+      const float4 bv = *reinterpret_cast<const float4 *>(bias + c);
+      const float4 rv = *reinterpret_cast<const float4 *>(residual + row * D + c);
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < NS; ++k) { a[0] += part[k].x; a[1] += part[k].y; a[2] += part[k].z; a[3] += part[k].w; }
+      const float bb[4] = {bv.x, bv.y, bv.z, bv.w}, rr[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = a[e] + bb[e];
+        if (p > 0.f) {
+          const uint2 u = words[c + e];
+          const uint32_t wd = (e_row >> 1) ? u.y : u.x, fv = (e_row & 1) ? wd >> 16 : wd & 0xffffu;
+          t = fv >= thr16 ? t * keep_scale : 0.f;
+        }
+        a[e] = t + rr[e];
+      }
+      v[j] = make_float4(a[0], a[1], a[2], a[3]);
+      *reinterpret_cast<float4 *>(x_out + row * D + c) = v[j];
+    }
+  }
+  layernorm_fwd_row<NV>(v, row, lane, D, gamma, beta, y, mean_out, rstd_out, row_scale, planes);
 }
 
 #ifndef PT_LN_BWD_BLOCKS
@@ -614,6 +684,29 @@ int ptamd_layernorm_fwd(const float *x, const float *gamma, const float *beta, i
   else if (D <= 512) hipLaunchKernelGGL(layernorm_fwd_kernel<2>, grid, block, 0, st, x, gamma, beta, T, D, y, mean, rstd, row_scale, planes);
   else if (D <= 1024) hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, block, 0, st, x, gamma, beta, T, D, y, mean, rstd, row_scale, planes);
   else hipLaunchKernelGGL(layernorm_fwd_kernel<8>, grid, block, 0, st, x, gamma, beta, T, D, y, mean, rstd, row_scale, planes);
+  return pt_check_launch();
+}
+
+int ptamd_layernorm_fwd_sum(const float *slabs, int n_slabs, int64_t slab_stride, const float *bias, const float *residual,
+                            float dropout_p, uint64_t seed, uint32_t stream_id, float *x_out, const float *gamma,
+                            const float *beta, int64_t T, int D, float *y, float *mean, float *rstd, uint32_t *row_scale,
+                            void *planes_out, void *stream) {
+  if (T <= 0 || D <= 0 || (D & 3) || D > 512) return PTAMD_ERR_BAD_SHAPE;
+  if (n_slabs < 2 || n_slabs > 4 || slab_stride < T * (int64_t)D || (slab_stride & 3)) return PTAMD_ERR_BAD_SHAPE;
+  if (!slabs || !bias || !residual || !x_out || dropout_p < 0.f || dropout_p >= 1.f) return PTAMD_ERR_BAD_SHAPE;
+  if (!pt_aligned16(slabs) || !pt_aligned16(bias) || !pt_aligned16(residual) || !pt_aligned16(x_out)) return PTAMD_ERR_ALIGN;
+  if (planes_out && (!row_scale || (D & 31) || !pt_aligned16(planes_out))) return PTAMD_ERR_BAD_SHAPE;
+  char *planes = static_cast<char *>(planes_out);
+  const dim3 grid((unsigned)((T + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define PT_LN_SUM(NV, NS)                                                                                                      \
+  hipLaunchKernelGGL((layernorm_fwd_sum_kernel<NV, NS>), grid, block, 0, st, slabs, slab_stride, bias, residual, dropout_p, seed, \
+                     stream_id, x_out, gamma, beta, T, D, y, mean, rstd, row_scale, planes)
+#define PT_LN_SUM_BY_N(NV) do { if (n_slabs == 2) PT_LN_SUM(NV, 2); else if (n_slabs == 3) PT_LN_SUM(NV, 3); else PT_LN_SUM(NV, 4); } while (0)
+  if (D <= 256) PT_LN_SUM_BY_N(1);
+  else PT_LN_SUM_BY_N(2);
+#undef PT_LN_SUM_BY_N
+#undef PT_LN_SUM
   return pt_check_launch();
 }
 

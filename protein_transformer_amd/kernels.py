@@ -173,14 +173,27 @@ def pick_split_k_rows(M, N, K, slots=256):
     return max(1, min(K // 512, slots // tiles))
 
 
-def linear_fwd(x, w, b, out=None, **epi):
-    """y[T,N] = x[T,K] w[N,K]^T + b with a fused epilogue."""
+def linear_fwd(x, w, b, out=None, defer_reduce=False, **epi):
+    """y[T,N] = x[T,K] w[N,K]^T + b with a fused epilogue.  `defer_reduce` (the caller hands the result to layernorm_fwd
+    and nothing else): where the product is split over K (few tokens) and its epilogue is bias + dropout + residual, the K
+    slices stay unreduced and a `PendingRows` is returned - that LayerNorm makes the rows as it reads them (same bits)."""
     T, K = x.shape
     N = w.shape[0]
+    sk = pick_split_k_rows(T, N, K)
+    if defer_reduce and DEFER_REDUCE and sk > 1 and out is None and b is not None and N % 4 == 0 and N <= 512 and \
+            epi.get("flags", 0) == 0 and epi.get("residual") is not None and epi.get("ldr") == N and \
+            epi["residual"].is_contiguous() and int(_DEFAULT_ARITH if epi.get("arith") is None else epi["arith"]) != GEMM_F32:
+        n = effective_splits(K, sk)
+        if 2 <= n <= 4:
+            ws = workspace("gemm_slabs", lib().ptamd_gemm_workspace_bytes(T, N, sk), x.device)
+            rest = {k: v for k, v in epi.items() if k not in ("residual", "ldr", "dropout_p", "seed", "stream_id", "flags")}
+            gemm(x, w, None, M=T, N=N, K=K, lda=x.stride(0), ldb=w.stride(0), ldc=N, split_k=sk, flags=EPI_SLABS, ws=ws, **rest)
+            return PendingRows(Slabs(ws, n, T * N, (T, N)), b, epi["residual"], epi.get("dropout_p", 0.0), epi.get("seed", 0),
+                               epi.get("stream_id", 0))
     if out is None:
         out = torch.empty(T, N, dtype=torch.float32, device=x.device)
     return gemm(x, w, out, M=T, N=N, K=K, lda=x.stride(0), ldb=w.stride(0), ldc=out.stride(0), bias=b,
-                split_k=pick_split_k_rows(T, N, K), **epi)
+                split_k=sk, **epi)
 
 
 def gate_mask_buffer(M, N, device):
@@ -206,6 +219,24 @@ class Slabs:
         for k in range(1, self.n):
             out += v[k]
         return out.view(T, D)
+
+
+class PendingRows:
+    """x = residual + dropout(product + bias) whose product is still K slices (`slabs`): made by the LayerNorm forward that
+    reads it (layernorm_fwd -> ptamd_layernorm_fwd_sum), which leaves the rows in `.value`."""
+    __slots__ = ("slabs", "bias", "residual", "dropout_p", "seed", "stream_id", "value")
+
+    def __init__(self, slabs, bias, residual, dropout_p, seed, stream_id):
+        self.slabs, self.bias, self.residual = slabs, bias, residual
+        self.dropout_p, self.seed, self.stream_id, self.value = float(dropout_p), int(seed) & (2 ** 64 - 1), int(stream_id), None
+
+    @property
+    def shape(self):
+        return self.slabs.shape
+
+    @property
+    def device(self):
+        return self.residual.device
 
 
 DEFER_REDUCE = os.environ.get("PTAMD_DEFER_REDUCE", "1") != "0"      # knob for A/B and tests
@@ -335,6 +366,15 @@ def layernorm_fwd(x, gamma, beta, row_scale=None, planes=None):
     """y, mean, rstd; `row_scale` (uint32-as-int32 [T], optional) receives the f16x2 scale of every row of y; `planes`
     (uint8 buffer of ptamd_hp_bytes(T, D), optional, needs row_scale) receives y once more in the pre-split hp format."""
     T, D = x.shape
+    if isinstance(x, PendingRows):           # (linear_fwd: defer_reduce) the rows are made here and left in x.value
+        r = x.residual
+        x.value, y = torch.empty_like(r), torch.empty_like(r)
+        mean = torch.empty(T, dtype=torch.float32, device=r.device)
+        rstd = torch.empty(T, dtype=torch.float32, device=r.device)
+        check(lib().ptamd_layernorm_fwd_sum(ptr(x.slabs), x.slabs.n, x.slabs.stride, ptr(x.bias), ptr(r), x.dropout_p, x.seed,
+                                            x.stream_id, ptr(x.value), ptr(gamma), ptr(beta), T, D, ptr(y), ptr(mean), ptr(rstd),
+                                            ptr(row_scale), ptr(planes), stream()), "layernorm_fwd_sum")
+        return y, mean, rstd
     y = torch.empty_like(x)
     mean = torch.empty(T, dtype=torch.float32, device=x.device)
     rstd = torch.empty(T, dtype=torch.float32, device=x.device)

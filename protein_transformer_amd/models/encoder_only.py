@@ -814,6 +814,8 @@ class _EncoderFn(torch.autograd.Function):
             h1, mean1, rstd1 = K.layernorm_fwd(x, W(b + "sublayer_connections.0.norm.weight"),
                                                W(b + "sublayer_connections.0.norm.bias"), row_scale=s_h1,
                                                planes=hplanes if hp_q else None)
+            if isinstance(x, K.PendingRows):          # (the layer below left its output as K slices: made by this LayerNorm)
+                x = x.value
             attn_ar_f = attn_default if m.attn_mode is None else m.attn_mode
             # K and V leave the QKV product as the pre-split planes the attention kernels of this batch shape read (no fp32 K / V at
             # all: the forward kernel fills its stages by LDS-DMA, the one-sweep backward kernel loads its key rows from them)
@@ -857,8 +859,9 @@ class _EncoderFn(torch.autograd.Function):
                                   dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_HID,
                                   **prod(i, 2, a_scale=s_h2, b_scale=sc and sc["rs_1"]))
             use_b = sc is not None and not (off is not None and off[i, 1])          # f1 on its bound
+            # (few tokens: the K slices of this product go to the next layer's LayerNorm unreduced - kernels.PendingRows)
             x3 = K.linear_fwd(f1, W(b + "pwff.layer2.weight"), W(b + "pwff.layer2.bias"), residual=x2, ldr=D,
-                              dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_OUT,
+                              dropout_p=p, seed=seed, stream_id=sid + _SITE_FFN_OUT, defer_reduce=i + 1 < m.nlayers,
                               **prod(i, 3, a_scale=sc["f1_scale"] if use_b else None, a_scale_stride=0 if use_b else 1,
                                      b_scale=sc and sc["rs_2"]))
             saved.append((x, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, f1, kbits, fmask, kv))

@@ -573,6 +573,39 @@ def test_unreduced_k_slices_into_the_layernorm_backward(dev, T, D, N, want):
                ws=torch.empty(K.lib().ptamd_gemm_workspace_bytes(T, D, want), dtype=torch.uint8, device=dev))
 
 
+@pytest.mark.parametrize("T,D,Kd,want,p", [(2048, 512, 2048, 4, 0.1), (4096, 512, 2048, 2, 0.1), (2048, 512, 1536, 3, 0.25),
+                                           (1900, 256, 2048, 4, 0.1), (2047, 512, 2048, 4, 0.0), (16384, 512, 2048, 0, 0.1)])
+def test_unreduced_k_slices_into_the_layernorm_forward(dev, T, D, Kd, want, p):
+    """... and the forward twin (ptamd_layernorm_fwd_sum): FFN layer 2's split product leaves its K slices to the next
+    layer's LayerNorm, which makes x = residual + dropout(sum + bias) with the epilogue's own decisions and normalises it from
+    registers - the bits of reduction launch + ptamd_layernorm_fwd, in x and in everything the LayerNorm writes."""
+    from protein_transformer_amd import kernels as K
+    g = torch.Generator().manual_seed(T + Kd)
+    a = (torch.randn(T, Kd, generator=g).clamp_min(0) * torch.exp(torch.randn(T, 1, generator=g))).to(dev)
+    w = (torch.randn(D, Kd, generator=g) * 0.05).to(dev)
+    bias, gam, bet = ((torch.randn(D, generator=g) * 0.3 + o).to(dev) for o in (0.0, 1.0, 0.0))
+    res = torch.randn(T, D, generator=g).to(dev)
+    kw = dict(residual=res, ldr=D, dropout_p=p, seed=77, stream_id=6, arith=K.GEMM_AUTO)
+    x_ref = K.linear_fwd(a, w, bias, **kw)
+    pend = K.linear_fwd(a, w, bias, defer_reduce=True, **kw)
+    if want == 0:
+        assert torch.is_tensor(pend) and torch.equal(pend, x_ref)
+        return
+    assert isinstance(pend, K.PendingRows) and pend.slabs.n == want and pend.value is None
+    outs = []
+    for x in (x_ref, pend):
+        rs = torch.zeros(T, dtype=torch.int32, device=dev)
+        planes = torch.zeros(K.lib().ptamd_hp_bytes(T, D), dtype=torch.uint8, device=dev)
+        y, mean, rstd = K.layernorm_fwd(x, gam, bet, row_scale=rs, planes=planes)
+        outs.append((x if torch.is_tensor(x) else x.value, y, mean, rstd, rs, planes))
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
+    assert torch.isfinite(outs[0][1]).all()
+    if p > 0:
+        dropped = float((outs[1][0] == res).float().mean())          # (where the product was dropped the row is the residual)
+        assert abs(dropped - p) < 0.01
+
+
 @pytest.mark.parametrize("nprot", [4, 8])
 def test_deferred_reduction_leaves_the_step_unchanged(dev, nprot, monkeypatch):
     """... and a training step with the K slices deferred == the step with the reduction launches, bit for bit (4 proteins:
@@ -583,15 +616,21 @@ def test_deferred_reduction_leaves_the_step_unchanged(dev, nprot, monkeypatch):
     from protein_transformer_amd.train import train_step
     args = types.SimpleNamespace(loss="drmsd", combined_drmsd_weight=0.5, backbone_loss=False, clip=1.0)
     flats, seen = [], []
-    real = K.layernorm_bwd_dropout
+    real, real_fwd = K.layernorm_bwd_dropout, K.layernorm_fwd
+    seen_fwd = []
 
     def spy(dy, *a, **kw):
         seen.append(dy.n if isinstance(dy, K.Slabs) else 1)
         return real(dy, *a, **kw)
+
+    def spy_fwd(x, *a, **kw):
+        seen_fwd.append(x.slabs.n if isinstance(x, K.PendingRows) else 1)
+        return real_fwd(x, *a, **kw)
     monkeypatch.setattr(K, "layernorm_bwd_dropout", spy)
+    monkeypatch.setattr(K, "layernorm_fwd", spy_fwd)
     for defer in (True, False):
         monkeypatch.setattr(K, "DEFER_REDUCE", defer)
-        del seen[:]
+        del seen[:], seen_fwd[:]
         m, data = _prep_model(dev, nl=3, seed=17, nprot=nprot)
         opt = FusedSGD(m, lr=1e-2, weight_decay=10e-3)
         for _ in range(2):
@@ -599,4 +638,6 @@ def test_deferred_reduction_leaves_the_step_unchanged(dev, nprot, monkeypatch):
         flats.append(m.flat_parameters()[0].clone())
         want = ([4, 3] if nprot == 4 else [2, 2]) if defer else [1, 1]
         assert seen == [want[0], want[1], want[0], want[1], want[0]] * 2, seen   # (layer 0's dh1 goes to the unfused kernel)
+        # forward: the first LayerNorm of layers 1 and 2 makes the output of the layer below (FFN layer 2: K = 2048)
+        assert seen_fwd == [1, 1, want[0], 1, want[0], 1] * 2, seen_fwd
     assert torch.isfinite(flats[0]).all() and torch.equal(flats[0], flats[1])
