@@ -134,7 +134,8 @@ int ptamd_mse_angles_bwd(const float *pred, const float *truth, int64_t T, const
 #define PTAMD_EPI_SLABS 16 /* split_k > 1 only, plain epilogue only (no bias / residual / activation / dropout / colsum): the K
                             * slices' partial products stay in `workspace` as [splits][M][N] fp32 and NO reduction is launched -
                             * the caller sums them in slab order in the kernel that reads the product next
-                            * (ptamd_layernorm_bwd_dropout: dy_slabs); C is not written.  Ignored when the effective split is 1. */
+                            * (ptamd_layernorm_bwd_dropout: dy_slabs; ptamd_layernorm_fwd_sum).  C is not written; with an
+                            * effective split of 1 (K of one or two 32-blocks) the flag is ignored and C is. */
 #define PTAMD_EPI_GATE 8  /* result = residual[m,n] > 0 ? result * gate_scale : 0 - the backward of ReLU + dropout through
                             the saved activation (Sublayers.py:34), instead of adding `residual` */
 typedef struct {
