@@ -39,6 +39,20 @@ def main():
         train_step(model, opt, args, *res[i % 2], n_res=n_res)
     torch.cuda.synchronize()
     print(f"{a.batch} proteins: {1e3 * (time.perf_counter() - t0) / a.steps:.3f} ms/step wall (resident batches)")
+    # the loop's own time against the GPU's: every step waits for its own loss statistics (LossReport.wait, behind the
+    # enqueued backward pass), so the host never runs ahead by more than a backward pass - where the GPU is the limit the
+    # loop takes the GPU's time and the GPU finishes a fraction of a step later; where the loop takes LONGER than the
+    # GPU-bound step of a fast-host box (2.64 ms at 4 proteins), the host is the limit
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(40):
+            train_step(model, opt, args, *res[i % 2], n_res=n_res)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print(f"   40 steps: the loop took {1e3 * (t1 - t0) / 40:.3f} ms/step; the GPU finished {1e3 * (t2 - t1):.1f} ms "
+              f"after the loop ({1e3 * (t2 - t0) / 40:.3f} ms/step in all)")
     # the backward pass runs on autograd's device thread: a profiler of its own around _EncoderFn.backward
     from protein_transformer_amd.models import encoder_only as EO
     pb = cProfile.Profile()
