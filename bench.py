@@ -407,17 +407,19 @@ def main():
 
     shares = {}                                                      # per-GPU shares of the host batches, packed like whole ones
 
-    def timed_upload(first_step, batches=None, proteins=None):
+    def timed_upload(first_step, batches=None, proteins=None, steps=None):
         """K steps with every batch coming from pinned host memory INSIDE the step, the way train_epoch gets them
         (train.py: dataset.DevicePrefetcher - the next batch's copy on a side stream under this step, the residue count on
-        the host).  `proteins`: only the first so many of every batch (the per-GPU share of a strongly scaled job)."""
+        the host).  `proteins`: only the first so many of every batch (the per-GPU share of a strongly scaled job);
+        `steps`: steps of this pass (default: K)."""
+        steps = a.steps if steps is None else steps
         src = host_batches if batches is None else batches
         if proteins is not None:
             key = (id(src), proteins)
             if key not in shares:
                 shares[key] = [pack_batch((s[:proteins], g[:proteins], c[:proteins]), pin=True) for s, g, c in src]
             src = shares[key]
-        feed = (src[(first_step + i) % len(src)] for i in range(a.steps))
+        feed = (src[(first_step + i) % len(src)] for i in range(steps))
         out, n_res = None, 0
         dp.barrier()
         torch.cuda.synchronize()
@@ -527,14 +529,16 @@ def main():
                 pb = a.batch // n_gpu
                 for i in range(a.warmup):
                     timed_upload(i, proteins=pb)
-                # the median of three passes, like `value`: a share of 4 proteins is ~150 launches in < 3 ms, and ONE pass on a
-                # box with a slow or noisy host read 3.03 where the same tree read 2.73 in the passes around it (profiles/r06)
-                runs = sorted(timed_upload(a.warmup, proteins=pb)[::2] for _ in range(3))
-                d, n = runs[1]
-                per[str(n_gpu)] = {"proteins_per_gpu": pb, "ms_per_step": round(1e3 * d / a.steps, 3),
-                                   "passes_ms_per_step": [round(1e3 * r[0] / a.steps, 3) for r in runs],
+                # the median of five passes of K x N steps each (as many proteins per pass as a pass of `value`): a share of 4
+                # proteins is ~135 launches in < 3 ms, and 20-step passes (53 ms) on a box with a busy host read 2.82, 3.07 and
+                # 3.82 where other boxes read 2.66 in every pass (profiles/r06/r06_final_box_spread.txt)
+                ks = a.steps * n_gpu
+                runs = sorted(timed_upload(a.warmup, proteins=pb, steps=ks)[::2] for _ in range(5))
+                d, n = runs[2]
+                per[str(n_gpu)] = {"proteins_per_gpu": pb, "ms_per_step": round(1e3 * d / ks, 3),
+                                   "passes_ms_per_step": [round(1e3 * r[0] / ks, 3) for r in runs], "steps_per_pass": ks,
                                    "residues_per_s_per_gpu": round(n / d, 1),
-                                   "speedup_ceiling": round(full_ms / (1e3 * d / a.steps), 3)}
+                                   "speedup_ceiling": round(full_ms / (1e3 * d / ks), 3)}
             strong = {"scaling": "strong", "global_batch": a.batch, "per_gpu_step_at_n_gpus": per,
                       "strong_scaling_ceiling_8gpu": per.get("8", {}).get("speedup_ceiling"),
                       "what": f"ONE GPU running the per-GPU share of the configuration's global batch of {a.batch} proteins at N = 2, 4, "
