@@ -194,24 +194,29 @@ __device__ __forceinline__ void placement_params(int p, int &res, int &col_th, i
   else { res = i; col_th = 3; col_chi = 0; l = BL_CA_C; }
 }
 
-// grid = B, block = 64 (one wavefront per protein). dynamic LDS: chunk * 64 float4 of cached (sin th, cos th, sin chi, cos chi)
-__global__ __launch_bounds__(PT_WAVE) void nerf_backbone_fwd_kernel(const float *__restrict__ ang,
-                                                                    const int64_t *__restrict__ seq, int L,
-                                                                    float *__restrict__ crd,
-                                                                    int32_t *__restrict__ status) {
+// grid = B, block = 64 NW (NW wavefronts per protein: round 6 - with one, 3 L = 1536 placements are 24 per lane and the
+// kernel takes 24.5 us whatever the batch; with four, 6 per lane, the wave-wide scans joined through LDS by at most three more
+// compositions).  dynamic LDS: chunk * 64 NW float4 of cached (sin th, cos th, sin chi, cos chi)
+template <int NW>
+__global__ __launch_bounds__(PT_WAVE * NW) void nerf_backbone_fwd_kernel(const float *__restrict__ ang,
+                                                                         const int64_t *__restrict__ seq, int L,
+                                                                         float *__restrict__ crd,
+                                                                         int32_t *__restrict__ status) {
+  constexpr int NT = PT_WAVE * NW;
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float wave_total[NW][12];
   float4 *trig = reinterpret_cast<float4 *>(lds);
-  const int b = blockIdx.x, lane = threadIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & (PT_WAVE - 1), wave = tid / PT_WAVE;
   ang += (size_t)b * L * 12;
   seq += (size_t)b * L;
   crd += (size_t)b * L * 42;
-  const int len = protein_len(seq, L, lane, status);
+  const int len = protein_len(seq, L, lane, status);   // (every wavefront counts: the same number, idempotent flags)
   if (len < 2) {
-    if (lane == 0) atomicOr(status, PTAMD_ST_TOO_SHORT);
+    if (tid == 0) atomicOr(status, PTAMD_ST_TOO_SHORT);
     return;  // the side-chain kernel zero-fills
   }
-  const int K = 3 * (len - 1), chunk = (K + PT_WAVE - 1) / PT_WAVE;
-  const int p0 = lane * chunk, p1 = min(K, p0 + chunk);
+  const int K = 3 * (len - 1), chunk = (K + NT - 1) / NT;
+  const int p0 = min(K, tid * chunk), p1 = min(K, p0 + chunk);
 
   // pass 1: local transforms of my chunk, composed in order
   Xf q = xf_identity();
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(PT_WAVE) void nerf_backbone_fwd_kernel(const float 
     sincosf(th, &st, &ct);
     sincosf(chi, &sx, &cx);
     if (!(fabsf(th) <= PI_F)) bad_theta = 1;  // fp32 pi itself is accepted
-    trig[(p - p0) * PT_WAVE + lane] = make_float4(st, ct, sx, cx);
+    trig[(p - p0) * NT + tid] = make_float4(st, ct, sx, cx);
     q = xf_mul(q, xf_local(l, st, ct, sx, cx));
   }
   {
@@ -242,6 +247,31 @@ __global__ __launch_bounds__(PT_WAVE) void nerf_backbone_fwd_kernel(const float 
   }
   Xf ex = xf_shfl_up(q, 1);
   if (lane == 0) ex = xf_identity();
+  if (NW > 1) {   // the wavefronts in front of mine: their products in order, then mine
+    if (lane == PT_WAVE - 1) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) wave_total[wave][i] = q.r[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) wave_total[wave][9 + i] = q.t[i];
+    }
+    __syncthreads();
+    if (wave > 0) {
+      Xf pre;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) pre.r[i] = wave_total[0][i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) pre.t[i] = wave_total[0][9 + i];
+      for (int v = 1; v < wave; ++v) {
+        Xf nx;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) nx.r[i] = wave_total[v][i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) nx.t[i] = wave_total[v][9 + i];
+        pre = xf_mul(pre, nx);
+      }
+      ex = xf_mul(pre, ex);
+    }
+  }
 
   // init_bb (StructureBuilder.py:181-191) and the frame of the first placement (N_1 from N_0, CA_0, C_0)
   const V3 pN = {0.f, 0.f, 0.001f};
@@ -258,7 +288,7 @@ __global__ __launch_bounds__(PT_WAVE) void nerf_backbone_fwd_kernel(const float 
     g.r[6] = x.z; g.r[7] = y.z; g.r[8] = z.z;
     g.t[0] = pC.x; g.t[1] = pC.y; g.t[2] = pC.z;
   }
-  if (lane == 0) {
+  if (tid == 0) {
     st3(crd + 0, pN);
     st3(crd + 3, pCA);
     st3(crd + 6, pC);
@@ -270,7 +300,7 @@ __global__ __launch_bounds__(PT_WAVE) void nerf_backbone_fwd_kernel(const float 
     int res, cth, cchi, slot;
     float l;
     placement_params(p, res, cth, cchi, l, slot);
-    const float4 tr = trig[(p - p0) * PT_WAVE + lane];
+    const float4 tr = trig[(p - p0) * NT + tid];
     g = xf_mul(g, xf_local(l, tr.x, tr.y, tr.z, tr.w));
     const int i = 1 + p / 3;
     float *o = crd + (size_t)i * 42 + slot * 3;
@@ -490,12 +520,16 @@ __device__ __forceinline__ void chain_atom(const float *__restrict__ crd, const 
   if (j == 3) g = g + ld3(gbb + 9);                                        // CB of residue 0 hangs off N_1
 }
 
-__global__ __launch_bounds__(PT_WAVE) void nerf_backbone_bwd_kernel(const float *__restrict__ ang,
-                                                                    const int64_t *__restrict__ seq,
-                                                                    const float *__restrict__ crd,
-                                                                    const float *__restrict__ gbb, int L,
-                                                                    float *__restrict__ dang) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+// (NW wavefronts per protein, as in the forward kernel: the suffix sums of the later wavefronts come through LDS)
+template <int NW>
+__global__ __launch_bounds__(PT_WAVE * NW) void nerf_backbone_bwd_kernel(const float *__restrict__ ang,
+                                                                         const int64_t *__restrict__ seq,
+                                                                         const float *__restrict__ crd,
+                                                                         const float *__restrict__ gbb, int L,
+                                                                         float *__restrict__ dang) {
+  constexpr int NT = PT_WAVE * NW;
+  __shared__ double wave_total[NW][6];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & (PT_WAVE - 1), wave = tid / PT_WAVE;
   ang += (size_t)b * L * 12;
   seq += (size_t)b * L;
   crd += (size_t)b * L * 42;
@@ -504,8 +538,8 @@ __global__ __launch_bounds__(PT_WAVE) void nerf_backbone_bwd_kernel(const float 
   int32_t dummy = 0;
   const int len = protein_len(seq, L, lane, &dummy);
   if (len < 2) return;
-  const int n = 3 * len, chunk = (n + PT_WAVE - 1) / PT_WAVE;
-  const int j0 = lane * chunk, j1 = min(n, j0 + chunk);
+  const int n = 3 * len, chunk = (n + NT - 1) / NT;
+  const int j0 = min(n, tid * chunk), j1 = min(n, j0 + chunk);
 
   double F[3] = {0, 0, 0}, T[3] = {0, 0, 0};
   for (int j = j0; j < j1; ++j) {
@@ -528,11 +562,28 @@ __global__ __launch_bounds__(PT_WAVE) void nerf_backbone_bwd_kernel(const float 
       }
     }
   }
+  if (NW > 1 && lane == 0) {   // my wavefront's total, for the wavefronts in front of it
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      wave_total[wave][c] = F[c];
+      wave_total[wave][3 + c] = T[c];
+    }
+  }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const double of = __shfl_down(F[c], 1, 64), ot = __shfl_down(T[c], 1, 64);
     F[c] = lane + 1 < PT_WAVE ? of : 0.0;
     T[c] = lane + 1 < PT_WAVE ? ot : 0.0;
+  }
+  if (NW > 1) {
+    __syncthreads();
+    for (int v = wave + 1; v < NW; ++v) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        F[c] += wave_total[v][c];
+        T[c] += wave_total[v][3 + c];
+      }
+    }
   }
   for (int j = j1 - 1; j >= j0; --j) {
     V3 P, g;
@@ -597,6 +648,17 @@ __global__ void pairwise_dist_kernel(const float *__restrict__ x, int n, int dim
 }  // namespace
 
 // ================================================================================================
+// wavefronts per protein of the two backbone-chain kernels (PTAMD_NERF_WAVES = 1 in the environment, read once: the
+// one-wavefront kernels, for A/B measurements and tests)
+constexpr int CHAIN_WAVES = 4;
+static int chain_waves() {
+  static const int nw = [] {
+    const char *e = getenv("PTAMD_NERF_WAVES");
+    return (e && e[0] == '1' && e[1] == 0) ? 1 : CHAIN_WAVES;
+  }();
+  return nw;
+}
+
 extern "C" {
 
 int ptamd_sidechain_atoms(int residue) { return (residue < 0 || residue > 19) ? -1 : h_pt_nsc[residue]; }
@@ -636,13 +698,23 @@ size_t ptamd_nerf_workspace_bytes(int B, int L) { return (size_t)(B > 0 ? B : 0)
 int ptamd_nerf_fwd(const float *ang, const int64_t *seq, int B, int L, float *crd, int32_t *status, void *stream) {
   if (B <= 0 || L <= 0) return PTAMD_ERR_BAD_SHAPE;
   if (L > MAX_L_CHAIN) return PTAMD_ERR_TOO_LONG;
-  const size_t lds = (size_t)((3 * L + PT_WAVE - 1) / PT_WAVE) * PT_WAVE * sizeof(float4);  // trig cache of the scan
-  if (lds > 48 * 1024) {
-    PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(nerf_backbone_fwd_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int nw = chain_waves();
+  const int nt = PT_WAVE * nw;
+  const size_t lds = (size_t)((3 * L + nt - 1) / nt) * nt * sizeof(float4);  // trig cache of the scan
+  if (nw == 1) {
+    if (lds > 48 * 1024) {
+      PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(nerf_backbone_fwd_kernel<1>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(nerf_backbone_fwd_kernel<1>, dim3(B), dim3(nt), lds, (hipStream_t)stream, ang, seq, L, crd, status);
+  } else {
+    if (lds > 48 * 1024) {
+      PT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(nerf_backbone_fwd_kernel<CHAIN_WAVES>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(nerf_backbone_fwd_kernel<CHAIN_WAVES>, dim3(B), dim3(nt), lds, (hipStream_t)stream, ang, seq, L, crd,
+                       status);
   }
-  hipLaunchKernelGGL(nerf_backbone_fwd_kernel, dim3(B), dim3(PT_WAVE), lds, (hipStream_t)stream, ang, seq, L, crd,
-                     status);
   int rc = pt_check_launch();
   if (rc) return rc;
   hipLaunchKernelGGL(nerf_sidechain_fwd_kernel, dim3((L + SC_BLOCK - 1) / SC_BLOCK, B), dim3(SC_BLOCK), 0,
@@ -660,8 +732,11 @@ int ptamd_nerf_bwd(const float *ang, const int64_t *seq, const float *crd, const
                      (hipStream_t)stream, ang, seq, crd, dcrd, L, dang, gbb);
   int rc = pt_check_launch();
   if (rc) return rc;
-  hipLaunchKernelGGL(nerf_backbone_bwd_kernel, dim3(B), dim3(PT_WAVE), 0, (hipStream_t)stream, ang, seq, crd, gbb, L,
-                     dang);
+  if (chain_waves() == 1)
+    hipLaunchKernelGGL(nerf_backbone_bwd_kernel<1>, dim3(B), dim3(PT_WAVE), 0, (hipStream_t)stream, ang, seq, crd, gbb, L, dang);
+  else
+    hipLaunchKernelGGL(nerf_backbone_bwd_kernel<CHAIN_WAVES>, dim3(B), dim3(PT_WAVE * CHAIN_WAVES), 0, (hipStream_t)stream, ang,
+                       seq, crd, gbb, L, dang);
   return pt_check_launch();
 }
 
