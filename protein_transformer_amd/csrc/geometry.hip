@@ -648,15 +648,19 @@ __global__ void pairwise_dist_kernel(const float *__restrict__ x, int n, int dim
 }  // namespace
 
 // ================================================================================================
-// wavefronts per protein of the two backbone-chain kernels (PTAMD_NERF_WAVES = 1 in the environment, read once: the
-// one-wavefront kernels, for A/B measurements and tests)
+// Wavefronts per protein of the two backbone-chain kernels.  The ADJOINT runs on four (its fp64 sums do not care how they are
+// cut).  The FORWARD chain stays on one: four re-round the backbone in another order - by 1e-6 ... 1e-5 A, inside every
+// tolerance - but the side-chain builder behind it follows the reference's cross products, which amplify such a difference by
+// up to 1 / |sin| of a backbone bond angle on arbitrary (random-init) angles: one L = 200 protein of the parity record's config-5
+// draws moved from 0.75 to 16 units of 1.6e-3 A (the reference's own fp32 chain: 2.4), past that record's bar - not worth 12 us.
+// PTAMD_NERF_WAVES = 1 / 4 in the environment (read once): both kernels on one / four wavefronts, for measurements.
 constexpr int CHAIN_WAVES = 4;
-static int chain_waves() {
-  static const int nw = [] {
+static int chain_waves(bool forward) {
+  static const int env = [] {
     const char *e = getenv("PTAMD_NERF_WAVES");
-    return (e && e[0] == '1' && e[1] == 0) ? 1 : CHAIN_WAVES;
+    return (e && (e[0] == '1' || e[0] == '4') && e[1] == 0) ? e[0] - '0' : 0;
   }();
-  return nw;
+  return env ? env : forward ? 1 : CHAIN_WAVES;
 }
 
 extern "C" {
@@ -698,7 +702,7 @@ size_t ptamd_nerf_workspace_bytes(int B, int L) { return (size_t)(B > 0 ? B : 0)
 int ptamd_nerf_fwd(const float *ang, const int64_t *seq, int B, int L, float *crd, int32_t *status, void *stream) {
   if (B <= 0 || L <= 0) return PTAMD_ERR_BAD_SHAPE;
   if (L > MAX_L_CHAIN) return PTAMD_ERR_TOO_LONG;
-  const int nw = chain_waves();
+  const int nw = chain_waves(true);
   const int nt = PT_WAVE * nw;
   const size_t lds = (size_t)((3 * L + nt - 1) / nt) * nt * sizeof(float4);  // trig cache of the scan
   if (nw == 1) {
@@ -732,7 +736,7 @@ int ptamd_nerf_bwd(const float *ang, const int64_t *seq, const float *crd, const
                      (hipStream_t)stream, ang, seq, crd, dcrd, L, dang, gbb);
   int rc = pt_check_launch();
   if (rc) return rc;
-  if (chain_waves() == 1)
+  if (chain_waves(false) == 1)
     hipLaunchKernelGGL(nerf_backbone_bwd_kernel<1>, dim3(B), dim3(PT_WAVE), 0, (hipStream_t)stream, ang, seq, crd, gbb, L, dang);
   else
     hipLaunchKernelGGL(nerf_backbone_bwd_kernel<CHAIN_WAVES>, dim3(B), dim3(PT_WAVE * CHAIN_WAVES), 0, (hipStream_t)stream, ang,
