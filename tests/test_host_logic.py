@@ -220,3 +220,25 @@ def test_selectors_golden(golden):
         for make in (torch.tensor, np.array, list):
             got = losses.remove_sos_eos_from_input(make(g[f"seq{i}"].tolist()))
             assert list(np.asarray(got)) == list(g[f"stripped{i}"])
+
+
+def test_k_splits_of_the_small_batch_products():
+    """Host-side choice of K splits (kernels.pick_split_k_rows) and the slices ptamd_gemm really makes of them
+    (kernels.effective_splits = the arithmetic of build_params in csrc/gemm.hip): what the deferred reductions of round 6 rest
+    on - at 2048 / 4096 tokens of the d512 model FFN-2 forward and the dX products of FFN-1 / QKV are cut 4, 4, 3 and 2, 2, 2
+    ways (slices the LayerNorm kernels can sum: 2 ... 4), from 8192 tokens on nothing is split."""
+    from protein_transformer_amd import kernels as K
+    D, F = 512, 2048
+    for tokens, want in ((2048, (4, 4, 3)), (4096, (2, 2, 2)), (8192, (1, 1, 1)), (16384, (1, 1, 1))):
+        got = tuple(K.effective_splits(red, K.pick_split_k_rows(tokens, D, red)) for red in (F, F, 3 * D))
+        assert got == want, (tokens, got)
+    assert K.pick_split_k_rows(2048, D, D) == 1                      # wo: K = 512 is not worth cutting
+    assert K.pick_split_k_rows(2048, F, D) == 1                      # FFN-1: 256 tiles already
+    # slices are whole 32-blocks of K and never empty: asking for more than there are blocks gives one per block
+    assert K.effective_splits(2048, 4) == 4 and K.effective_splits(1536, 4) == 4 and K.effective_splits(1536, 3) == 3
+    assert K.effective_splits(96, 8) == 3 and K.effective_splits(100, 3) == 2 and K.effective_splits(32, 4) == 1
+    for red in (33, 64, 1000, 1536, 2048, 4097):
+        for ask in range(1, 9):
+            n = K.effective_splits(red, ask)
+            per = -(-(-(-red // 32)) // min(ask, -(-red // 32))) * 32     # k_per_split of build_params
+            assert 1 <= n <= ask and (n - 1) * per < red <= n * per
